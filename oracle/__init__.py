@@ -1,0 +1,27 @@
+"""CPU oracle for the LINNA emulator hot path -- TEST INFRASTRUCTURE ONLY.
+
+A plain-numpy restatement of the reference's algorithm (chto/linna, pure Python/torch) for
+the path named in BASELINE.json: emulator forward/backward, transforms, Gaussian
+log-likelihood, training loss, AdamW, HMC leapfrog and the ensemble stretch move.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this package, and only as the checker.  The product (``linna_amd``) never
+imports it: the product path fails loudly when the HIP library is missing.
+
+Parity status
+-------------
+* emulator / transforms / likelihood / loss / gradients / AdamW / HMCSampler.py: PINNED
+  against the live reference imported in the build container
+  (``tests/golden/make_golden.py`` -> ``tests/golden/*.npz``) and against the reference's
+  own committed fixture ``tests/test_data/2dgaussian_Fulltconn/iter_0`` (copied as data
+  under ``tests/golden/2dgaussian_Fulltconn``).
+* ensemble stretch move (``oracle.sampling.stretch_*``): PARITY UNPINNED.  The arithmetic
+  lives in emcee (requirements.txt:14 pins emcee==3.0.2), which is neither vendored in the
+  reference tree nor installed here; it is restated from emcee's published algorithm
+  (Goodman & Weare 2010; emcee ``RedBlueMove``/``StretchMove``) and anchored on the
+  reference's call sites sampler.py:493-495, 519-530.
+
+Every function cites the reference file:line it follows (paths relative to the
+reference root).
+"""
+from . import emulator, likelihood, training, sampling  # noqa: F401

@@ -1,0 +1,161 @@
+"""Oracle: counter RNG, ensemble stretch move, leapfrog HMC (numpy).
+
+TEST INFRASTRUCTURE ONLY.
+
+* ``hmc_chain`` restates linna/HMCSampler.py:19-68 (PINNED by tests/golden/hmc_trace.npz).
+* ``hmc_batched_step`` is the same leapfrog applied independently per walker (the
+  per-walker semantics of sampler.py:67-98).
+* ``stretch_half_step`` restates emcee 3.0.2 ``RedBlueMove.propose`` /
+  ``StretchMove.get_proposal`` (Goodman & Weare 2010, a = 2): PARITY UNPINNED -- emcee is
+  a third-party dependency (requirements.txt:14) absent from the reference tree and from
+  this image; anchored on the reference call sites sampler.py:493-495, 519-530.
+* ``philox4x32`` is the published Philox4x32-10 generator (Salmon et al. 2011); the HIP
+  sampler kernels use the same counter layout so draws can be replayed here.
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------- Philox
+_M0 = np.uint64(0xD2511F53)
+_M1 = np.uint64(0xCD9E8D57)
+_W0 = np.uint32(0x9E3779B9)
+_W1 = np.uint32(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32(counter, key, rounds=10):
+    """counter: uint32[..., 4], key: uint32[..., 2] -> uint32[..., 4]."""
+    c = np.array(counter, dtype=np.uint32, copy=True)
+    k = np.array(np.broadcast_to(key, c.shape[:-1] + (2,)), dtype=np.uint32, copy=True)
+    with np.errstate(over="ignore"):
+        for _ in range(rounds):
+            p0 = _M0 * c[..., 0].astype(np.uint64)
+            p1 = _M1 * c[..., 2].astype(np.uint64)
+            hi0 = (p0 >> np.uint64(32)).astype(np.uint32)
+            lo0 = (p0 & _MASK).astype(np.uint32)
+            hi1 = (p1 >> np.uint64(32)).astype(np.uint32)
+            lo1 = (p1 & _MASK).astype(np.uint32)
+            n0 = hi1 ^ c[..., 1] ^ k[..., 0]
+            n2 = hi0 ^ c[..., 3] ^ k[..., 1]
+            c = np.stack([n0, lo1, n2, lo0], axis=-1)
+            k = np.stack([k[..., 0] + _W0, k[..., 1] + _W1], axis=-1)
+    return c
+
+
+def u01(bits):
+    """uint32 -> float32 uniform in (0, 1): (bits >> 8 + 0.5) * 2^-24."""
+    return ((bits >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0)
+
+
+def walker_draws(seed, step, stream, nwalkers):
+    """4 uniforms per walker for (seed, step, stream): counter = (walker, step, stream, 0),
+    key = (seed_lo, seed_hi)."""
+    ctr = np.zeros((nwalkers, 4), np.uint32)
+    ctr[:, 0] = np.arange(nwalkers, dtype=np.uint32)
+    ctr[:, 1] = np.uint32(step & 0xFFFFFFFF)
+    ctr[:, 2] = np.uint32(stream)
+    key = np.array([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF], np.uint32)
+    return u01(philox4x32(ctr, key))
+
+
+def normal_from_uniform(u1, u2):
+    """Box-Muller, float32."""
+    r = np.sqrt(np.float32(-2.0) * np.log(u1))
+    return (r * np.cos(np.float32(2 * np.pi) * u2)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- stretch move
+def stretch_propose(s, c, u_z, rint, a=2.0):
+    """emcee StretchMove.get_proposal: zz = ((a-1)u+1)^2/a; q = c[r] - (c[r]-s) zz;
+    factor = (ndim-1) log zz."""
+    dt = s.dtype
+    zz = ((dt.type(a) - dt.type(1)) * u_z.astype(dt) + dt.type(1)) ** 2 / dt.type(a)
+    cr = c[rint]
+    q = cr - (cr - s) * zz[:, None]
+    factors = dt.type(s.shape[1] - 1.0) * np.log(zz)
+    return q.astype(dt), factors.astype(dt)
+
+
+def stretch_accept(logp_old, logp_new, factors, u_acc):
+    """emcee RedBlueMove.propose: accept iff factor + new - old > log(u)."""
+    lnpdiff = factors + logp_new - logp_old
+    with np.errstate(invalid="ignore"):
+        return lnpdiff > np.log(u_acc)
+
+
+def stretch_half_step(coords, logp, S, C, u_z, rint, u_acc, logprob_fn, a=2.0):
+    """Advance the walkers ``S`` (index array) against the complementary set ``C``."""
+    q, f = stretch_propose(coords[S], coords[C], u_z, rint, a)
+    new_lp = logprob_fn(q)
+    acc = stretch_accept(logp[S], new_lp, f, u_acc)
+    coords = coords.copy()
+    logp = logp.copy()
+    coords[S[acc]] = q[acc]
+    logp[S[acc]] = new_lp[acc]
+    return coords, logp, acc
+
+
+# --------------------------------------------------------------------------- HMC
+def hmc_chain(lnp_and_grad, x0, mass, num_samps, num_steps, step_size, momenta, uniforms):
+    """linna/HMCSampler.py:19-68 with the random draws passed in explicitly.
+
+    ``lnp_and_grad(x[nin]) -> (lnP, grad[nin])``; ``momenta[num_samps, nin]`` are the
+    standard-normal draws of :26 (before ``* sqrt(m)``), ``uniforms[num_samps]`` those of :59.
+    Returns (xs[num_samps, nin], lnPs[num_samps], accepted[num_samps]).
+    """
+    f = np.float32
+    x_cur = np.asarray(x0, f).copy()
+    mass = np.asarray(mass, f)
+    xs, lnps, accs = [], [], []
+    for i in range(num_samps):
+        x = x_cur.copy()
+        p = momenta[i].astype(f) * np.sqrt(mass)                      # :26
+        lnP, grad = lnp_and_grad(x)                                   # :29,32
+        prev = lnP
+        H_init = f(0.5) * np.sum(p * p / mass) - lnP                  # :31
+        p = p + f(0.5) * grad * f(step_size)                          # :35
+        x = x + (p / mass) * f(step_size)                             # :36
+        lnP, grad = lnp_and_grad(x)                                   # :39-40
+        for _ in range(1, num_steps):                                 # :43-48
+            p = p + grad * f(step_size)
+            x = x + (p / mass) * f(step_size)
+            lnP, grad = lnp_and_grad(x)
+        p = p + f(0.5) * grad * f(step_size)                          # :51
+        H_prime = f(0.5) * np.sum(p * p / mass) - lnP                 # :54
+        ratio = np.exp(np.minimum(H_init - H_prime, 0))               # :57
+        if uniforms[i] < min(ratio, 1):                               # :58-59
+            x_cur = x
+            xs.append(x.copy()); lnps.append(lnP); accs.append(True)
+        else:
+            xs.append(x_cur.copy()); lnps.append(prev); accs.append(False)
+    return np.array(xs, f), np.array(lnps, f), np.array(accs)
+
+
+def hmc_batched_step(lnp_and_grad_rows, x, lnp, grad, mass, num_steps, step_size, p0, u):
+    """One HMC transition for every row of ``x[B, nin]`` independently.
+
+    ``lnp_and_grad_rows(x[B,nin]) -> (lnP[B], grad[B,nin])``; ``p0`` standard-normal draws,
+    ``u`` uniforms.  (lnp, grad) are the cached values at ``x``.  Returns the new
+    (x, lnp, grad, accepted).
+    """
+    f = np.float32
+    mass = np.asarray(mass, f)[None, :]
+    eps = f(step_size)
+    p = p0.astype(f) * np.sqrt(mass)
+    H0 = f(0.5) * np.sum(p * p / mass, -1) - lnp
+    q = x.copy()
+    g = grad
+    p = p + f(0.5) * eps * g
+    for i in range(num_steps):
+        q = q + eps * (p / mass)
+        l, g = lnp_and_grad_rows(q)
+        if i < num_steps - 1:
+            p = p + eps * g
+    p = p + f(0.5) * eps * g
+    H1 = f(0.5) * np.sum(p * p / mass, -1) - l
+    with np.errstate(invalid="ignore", over="ignore"):
+        acc = u < np.exp(np.minimum(H0 - H1, 0))
+    acc &= np.isfinite(l)
+    xn = np.where(acc[:, None], q, x)
+    ln = np.where(acc, l, lnp)
+    gn = np.where(acc[:, None], g, grad)
+    return xn.astype(f), ln.astype(f), gn.astype(f), acc

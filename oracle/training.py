@@ -1,0 +1,139 @@
+"""Oracle: training statistics, chi^2-ratio loss, analytic gradients, AdamW (numpy).
+
+TEST INFRASTRUCTURE ONLY.  Restates linna/util.py:1055-1127 (Auxilleryfunc, Loss_fn,
+Val_metric_fn), :1308-1313, :1410-1460 (train_NN statistics) and the torch.optim.AdamW
+update used at linna/predictor_gpu.py:267,287.
+"""
+import numpy as np
+
+from . import emulator
+
+
+def lower_median(a, axis=0):
+    """torch.median semantics (util.py:1313,1449; predictor_gpu.py:62): for an even count
+    the LOWER of the two middle values, not their mean."""
+    a = np.asarray(a)
+    s = np.sort(a, axis=axis)
+    n = a.shape[axis]
+    return np.take(s, (n - 1) // 2, axis=axis)
+
+
+def data_statistics(train_x, train_y, train_y_last, sigma, dolog10index=None):
+    """X_mean/X_std, y_mean/y_std of util.py:1433-1451 (``ypositive=False`` branch).
+
+    Sentinel clipping (util.py:1433-1438) is applied to copies.  Returns float32 arrays.
+    """
+    train_y = np.clip(np.array(train_y, np.float64), -1e5, 1e10)
+    train_y_last = np.clip(np.array(train_y_last, np.float64), -1e5, 1e10)
+    X1 = np.array(train_x, np.float32)
+    if dolog10index is not None:
+        for i in dolog10index:
+            X1[:, i] = np.log10(X1[:, i])
+    X_mean = X1.mean(axis=0, dtype=np.float32)
+    X_std = X1.std(axis=0, ddof=1, dtype=np.float32)              # torch .std is unbiased
+    ys = train_y_last.astype(np.float32) / np.asarray(sigma, np.float32)[None, :]
+    y_mean = lower_median(ys, 0)
+    y_std = lower_median(np.abs(ys - y_mean[None, :]), 0)
+    y_std = np.where(y_std < 1e-10, np.float32(1.0), y_std)       # util.py:1451
+    return X_mean, X_std.astype(np.float32), y_mean.astype(np.float32), y_std.astype(np.float32)
+
+
+def normalised_inverse_cov(cov, sigma, y_std):
+    """util.py:1063-1064 with util.py:447 and :590: C~ = D2 (D1 cov^T D1)^T D2 in fp64 with
+    D1 = diag(1/sigma_f32), D2 = diag(1/y_std_f32); returns inverse cast to fp32."""
+    d1 = 1.0 / np.asarray(sigma, np.float32).astype(np.float64)
+    d2 = 1.0 / np.asarray(y_std, np.float32).astype(np.float64)
+    c1 = (np.diag(d1) @ np.asarray(cov, np.float64).T) @ np.diag(d1).T
+    c2 = (np.diag(d2) @ c1.T) @ np.diag(d2).T
+    return np.linalg.inv(c2).astype(np.float32)
+
+
+def normalise_target(y, sigma, y_mean, y_std):
+    """y_inv_transform(y_transform_data(y)) (util.py:1071): ((y/sigma) - y_mean)/y_std."""
+    y = np.asarray(y, np.float32)
+    return (y / np.asarray(sigma, np.float32)[None, :] - y_mean[None, :]) / y_std[None, :]
+
+
+def aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+    """util.py:1070-1088.  ``pred`` is the raw network output (normalised space),
+    ``target`` is the physical data vector batch, ``data_norm`` the normalised data.
+
+    Returns loss[B], chisqMd[B], chisqnnd[B], plus (delta, notmask) used by ``loss_grad``.
+    """
+    dt = pred.dtype
+    target = np.asarray(target, dt)
+    tnorm = normalise_target(target, sigma, y_mean, y_std).astype(dt)
+    mask = (target == dt.type(1e-30)) | (target == dt.type(1e10)) | (data_norm[None, :] == dt.type(1e-30))
+    C = icov_norm.astype(dt)
+
+    def chisq(delta):
+        delta = np.where(mask, dt.type(0), delta)
+        return ((delta @ C) * delta).sum(-1), delta
+
+    chisqnnd, _ = chisq(pred - data_norm[None, :])
+    chisqMd, _ = chisq(tnorm - data_norm[None, :])
+    chisqMnn, delta = chisq(tnorm - pred)
+    floor = dt.type(0.5 * target.shape[1])
+    chisqMd = np.where(chisqMd < floor, floor, chisqMd)             # util.py:1086
+    return chisqMnn / chisqMd, chisqMd, chisqnnd, delta, ~mask
+
+
+def loss(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+    """util.py:1105-1116: mean over the batch."""
+    return aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std)[0].mean(dtype=pred.dtype)
+
+
+def val_metric(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+    """util.py:1124-1127: [median(loss), max|chisqnnd/chisqMd - 1|, median(same)]."""
+    l, cMd, cnnd, _, _ = aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std)
+    frac = np.abs(cnnd / cMd - 1)
+    return np.array([lower_median(l), frac.max(), lower_median(frac)], np.float32)
+
+
+def loss_grad(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+    """d mean(loss) / d pred: -(delta (C + C^T)) / (B * chisqMd), zero where masked."""
+    l, cMd, _, delta, notmask = aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std)
+    C = icov_norm.astype(pred.dtype)
+    g = -(delta @ C + delta @ C.T) / (pred.dtype.type(pred.shape[0]) * cMd[:, None])
+    return l.mean(dtype=pred.dtype), np.where(notmask, g, 0).astype(pred.dtype)
+
+
+def adamw_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-4):
+    """One torch.optim.AdamW update on float32 arrays (in place); ``step`` is 1-based."""
+    f = np.float32
+    p *= f(1 - lr * weight_decay)
+    m += (g - m) * f(1 - beta1)
+    v *= f(beta2)
+    v += f(1 - beta2) * g * g
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = np.sqrt(v) / f(np.sqrt(bc2)) + f(eps)
+    p -= f(lr / bc1) * (m / denom)
+    return p, m, v
+
+
+def train_step(params, opt_state, X, y, stats, kind, in_size, out_size, lr, weight_decay=1e-4,
+               **topo_kw):
+    """One minibatch of predictor_gpu.py:273-288: forward -> loss -> backward -> AdamW.
+
+    ``stats`` = dict(X_mean, X_std, y_mean, y_std, sigma, data_norm, icov_norm).
+    ``opt_state`` = dict(step:int, m:{key:arr}, v:{key:arr}).  Returns (loss, grads).
+    """
+    x = (np.asarray(X, np.float32) - stats["X_mean"][None, :]) / stats["X_std"][None, :]
+    pred, caches = emulator.forward(params, x, kind, in_size, out_size, keep=True, **topo_kw)
+    l, dpred = loss_grad(pred, y, stats["data_norm"], stats["icov_norm"], stats["sigma"],
+                         stats["y_mean"], stats["y_std"])
+    _, grads = emulator.backward(params, caches, dpred, kind, in_size, out_size, **topo_kw)
+    opt_state["step"] += 1
+    for k in params:
+        g = grads.get(k)
+        if g is None:
+            continue
+        adamw_step(params[k], g.astype(np.float32), opt_state["m"][k], opt_state["v"][k],
+                   opt_state["step"], lr, weight_decay=weight_decay)
+    return l, grads
+
+
+def new_opt_state(params):
+    return {"step": 0, "m": {k: np.zeros_like(v) for k, v in params.items()},
+            "v": {k: np.zeros_like(v) for k, v in params.items()}}

@@ -1,0 +1,384 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the LIVE reference.
+
+Runs only in the build container (needs /root/reference).  It imports the reference
+package (with inert stubs for absent third-party modules, see _ref_import.py), feeds it
+deterministic synthetic weights / inputs (synth.py) and stores inputs + expected outputs
+as small .npz files.  It also copies the DATA files of the reference's own test fixture
+(tests/test_data/2dgaussian_Fulltconn/iter_0) -- checkpoints, transform pickles, sample
+arrays -- which the reference's tests/test_main.py:47-51 reads.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+No reference source text is copied anywhere.
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+import _ref_import  # noqa: E402
+
+rnn, rutil, rpred, rhmc = _ref_import.import_reference()
+import torch  # noqa: E402
+from torch import nn as tnn  # noqa: E402
+
+torch.set_num_threads(4)
+FIX_SRC = os.path.join(_ref_import.REFERENCE_ROOT, "tests/test_data/2dgaussian_Fulltconn/iter_0")
+FIX_DST = os.path.join(HERE, "2dgaussian_Fulltconn/iter_0")
+FIX_FILES = ["best.pth.tar", "last.pth.tar", "X_transform.pkl", "y_transform.pkl", "y_invtransform.pkl",
+             "y_transform_data.pkl", "y_invtransform_data.pkl", "train_samples_x.txt",
+             "train_samples_y.npy", "val_samples_x.txt", "val_samples_y.npy", "lr.npy"]
+
+
+class TorchMLP(tnn.Module):
+    """Plain ReLU MLP (BASELINE configs 2/5); not a reference class, built here so that
+    the reference's Predictor / Log_prob can drive it through the nnmodel_in signature."""
+
+    def __init__(self, in_size, out_size, linearmodel=None, docpu=False, width=512, depth=4):
+        super().__init__()
+        k = in_size
+        self.depth = depth
+        for i in range(depth):
+            setattr(self, "layer%d" % (i + 1), tnn.Linear(k, width))
+            k = width
+        setattr(self, "layer%d" % (depth + 1), tnn.Linear(k, out_size))
+
+    def forward(self, s):
+        for i in range(self.depth):
+            s = torch.relu(getattr(self, "layer%d" % (i + 1))(s))
+        return getattr(self, "layer%d" % (self.depth + 1))(s)
+
+
+def build_model(kind, nin, nout, seed, **kw):
+    cls = {"ChtoModelv2": rnn.ChtoModelv2, "ChtoModelsimple": rnn.ChtoModelsimple,
+           "ChtoModelv2_linear": rnn.ChtoModelv2_linear, "MLP": TorchMLP}[kind]
+    model = cls(nin, nout, None, **kw) if kind == "MLP" else cls(nin, nout, None)
+    w = synth.weights(kind, nin, nout, seed, **kw)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in w.items()}
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+def t32(a):
+    return torch.from_numpy(np.asarray(a, np.float32))
+
+
+# ------------------------------------------------------------------ serving cases
+SERVING = [
+    # name, kind, nin, nout, seed, dense, n, dolog10, ypositive, extra kw
+    ("v2_33_33", "ChtoModelv2", 33, 33, 101, False, 64, None, False, {}),
+    ("mlp_33_33", "MLP", 33, 33, 102, False, 64, None, False, {}),
+    ("mlp_33_33_dense", "MLP", 33, 33, 103, True, 64, None, False, {}),
+    ("v2_26_457", "ChtoModelv2", 26, 457, 104, True, 24, None, False, {}),
+    ("v2_40_1000", "ChtoModelv2", 40, 1000, 105, True, 12, None, False, {}),
+    ("simple_6_4", "ChtoModelsimple", 6, 4, 106, True, 64, None, False, {}),
+    ("v2lin_5_3_log10", "ChtoModelv2_linear", 5, 3, 107, True, 64, [0, 1], False, {}),
+    ("v2_4_2_ypos", "ChtoModelv2", 4, 2, 108, False, 64, None, True, {}),
+    ("mlp_7_5_small", "MLP", 7, 5, 109, True, 64, None, False, {"width": 48, "depth": 3}),
+]
+TEMPS = [1.0, 4.0, 16.0]
+
+
+def make_logprob(kind, nin, nout, seed, dense, dolog10, ypositive, kw, temperature, nograd=True):
+    data, cov, priors = synth.gaussian_problem(nin, nout, seed, dense=dense)
+    if dolog10 is not None:
+        for i in dolog10:
+            priors[i] = {"param": "p%d" % i, "dist": "flat", "arg1": 0.1, "arg2": 2.0}
+    if ypositive:
+        data = np.abs(data) + 0.5
+    X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
+    if ypositive:
+        y_std = (0.1 * y_std).astype(np.float32)
+    sigma = np.sqrt(np.diag(cov))
+    invcov = np.linalg.inv(cov)
+    model = build_model(kind, nin, nout, seed, **kw)
+    Xt = rutil.X_transform_class(t32(X_mean), t32(X_std), "cpu", dolog10)
+    Yt = rutil.Y_transform_class(t32(y_mean), t32(y_std), "cpu", ypositive=ypositive)
+    pred = rpred.Predictor(nin, nout, model=model, X_transform=Xt, y_transform=Yt, device="cpu")
+    yinv = rutil.Y_invtransform_data(sigma, "cpu")
+    transform = rutil.Transform(priors)
+    lp = rutil.Log_prob(t32(data), t32(invcov), pred, yinv, transform, temperature,
+                        rutil.gaussianlogliklihood, nograd=nograd)
+    return lp, pred, yinv, transform, dict(data=data, cov=cov, invcov=invcov, sigma=sigma)
+
+
+def gen_serving(out):
+    for name, kind, nin, nout, seed, dense, n, dolog10, ypos, kw in SERVING:
+        z = synth.latent_points(n, nin, seed)
+        lp, pred, yinv, transform, prob = make_logprob(kind, nin, nout, seed, dense, dolog10, ypos, kw, 1.0)
+        theta = np.stack([np.atleast_1d(transform(zi)) for zi in z]).astype(np.float32)
+        with torch.no_grad():
+            m = np.stack([yinv(pred.predict(t32(th))[None, :])[0].numpy() for th in theta])
+            # batched predict (predictor_gpu.py:461 accepts [B, nin])
+            mb = yinv(pred.predict(t32(theta))).numpy()
+        assert np.allclose(m, mb, rtol=2e-4, atol=2e-5), name
+        ll = np.zeros((n, len(TEMPS)), np.float32)
+        for j, T in enumerate(TEMPS):
+            lpT = make_logprob(kind, nin, nout, seed, dense, dolog10, ypos, kw, T)[0]
+            ll[:, j] = [float(lpT(zi)) for zi in z]
+        # gradient of lnP wrt z (autograd through Log_prob(nograd=False), HMCSampler.py:32)
+        lpg = make_logprob(kind, nin, nout, seed, dense, dolog10, ypos, kw, 1.0, nograd=False)[0]
+        grads = np.zeros((n, nin), np.float32)
+        for i, zi in enumerate(z):
+            x = t32(zi).clone().requires_grad_()
+            val = lpg(x, inputnumpy=False)
+            grads[i] = torch.autograd.grad(val, x)[0].numpy()
+        out[name] = dict(z=z, theta=theta, m=m.astype(np.float32), loglike=ll, grad=grads,
+                         temps=np.array(TEMPS, np.float32))
+        print("serving", name, "lnP[0..2] =", ll[:3, 0], flush=True)
+
+
+# ------------------------------------------------------------------ fixture (2-D)
+def gen_fixture(out):
+    os.makedirs(FIX_DST, exist_ok=True)
+    for f in FIX_FILES:
+        shutil.copyfile(os.path.join(FIX_SRC, f), os.path.join(FIX_DST, f))
+    model, yinv = rutil.retrieve_model(FIX_SRC + "/", 2, 2, rnn.ChtoModelv2)
+    priors = [{"param": "test_%d" % i, "dist": "flat", "arg1": -2.0, "arg2": 2.0} for i in range(2)]
+    cov = np.diag([0.5, 0.2])
+    data = np.array([0.1, 1.0])
+    transform = rutil.Transform(priors)
+    lp = rutil.Log_prob(t32(data), t32(np.linalg.inv(cov)), model, yinv, transform, 1.0,
+                        rutil.gaussianlogliklihood, nograd=True)
+    z = np.concatenate([np.array([[0, 0], [0.3, -0.2], [1, 1], [-1.5, 0.7]], np.float32),
+                        synth.latent_points(28, 2, 5)])
+    vals = np.array([float(lp(zi)) for zi in z], np.float32)
+    model.MKLDNN = True          # main.py:266-268 branch
+    vals_mkl = np.array([float(lp(zi)) for zi in z], np.float32)
+    assert np.allclose(vals, vals_mkl, rtol=1e-5, atol=1e-6)
+    out["fixture2d"] = dict(z=z, loglike=vals,
+                            X_mean=model.X_transform.X_mean.numpy(), X_std=model.X_transform.X_std.numpy(),
+                            y_mean=model.y_transform.y_mean.numpy(), y_std=model.y_transform.y_std.numpy(),
+                            sigma=yinv.sigma.detach().numpy())
+    print("fixture2d", vals[:4], flush=True)
+
+
+# ------------------------------------------------------------------ training
+TRAIN = [
+    ("train_v2_5_3", "ChtoModelv2", 5, 3, 201, 40, {}, True),
+    ("train_mlp_7_5", "MLP", 7, 5, 202, 40, {"width": 48, "depth": 3}, True),
+    ("train_v2_33_33", "ChtoModelv2", 33, 33, 203, 100, {}, False),
+    ("train_v2_12_40", "ChtoModelv2", 12, 40, 204, 50, {}, False),
+]
+
+
+def training_problem(nin, nout, seed, B):
+    rs = np.random.RandomState(seed + 31)
+    data, cov, _ = synth.gaussian_problem(nin, nout, seed, dense=True, cond=1e2)
+    sigma = np.sqrt(np.diag(cov))
+    X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
+    X = (X_mean[None, :] + X_std[None, :] * rs.standard_normal((3, B, nin))).astype(np.float32)
+    Y = (data[None, None, :] + 3 * sigma[None, None, :] * rs.standard_normal((3, B, nout))).astype(np.float32)
+    Y[0, 1, 0] = 1e10        # sentinel masks (util.py:1072)
+    Y[1, 2, nout - 1] = 1e-30
+    return data, cov, sigma, X_mean, X_std, y_mean, y_std, X, Y
+
+
+def gen_training(out):
+    for name, kind, nin, nout, seed, B, kw, full in TRAIN:
+        data, cov, sigma, X_mean, X_std, y_mean, y_std, X, Y = training_problem(nin, nout, seed, B)
+        model = build_model(kind, nin, nout, seed, **kw)
+        ytd = rutil.Y_transform_data(sigma, device="cpu")
+        data_t = t32(data)
+        yinv = rutil.Y_invtransform_class(t32(y_mean), t32(y_std), data_t, "cpu", ypositive=False)
+        cov_t = torch.tensor(cov, dtype=torch.float64)
+        icov_t = torch.tensor(np.linalg.inv(cov), dtype=torch.float64)
+        loss_fn = rutil.Loss_fn(data_t, cov_t, icov_t, ytd, yinv, "cpu")
+        val_fn = rutil.Val_metric_fn(data_t, cov_t, icov_t, ytd, yinv, "cpu")
+        Xt = rutil.X_transform_class(t32(X_mean), t32(X_std), "cpu", None)
+        lr = 1e-3
+        opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=1e-4)
+        rec = dict(icov_norm=loss_fn.auxileryfunction.inv_transformed_cov.numpy(),
+                   data_norm=loss_fn.auxileryfunction.data_in.numpy(), lr=np.float32(lr))
+        losses = []
+        for s in range(3):
+            opt.zero_grad()
+            pred = model(Xt(t32(X[s])))
+            pred.retain_grad()
+            loss = loss_fn(pred, t32(Y[s]))
+            loss.backward()
+            if s == 0:
+                rec["pred0"] = pred.detach().numpy().copy()
+                rec["dpred0"] = pred.grad.numpy().copy()
+                rec["val0"] = val_fn(pred.detach(), t32(Y[s])).numpy()
+                l_b, cMd, cnnd = loss_fn.auxileryfunction(pred.detach(), t32(Y[s]))
+                rec["loss_rows0"] = l_b.numpy()
+                rec["chisqMd0"] = cMd.numpy()
+                rec["chisqnnd0"] = cnnd.numpy()
+                for k, p in model.named_parameters():
+                    g = p.grad.numpy()
+                    rec["grad0/" + k] = g.copy() if full else synth.tensor_digest(g)
+            opt.step()
+            losses.append(loss.item())
+            for k, p in model.named_parameters():
+                v = p.detach().numpy()
+                rec["param%d/%s" % (s + 1, k)] = v.copy() if full else synth.tensor_digest(v)
+        rec["losses"] = np.array(losses, np.float32)
+        out[name] = rec
+        print("training", name, losses, flush=True)
+
+
+# ------------------------------------------------------------------ full train_NN run
+def gen_train_nn(out):
+    nin, nout, seed = 5, 3, 301
+    rs = np.random.RandomState(seed)
+    data, cov, _ = synth.gaussian_problem(nin, nout, seed, dense=True, cond=1e2)
+    sigma = np.sqrt(np.diag(cov))
+    A = rs.standard_normal((nout, nin)) * 0.3
+    def theory(x):
+        return data[None, :] + np.tanh(x @ A.T) * 3 * sigma[None, :]
+    ntrain, nval, batch, nep = 200, 50, 50, 6
+    train_x = rs.uniform(-1, 1, (ntrain, nin)); val_x = rs.uniform(-1, 1, (nval, nin))
+    train_y = theory(train_x); val_y = theory(val_x)
+    w0 = synth.weights("ChtoModelv2", nin, nout, seed)
+
+    def factory(in_size, out_size, linearmodel, docpu=False):
+        m = rnn.ChtoModelv2(in_size, out_size, linearmodel, docpu=docpu)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w0.items()})
+        return m
+
+    tmp = tempfile.mkdtemp(prefix="linna_golden_") + "/"
+    np.savetxt(tmp + "train_samples_x.txt", train_x); np.save(tmp + "train_samples_y.npy", train_y)
+    np.savetxt(tmp + "val_samples_x.txt", val_x); np.save(tmp + "val_samples_y.npy", val_y)
+    np.save(tmp + "lr.npy", 2e-3)
+
+    class _S(object):
+        pass
+    captured = {}
+    orig_train = rpred.Predictor.train
+
+    def spy(self, *a, **k):
+        r = orig_train(self, *a, **k)
+        captured["ret"] = r
+        captured["state"] = {kk: vv.detach().numpy().copy() for kk, vv in self.model.state_dict().items()}
+        return r
+    rpred.Predictor.train = spy
+    try:
+        rutil.train_NN(_S(), cov, np.linalg.inv(cov), sigma, tmp, [tmp], data, None, False, True, 2, 1.0,
+                       False, None, 1, factory, {"num_epochs": nep, "batch_size": batch}, False)
+    finally:
+        rpred.Predictor.train = orig_train
+    train_losses, val_metrics = captured["ret"]
+    import pickle
+    with open(tmp + "X_transform.pkl", "rb") as f:
+        Xt = rutil.CPU_Unpickler(f).load()
+    with open(tmp + "y_transform.pkl", "rb") as f:
+        Yt = rutil.CPU_Unpickler(f).load()
+    best = torch.load(tmp + "best.pth.tar", map_location="cpu", weights_only=False)
+    rec = dict(train_x=train_x, train_y=train_y, val_x=val_x, val_y=val_y, data=data, cov=cov,
+               lr=np.float64(2e-3), num_epochs=np.int64(nep), batch_size=np.int64(batch),
+               X_mean=Xt.X_mean.numpy(), X_std=Xt.X_std.numpy(), y_mean=Yt.y_mean.numpy(), y_std=Yt.y_std.numpy(),
+               train_losses=np.asarray(train_losses, np.float64), val_metrics=np.asarray(val_metrics, np.float64),
+               best_epoch=np.int64(best["epoch"]))
+    for k, v in captured["state"].items():
+        rec["final/" + k] = v
+    for k, v in best["state_dict"].items():
+        rec["best/" + k] = v.numpy()
+    out["train_nn_run"] = rec
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("train_NN run: losses", np.asarray(train_losses)[:4], "val", np.asarray(val_metrics)[:2], flush=True)
+
+
+# ------------------------------------------------------------------ DataLoader order
+def gen_loader_order(out):
+    from torch.utils.data import DataLoader
+    n, batch = 200, 50
+    X = np.arange(n, dtype=np.float32)[:, None] * np.ones((1, 2), np.float32)
+    ds = rutil.ArrayDataset(X, X)
+    torch.manual_seed(1234)                           # predictor_gpu.py:221
+    loader = DataLoader(ds, batch_size=batch, shuffle=True, drop_last=True, num_workers=0)  # util.py:1285
+    order = []
+    for ep in range(3):
+        order.append(np.concatenate([xb[:, 0].numpy().astype(np.int64) for xb, _ in loader]))
+    out["loader_order"] = dict(order=np.stack(order), n=np.int64(n), batch=np.int64(batch))
+
+
+# ------------------------------------------------------------------ EarlyStopping traces
+def gen_early_stopping(out):
+    rs = np.random.RandomState(401)
+    seqs = {}
+    n = 1500
+    t = np.arange(n)
+    seqs["improve_then_plateau"] = (np.exp(-t / 120.0) + 0.05 + 0.002 * rs.standard_normal(n),
+                                    np.exp(-t / 100.0) + 0.02 + 0.002 * rs.standard_normal(n))
+    seqs["overfit"] = (0.2 + 0.3 * np.exp(-t / 50.0) + t * 2e-4 + 0.003 * rs.standard_normal(n),
+                       0.5 * np.exp(-t / 200.0) + 0.003 * rs.standard_normal(n) + 0.01)
+    seqs["noisy_flat"] = (1.0 + 0.05 * rs.standard_normal(n), 1.0 + 0.05 * rs.standard_normal(n))
+    v = 1.0 / (1 + t / 30.0) + 0.01 * rs.standard_normal(n); v[700] = np.nan
+    seqs["with_nan"] = (v, 1.0 / (1 + t / 25.0))
+    rec = {}
+    for name, (val, trn) in seqs.items():
+        es = rpred.EarlyStopping(patience=500)
+        codes = []
+        for a, b in zip(val, trn):
+            c = es.step(float(a), torch.tensor(float(b)))
+            codes.append(int(c))
+            if c == 2:
+                break
+        rec[name + "/val"] = np.asarray(val, np.float64)
+        rec[name + "/train"] = np.asarray(trn, np.float64)
+        rec[name + "/codes"] = np.asarray(codes, np.int64)
+        print("early stopping", name, "len", len(codes), "codes used", sorted(set(codes)), flush=True)
+    # a short-patience trace exercises codes 1 and 2 quickly
+    es = rpred.EarlyStopping(patience=40, nqueue=20)
+    val, trn = seqs["overfit"]
+    codes = []
+    for a, b in zip(val, trn):
+        c = es.step(float(a), torch.tensor(float(b)))
+        codes.append(int(c))
+        if c == 2:
+            break
+    rec["overfit_p40/codes"] = np.asarray(codes, np.int64)
+    out["early_stopping"] = rec
+
+
+# ------------------------------------------------------------------ HMC trace
+def gen_hmc(out):
+    name, kind, nin, nout, seed, dense, n, dolog10, ypos, kw = SERVING[5]   # simple_6_4
+    lp = make_logprob(kind, nin, nout, seed, dense, dolog10, ypos, kw, 1.0, nograd=False)[0]
+    num_samps, num_steps, step = 40, 5, 0.02
+    x0 = torch.zeros(nin)
+    mass = torch.ones(nin)
+    # replay the sampler's own draw order: torch.randn per sample (:26), np.random.uniform (:59)
+    torch.manual_seed(77)
+    momenta = np.stack([torch.randn(nin).numpy() for _ in range(num_samps)])
+    np.random.seed(78)
+    uniforms = np.array([np.random.uniform() for _ in range(num_samps)])
+    torch.manual_seed(77)
+    np.random.seed(78)
+    s = rhmc.HMCSampler(lambda x: lp(x, inputnumpy=False), x0, mass)
+    import linna.HMCSampler as mod
+    mod.tqdm = lambda it: it
+    chain = s.sample(num_samps, num_steps, step)
+    out["hmc_trace"] = dict(momenta=momenta.astype(np.float32), uniforms=uniforms,
+                            x=np.stack([c["x"] for c in chain]).astype(np.float32),
+                            lnP=np.array([float(c["lnP"]) for c in chain], np.float32),
+                            accepted=np.array([c["accepted"] for c in chain]),
+                            num_steps=np.int64(num_steps), step_size=np.float64(step),
+                            case=np.array(name))
+    print("hmc accepted", int(sum(c["accepted"] for c in chain)), "of", num_samps, flush=True)
+
+
+def main():
+    out = {}
+    gen_fixture(out)
+    gen_serving(out)
+    gen_training(out)
+    gen_train_nn(out)
+    gen_loader_order(out)
+    gen_early_stopping(out)
+    gen_hmc(out)
+    for name, rec in out.items():
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
+        sz = os.path.getsize(os.path.join(HERE, name + ".npz"))
+        print("wrote %s.npz (%d KB)" % (name, sz // 1024))
+
+
+if __name__ == "__main__":
+    main()
