@@ -1,0 +1,262 @@
+/* liblinna_hip.so -- C ABI of the MI355X-native LINNA emulator hot path.
+ *
+ * The reference (chto/linna) has no FFI: its hot path is Python calling torch ops.  This
+ * header is the boundary a maintainer binds instead (ctypes stub in INTEGRATION.md); each
+ * entry point names the reference call site it replaces (paths relative to the reference
+ * root).
+ *
+ * Conventions
+ *  - every function returns int: 0 = OK, <0 = error; linna_last_error() gives the text
+ *    (thread-local).  No C++ exception crosses the boundary.
+ *  - every pointer named like a matrix/vector is a CALLER-OWNED DEVICE pointer (fp32,
+ *    row-major, leading dimension in elements).  The library never allocates device memory
+ *    and never synchronises (except linna_stream_sync); all work is enqueued on `stream`
+ *    (a hipStream_t passed as void*).
+ *  - handles (linna_ctx_t, linna_net_t, ...) are small host objects; a handle is
+ *    single-threaded, distinct handles are independent.
+ *  - leading dimensions of activation/workspace matrices produced by the library are
+ *    rounded up to a multiple of 4 floats (16-byte rows for vector loads).
+ */
+#ifndef LINNA_HIP_H
+#define LINNA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LINNA_ABI_VERSION 1
+
+typedef struct linna_ctx linna_ctx_t;
+typedef struct linna_net linna_net_t;
+typedef struct linna_logprob linna_logprob_t;
+typedef struct linna_graph linna_graph_t;
+
+/* ------------------------------------------------------------------ runtime */
+int linna_abi_version(void);
+const char* linna_last_error(void);
+int linna_ctx_create(int device, linna_ctx_t** out);
+int linna_ctx_destroy(linna_ctx_t* ctx);
+int linna_stream_sync(void* stream);
+/* hipGraph capture of everything enqueued on `stream` between begin and end. */
+int linna_graph_begin(void* stream);
+int linna_graph_end(void* stream, linna_graph_t** out);
+int linna_graph_launch(linna_graph_t* g, void* stream);
+int linna_graph_destroy(linna_graph_t* g);
+/* HIP-event timing helpers for bench.py (events recorded on the launch stream). */
+int linna_event_create(void** ev);
+int linna_event_record(void* ev, void* stream);
+int linna_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on stop */
+int linna_event_destroy(void* ev);
+
+/* ------------------------------------------------------------------ generic fused GEMM
+ * C = epi( alpha0 * (A0.B0 + bias0) + (A1.B1 + bias1) ),  fp32 MFMA, exact fp32.
+ * Layout codes: 0 = contraction index contiguous (A[M][K], B[N][K]);
+ *               1 = k-major (A[K][M], B[K][N]).
+ * epi(v): v += R; relu; v = mask>0 ? v : 0; v = v*cscale + cshift; [exp: v = exp(v)*cpost
+ * + cshift2]; store C (if C != NULL); row-dot partial sums with `dotwith`. */
+typedef struct {
+    const float* A; const float* B;
+    int lda, ldb, K;
+    int alay, blay;
+} linna_gemm_pair_t;
+
+typedef struct {
+    linna_gemm_pair_t p[2];
+    int npairs;
+    int M, N;
+    float* C; int ldc;
+    const float* bias0; const float* bias1;
+    float alpha0;
+    const float* R; int ldr;
+    int relu;
+    const float* mask; int ldmask;
+    const float* cscale; const float* cshift;
+    int cexp; const float* cpost; const float* cshift2;
+    const float* dotwith; int lddot;
+    float* dot_partial; int dot_slots;
+} linna_gemm_t;
+
+int linna_gemm_f32(linna_ctx_t* ctx, const linna_gemm_t* desc, void* stream);
+int linna_gemm_dot_slots(int M, int N);
+
+/* ------------------------------------------------------------------ emulator layers
+ * linna_linear_fwd: Y = act(alpha*(X W^T + b) + R)          nn.Linear + F.relu, nn.py:121,125-130
+ * linna_resblock_fwd: T = relu(X W1^T + b1);
+ *                     Y = relu(0.1*(T W2^T + b2) + X Ws^T)  (Ws NULL: + X)   nn.py:53-54
+ * linna_linear_bwd: dX = (dY W) [* (Xmask>0)], dW = dY^T X, db = colsum dY   autograd of the above,
+ *                   predictor_gpu.py:285; any of dX/dW/db may be NULL.       */
+int linna_linear_fwd(linna_ctx_t* ctx, const float* X, int ldx, const float* W, const float* b,
+                     float* Y, int ldy, int B, int K, int N, int relu, float alpha,
+                     const float* R, int ldr, void* stream);
+int linna_resblock_fwd(linna_ctx_t* ctx, const float* X, int ldx, const float* W1, const float* b1,
+                       const float* W2, const float* b2, const float* Ws, float* T, int ldt,
+                       float* Y, int ldy, int B, int K, int C, int N, void* stream);
+int linna_linear_bwd(linna_ctx_t* ctx, const float* dY, int lddy, const float* X, int ldx,
+                     const float* W, float* dX, int lddx, const float* Xmask, int ldxm,
+                     float* dW, float* db, int B, int K, int N, float scale, void* stream);
+
+/* ------------------------------------------------------------------ whole network
+ * A network is an ordered list of ops (nn.py:110-133, 185-198, 351-374).  Parameter
+ * pointers reference the caller's flat parameter buffer; gradient pointers (may be NULL)
+ * reference the caller's flat gradient buffer with the same layout. */
+#define LINNA_OP_LINEAR 0     /* Y = [relu](X W^T + b)                                         */
+#define LINNA_OP_RESBLOCK 1   /* nn.py:11-56                                                    */
+#define LINNA_OP_INSKIP 2     /* out += alpha*(X0 W^T + b), X0 = network input (nn.py:195)     */
+
+typedef struct {
+    int op;
+    int K, C, N;
+    int relu;
+    float alpha;
+    const float *W, *b;                       /* linear / inskip */
+    const float *W1, *b1, *W2, *b2, *Ws;      /* resblock; Ws NULL => identity skip */
+    float *gW, *gb, *gW1, *gb1, *gW2, *gb2, *gWs;
+} linna_layer_t;
+
+/* Output-side column epilogue fused into the last GEMM (util.py:532-542, 457-458):
+ *   v = v*cscale + cshift;  if cexp: v = exp(v)*cpost + cshift2.  Any pointer may be NULL. */
+typedef struct {
+    const float* cscale; const float* cshift;
+    int cexp; const float* cpost; const float* cshift2;
+} linna_colmap_t;
+
+int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers, int in_size,
+                     linna_net_t** out);
+int linna_net_destroy(linna_net_t* net);
+/* bytes of activation workspace needed for a batch of B rows (forward, all activations
+ * kept) and for the backward scratch. */
+size_t linna_net_fwd_ws_bytes(const linna_net_t* net, int B);
+size_t linna_net_bwd_ws_bytes(const linna_net_t* net, int B);
+/* forward: X[B][ldx] -> OUT[B][ldo] (network output after `outmap`, NULL = identity).
+ * `ws` keeps every intermediate activation for a following backward.  Predictor.predict,
+ * predictor_gpu.py:461-504; training forward, predictor_gpu.py:278. */
+int linna_net_forward(linna_net_t* net, const float* X, int ldx, int B, void* ws, float* OUT, int ldo,
+                      const linna_colmap_t* outmap, void* stream);
+/* backward from dOUT[B][lddo] (gradient wrt the raw network output): parameter gradients
+ * into the layers' g* pointers when param_grads != 0, input gradient into dX (may be
+ * NULL).  torch autograd at predictor_gpu.py:285 / HMCSampler.py:32. */
+int linna_net_backward(linna_net_t* net, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws,
+                       const float* dOUT, int lddo, float* dX, int lddx, int param_grads, void* stream);
+
+/* ------------------------------------------------------------------ prior map + input transform
+ * util.py:339-347 (Transform) fused with util.py:483-497 (X_transform_class):
+ *   theta_j = flat ? 0.5*(1+erf(z_j/sqrt2))*width_j + a1_j : z_j*a2_j + a1_j
+ *   x_j = ((log10_j ? log10(theta_j) : theta_j) - xmean_j) / xstd_j
+ * is_flat/log10 flags are int32 device arrays of length nin; THETA may be NULL. */
+int linna_prior_map_fwd(linna_ctx_t* ctx, const float* Z, int ldz, int B, int nin, const int* is_flat,
+                        const float* a1, const float* a2, const int* log10_flag, const float* xmean,
+                        const float* xstd, float* X, int ldx, float* THETA, int ldt, void* stream);
+/* chain rule back to z and the prior term: dz_j = dx_j/xstd_j * [1/(theta_j ln10)] *
+ * dtheta_j/dz_j - z_j. */
+int linna_prior_map_bwd(linna_ctx_t* ctx, const float* Z, int ldz, int B, int nin, const int* is_flat,
+                        const float* a1, const float* a2, const int* log10_flag, const float* xstd,
+                        const float* dX, int lddx, float* dZ, int lddz, void* stream);
+
+/* ------------------------------------------------------------------ Gaussian log-likelihood
+ * util.py:953-955 + :1013-1016 + :1160-1165, row-wise for a batch of walkers:
+ *   out_b = (-0.5 * d_b S d_b^T)/T - 0.5*|z_b|^2 ; NaN -> -inf,   d = D row (model - data)
+ * diag: S = diag(w) (coalesced row read + wavefront shuffle reduction, HBM-bound);
+ * dense: MFMA GEMM D.S fused with the row-dot, then a finishing reduction.
+ * `scratch` for dense: B * linna_gemm_dot_slots(B, nout) floats. */
+int linna_gauss_loglike_diag(linna_ctx_t* ctx, const float* D, int ldd, int B, int nout, const float* w,
+                             const float* Z, int ldz, int nin, float temperature, float* out,
+                             void* stream);
+int linna_gauss_loglike_dense(linna_ctx_t* ctx, const float* D, int ldd, int B, int nout,
+                              const float* S, int lds, const float* Z, int ldz, int nin,
+                              float temperature, float* scratch, float* out, void* stream);
+
+/* ------------------------------------------------------------------ full serving pipeline
+ * One call = Log_prob.__call__ (util.py:990-1021) for B walkers: prior map -> X transform
+ * -> network -> Y transform -> *sigma -> log-likelihood/T + ln prior.  The struct holds
+ * device pointers to constants (all caller-owned). */
+typedef struct {
+    int nin, nout;
+    const int* is_flat; const float* a1; const float* a2;       /* priors, [nin] */
+    const int* log10_flag; const float* xmean; const float* xstd;
+    linna_colmap_t outmap;        /* maps raw network output to d = model - data */
+    const float* S; int lds;      /* dense inverse covariance [nout][nout] (or NULL) */
+    const float* Ssym;            /* 0.5*(S+S^T) for the gradient (dense) */
+    const float* w;               /* diagonal of S when S is diagonal (or NULL) */
+    const float* gscale;          /* [nout] d(d)/d(raw output) = y_std*sigma, for the gradient */
+    float temperature;
+} linna_logprob_desc_t;
+
+int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc,
+                         linna_logprob_t** out);
+int linna_logprob_destroy(linna_logprob_t* lp);
+size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad);
+/* lnP[B]; THETA[B][ldt] optional (physical parameters, for chain_transformed). */
+int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
+                       float* THETA, int ldt, void* stream);
+/* lnP[B] and d lnP / d z [B][ldg]  (intended semantics of util.py:1023-1035; HMCSampler.py:32). */
+int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
+                       float* G, int ldg, void* stream);
+
+/* ------------------------------------------------------------------ training
+ * chi^2-ratio loss of util.py:1070-1088,1114-1116 on the raw network output PRED:
+ *   delta = mask ? 0 : ((y/sigma - ymean)/ystd - pred);  chi2 = delta Cinv delta^T
+ *   loss_b = chi2 / den_b ; L = inv_batch * sum_b loss_b ;  dPRED = -2 (delta Cinv) inv_batch/den_b
+ *   (Cinv symmetric; inv_batch = 1/global batch so data-parallel shards sum to the mean)
+ * den_b = max(chisqMd_b, nout/2) is precomputed per dataset row (linna_chi2_md).
+ * ROWS (int32, may be NULL = identity) selects minibatch rows out of the resident dataset. */
+typedef struct {
+    int nout;
+    const float* sigma; const float* ymean; const float* ystd;   /* [nout] */
+    const float* data_norm;                                       /* [nout] */
+    const float* Cinv; int ldc;                                   /* [nout][nout], symmetric */
+} linna_loss_desc_t;
+
+/* floats of scratch the three loss entry points need for a batch of B rows, in bytes */
+size_t linna_loss_scratch_bytes(int B, int nout);
+int linna_chi2_md(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows,
+                  float* scratch, float* den, void* stream);
+int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED,
+                                  int ldp, const float* Y, int ldy, const float* den, const int* ROWS,
+                                  int B, float* scratch, float* loss_rows, float* loss_mean,
+                                  float* dPRED, int lddp, float inv_batch, void* stream);
+/* validation pieces (util.py:1124-1127): per-row loss and chisq_nnd/chisq_Md. */
+int linna_val_rows(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp,
+                   const float* Y, int ldy, const float* den, int B, float* scratch, float* loss_rows,
+                   float* frac_rows, void* stream);
+/* gather + input transform of a minibatch: XB[i] = (X[rows[i]] (log10 on flagged cols) - mean)/std */
+int linna_gather_xform(linna_ctx_t* ctx, const float* X, int ldx, const int* ROWS, int B, int nin,
+                       const int* log10_flag, const float* xmean, const float* xstd, float* XB, int ldxb,
+                       void* stream);
+/* torch.optim.AdamW step on a flat parameter vector (predictor_gpu.py:267,287).
+ * `hyper` is a 4-float DEVICE array [lr, weight_decay, bc1, sqrt(bc2)]: the caller writes
+ * lr/weight_decay (so a captured graph replays with new values), the library increments the
+ * device int32 `step_dev` and refreshes the two bias-correction slots before the update. */
+int linna_adamw_step(linna_ctx_t* ctx, float* p, const float* g, float* m, float* v, size_t n,
+                     float* hyper, int* step_dev, float beta1, float beta2, float eps,
+                     void* stream);
+
+/* ------------------------------------------------------------------ ensemble / HMC moves
+ * Stretch move (emcee StretchMove, called at sampler.py:493-495,530): for the active half
+ *   zz = ((a-1)u+1)^2/a ; q = c[r] - (c[r]-s) zz ; factor = (ndim-1) log zz
+ * with Philox4x32-10 draws keyed (seed; walker, step, stream).  `S_idx`/`C_idx` are int32
+ * device arrays listing the active and complementary walkers. */
+int linna_stretch_propose(linna_ctx_t* ctx, const float* coords, int ldc, int ndim, const int* S_idx,
+                          int ns, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
+                          int stream_id, float a, float* Q, int ldq, float* factors, void* stream);
+int linna_stretch_accept(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float* logp,
+                         const int* S_idx, int ns, const float* Q, int ldq, const float* logp_new,
+                         const float* factors, uint64_t seed, const int* step_dev, int stream_id,
+                         int* naccept, void* stream);
+/* leapfrog pieces for batched per-walker HMC (HMCSampler.py:26-54, sampler.py:67-98). */
+int linna_hmc_init(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint64_t seed,
+                   const int* step_dev, const float* lnp, float* P, int ldp, float* H0, void* stream);
+int linna_hmc_kick_drift(linna_ctx_t* ctx, int B, int ndim, const float* mass, float eps_kick,
+                         float eps_drift, const float* G, int ldg, float* P, int ldp, float* Q, int ldq,
+                         void* stream);
+int linna_hmc_accept(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint64_t seed,
+                     const int* step_dev, const float* H0, const float* P, int ldp, const float* Qnew,
+                     int ldq, const float* lnp_new, const float* Gnew, int ldg, float* X, int ldx,
+                     float* lnp, float* G, int* naccept, void* stream);
+int linna_step_increment(linna_ctx_t* ctx, int* step_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LINNA_HIP_H */

@@ -1,0 +1,554 @@
+// C-ABI entry points of liblinna_hip.so (declared in include/linna_hip.h) and the host-side
+// orchestration above the kernels: network forward/backward as chains of fused GEMMs, the
+// serving pipeline (Log_prob), the training loss.  No device allocation, no sync.
+#include "common.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <new>
+
+namespace linna {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return LINNA_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return LINNA_ERR_HIP;
+}
+
+static inline int ld4(int w) { return (w + 3) & ~3; }
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define TRY(expr) do { int rc__ = (expr); if (rc__ != LINNA_OK) return rc__; } while (0)
+
+static GemmArgs gemm_zero() {
+    GemmArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.npairs = 1;
+    a.alpha0 = 1.f;
+    return a;
+}
+static void set_pair(GemmArgs& a, int i, const float* A, int lda, int alay, const float* B, int ldb, int blay, int K) {
+    a.p[i].A = A; a.p[i].lda = lda; a.p[i].alay = alay;
+    a.p[i].B = B; a.p[i].ldb = ldb; a.p[i].blay = blay; a.p[i].K = K;
+}
+
+}  // namespace linna
+
+using namespace linna;
+
+struct linna_ctx { int device; };
+struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
+
+struct linna_net {
+    linna_ctx* ctx;
+    std::vector<linna_layer_t> L;   // without the trailing INSKIP
+    int in_size, out_size;
+    bool has_inskip;
+    linna_layer_t inskip;
+    int max_w, max_c;
+};
+
+struct FwdLayout {
+    std::vector<size_t> t_off, y_off;   // float offsets, per op (y_off of the last op unused)
+    size_t total;
+};
+
+static FwdLayout fwd_layout(const linna_net* n, int B) {
+    FwdLayout f;
+    size_t off = 0;
+    const int nl = (int)n->L.size();
+    f.t_off.assign(nl, 0);
+    f.y_off.assign(nl, 0);
+    for (int i = 0; i < nl; ++i) {
+        const linna_layer_t& l = n->L[i];
+        if (l.op == LINNA_OP_RESBLOCK) { f.t_off[i] = off; off += (size_t)B * ld4(l.C); }
+        if (i + 1 < nl) { f.y_off[i] = off; off += (size_t)B * ld4(l.N); }
+    }
+    f.total = off;
+    return f;
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------ runtime
+int linna_abi_version(void) { return LINNA_ABI_VERSION; }
+const char* linna_last_error(void) { return g_err.c_str(); }
+
+int linna_ctx_create(int device, linna_ctx_t** out) {
+    if (!out) { set_error("ctx_create: null out"); return LINNA_ERR_INVALID; }
+    int n = 0;
+    TRY(check_hip(hipGetDeviceCount(&n), "hipGetDeviceCount"));
+    if (device < 0 || device >= n) { set_error("ctx_create: device %d of %d", device, n); return LINNA_ERR_INVALID; }
+    hipDeviceProp_t prop;
+    TRY(check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties"));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        set_error("ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return LINNA_ERR_UNSUPPORTED;
+    }
+    *out = new (std::nothrow) linna_ctx{device};
+    return *out ? LINNA_OK : LINNA_ERR_INVALID;
+}
+int linna_ctx_destroy(linna_ctx_t* ctx) { delete ctx; return LINNA_OK; }
+int linna_stream_sync(void* stream) { return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize"); }
+
+int linna_graph_begin(void* stream) {
+    return check_hip(hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
+}
+int linna_graph_end(void* stream, linna_graph_t** out) {
+    hipGraph_t g = nullptr;
+    TRY(check_hip(hipStreamEndCapture(S(stream), &g), "hipStreamEndCapture"));
+    hipGraphExec_t e = nullptr;
+    int rc = check_hip(hipGraphInstantiate(&e, g, nullptr, nullptr, 0), "hipGraphInstantiate");
+    if (rc != LINNA_OK) { (void)hipGraphDestroy(g); return rc; }
+    *out = new linna_graph{g, e};
+    return LINNA_OK;
+}
+int linna_graph_launch(linna_graph_t* g, void* stream) {
+    if (!g) { set_error("graph_launch: null graph"); return LINNA_ERR_INVALID; }
+    return check_hip(hipGraphLaunch(g->exec, S(stream)), "hipGraphLaunch");
+}
+int linna_graph_destroy(linna_graph_t* g) {
+    if (!g) return LINNA_OK;
+    (void)hipGraphExecDestroy(g->exec);
+    (void)hipGraphDestroy(g->graph);
+    delete g;
+    return LINNA_OK;
+}
+int linna_event_create(void** ev) {
+    hipEvent_t e;
+    TRY(check_hip(hipEventCreate(&e), "hipEventCreate"));
+    *ev = e;
+    return LINNA_OK;
+}
+int linna_event_record(void* ev, void* stream) { return check_hip(hipEventRecord((hipEvent_t)ev, S(stream)), "hipEventRecord"); }
+int linna_event_elapsed_ms(void* a, void* b, float* ms) {
+    TRY(check_hip(hipEventSynchronize((hipEvent_t)b), "hipEventSynchronize"));
+    return check_hip(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b), "hipEventElapsedTime");
+}
+int linna_event_destroy(void* ev) { return check_hip(hipEventDestroy((hipEvent_t)ev), "hipEventDestroy"); }
+
+// ------------------------------------------------------------------ GEMM
+int linna_gemm_f32(linna_ctx_t*, const linna_gemm_t* d, void* stream) {
+    if (!d) { set_error("gemm: null descriptor"); return LINNA_ERR_INVALID; }
+    return gemm_launch(*d, S(stream));
+}
+int linna_gemm_dot_slots(int M, int N) { return gemm_slots(M, N); }
+
+// ------------------------------------------------------------------ layers
+int linna_linear_fwd(linna_ctx_t*, const float* X, int ldx, const float* W, const float* b, float* Y, int ldy, int B,
+                     int K, int N, int relu, float alpha, const float* R, int ldr, void* stream) {
+    GemmArgs a = gemm_zero();
+    set_pair(a, 0, X, ldx, LAY_K, W, K, LAY_K, K);
+    a.M = B; a.N = N; a.C = Y; a.ldc = ldy; a.bias0 = b; a.alpha0 = alpha; a.R = R; a.ldr = ldr; a.relu = relu;
+    return gemm_launch(a, S(stream));
+}
+
+int linna_resblock_fwd(linna_ctx_t*, const float* X, int ldx, const float* W1, const float* b1, const float* W2,
+                       const float* b2, const float* Ws, float* T, int ldt, float* Y, int ldy, int B, int K, int C,
+                       int N, void* stream) {
+    if (!Ws && K != N) { set_error("resblock: identity skip needs K == N"); return LINNA_ERR_INVALID; }
+    TRY(linna_linear_fwd(nullptr, X, ldx, W1, b1, T, ldt, B, K, C, 1, 1.f, nullptr, 0, stream));
+    GemmArgs a = gemm_zero();
+    set_pair(a, 0, T, ldt, LAY_K, W2, C, LAY_K, C);
+    a.M = B; a.N = N; a.C = Y; a.ldc = ldy; a.bias0 = b2; a.alpha0 = 0.1f; a.relu = 1;
+    if (Ws) { a.npairs = 2; set_pair(a, 1, X, ldx, LAY_K, Ws, K, LAY_K, K); }
+    else { a.R = X; a.ldr = ldx; }
+    return gemm_launch(a, S(stream));
+}
+
+int linna_linear_bwd(linna_ctx_t*, const float* dY, int lddy, const float* X, int ldx, const float* W, float* dX,
+                     int lddx, const float* Xmask, int ldxm, float* dW, float* db, int B, int K, int N, float scale,
+                     void* stream) {
+    if (dW) {   // dW[n][k] = scale * sum_b dY[b][n] X[b][k]
+        GemmArgs a = gemm_zero();
+        set_pair(a, 0, dY, lddy, LAY_MN, X, ldx, LAY_MN, B);
+        a.M = N; a.N = K; a.C = dW; a.ldc = K; a.alpha0 = scale;
+        TRY(gemm_launch(a, S(stream)));
+    }
+    if (db) TRY(launch_colsum(dY, lddy, B, N, scale, db, S(stream)));
+    if (dX) {   // dX[b][k] = scale * sum_n dY[b][n] W[n][k]
+        GemmArgs a = gemm_zero();
+        set_pair(a, 0, dY, lddy, LAY_K, W, K, LAY_MN, N);
+        a.M = B; a.N = K; a.C = dX; a.ldc = lddx; a.alpha0 = scale; a.mask = Xmask; a.ldmask = ldxm;
+        TRY(gemm_launch(a, S(stream)));
+    }
+    return LINNA_OK;
+}
+
+// ------------------------------------------------------------------ network
+int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers, int in_size, linna_net_t** out) {
+    if (!layers || nlayers < 1 || !out) { set_error("net_create: bad arguments"); return LINNA_ERR_INVALID; }
+    linna_net* n = new linna_net();
+    n->ctx = ctx; n->in_size = in_size; n->has_inskip = false; n->max_w = in_size; n->max_c = 4;
+    int width = in_size;
+    for (int i = 0; i < nlayers; ++i) {
+        const linna_layer_t& l = layers[i];
+        if (l.op == LINNA_OP_INSKIP) {
+            if (i != nlayers - 1 || l.K != in_size || l.N != width) {
+                set_error("net_create: INSKIP must be the last op, K = in_size, N = network width");
+                delete n; return LINNA_ERR_INVALID;
+            }
+            n->has_inskip = true; n->inskip = l;
+            continue;
+        }
+        if (l.K != width) { set_error("net_create: op %d expects K=%d, got %d", i, width, l.K); delete n; return LINNA_ERR_INVALID; }
+        if (l.op == LINNA_OP_RESBLOCK) {
+            if (!l.Ws && l.K != l.N) { set_error("net_create: op %d identity skip with K != N", i); delete n; return LINNA_ERR_INVALID; }
+            if (l.C > n->max_c) n->max_c = l.C;
+        } else if (l.op != LINNA_OP_LINEAR) { set_error("net_create: unknown op %d", l.op); delete n; return LINNA_ERR_INVALID; }
+        width = l.N;
+        if (width > n->max_w) n->max_w = width;
+        n->L.push_back(l);
+    }
+    const linna_layer_t& last = n->L.back();
+    if (last.op != LINNA_OP_LINEAR || last.relu) {
+        set_error("net_create: the last op must be a LINEAR without ReLU"); delete n; return LINNA_ERR_INVALID;
+    }
+    if (n->has_inskip && n->L[0].op != LINNA_OP_LINEAR) {
+        set_error("net_create: INSKIP needs a LINEAR first op"); delete n; return LINNA_ERR_INVALID;
+    }
+    n->out_size = width;
+    *out = n;
+    return LINNA_OK;
+}
+int linna_net_destroy(linna_net_t* net) { delete net; return LINNA_OK; }
+
+size_t linna_net_fwd_ws_bytes(const linna_net_t* n, int B) { return (fwd_layout(n, B).total + 16) * sizeof(float); }
+size_t linna_net_bwd_ws_bytes(const linna_net_t* n, int B) {
+    return ((size_t)B * (2 * (size_t)ld4(n->max_w) + ld4(n->max_c)) + 16) * sizeof(float);
+}
+
+int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, float* OUT, int ldo,
+                      const linna_colmap_t* om, void* stream) {
+    if (!n || !X || !OUT || B < 1) { set_error("net_forward: bad arguments"); return LINNA_ERR_INVALID; }
+    const FwdLayout f = fwd_layout(n, B);
+    float* w = static_cast<float*>(ws);
+    const int nl = (int)n->L.size();
+    if (nl > 1 && !w) { set_error("net_forward: workspace required"); return LINNA_ERR_INVALID; }
+    const float* hin = X; int ldh = ldx;
+    for (int i = 0; i < nl; ++i) {
+        const linna_layer_t& l = n->L[i];
+        const bool last = (i == nl - 1);
+        float* Y = last ? OUT : w + f.y_off[i];
+        const int ldy = last ? ldo : ld4(l.N);
+        if (l.op == LINNA_OP_LINEAR) {
+            GemmArgs a = gemm_zero();
+            a.M = B; a.N = l.N; a.C = Y; a.ldc = ldy; a.relu = l.relu;
+            if (last && n->has_inskip) {
+                // out = (hin W^T + b) + alpha * (X0 Wl^T + bl): pair 0 carries the scaled input skip
+                const linna_layer_t& s = n->inskip;
+                a.npairs = 2;
+                set_pair(a, 0, X, ldx, LAY_K, s.W, s.K, LAY_K, s.K);
+                a.bias0 = s.b; a.alpha0 = s.alpha;
+                set_pair(a, 1, hin, ldh, LAY_K, l.W, l.K, LAY_K, l.K);
+                a.bias1 = l.b;
+            } else {
+                set_pair(a, 0, hin, ldh, LAY_K, l.W, l.K, LAY_K, l.K);
+                a.bias0 = l.b;
+            }
+            if (last && om) {
+                a.cscale = om->cscale; a.cshift = om->cshift; a.cexp = om->cexp; a.cpost = om->cpost; a.cshift2 = om->cshift2;
+            }
+            TRY(gemm_launch(a, S(stream)));
+        } else {
+            float* T = w + f.t_off[i];
+            TRY(linna_resblock_fwd(nullptr, hin, ldh, l.W1, l.b1, l.W2, l.b2, l.Ws, T, ld4(l.C), Y, ldy, B, l.K, l.C, l.N, stream));
+        }
+        hin = Y; ldh = ldy;
+    }
+    return LINNA_OK;
+}
+
+int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
+                       int lddo, float* dX, int lddx, int pg, void* stream) {
+    if (!n || !X || !dOUT || !bwd_ws || B < 1) { set_error("net_backward: bad arguments"); return LINNA_ERR_INVALID; }
+    const FwdLayout f = fwd_layout(n, B);
+    const float* w = static_cast<const float*>(fwd_ws);
+    float* bw = static_cast<float*>(bwd_ws);
+    const int ldw = ld4(n->max_w);
+    float* buf[2] = {bw, bw + (size_t)B * ldw};
+    float* dT = bw + 2 * (size_t)B * ldw;
+    const int nl = (int)n->L.size();
+    hipStream_t st = S(stream);
+
+    if (n->has_inskip && pg) {
+        const linna_layer_t& s = n->inskip;
+        TRY(linna_linear_bwd(nullptr, dOUT, lddo, X, ldx, s.W, nullptr, 0, nullptr, 0, s.gW, s.gb, B, s.K, s.N, s.alpha, stream));
+    }
+    const float* dcur = dOUT; int ldd = lddo;
+    int flip = 0;
+    for (int i = nl - 1; i >= 0; --i) {
+        const linna_layer_t& l = n->L[i];
+        const float* hin = (i == 0) ? X : w + f.y_off[i - 1];
+        const int ldh = (i == 0) ? ldx : ld4(n->L[i - 1].N);
+        const bool need_dx = (i > 0) || (dX != nullptr);
+        float* dprev = (i == 0) ? dX : buf[flip];
+        const int ldp = (i == 0) ? lddx : ldw;
+        // hin went through a ReLU iff the producing op is a resblock or a linear with relu
+        const bool hin_relu = (i > 0) && (n->L[i - 1].op == LINNA_OP_RESBLOCK || n->L[i - 1].relu);
+        const float* mask = hin_relu ? hin : nullptr;
+        if (l.op == LINNA_OP_LINEAR) {
+            if (pg) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.W, nullptr, 0, nullptr, 0, l.gW, l.gb, B, l.K, l.N, 1.f, stream));
+            if (need_dx) {
+                GemmArgs a = gemm_zero();
+                a.M = B; a.N = l.K; a.C = dprev; a.ldc = ldp; a.mask = mask; a.ldmask = ldh;
+                if (i == 0 && n->has_inskip) {
+                    const linna_layer_t& s = n->inskip;
+                    a.npairs = 2;
+                    set_pair(a, 0, dOUT, lddo, LAY_K, s.W, s.K, LAY_MN, s.N);
+                    a.alpha0 = s.alpha;
+                    set_pair(a, 1, dcur, ldd, LAY_K, l.W, l.K, LAY_MN, l.N);
+                } else {
+                    set_pair(a, 0, dcur, ldd, LAY_K, l.W, l.K, LAY_MN, l.N);
+                }
+                TRY(gemm_launch(a, st));
+            }
+        } else {
+            const float* T = w + f.t_off[i];
+            const int ldt = ld4(l.C);
+            {   // dT = 0.1 * (dcur W2) * (T > 0)
+                GemmArgs a = gemm_zero();
+                set_pair(a, 0, dcur, ldd, LAY_K, l.W2, l.C, LAY_MN, l.N);
+                a.M = B; a.N = l.C; a.C = dT; a.ldc = ldt; a.alpha0 = 0.1f; a.mask = T; a.ldmask = ldt;
+                TRY(gemm_launch(a, st));
+            }
+            if (pg) {
+                TRY(linna_linear_bwd(nullptr, dcur, ldd, T, ldt, l.W2, nullptr, 0, nullptr, 0, l.gW2, l.gb2, B, l.C, l.N, 0.1f, stream));
+                TRY(linna_linear_bwd(nullptr, dT, ldt, hin, ldh, l.W1, nullptr, 0, nullptr, 0, l.gW1, l.gb1, B, l.K, l.C, 1.f, stream));
+                if (l.Ws) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.Ws, nullptr, 0, nullptr, 0, l.gWs, nullptr, B, l.K, l.N, 1.f, stream));
+            }
+            if (need_dx) {   // dprev = (dT W1 + dcur Ws [+ dcur]) * (hin > 0)
+                GemmArgs a = gemm_zero();
+                set_pair(a, 0, dT, ldt, LAY_K, l.W1, l.K, LAY_MN, l.C);
+                a.M = B; a.N = l.K; a.C = dprev; a.ldc = ldp; a.mask = mask; a.ldmask = ldh;
+                if (l.Ws) { a.npairs = 2; set_pair(a, 1, dcur, ldd, LAY_K, l.Ws, l.K, LAY_MN, l.N); }
+                else { a.R = dcur; a.ldr = ldd; }
+                TRY(gemm_launch(a, st));
+            }
+        }
+        dcur = dprev; ldd = ldp;
+        flip ^= 1;
+    }
+    return LINNA_OK;
+}
+
+// ------------------------------------------------------------------ prior map
+int linna_prior_map_fwd(linna_ctx_t*, const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1,
+                        const float* a2, const int* lg, const float* xmean, const float* xstd, float* X, int ldx,
+                        float* TH, int ldt, void* stream) {
+    if (ldx < nin || ldz < nin) { set_error("prior_map_fwd: leading dimension < nin"); return LINNA_ERR_INVALID; }
+    return launch_prior_map_fwd(Z, ldz, B, nin, is_flat, a1, a2, lg, xmean, xstd, X, ldx, TH, ldt, S(stream));
+}
+int linna_prior_map_bwd(linna_ctx_t*, const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1,
+                        const float* a2, const int* lg, const float* xstd, const float* dX, int lddx, float* dZ,
+                        int lddz, void* stream) {
+    return launch_prior_map_bwd(Z, ldz, B, nin, is_flat, a1, a2, lg, xstd, dX, lddx, dZ, lddz, S(stream));
+}
+
+// ------------------------------------------------------------------ log-likelihood
+int linna_gauss_loglike_diag(linna_ctx_t*, const float* D, int ldd, int B, int nout, const float* w, const float* Z,
+                             int ldz, int nin, float T, float* out, void* stream) {
+    return launch_loglike_diag(D, ldd, B, nout, w, Z, ldz, nin, T, out, S(stream));
+}
+int linna_gauss_loglike_dense(linna_ctx_t*, const float* D, int ldd, int B, int nout, const float* Sm, int lds,
+                              const float* Z, int ldz, int nin, float T, float* scratch, float* out, void* stream) {
+    const int slots = gemm_slots(B, nout);
+    GemmArgs a = gemm_zero();          // rows of (D S) dotted with D, no C store
+    set_pair(a, 0, D, ldd, LAY_K, Sm, lds, LAY_MN, nout);
+    a.M = B; a.N = nout; a.dotwith = D; a.lddot = ldd; a.dot_partial = scratch; a.dot_slots = slots;
+    TRY(gemm_launch(a, S(stream)));
+    return launch_loglike_finish(scratch, slots, slots, B, Z, ldz, nin, T, out, S(stream));
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ serving pipeline
+struct linna_logprob {
+    linna_ctx* ctx;
+    linna_net* net;
+    linna_logprob_desc_t d;
+};
+
+struct LpLayout { size_t x0, fwd, d, part, dh, bwd, dx, total; int slots; };
+static LpLayout lp_layout(const linna_logprob* lp, int B, int with_grad) {
+    LpLayout L;
+    size_t off = 0;
+    auto take = [&](size_t nfloats) { size_t o = off; off += (nfloats + 3) & ~(size_t)3; return o; };
+    L.x0 = take((size_t)B * ld4(lp->d.nin));
+    L.fwd = take(linna_net_fwd_ws_bytes(lp->net, B) / sizeof(float));
+    L.d = take((size_t)B * ld4(lp->d.nout));
+    L.slots = gemm_slots(B, lp->d.nout);
+    L.part = take((size_t)B * L.slots);
+    L.dh = L.bwd = L.dx = 0;
+    if (with_grad) {
+        L.dh = take((size_t)B * ld4(lp->d.nout));
+        L.bwd = take(linna_net_bwd_ws_bytes(lp->net, B) / sizeof(float));
+        L.dx = take((size_t)B * ld4(lp->d.nin));
+    }
+    L.total = off;
+    return L;
+}
+
+static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
+                      float* TH, int ldt, void* stream) {
+    const linna_logprob_desc_t& d = lp->d;
+    const int ldx = ld4(d.nin), ldd = ld4(d.nout);
+    TRY(launch_prior_map_fwd(Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag, d.xmean, d.xstd, w + L.x0, ldx, TH,
+                             ldt, S(stream)));
+    TRY(linna_net_forward(lp->net, w + L.x0, ldx, B, w + L.fwd, w + L.d, ldd, &d.outmap, stream));
+    if (d.w) return launch_loglike_diag(w + L.d, ldd, B, d.nout, d.w, Z, ldz, d.nin, d.temperature, lnP, S(stream));
+    return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
+                                     w + L.part, lnP, stream);
+}
+
+extern "C" {
+
+int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc, linna_logprob_t** out) {
+    if (!net || !desc || !out) { set_error("logprob_create: null argument"); return LINNA_ERR_INVALID; }
+    if (desc->nin != net->in_size || desc->nout != net->out_size) {
+        set_error("logprob_create: network is %d->%d, descriptor says %d->%d", net->in_size, net->out_size, desc->nin, desc->nout);
+        return LINNA_ERR_INVALID;
+    }
+    if (!desc->w && !desc->S) { set_error("logprob_create: need S (dense) or w (diagonal)"); return LINNA_ERR_INVALID; }
+    if (!(desc->temperature > 0.f)) { set_error("logprob_create: temperature must be > 0"); return LINNA_ERR_INVALID; }
+    *out = new linna_logprob{ctx, net, *desc};
+    return LINNA_OK;
+}
+int linna_logprob_destroy(linna_logprob_t* lp) { delete lp; return LINNA_OK; }
+size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad) {
+    return (lp_layout(lp, B, with_grad).total + 16) * sizeof(float);
+}
+
+int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* TH, int ldt,
+                       void* stream) {
+    if (!lp || !Z || !ws || !lnP || B < 1) { set_error("logprob_eval: bad arguments"); return LINNA_ERR_INVALID; }
+    const LpLayout L = lp_layout(lp, B, 0);
+    return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream);
+}
+
+int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
+                       void* stream) {
+    if (!lp || !Z || !ws || !lnP || !G || B < 1) { set_error("logprob_grad: bad arguments"); return LINNA_ERR_INVALID; }
+    const linna_logprob_desc_t& d = lp->d;
+    if (d.outmap.cexp) { set_error("logprob_grad: ypositive (exp) output map has no gradient path"); return LINNA_ERR_UNSUPPORTED; }
+    if (!d.gscale || (!d.w && !d.Ssym)) { set_error("logprob_grad: descriptor lacks gscale / Ssym"); return LINNA_ERR_INVALID; }
+    const LpLayout L = lp_layout(lp, B, 1);
+    float* w = static_cast<float*>(ws);
+    const int ldx = ld4(d.nin), ldd = ld4(d.nout);
+    TRY(lp_forward(lp, Z, ldz, B, w, L, lnP, nullptr, 0, stream));
+    if (d.w) {
+        TRY(launch_loglike_diag_grad(w + L.d, ldd, B, d.nout, d.w, d.gscale, d.temperature, w + L.dh, ldd, S(stream)));
+    } else {   // dH = -(1/T) * (D Ssym) * gscale
+        GemmArgs a = gemm_zero();
+        set_pair(a, 0, w + L.d, ldd, LAY_K, d.Ssym, d.lds, LAY_MN, d.nout);
+        a.M = B; a.N = d.nout; a.C = w + L.dh; a.ldc = ldd; a.alpha0 = -1.f / d.temperature; a.cscale = d.gscale;
+        TRY(gemm_launch(a, S(stream)));
+    }
+    TRY(linna_net_backward(lp->net, w + L.x0, ldx, B, w + L.fwd, w + L.bwd, w + L.dh, ldd, w + L.dx, ldx, 0, stream));
+    return launch_prior_map_bwd(Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag, d.xstd, w + L.dx, ldx, G, ldg, S(stream));
+}
+
+// ------------------------------------------------------------------ training
+// scratch layout for the loss entry points: DELTA[B][ld] | U[B][ld] | partial[B][slots]
+static size_t loss_scratch_floats(int B, int nout) { return (size_t)B * (2 * (size_t)ld4(nout) + gemm_slots(B, nout)); }
+
+static int chi2_partials(const linna_loss_desc_t* d, int mode, const float* PRED, int ldp, const float* Y, int ldy,
+                         const int* ROWS, int B, float* scratch, bool keepU, hipStream_t st) {
+    const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
+    float* DELTA = scratch;
+    float* U = scratch + (size_t)B * ld;
+    float* part = scratch + 2 * (size_t)B * ld;
+    TRY(launch_loss_delta(mode, PRED, ldp, Y, ldy, ROWS, B, *d, DELTA, ld, st));
+    GemmArgs a = gemm_zero();
+    set_pair(a, 0, DELTA, ld, LAY_K, d->Cinv, d->ldc, LAY_MN, d->nout);
+    a.M = B; a.N = d->nout; a.C = keepU ? U : nullptr; a.ldc = ld;
+    a.dotwith = DELTA; a.lddot = ld; a.dot_partial = part; a.dot_slots = slots;
+    return gemm_launch(a, st);
+}
+
+size_t linna_loss_scratch_bytes(int B, int nout) { return (loss_scratch_floats(B, nout) + 16) * sizeof(float); }
+
+int linna_chi2_md(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* scratch,
+                  float* den, void* stream) {
+    const int slots = gemm_slots(nrows, d->nout);
+    TRY(chi2_partials(d, 1, nullptr, 0, Y, ldy, nullptr, nrows, scratch, false, S(stream)));
+    return launch_loss_rows(0, scratch + 2 * (size_t)nrows * ld4(d->nout), slots, slots, nrows, nullptr, nullptr,
+                            0.5f * (float)d->nout, den, S(stream));
+}
+
+int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t*, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y,
+                                  int ldy, const float* den, const int* ROWS, int B, float* scratch, float* loss_rows,
+                                  float* loss_mean, float* dPRED, int lddp, float inv_batch, void* stream) {
+    const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
+    hipStream_t st = S(stream);
+    TRY(chi2_partials(d, 0, PRED, ldp, Y, ldy, ROWS, B, scratch, dPRED != nullptr, st));
+    TRY(launch_loss_rows(1, scratch + 2 * (size_t)B * ld, slots, slots, B, den, ROWS, 0.f, loss_rows, st));
+    if (loss_mean) TRY(launch_sum_scale(loss_rows, B, inv_batch, loss_mean, st));
+    if (dPRED) TRY(launch_loss_grad(scratch + (size_t)B * ld, ld, Y, ldy, ROWS, B, d->nout, d->data_norm, den, inv_batch, dPRED, lddp, st));
+    return LINNA_OK;
+}
+
+int linna_val_rows(linna_ctx_t*, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y, int ldy,
+                   const float* den, int B, float* scratch, float* loss_rows, float* frac_rows, void* stream) {
+    const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
+    hipStream_t st = S(stream);
+    TRY(chi2_partials(d, 0, PRED, ldp, Y, ldy, nullptr, B, scratch, false, st));
+    TRY(launch_loss_rows(1, scratch + 2 * (size_t)B * ld, slots, slots, B, den, nullptr, 0.f, loss_rows, st));
+    TRY(chi2_partials(d, 2, PRED, ldp, Y, ldy, nullptr, B, scratch, false, st));
+    return launch_val_frac(scratch + 2 * (size_t)B * ld, slots, slots, B, den, frac_rows, st);
+}
+
+int linna_gather_xform(linna_ctx_t*, const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg,
+                       const float* xmean, const float* xstd, float* XB, int ldxb, void* stream) {
+    return launch_gather_xform(X, ldx, ROWS, B, nin, lg, xmean, xstd, XB, ldxb, S(stream));
+}
+
+int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev,
+                     float b1, float b2, float eps, void* stream) {
+    if (!p || !g || !m || !v || !hyper || !step_dev) { set_error("adamw_step: null pointer"); return LINNA_ERR_INVALID; }
+    return launch_adamw(p, g, m, v, n, hyper, step_dev, b1, b2, eps, S(stream));
+}
+
+// ------------------------------------------------------------------ moves
+int linna_stretch_propose(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns, const int* C_idx,
+                          int nc, uint64_t seed, const int* step_dev, int stream_id, float a, float* Q, int ldq,
+                          float* factors, void* stream) {
+    if (ns < 1 || nc < 1) { set_error("stretch_propose: empty walker set"); return LINNA_ERR_INVALID; }
+    return launch_stretch_propose(coords, ldc, ndim, S_idx, ns, C_idx, nc, seed, step_dev, stream_id, a, Q, ldq, factors, S(stream));
+}
+int linna_stretch_accept(linna_ctx_t*, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
+                         const float* Q, int ldq, const float* logp_new, const float* factors, uint64_t seed,
+                         const int* step_dev, int stream_id, int* naccept, void* stream) {
+    return launch_stretch_accept(coords, ldc, ndim, logp, S_idx, ns, Q, ldq, logp_new, factors, seed, step_dev, stream_id, naccept, S(stream));
+}
+int linna_hmc_init(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
+                   float* P, int ldp, float* H0, void* stream) {
+    return launch_hmc_init(B, ndim, mass, seed, step_dev, lnp, P, ldp, H0, S(stream));
+}
+int linna_hmc_kick_drift(linna_ctx_t*, int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg,
+                         float* P, int ldp, float* Q, int ldq, void* stream) {
+    return launch_hmc_kick_drift(B, ndim, mass, ek, ed, G, ldg, P, ldp, Q, ldq, S(stream));
+}
+int linna_hmc_accept(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
+                     const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
+                     float* X, int ldx, float* lnp, float* G, int* naccept, void* stream) {
+    return launch_hmc_accept(B, ndim, mass, seed, step_dev, H0, P, ldp, Qn, ldq, lnp_new, Gn, ldg, X, ldx, lnp, G, naccept, S(stream));
+}
+int linna_step_increment(linna_ctx_t*, int* step_dev, void* stream) { return launch_step_increment(step_dev, S(stream)); }
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Internal declarations shared by the HIP translation units of liblinna_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, fp32-input MFMA, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/linna_hip.h"
+
+#define LINNA_OK 0
+#define LINNA_ERR_INVALID (-1)
+#define LINNA_ERR_HIP (-2)
+#define LINNA_ERR_UNSUPPORTED (-3)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace linna {
+
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+// Operand storage seen by the GEMM: LAY_K = contraction index contiguous
+// (A as [M][K], B as [N][K]); LAY_MN = k-major (A as [K][M], B as [K][N]).
+enum { LAY_K = 0, LAY_MN = 1 };
+
+typedef linna_gemm_pair_t GemmPair;
+typedef linna_gemm_t GemmArgs;   // the public descriptor is passed to the kernel by value
+
+// pointwise.hip launchers
+int launch_prior_map_fwd(const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1, const float* a2,
+                         const int* lg, const float* xmean, const float* xstd, float* X, int ldx, float* TH, int ldt,
+                         hipStream_t s);
+int launch_prior_map_bwd(const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1, const float* a2,
+                         const int* lg, const float* xstd, const float* dX, int lddx, float* dZ, int lddz, hipStream_t s);
+int launch_loglike_diag(const float* D, int ldd, int B, int nout, const float* w, const float* Z, int ldz, int nin,
+                        float T, float* out, hipStream_t s);
+int launch_loglike_finish(const float* partial, int slots_ld, int nslots, int B, const float* Z, int ldz, int nin,
+                          float T, float* out, hipStream_t s);
+int launch_loglike_diag_grad(const float* D, int ldd, int B, int nout, const float* w, const float* gscale, float T,
+                             float* dH, int lddh, hipStream_t s);
+int launch_loss_delta(int mode, const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
+                      const linna_loss_desc_t& d, float* DELTA, int ldd, hipStream_t s);
+int launch_loss_rows(int mode, const float* partial, int slots_ld, int nslots, int B, const float* den, const int* ROWS,
+                     float floorv, float* out, hipStream_t s);
+int launch_loss_grad(const float* U, int ldu, const float* Y, int ldy, const int* ROWS, int B, int nout,
+                     const float* data_norm, const float* den, float inv_batch, float* dP, int lddp, hipStream_t s);
+int launch_sum_scale(const float* v, int n, float scale, float* out, hipStream_t s);
+int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const float* den, float* frac, hipStream_t s);
+int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg, const float* xmean,
+                        const float* xstd, float* XB, int ldxb, hipStream_t s);
+int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s);
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,
+                 float eps, hipStream_t s);
+int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const int* C, int nc,
+                           uint64_t seed, const int* step_dev, int stream_id, float a, float* Q, int ldq, float* factors,
+                           hipStream_t s);
+int launch_stretch_accept(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* Q, int ldq,
+                          const float* lp_new, const float* factors, uint64_t seed, const int* step_dev, int stream_id,
+                          int* naccept, hipStream_t s);
+int launch_hmc_init(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp, float* P,
+                    int ldp, float* H0, hipStream_t s);
+int launch_hmc_kick_drift(int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg, float* P,
+                          int ldp, float* Q, int ldq, hipStream_t s);
+int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
+                      const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
+                      float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s);
+int launch_step_increment(int* step, hipStream_t s);
+
+int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
+int gemm_launch(const GemmArgs& a, hipStream_t stream);
+
+}  // namespace linna

@@ -1,0 +1,474 @@
+// Element-wise and reduction kernels of the LINNA hot path for gfx950: prior map + input
+// transform, Gaussian log-likelihood reductions (wavefront-shuffle), chi^2-ratio loss
+// pieces, AdamW, bias-gradient column sums, Philox-driven ensemble / HMC moves.
+// All HBM-bound: coalesced row reads, 64-lane shuffle reductions, no LDS round trips
+// except the cross-wave column sum.
+#include "common.h"
+#include <math.h>
+
+namespace linna {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline dim3 grid1d(size_t n, int block) { return dim3((unsigned)((n + block - 1) / block)); }
+
+// ------------------------------------------------------------------ prior map (util.py:339-347, 483-497)
+__device__ __forceinline__ float prior_theta(float z, int flat, float a1, float a2) {
+    if (flat) return (0.5f * (1.f + erff(z / 1.41421356237309515f))) * a2 + a1;   // a2 = hi - lo
+    return z * a2 + a1;
+}
+
+__global__ void prior_map_fwd_kernel(const float* __restrict__ Z, int ldz, int B, int nin,
+                                     const int* __restrict__ is_flat, const float* __restrict__ a1,
+                                     const float* __restrict__ a2, const int* __restrict__ lg,
+                                     const float* __restrict__ xmean, const float* __restrict__ xstd,
+                                     float* __restrict__ X, int ldx, float* __restrict__ TH, int ldt) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * ldx) return;
+    const int row = (int)(idx / ldx), col = (int)(idx % ldx);
+    if (col >= nin) { X[idx] = 0.f; return; }
+    const float z = Z[(size_t)row * ldz + col];
+    const float th = prior_theta(z, is_flat[col], a1[col], a2[col]);
+    if (TH) TH[(size_t)row * ldt + col] = th;
+    const float t = (lg && lg[col]) ? log10f(th) : th;
+    X[idx] = (t - xmean[col]) / xstd[col];
+}
+
+__global__ void prior_map_bwd_kernel(const float* __restrict__ Z, int ldz, int B, int nin,
+                                     const int* __restrict__ is_flat, const float* __restrict__ a1,
+                                     const float* __restrict__ a2, const int* __restrict__ lg,
+                                     const float* __restrict__ xstd, const float* __restrict__ dX, int lddx,
+                                     float* __restrict__ dZ, int lddz) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * nin) return;
+    const int row = (int)(idx / nin), col = (int)(idx % nin);
+    const float z = Z[(size_t)row * ldz + col];
+    const int flat = is_flat[col];
+    float g = dX[(size_t)row * lddx + col] / xstd[col];
+    if (lg && lg[col]) g = g / (prior_theta(z, flat, a1[col], a2[col]) * 2.30258509299404568f);
+    const float dth = flat ? a2[col] * (expf(-0.5f * z * z) * 0.398942280401432678f) : a2[col];
+    dZ[(size_t)row * lddz + col] = g * dth - z;
+}
+
+// ------------------------------------------------------------------ Gaussian log-likelihood
+// One wavefront per walker row: coalesced reads of d and z, shuffle reduction.
+// out = (-0.5 * sum_j (d_j w_j) d_j)/T - 0.5 sum z^2 ; NaN -> -inf (util.py:953-955,1013-1016,1165)
+__global__ __launch_bounds__(256) void loglike_diag_kernel(const float* __restrict__ D, int ldd, int B, int nout,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ Z, int ldz, int nin,
+                                                           float T, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* d = D + (size_t)row * ldd;
+    float acc = 0.f;
+    if ((ldd & 3) == 0 && (nout & 3) == 0 && ((reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
+        for (int j = lane * 4; j < nout; j += 256) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(d + j);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc += (dv[e] * wv[e]) * dv[e];
+        }
+    } else {
+        for (int j = lane; j < nout; j += 64) { const float dv = d[j]; acc += (dv * w[j]) * dv; }
+    }
+    float zz = 0.f;
+    for (int j = lane; j < nin; j += 64) { const float zv = Z[(size_t)row * ldz + j]; zz += zv * zv; }
+    acc = wave_sum(acc);
+    zz = wave_sum(zz);
+    if (lane == 0) {
+        const float v = (-0.5f * acc) / T + (-0.5f * zz);
+        out[row] = isnan(v) ? -INFINITY : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void loglike_finish_kernel(const float* __restrict__ partial, int slots_ld, int nslots,
+                                                             int B, const float* __restrict__ Z, int ldz, int nin,
+                                                             float T, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    float acc = 0.f, zz = 0.f;
+    for (int s = lane; s < nslots; s += 64) acc += partial[(size_t)row * slots_ld + s];
+    for (int j = lane; j < nin; j += 64) { const float zv = Z[(size_t)row * ldz + j]; zz += zv * zv; }
+    acc = wave_sum(acc);
+    zz = wave_sum(zz);
+    if (lane == 0) {
+        const float v = (-0.5f * acc) / T + (-0.5f * zz);
+        out[row] = isnan(v) ? -INFINITY : v;
+    }
+}
+
+// dH = -(1/T) * gscale_j * w_j * d_j   (gradient of the diagonal log-likelihood wrt raw net output)
+__global__ void loglike_diag_grad_kernel(const float* __restrict__ D, int ldd, int B, int nout,
+                                         const float* __restrict__ w, const float* __restrict__ gscale,
+                                         float T, float* __restrict__ dH, int lddh) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * lddh) return;
+    const int row = (int)(idx / lddh), col = (int)(idx % lddh);
+    dH[idx] = col < nout ? -(D[(size_t)row * ldd + col] * w[col]) * gscale[col] / T : 0.f;
+}
+
+// ------------------------------------------------------------------ chi^2-ratio loss pieces (util.py:1070-1088)
+// mode 0: delta = ynorm - pred ; mode 1: ynorm - data_norm ; mode 2: pred - data_norm ; masked -> 0
+__global__ void loss_delta_kernel(int mode, const float* __restrict__ PRED, int ldp, const float* __restrict__ Y, int ldy,
+                                  const int* __restrict__ ROWS, int B, int nout, const float* __restrict__ sigma,
+                                  const float* __restrict__ ymean, const float* __restrict__ ystd,
+                                  const float* __restrict__ data_norm, float* __restrict__ DELTA, int ldd) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * ldd) return;
+    const int i = (int)(idx / ldd), j = (int)(idx % ldd);
+    if (j >= nout) { DELTA[idx] = 0.f; return; }
+    const int r = ROWS ? ROWS[i] : i;
+    const float y = Y[(size_t)r * ldy + j];
+    const float dn = data_norm[j];
+    const bool masked = (y == 1e-30f) | (y == 1e10f) | (dn == 1e-30f);
+    const float yn = (y / sigma[j] - ymean[j]) / ystd[j];
+    float v;
+    if (mode == 0) v = yn - PRED[(size_t)i * ldp + j];
+    else if (mode == 1) v = yn - dn;
+    else v = PRED[(size_t)i * ldp + j] - dn;
+    DELTA[idx] = masked ? 0.f : v;
+}
+
+// chi2_b = sum_s partial[b][s]; mode 0: out[b] = max(chi2, floor) (denominator, util.py:1086)
+// mode 1: out[b] = chi2 / den[r]
+__global__ void loss_rows_kernel(int mode, const float* __restrict__ partial, int slots_ld, int nslots, int B,
+                                 const float* __restrict__ den, const int* __restrict__ ROWS, float floorv,
+                                 float* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float c = 0.f;
+    for (int s = 0; s < nslots; ++s) c += partial[(size_t)b * slots_ld + s];
+    if (mode == 0) out[b] = c < floorv ? floorv : c;
+    else out[b] = c / den[ROWS ? ROWS[b] : b];
+}
+
+// dPRED[i][j] = masked ? 0 : -2 * U[i][j] * inv_batch / den   (U = delta Cinv, Cinv symmetric)
+__global__ void loss_grad_kernel(const float* __restrict__ U, int ldu, const float* __restrict__ Y, int ldy,
+                                 const int* __restrict__ ROWS, int B, int nout, const float* __restrict__ data_norm,
+                                 const float* __restrict__ den, float inv_batch, float* __restrict__ dP, int lddp) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * lddp) return;
+    const int i = (int)(idx / lddp), j = (int)(idx % lddp);
+    if (j >= nout) { dP[idx] = 0.f; return; }
+    const int r = ROWS ? ROWS[i] : i;
+    const float y = Y[(size_t)r * ldy + j];
+    const bool masked = (y == 1e-30f) | (y == 1e10f) | (data_norm[j] == 1e-30f);
+    dP[idx] = masked ? 0.f : (-2.f * U[(size_t)i * ldu + j]) * inv_batch / den[r];
+}
+
+// deterministic single-block sum: out[0] = scale * sum_i v[i]
+__global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out) {
+    __shared__ float part[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += v[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = t * scale;
+    }
+}
+
+// frac[b] = |nnd_b / den_b - 1|  (util.py:1126)
+__global__ void val_frac_kernel(const float* __restrict__ partial, int slots_ld, int nslots, int B,
+                                const float* __restrict__ den, float* __restrict__ frac) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float c = 0.f;
+    for (int s = 0; s < nslots; ++s) c += partial[(size_t)b * slots_ld + s];
+    frac[b] = fabsf(c / den[b] - 1.f);
+}
+
+// ------------------------------------------------------------------ minibatch gather + X transform
+__global__ void gather_xform_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ ROWS, int B, int nin,
+                                    const int* __restrict__ lg, const float* __restrict__ xmean,
+                                    const float* __restrict__ xstd, float* __restrict__ XB, int ldxb) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * ldxb) return;
+    const int i = (int)(idx / ldxb), j = (int)(idx % ldxb);
+    if (j >= nin) { XB[idx] = 0.f; return; }
+    const int r = ROWS ? ROWS[i] : i;
+    float t = X[(size_t)r * ldx + j];
+    if (lg && lg[j]) t = log10f(t);
+    XB[idx] = (t - xmean[j]) / xstd[j];
+}
+
+// ------------------------------------------------------------------ bias gradient: db[n] = scale * sum_b dZ[b][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dZ, int ld, int B, int N, float scale,
+                                                     float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (col < N)
+        for (int b = wave; b < B; b += 4) acc += dZ[(size_t)b * ld + col];
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && col < N) db[col] = scale * (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+
+// ------------------------------------------------------------------ AdamW (torch.optim.AdamW single-tensor update)
+// hyper = [lr, weight_decay, bc1 = 1-b1^t, sqrt(bc2) = sqrt(1-b2^t)]
+__global__ void adamw_prepare_kernel(int* step, float* hyper, float beta1, float beta2) {
+    const int t = ++step[0];
+    hyper[2] = (float)(1.0 - pow((double)beta1, (double)t));
+    hyper[3] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, const float* __restrict__ hyper, float beta1,
+                             float beta2, float eps) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float lr = hyper[0], wd = hyper[1], bc1 = hyper[2], sbc2 = hyper[3];
+    const float gi = g[i];
+    float pi = p[i] * (1.f - lr * wd);
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / sbc2 + eps;
+    pi = pi - (lr / bc1) * (mi / denom);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// ------------------------------------------------------------------ Philox4x32-10 (Salmon et al. 2011)
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ float u01(uint32_t b) { return ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// draws for walker w at (step, stream): counter = (w, step, stream, sub), key = seed
+__device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t step, uint32_t stream, uint32_t sub) {
+    U4 c = {w, step, stream, sub};
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// ------------------------------------------------------------------ stretch move (emcee StretchMove / RedBlueMove)
+__global__ void stretch_propose_kernel(const float* __restrict__ coords, int ldc, int ndim, const int* __restrict__ S,
+                                       int ns, const int* __restrict__ C, int nc, uint64_t seed,
+                                       const int* __restrict__ step_dev, int stream_id, float a,
+                                       float* __restrict__ Q, int ldq, float* __restrict__ factors) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ns * ldq) return;
+    const int k = (int)(idx / ldq), d = (int)(idx % ldq);
+    if (d >= ndim) { Q[idx] = 0.f; return; }
+    const int wk = S[k];
+    const U4 r = walker_bits(seed, (uint32_t)wk, (uint32_t)step_dev[0], (uint32_t)stream_id, 0u);
+    const float t = (a - 1.f) * u01(r.x) + 1.f;
+    const float zz = t * t / a;
+    int j = (int)(((uint64_t)r.y * (uint64_t)nc) >> 32);
+    const int wc = C[j];
+    const float cr = coords[(size_t)wc * ldc + d], s = coords[(size_t)wk * ldc + d];
+    Q[idx] = cr - (cr - s) * zz;
+    if (d == 0) factors[k] = ((float)ndim - 1.f) * logf(zz);
+}
+
+__global__ void stretch_accept_kernel(float* __restrict__ coords, int ldc, int ndim, float* __restrict__ logp,
+                                      const int* __restrict__ S, int ns, const float* __restrict__ Q, int ldq,
+                                      const float* __restrict__ lp_new, const float* __restrict__ factors,
+                                      uint64_t seed, const int* __restrict__ step_dev, int stream_id,
+                                      int* __restrict__ naccept) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const int wk = S[k];
+    const U4 r = walker_bits(seed, (uint32_t)wk, (uint32_t)step_dev[0], (uint32_t)stream_id, 0u);
+    const float lnpdiff = factors[k] + lp_new[k] - logp[wk];
+    if (lnpdiff > logf(u01(r.z))) {
+        for (int d = 0; d < ndim; ++d) coords[(size_t)wk * ldc + d] = Q[(size_t)k * ldq + d];
+        logp[wk] = lp_new[k];
+        if (naccept) atomicAdd(naccept + wk, 1);
+    }
+}
+
+// ------------------------------------------------------------------ batched per-walker HMC (HMCSampler.py:26-59)
+__device__ __forceinline__ float normal_draw(uint64_t seed, uint32_t w, uint32_t step, uint32_t stream, int d) {
+    const U4 r = walker_bits(seed, w, step, stream, (uint32_t)(d >> 1) + 1u);
+    const float u1 = (d & 1) ? u01(r.z) : u01(r.x), u2 = (d & 1) ? u01(r.w) : u01(r.y);
+    return sqrtf(-2.f * logf(u1)) * cosf(6.28318530717958648f * u2);
+}
+
+__global__ void hmc_init_kernel(int B, int ndim, const float* __restrict__ mass, uint64_t seed,
+                                const int* __restrict__ step_dev, const float* __restrict__ lnp,
+                                float* __restrict__ P, int ldp, float* __restrict__ H0) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float ke = 0.f;
+    for (int d = 0; d < ndim; ++d) {
+        const float m = mass[d];
+        const float p = normal_draw(seed, (uint32_t)b, (uint32_t)step_dev[0], 1u, d) * sqrtf(m);
+        P[(size_t)b * ldp + d] = p;
+        ke += p * p / m;
+    }
+    H0[b] = 0.5f * ke - lnp[b];
+}
+
+// P += eps_kick * G ; Q += eps_drift * P / m   (either eps may be 0)
+__global__ void hmc_kick_drift_kernel(int B, int ndim, const float* __restrict__ mass, float ek, float ed,
+                                      const float* __restrict__ G, int ldg, float* __restrict__ P, int ldp,
+                                      float* __restrict__ Q, int ldq) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * ndim) return;
+    const int b = (int)(idx / ndim), d = (int)(idx % ndim);
+    float p = P[(size_t)b * ldp + d];
+    if (ek != 0.f) { p += ek * G[(size_t)b * ldg + d]; P[(size_t)b * ldp + d] = p; }
+    if (ed != 0.f) Q[(size_t)b * ldq + d] += ed * (p / mass[d]);
+}
+
+__global__ void hmc_accept_kernel(int B, int ndim, const float* __restrict__ mass, uint64_t seed,
+                                  const int* __restrict__ step_dev, const float* __restrict__ H0,
+                                  const float* __restrict__ P, int ldp, const float* __restrict__ Qn, int ldq,
+                                  const float* __restrict__ lnp_new, const float* __restrict__ Gn, int ldg,
+                                  float* __restrict__ X, int ldx, float* __restrict__ lnp, float* __restrict__ G,
+                                  int* __restrict__ naccept) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float ke = 0.f;
+    for (int d = 0; d < ndim; ++d) { const float p = P[(size_t)b * ldp + d]; ke += p * p / mass[d]; }
+    const float ln = lnp_new[b];
+    const float H1 = 0.5f * ke - ln;
+    const U4 r = walker_bits(seed, (uint32_t)b, (uint32_t)step_dev[0], 2u, 0u);
+    const float ratio = expf(fminf(H0[b] - H1, 0.f));
+    if (isfinite(ln) && u01(r.x) < ratio) {
+        for (int d = 0; d < ndim; ++d) {
+            X[(size_t)b * ldx + d] = Qn[(size_t)b * ldq + d];
+            G[(size_t)b * ldg + d] = Gn[(size_t)b * ldg + d];
+        }
+        lnp[b] = ln;
+        if (naccept) atomicAdd(naccept + b, 1);
+    }
+}
+
+__global__ void step_increment_kernel(int* step) { step[0] += 1; }
+
+// ------------------------------------------------------------------ host-side launchers (namespace-internal)
+#define LAUNCH_CHECK(name) return check_hip(hipGetLastError(), name)
+
+int launch_prior_map_fwd(const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1, const float* a2,
+                         const int* lg, const float* xmean, const float* xstd, float* X, int ldx, float* TH, int ldt,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(prior_map_fwd_kernel, grid1d((size_t)B * ldx, 256), dim3(256), 0, s, Z, ldz, B, nin, is_flat, a1,
+                       a2, lg, xmean, xstd, X, ldx, TH, ldt);
+    LAUNCH_CHECK("prior_map_fwd");
+}
+int launch_prior_map_bwd(const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1, const float* a2,
+                         const int* lg, const float* xstd, const float* dX, int lddx, float* dZ, int lddz, hipStream_t s) {
+    hipLaunchKernelGGL(prior_map_bwd_kernel, grid1d((size_t)B * nin, 256), dim3(256), 0, s, Z, ldz, B, nin, is_flat, a1,
+                       a2, lg, xstd, dX, lddx, dZ, lddz);
+    LAUNCH_CHECK("prior_map_bwd");
+}
+int launch_loglike_diag(const float* D, int ldd, int B, int nout, const float* w, const float* Z, int ldz, int nin,
+                        float T, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(loglike_diag_kernel, dim3((B + 3) / 4), dim3(256), 0, s, D, ldd, B, nout, w, Z, ldz, nin, T, out);
+    LAUNCH_CHECK("loglike_diag");
+}
+int launch_loglike_finish(const float* partial, int slots_ld, int nslots, int B, const float* Z, int ldz, int nin,
+                          float T, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(loglike_finish_kernel, dim3((B + 3) / 4), dim3(256), 0, s, partial, slots_ld, nslots, B, Z, ldz,
+                       nin, T, out);
+    LAUNCH_CHECK("loglike_finish");
+}
+int launch_loglike_diag_grad(const float* D, int ldd, int B, int nout, const float* w, const float* gscale, float T,
+                             float* dH, int lddh, hipStream_t s) {
+    hipLaunchKernelGGL(loglike_diag_grad_kernel, grid1d((size_t)B * lddh, 256), dim3(256), 0, s, D, ldd, B, nout, w,
+                       gscale, T, dH, lddh);
+    LAUNCH_CHECK("loglike_diag_grad");
+}
+int launch_loss_delta(int mode, const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
+                      const linna_loss_desc_t& d, float* DELTA, int ldd, hipStream_t s) {
+    hipLaunchKernelGGL(loss_delta_kernel, grid1d((size_t)B * ldd, 256), dim3(256), 0, s, mode, PRED, ldp, Y, ldy, ROWS,
+                       B, d.nout, d.sigma, d.ymean, d.ystd, d.data_norm, DELTA, ldd);
+    LAUNCH_CHECK("loss_delta");
+}
+int launch_loss_rows(int mode, const float* partial, int slots_ld, int nslots, int B, const float* den, const int* ROWS,
+                     float floorv, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(loss_rows_kernel, grid1d(B, 256), dim3(256), 0, s, mode, partial, slots_ld, nslots, B, den, ROWS,
+                       floorv, out);
+    LAUNCH_CHECK("loss_rows");
+}
+int launch_loss_grad(const float* U, int ldu, const float* Y, int ldy, const int* ROWS, int B, int nout,
+                     const float* data_norm, const float* den, float inv_batch, float* dP, int lddp, hipStream_t s) {
+    hipLaunchKernelGGL(loss_grad_kernel, grid1d((size_t)B * lddp, 256), dim3(256), 0, s, U, ldu, Y, ldy, ROWS, B, nout,
+                       data_norm, den, inv_batch, dP, lddp);
+    LAUNCH_CHECK("loss_grad");
+}
+int launch_sum_scale(const float* v, int n, float scale, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, s, v, n, scale, out);
+    LAUNCH_CHECK("sum_scale");
+}
+int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const float* den, float* frac, hipStream_t s) {
+    hipLaunchKernelGGL(val_frac_kernel, grid1d(B, 256), dim3(256), 0, s, partial, slots_ld, nslots, B, den, frac);
+    LAUNCH_CHECK("val_frac");
+}
+int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg, const float* xmean,
+                        const float* xstd, float* XB, int ldxb, hipStream_t s) {
+    hipLaunchKernelGGL(gather_xform_kernel, grid1d((size_t)B * ldxb, 256), dim3(256), 0, s, X, ldx, ROWS, B, nin, lg,
+                       xmean, xstd, XB, ldxb);
+    LAUNCH_CHECK("gather_xform");
+}
+int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, s, dZ, ld, B, N, scale, db);
+    LAUNCH_CHECK("colsum");
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,
+                 float eps, hipStream_t s) {
+    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, s, step_dev, hyper, b1, b2);
+    hipLaunchKernelGGL(adamw_kernel, grid1d(n, 256), dim3(256), 0, s, p, g, m, v, n, hyper, b1, b2, eps);
+    LAUNCH_CHECK("adamw");
+}
+int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const int* C, int nc,
+                           uint64_t seed, const int* step_dev, int stream_id, float a, float* Q, int ldq, float* factors,
+                           hipStream_t s) {
+    hipLaunchKernelGGL(stretch_propose_kernel, grid1d((size_t)ns * ldq, 256), dim3(256), 0, s, coords, ldc, ndim, S, ns,
+                       C, nc, seed, step_dev, stream_id, a, Q, ldq, factors);
+    LAUNCH_CHECK("stretch_propose");
+}
+int launch_stretch_accept(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* Q, int ldq,
+                          const float* lp_new, const float* factors, uint64_t seed, const int* step_dev, int stream_id,
+                          int* naccept, hipStream_t s) {
+    hipLaunchKernelGGL(stretch_accept_kernel, grid1d(ns, 256), dim3(256), 0, s, coords, ldc, ndim, logp, S, ns, Q, ldq,
+                       lp_new, factors, seed, step_dev, stream_id, naccept);
+    LAUNCH_CHECK("stretch_accept");
+}
+int launch_hmc_init(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp, float* P,
+                    int ldp, float* H0, hipStream_t s) {
+    hipLaunchKernelGGL(hmc_init_kernel, grid1d(B, 256), dim3(256), 0, s, B, ndim, mass, seed, step_dev, lnp, P, ldp, H0);
+    LAUNCH_CHECK("hmc_init");
+}
+int launch_hmc_kick_drift(int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg, float* P,
+                          int ldp, float* Q, int ldq, hipStream_t s) {
+    hipLaunchKernelGGL(hmc_kick_drift_kernel, grid1d((size_t)B * ndim, 256), dim3(256), 0, s, B, ndim, mass, ek, ed, G,
+                       ldg, P, ldp, Q, ldq);
+    LAUNCH_CHECK("hmc_kick_drift");
+}
+int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
+                      const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
+                      float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s) {
+    hipLaunchKernelGGL(hmc_accept_kernel, grid1d(B, 256), dim3(256), 0, s, B, ndim, mass, seed, step_dev, H0, P, ldp, Qn,
+                       ldq, lnp_new, Gn, ldg, X, ldx, lnp, G, naccept);
+    LAUNCH_CHECK("hmc_accept");
+}
+int launch_step_increment(int* step, hipStream_t s) {
+    hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, step);
+    LAUNCH_CHECK("step_increment");
+}
+
+}  // namespace linna

@@ -1,0 +1,413 @@
+"""Likelihood, transforms and model retrieval of LINNA on MI355X.
+
+Mirrors the hot-path part of the reference's ``linna/util.py`` (same class names and
+constructor signatures) so that code written against ``linna.util`` keeps working:
+``Transform``/``invTransform`` (util.py:313-381), ``X_transform_class`` (:466-510),
+``Y_transform_class``/``Y_invtransform_class`` (:512-596), ``Y_transform_data``/
+``Y_invtransform_data`` (:402-464), ``gaussianlogliklihood`` (:953-955), ``Log_prob``
+(:957-1021), ``lnprior`` (:1160-1165), ``retrieve_model`` (:611-639).
+
+The small transform classes are containers of constants (their ``__call__`` is kept for
+API parity and operates on whatever tensor it is given); the hot path -- ``Log_prob`` on
+a batch of walkers -- runs as ONE fused pipeline of HIP kernels (``linna_logprob_eval``).
+"""
+import ctypes as C
+import io
+import os
+import pickle
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import nn as lnn
+from . import predictor_gpu
+from .nn import *  # noqa: F401,F403  (the reference re-exports its network classes here)
+
+SQRT2 = float(np.sqrt(2.0))
+
+
+# ------------------------------------------------------------------ prior map (util.py:291-381)
+def gauss2unif(x):
+    return 0.5 * (1 + torch.erf(x / SQRT2))
+
+
+def invgauss2unif(x):
+    return SQRT2 * torch.erfinv(2 * x - 1)
+
+
+def _as_2d_tensor(x, inputnumpy):
+    if inputnumpy:
+        x = torch.from_numpy(np.asarray(x).astype(np.float32))
+    if x.dim() < 2:
+        x = x.reshape(-1, len(x))
+    return x
+
+
+class Transform(object):
+    """latent z (unit Gaussian per parameter) -> physical parameter theta (util.py:313-347)."""
+
+    def __init__(self, priors):
+        self.priors = priors
+
+    def arrays(self):
+        """(is_flat int32[n], a1 float32[n], a2 float32[n]) as consumed by linna_prior_map_fwd;
+        for flat priors a2 is the width arg2-arg1 (the scalar the reference multiplies by)."""
+        is_flat = np.array([0 if p["dist"] == "gauss" else 1 for p in self.priors], np.int32)
+        a1 = np.array([p["arg1"] for p in self.priors], np.float32)
+        a2 = np.array([p["arg2"] if p["dist"] == "gauss" else (p["arg2"] - p["arg1"]) for p in self.priors], np.float32)
+        return is_flat, a1, a2
+
+    def __call__(self, x, returnnumpy=True, inputnumpy=True):
+        x = _as_2d_tensor(x, inputnumpy)
+        cols = []
+        for i, p in enumerate(self.priors):
+            if p["dist"] == "gauss":
+                cols.append(x[:, i] * p["arg2"] + p["arg1"])
+            else:
+                cols.append(gauss2unif(x[:, i]) * (p["arg2"] - p["arg1"]) + p["arg1"])
+        out = torch.stack(cols).T.squeeze()
+        return out.detach().cpu().numpy() if returnnumpy else out
+
+
+class invTransform(object):
+    """theta -> z (util.py:349-381); used once on ``init`` (main.py:132)."""
+
+    def __init__(self, priors):
+        self.priors = priors
+
+    def __call__(self, x, returnnumpy=True, inputnumpy=True):
+        x = _as_2d_tensor(x, inputnumpy)
+        cols = []
+        for i, p in enumerate(self.priors):
+            if p["dist"] == "gauss":
+                cols.append((x[:, i] - p["arg1"]) / p["arg2"])
+            else:
+                cols.append(invgauss2unif((x[:, i] - p["arg1"]) / (p["arg2"] - p["arg1"])))
+        out = torch.stack(cols).T.squeeze()
+        return out.detach().cpu().numpy() if returnnumpy else out
+
+
+# ------------------------------------------------------------------ data-vector transforms
+class _Picklable(object):
+    def pickle(self, path):
+        with open(path, "wb") as f:
+            new = deepcopy(self)
+            new.dev = "cpu"
+            for k, v in list(new.__dict__.items()):
+                if torch.is_tensor(v):
+                    new.__dict__[k] = v.detach().cpu()
+            pickle.dump(new, f, pickle.HIGHEST_PROTOCOL)
+
+
+class Y_transform_data(_Picklable):
+    """y -> y / sigma (util.py:402-447)."""
+
+    def __init__(self, sigma, device="cpu"):
+        self.device = device
+        self.sigma = torch.from_numpy(np.asarray(sigma).astype(np.float32)).to(device)
+
+    def __call__(self, y):
+        return y / self.sigma[None, :].to(y.device)
+
+    def transform_cov(self, cov):
+        d = torch.diag(1 / self.sigma.detach().cpu().type(torch.float64))
+        return d.inner(torch.as_tensor(cov, dtype=torch.float64).cpu()).inner(d)
+
+
+class Y_invtransform_data(_Picklable):
+    """y -> y * sigma (util.py:449-464)."""
+
+    def __init__(self, sigma, device="cpu"):
+        self.device = device
+        self.sigma = torch.from_numpy(np.asarray(sigma).astype(np.float32)).to(device)
+
+    def __call__(self, y):
+        return y * self.sigma[None, :].to(y.device)
+
+
+class X_transform_class(_Picklable):
+    """x -> (x - mean)/std, log10 first on ``dolog10index`` columns (util.py:466-497)."""
+
+    def __init__(self, X_mean, X_std, device="cpu", dolog10index=None):
+        self.X_mean, self.X_std, self.dev, self.dolog10index = X_mean, X_std, device, dolog10index
+
+    def __call__(self, X):
+        X1 = X.clone()
+        if self.dolog10index is not None:
+            for ind in self.dolog10index:
+                if X1.dim() > 1:
+                    X1[:, ind] = torch.log10(X[:, ind])
+                else:
+                    X1[ind] = torch.log10(X1[ind])
+        return (X1 - self.X_mean[None, :].to(X.device)) / self.X_std[None, :].to(X.device)
+
+
+class Y_transform_class(_Picklable):
+    """network space -> sigma units: y*std+mean, exp(.) if ``ypositive`` (util.py:512-542)."""
+
+    def __init__(self, y_mean, y_std, dev="cpu", ypositive=False):
+        self.y_mean, self.y_std, self.dev, self.ypositive = y_mean, y_std, dev, ypositive
+
+    def __call__(self, y):
+        v = y * self.y_std[None, :].to(y.device) + self.y_mean[None, :].to(y.device)
+        return torch.exp(v) if self.ypositive else v
+
+
+class Y_invtransform_class(_Picklable):
+    """inverse of ``Y_transform_class`` (util.py:556-590)."""
+
+    def __init__(self, y_mean, y_std, data_tensor, dev="cpu", ypositive=False):
+        self.y_mean, self.y_std, self.dev, self.ypositive, self.data_tensor = y_mean, y_std, dev, ypositive, data_tensor
+
+    def __call__(self, y):
+        v = torch.log(y) if self.ypositive else y
+        return (v - self.y_mean[None, :].to(y.device)) / self.y_std[None, :].to(y.device)
+
+    def transform_cov(self, cov):
+        cov = torch.as_tensor(cov, dtype=torch.float64).cpu()
+        s = torch.diag(1 / self.y_std.detach().cpu().type(torch.float64))
+        if self.ypositive:
+            e = torch.diag(1 / self.data_tensor.detach().cpu().type(torch.float64))
+            cov0 = e.inner(cov).inner(e)
+            cov0[cov0 <= -1] = 1e-10 - 1
+            cov = torch.log(1 + cov0)
+        return s.inner(cov).inner(s)
+
+
+# ------------------------------------------------------------------ reading the reference's artefacts
+_REFERENCE_CLASSES = ("Transform", "invTransform", "Y_transform_data", "Y_invtransform_data",
+                      "X_transform_class", "Y_transform_class", "Y_invtransform_class")
+
+
+class CPU_Unpickler(pickle.Unpickler):
+    """util.py:51-55 plus a module remap: pickles written by the reference name their classes
+    ``linna.util.*``; they load as the classes of this module (same attribute names)."""
+
+    def find_class(self, module, name):
+        if module == "torch.storage" and name == "_load_from_bytes":
+            return lambda b: torch.load(io.BytesIO(b), map_location="cpu", weights_only=False)
+        if module in ("linna.util", "linna_amd.util") and name in _REFERENCE_CLASSES:
+            return globals()[name]
+        return super().find_class(module, name)
+
+
+def retrieve_model(outdir, inshape, outshape, nnmodel_in=lnn.ChtoModelv2, device=None):
+    """Rebuild the trained emulator from ``outdir`` (util.py:611-639): ``best.pth.tar`` plus the
+    three transform pickles, in the reference's on-disk formats."""
+    with open(os.path.join(outdir, "y_invtransform_data.pkl"), "rb") as f:
+        y_invtransform_data = CPU_Unpickler(f).load()
+    with open(os.path.join(outdir, "X_transform.pkl"), "rb") as f:
+        X_transform = CPU_Unpickler(f).load()
+    X_transform.dev = "cpu"
+    with open(os.path.join(outdir, "y_transform.pkl"), "rb") as f:
+        y_transform = CPU_Unpickler(f).load()
+    y_transform.dev = "cpu"
+    nnmodel = nnmodel_in(inshape, outshape, None)
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    model = predictor_gpu.Predictor(inshape, outshape, X_transform=X_transform, y_transform=y_transform,
+                                    device=device, outdir=outdir, model=nnmodel)
+    model.load_checkpoint()
+    return model, y_invtransform_data
+
+
+# ------------------------------------------------------------------ likelihood
+def gaussianlogliklihood(m, data, invcov):
+    """util.py:953-955 (per walker, m is [1, nout]).  Kept for callers that pass it around;
+    ``Log_prob`` recognises it and runs the fused HIP pipeline instead."""
+    d = m - data
+    return (d @ invcov @ d.T * (-0.5))[0][0]
+
+
+def lnprior(x):
+    """util.py:1160-1165."""
+    return -0.5 * torch.sum(x.square())
+
+
+def _np32(t):
+    if torch.is_tensor(t):
+        return t.detach().cpu().numpy().astype(np.float32)
+    return np.asarray(t, np.float32)
+
+
+class Log_prob(object):
+    """Posterior log-probability of latent walker positions (util.py:957-1021).
+
+    ``__call__`` accepts one walker ``x[ndim]`` (reference semantics: returns a scalar) or a
+    batch ``x[B, ndim]`` (returns ``[B]``, every row evaluated as the reference evaluates one
+    walker -- the reference itself is only correct for B = 1).
+    """
+
+    def __init__(self, data_new, invcov_new, model, y_invtransform_data, transform, temperature, loglikelihoodfunc=None,
+                 nograd=False, externalloglike=None):
+        self.data_new = data_new
+        self.invcov_new = invcov_new
+        self.model = model
+        self.y_invtransform_data = y_invtransform_data
+        self.transform = transform
+        self.T = float(temperature)
+        self.no_grad = nograd
+        self.loglikelihoodfunc = loglikelihoodfunc if loglikelihoodfunc is not None else gaussianlogliklihood
+        self.noduplicate = True            # consumed by the reference's MPI pool (util.py:987)
+        self.externalloglike = externalloglike
+        self._plan = None
+        self._ws = {}
+
+    # -------------------------------------------------------------- device plan
+    def _build(self):
+        pred = self.model
+        net = pred.model
+        dev = net.device
+        if dev.type != "cuda":
+            raise _lib.LinnaHipError("Log_prob needs the emulator on the GPU (no CPU fallback)")
+        nin, nout = net.in_size, net.out_size
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev)
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
+        is_flat, a1, a2 = self.transform.arrays()
+        if len(is_flat) != nin:
+            raise ValueError("%d priors for a %d-input emulator" % (len(is_flat), nin))
+        Xt, Yt = pred.X_transform, pred.y_transform
+        lg = np.zeros(nin, np.int32)
+        if getattr(Xt, "dolog10index", None) is not None:
+            lg[list(Xt.dolog10index)] = 1
+        sigma = _np32(self.y_invtransform_data.sigma).astype(np.float64)
+        y_mean, y_std = _np32(Yt.y_mean).astype(np.float64), _np32(Yt.y_std).astype(np.float64)
+        data = _np32(self.data_new).astype(np.float64)
+        S = _np32(self.invcov_new)
+        k = dict(is_flat=i32(is_flat), a1=f32(a1), a2=f32(a2), lg=i32(lg), xmean=f32(_np32(Xt.X_mean)),
+                 xstd=f32(_np32(Xt.X_std)), gscale=f32(y_std * sigma))
+        d = _lib.LogprobDesc()
+        d.nin, d.nout = nin, nout
+        d.is_flat, d.a1, d.a2 = _lib.iptr(k["is_flat"]), _lib.ptr(k["a1"]), _lib.ptr(k["a2"])
+        d.log10_flag = _lib.iptr(k["lg"]) if lg.any() else None
+        d.xmean, d.xstd = _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"])
+        if getattr(Yt, "ypositive", False):
+            # m - data = exp(h*ystd + ymean)*sigma - data            (util.py:540, 458)
+            k.update(cscale=f32(y_std), cshift=f32(y_mean), cpost=f32(sigma), cshift2=f32(-data))
+            d.outmap.cexp = 1
+            d.outmap.cpost, d.outmap.cshift2 = _lib.ptr(k["cpost"]), _lib.ptr(k["cshift2"])
+        else:
+            # m - data = h*(ystd*sigma) + (ymean*sigma - data)       (util.py:542, 458)
+            k.update(cscale=f32(y_std * sigma), cshift=f32(y_mean * sigma - data))
+        d.outmap.cscale, d.outmap.cshift = _lib.ptr(k["cscale"]), _lib.ptr(k["cshift"])
+        if np.count_nonzero(S - np.diag(np.diagonal(S))) == 0:
+            k["w"] = f32(np.diagonal(S))
+            d.w = _lib.ptr(k["w"])
+        else:
+            k["S"] = f32(S)
+            k["Ssym"] = f32(0.5 * (S.astype(np.float64) + S.astype(np.float64).T))
+            d.S, d.lds, d.Ssym = _lib.ptr(k["S"]), nout, _lib.ptr(k["Ssym"])
+        d.gscale = _lib.ptr(k["gscale"])
+        d.temperature = self.T
+        h = C.c_void_p()
+        _lib.call("linna_logprob_create", _lib.ctx(dev.index), net.net_handle(), C.byref(d), C.byref(h))
+        self._plan = dict(handle=h, keep=k, desc=d, dev=dev, nin=nin, nout=nout, net_sig=net._net_sig)
+        self._ws = {}
+
+    def _ensure(self):
+        net = self.model.model
+        if self._plan is None or self._plan["dev"] != net.device or net._net is None or net._net_sig != self._plan["net_sig"]:
+            if self._plan is not None:
+                _lib.load().linna_logprob_destroy(self._plan["handle"])
+                self._plan = None
+            self._build()
+        return self._plan
+
+    def _workspace(self, B, with_grad):
+        key = (int(B), bool(with_grad))
+        ws = self._ws.get(key)
+        if ws is None:
+            n = _lib.load().linna_logprob_ws_bytes(self._plan["handle"], int(B), 1 if with_grad else 0)
+            ws = torch.empty(n // 4 + 4, dtype=torch.float32, device=self._plan["dev"])
+            self._ws[key] = ws
+        return ws
+
+    def _to_device(self, x):
+        p = self._ensure()
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        z = x.detach().to(device=p["dev"], dtype=torch.float32)
+        one = z.dim() == 1
+        z = z.view(1, -1) if one else z
+        if z.shape[1] != p["nin"]:
+            raise ValueError("expected %d parameters per walker, got %d" % (p["nin"], z.shape[1]))
+        return z.contiguous(), one
+
+    # -------------------------------------------------------------- evaluation
+    def evaluate(self, z, out=None, theta=None):
+        """Device-to-device batch evaluation: ``z[B, nin]`` (cuda, fp32, row stride free) ->
+        ``lnP[B]``.  No host synchronisation; graph-capturable."""
+        p = self._ensure()
+        B = z.shape[0]
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=z.device)
+        _lib.call("linna_logprob_eval", p["handle"], _lib.ptr(z) if z.is_contiguous() else C.c_void_p(z.data_ptr()),
+                  z.stride(0), B, _lib.ptr(self._workspace(B, False)), _lib.ptr(out),
+                  C.c_void_p(theta.data_ptr()) if theta is not None else None,
+                  theta.stride(0) if theta is not None else 0, _lib.stream())
+        return out
+
+    def evaluate_with_grad(self, z, out=None, grad=None):
+        """``(lnP[B], d lnP/d z [B, nin])`` -- what ``torch.autograd.grad(lnP, x)`` yields in
+        HMCSampler.py:32, batched per walker."""
+        p = self._ensure()
+        B = z.shape[0]
+        if out is None:
+            out = torch.empty(B, dtype=torch.float32, device=z.device)
+        if grad is None:
+            grad = torch.empty((B, p["nin"]), dtype=torch.float32, device=z.device)
+        _lib.call("linna_logprob_grad", p["handle"], C.c_void_p(z.data_ptr()), z.stride(0), B,
+                  _lib.ptr(self._workspace(B, True)), _lib.ptr(out), C.c_void_p(grad.data_ptr()), grad.stride(0),
+                  _lib.stream())
+        return out, grad
+
+    def __call__(self, x, returntorch=True, inputnumpy=True):
+        z, one = self._to_device(x)
+        if self.loglikelihoodfunc is not gaussianlogliklihood:
+            like = self._generic(z)
+        else:
+            theta = None
+            if self.externalloglike is not None:
+                theta = torch.empty_like(z)
+            like = self.evaluate(z, theta=theta)
+            if self.externalloglike is not None:
+                th = theta.cpu().numpy()
+                ext = np.array([np.float32(self.externalloglike(t)) for t in th], np.float32)
+                like = like + torch.from_numpy(ext).to(like.device)
+                like = torch.where(torch.isnan(like), torch.full_like(like, -float("inf")), like)
+        like = like.cpu()
+        if one:
+            like = like[0]
+        return like if returntorch else like.numpy()
+
+    def _generic(self, z):
+        """User-supplied ``loglikelihoodfunc(m[1,nout], data, invcov)`` (main.py:277-278): the
+        emulator still runs on the GPU, the callback is applied per walker on the host."""
+        theta = self.transform(z.cpu(), inputnumpy=False, returnnumpy=False).reshape(z.shape[0], -1)
+        m = self.y_invtransform_data(self.model.predict(theta, no_grad=True)).cpu()
+        data = torch.as_tensor(_np32(self.data_new))
+        invcov = torch.as_tensor(_np32(self.invcov_new))
+        out = []
+        for i in range(z.shape[0]):
+            v = self.loglikelihoodfunc(m[i:i + 1], data, invcov) / self.T + lnprior(z[i].cpu())
+            if self.externalloglike is not None:
+                v = v + np.float32(self.externalloglike(theta[i].numpy()))
+            out.append(float(v))
+        out = torch.tensor(out, dtype=torch.float32)
+        return torch.where(torch.isnan(out), torch.full_like(out, -float("inf")), out)
+
+
+class Dlnp(object):
+    """Gradient of ``Log_prob`` wrt the latent position -- the INTENDED semantics of
+    util.py:1023-1035 (broken as shipped: SURVEY §8 a17)."""
+
+    def __init__(self, data_new, invcov_new, model, y_invtransform_data, transform, temperature):
+        self.log_prob = Log_prob(data_new, invcov_new, model, y_invtransform_data, transform, temperature)
+
+    def __call__(self, x, lnP=None, returntorch=None, inputnumpy=None):
+        z, one = self.log_prob._to_device(x)
+        _, g = self.log_prob.evaluate_with_grad(z)
+        g = g.cpu().numpy()
+        return g[0] if one else g

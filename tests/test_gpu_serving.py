@@ -1,0 +1,187 @@
+"""GPU parity (through the C ABI): fused GEMM, network forward, Log_prob and its gradient
+against the numpy oracle and the golden vectors captured from the live reference."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def dev(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda", dtype=dtype)
+
+
+def run_gemm(**kw):
+    from linna_amd import _lib
+    g = _lib.Gemm()
+    g.npairs = kw.get("npairs", 1)
+    g.alpha0 = kw.get("alpha0", 1.0)
+    for k, v in kw.items():
+        if k.startswith("p0") or k.startswith("p1"):
+            setattr(g.p[int(k[1])], k[3:], v)
+        elif k not in ("npairs", "alpha0"):
+            setattr(g, k, v)
+    _lib.call("linna_gemm_f32", _lib.ctx(), C.byref(g), _lib.stream())
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (4096, 512, 512), (500, 1000, 33), (37, 33, 125), (1, 5, 7),
+                                   (300, 16, 1000), (4096, 33, 512), (129, 65, 40)])
+def test_gemm_nt_bias_relu(M, N, K):
+    from linna_amd import _lib
+    rs = np.random.RandomState(M + N + K)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = rs.standard_normal((N, K)).astype(np.float32)
+    b = rs.standard_normal(N).astype(np.float32)
+    dA, dW, db = dev(A), dev(W), dev(b)
+    ldc = _lib.ld4(N)
+    out = torch.full((M, ldc), 7.0, device="cuda")
+    run_gemm(p0_A=dA.data_ptr(), p0_lda=K, p0_alay=0, p0_B=dW.data_ptr(), p0_ldb=K, p0_blay=0, p0_K=K, M=M, N=N,
+             C=out.data_ptr(), ldc=ldc, bias0=db.data_ptr(), relu=1)
+    ref = np.maximum(A.astype(np.float64) @ W.T.astype(np.float64) + b, 0)
+    got = out.cpu().numpy()
+    scale = np.abs(A).astype(np.float64) @ np.abs(W.T).astype(np.float64) + np.abs(b)
+    assert np.all(np.abs(got[:, :N] - ref) <= 4e-7 * scale + 1e-6)
+    if ldc > N:
+        assert np.all(got[:, N:] == 7.0)          # padding columns untouched
+
+
+def test_gemm_identity_asymmetric_layout_check():
+    """A = I with an ASYMMETRIC B catches a transposed C write (cdna guide, section 3)."""
+    n = 96
+    A = np.eye(n, dtype=np.float32)
+    Bm = (np.arange(n)[:, None] * 1000 + np.arange(n)[None, :]).astype(np.float32)   # B[n][k]
+    out = torch.zeros((n, n), device="cuda")
+    dA, dB = dev(A), dev(Bm)
+    run_gemm(p0_A=dA.data_ptr(), p0_lda=n, p0_alay=0, p0_B=dB.data_ptr(), p0_ldb=n, p0_blay=0, p0_K=n, M=n, N=n,
+             C=out.data_ptr(), ldc=n)
+    np.testing.assert_array_equal(out.cpu().numpy(), Bm.T)
+    # k-major B: C = A . B[k][n]
+    run_gemm(p0_A=dA.data_ptr(), p0_lda=n, p0_alay=0, p0_B=dB.data_ptr(), p0_ldb=n, p0_blay=1, p0_K=n, M=n, N=n,
+             C=out.data_ptr(), ldc=n)
+    np.testing.assert_array_equal(out.cpu().numpy(), Bm)
+    # k-major A as well: C = A^T-stored . B
+    At = (np.arange(n)[:, None] * 3 + np.arange(n)[None, :] * 5).astype(np.float32) / 64.0     # stored [K][M]
+    I = np.eye(n, dtype=np.float32)
+    dAt, dI = dev(At), dev(I)
+    run_gemm(p0_A=dAt.data_ptr(), p0_lda=n, p0_alay=1, p0_B=dI.data_ptr(), p0_ldb=n, p0_blay=1, p0_K=n, M=n, N=n,
+             C=out.data_ptr(), ldc=n)
+    np.testing.assert_array_equal(out.cpu().numpy(), At.T)
+
+
+@pytest.mark.parametrize("M,N,K0,K1", [(500, 250, 32, 500), (130, 70, 16, 90), (4096, 500, 16, 1000)])
+def test_gemm_dual_pair_resblock_epilogue(M, N, K0, K1):
+    rs = np.random.RandomState(1)
+    T = rs.standard_normal((M, K0)).astype(np.float32); W2 = rs.standard_normal((N, K0)).astype(np.float32)
+    X = rs.standard_normal((M, K1)).astype(np.float32); Ws = (rs.standard_normal((N, K1)) / np.sqrt(K1)).astype(np.float32)
+    b2 = rs.standard_normal(N).astype(np.float32)
+    dT, dW2, dX, dWs, db2 = dev(T), dev(W2), dev(X), dev(Ws), dev(b2)
+    out = torch.zeros((M, N), device="cuda")
+    run_gemm(npairs=2, alpha0=0.1, p0_A=dT.data_ptr(), p0_lda=K0, p0_alay=0, p0_B=dW2.data_ptr(), p0_ldb=K0, p0_blay=0,
+             p0_K=K0, p1_A=dX.data_ptr(), p1_lda=K1, p1_alay=0, p1_B=dWs.data_ptr(), p1_ldb=K1, p1_blay=0, p1_K=K1,
+             M=M, N=N, C=out.data_ptr(), ldc=N, bias0=db2.data_ptr(), relu=1)
+    ref = np.maximum(0.1 * (T.astype(np.float64) @ W2.T + b2) + X.astype(np.float64) @ Ws.T, 0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(500, 33, 33), (4096, 457, 457), (77, 1000, 1000)])
+def test_gemm_rowdot_matches_quadratic_form(M, N, K):
+    from linna_amd import _lib
+    rs = np.random.RandomState(2)
+    D = rs.standard_normal((M, K)).astype(np.float32)
+    S = rs.standard_normal((K, N)).astype(np.float32)
+    slots = _lib.load().linna_gemm_dot_slots(M, N)
+    part = torch.zeros((M, slots), device="cuda")
+    dD, dS = dev(D), dev(S)
+    run_gemm(p0_A=dD.data_ptr(), p0_lda=K, p0_alay=0, p0_B=dS.data_ptr(), p0_ldb=N, p0_blay=1, p0_K=K, M=M, N=N,
+             dotwith=dD.data_ptr(), lddot=K, dot_partial=part.data_ptr(), dot_slots=slots)
+    ref = ((D.astype(np.float64) @ S) * D).sum(-1)
+    scale = (np.abs(D.astype(np.float64)) @ np.abs(S) * np.abs(D)).sum(-1)
+    got = part.cpu().numpy().astype(np.float64).sum(-1)
+    assert np.all(np.abs(got - ref) <= 1e-6 * scale)
+
+
+def build_logprob(name, temperature=1.0):
+    from linna_amd import nn, util, predictor_gpu
+    prob = cases.serving_problem(name)
+    cls = {"ChtoModelv2": nn.ChtoModelv2, "ChtoModelsimple": nn.ChtoModelsimple,
+           "ChtoModelv2_linear": nn.ChtoModelv2_linear, "MLP": nn.MLP}[prob["kind"]]
+    model = cls(prob["nin"], prob["nout"], None, **prob["kw"])
+    model.load_state_dict(prob["weights"])
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    Xt = util.X_transform_class(t(prob["X_mean"]), t(prob["X_std"]), "cpu", prob["dolog10"])
+    Yt = util.Y_transform_class(t(prob["y_mean"]), t(prob["y_std"]), "cpu", ypositive=prob["ypositive"])
+    pred = predictor_gpu.Predictor(prob["nin"], prob["nout"], model=model, X_transform=Xt, y_transform=Yt, device="cuda")
+    yinv = util.Y_invtransform_data(prob["sigma"], "cpu")
+    lp = util.Log_prob(t(prob["data"]), t(prob["invcov"]), pred, yinv, util.Transform(prob["priors"]), temperature,
+                       util.gaussianlogliklihood, nograd=True)
+    return lp, pred, yinv, prob
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.SERVING])
+def test_predict_and_logprob_match_reference(name):
+    g = cases.golden(name)
+    lp, pred, yinv, prob = build_logprob(name)
+    m = yinv(pred.predict(torch.as_tensor(g["theta"]))).cpu().numpy()
+    scale = np.abs(g["m"]).max()
+    np.testing.assert_allclose(m, g["m"], rtol=3e-4, atol=3e-5 * scale)
+    for j, T in enumerate(g["temps"]):
+        lpT = build_logprob(name, float(T))[0]
+        got = lpT(g["z"], returntorch=False)
+        np.testing.assert_allclose(got, g["loglike"][:, j], rtol=6e-4)
+        one = lpT(g["z"][3])                      # single-walker call: reference semantics (scalar)
+        assert one.dim() == 0
+        np.testing.assert_allclose(float(one), g["loglike"][3, j], rtol=6e-4)
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.SERVING if not c[8]])
+def test_logprob_gradient_matches_autograd(name):
+    g = cases.golden(name)
+    lp = build_logprob(name)[0]
+    z, _ = lp._to_device(g["z"])
+    lnp, grad = lp.evaluate_with_grad(z)
+    np.testing.assert_allclose(lnp.cpu().numpy(), g["loglike"][:, 0], rtol=6e-4)
+    grad = grad.cpu().numpy()
+    scale = np.abs(g["grad"]).max(axis=1, keepdims=True)
+    assert np.all(np.abs(grad - g["grad"]) <= 3e-3 * scale + 1e-5)
+
+
+def test_oracle_agrees_at_large_batch():
+    """Full-size batch (4096 walkers, BASELINE config 2 shape) against the numpy oracle."""
+    from oracle import likelihood
+    lp, pred, yinv, prob = build_logprob("mlp_33_33")
+    emu = cases.oracle_emulator(prob)
+    z = np.random.RandomState(3).standard_normal((4096, 33)).astype(np.float32)
+    got = lp(z, returntorch=False)
+    ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0, dtype=np.float64)
+    np.testing.assert_allclose(got, ref, rtol=5e-4)
+
+
+def test_reference_fixture_known_answers():
+    """The reference's own test fixture (tests/test_main.py:47-51 reads it): checkpoint and
+    transform pickles load through the product's retrieve_model; log-probabilities match."""
+    from linna_amd import util, nn
+    g = cases.golden("fixture2d")
+    outdir = os.path.join(cases.GOLDEN, "2dgaussian_Fulltconn/iter_0/")
+    model, yinv = util.retrieve_model(outdir, 2, 2, nn.ChtoModelv2)
+    priors = [{"param": "test_%d" % i, "dist": "flat", "arg1": -2.0, "arg2": 2.0} for i in range(2)]
+    lp = util.Log_prob(np.array([0.1, 1.0]), np.linalg.inv(np.diag([0.5, 0.2])), model, yinv, util.Transform(priors),
+                       1.0, util.gaussianlogliklihood, nograd=True)
+    got = lp(g["z"], returntorch=False)
+    np.testing.assert_allclose(got, g["loglike"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(got[:4], [-2.9208457, -3.2061472, -4.2610073, -4.2800837], rtol=2e-5)
+
+
+def test_nan_maps_to_minus_inf_and_empty_edge():
+    lp = build_logprob("simple_6_4")[0]
+    z = np.zeros((3, 6), np.float32)
+    z[1, 2] = np.nan
+    out = lp(z, returntorch=False)
+    assert np.isfinite(out[0]) and out[1] == -np.inf and np.isfinite(out[2])
+    with pytest.raises(ValueError):
+        lp(np.zeros((2, 5), np.float32))
