@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""Headline benchmark: emulator log-likelihood evaluations per second on MI355X.
+
+Workload (BASELINE.json configs[1]): 33-D Gaussian posterior, 4 x 512 ReLU MLP emulator
+(33 -> 512 x 4 -> 33, fp32), nwalkers = 4096 walkers evaluated per step.  One "step" is one
+pass of the serving hot path over the batch: prior map -> input transform -> MLP forward ->
+output transform -> Gaussian log-likelihood / T + ln prior  (== 4096 x util.Log_prob.__call__
+of the reference).  Inputs are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+For N > 1 launch with torch.distributed.run (one rank per GPU); walkers shard across ranks
+with no data-path collective (weak scaling: 4096 walkers per GPU).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+NWALKERS = 4096
+NIN = NOUT = 33
+WIDTH, DEPTH = 512, 4
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MACS_PER_EVAL = NIN * WIDTH + (DEPTH - 1) * WIDTH * WIDTH + WIDTH * NOUT     # 820 224
+
+
+def build_problem(device):
+    """README.rst:69-83 shaped problem with a random-init emulator (seed 1234, Xavier-uniform
+    weights, bias 0.01 -- nn.py:97-99); synthetic: there is no trained checkpoint offline."""
+    import torch
+    from linna_amd import nn, util, predictor_gpu
+    rs = np.random.RandomState(0)
+    means = rs.uniform(size=NOUT)
+    cov = np.diag(0.1 * rs.uniform(0.05, 1.0, size=NOUT))
+    priors = [{"param": "test_%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(NIN)]
+    torch.manual_seed(1234)
+    model = nn.MLP(NIN, NOUT, None, width=WIDTH, depth=DEPTH)
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    X_mean, X_std = np.zeros(NIN), np.full(NIN, 10.0 / np.sqrt(12.0))
+    y_mean, y_std = means / np.sqrt(np.diag(cov)), np.ones(NOUT)
+    pred = predictor_gpu.Predictor(NIN, NOUT, model=model, device=device,
+                                   X_transform=util.X_transform_class(t(X_mean), t(X_std), "cpu", None),
+                                   y_transform=util.Y_transform_class(t(y_mean), t(y_std), "cpu"))
+    sigma = np.sqrt(np.diag(cov))
+    lp = util.Log_prob(t(means), t(np.linalg.inv(cov)), pred, util.Y_invtransform_data(sigma, "cpu"),
+                       util.Transform(priors), 1.0, util.gaussianlogliklihood, nograd=True)
+    consts = dict(means=means, cov=cov, priors=priors, X_mean=X_mean, X_std=X_std, y_mean=y_mean, y_std=y_std,
+                  sigma=sigma, weights={k: v.cpu().numpy().copy() for k, v in model.state_dict().items()})
+    return lp, model, consts
+
+
+def cpu_baseline(consts, z, budget_s=12.0):
+    """The numpy oracle (CPU restatement of the reference path) timed on this host: batched
+    BLAS evaluation on all cores (value) and the reference-faithful per-walker loop."""
+    from oracle import likelihood
+    emu = likelihood.Emulator("MLP", NIN, NOUT, consts["weights"], consts["X_mean"], consts["X_std"], consts["y_mean"],
+                              consts["y_std"], consts["sigma"], width=WIDTH, depth=DEPTH)
+    invcov = np.linalg.inv(consts["cov"])
+    f = lambda zz: likelihood.log_prob(zz, emu, consts["priors"], consts["means"], invcov, 1.0)
+    f(z)                                             # warm up BLAS threads
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s * 0.6:
+        f(z)
+        n += 1
+    batched = n * len(z) / (time.perf_counter() - t0)
+    m, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s * 0.4:
+        f(z[m % len(z)][None, :])
+        m += 1
+    per_walker = m / (time.perf_counter() - t0)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return {"value": batched, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": "numpy oracle (oracle/likelihood.log_prob), fp32, %d passes of the same %d-walker batch on all "
+                      "host cores; reference-faithful per-walker loop (batch 1, one core): %.0f evals/s over %d calls"
+                      % (n, len(z), per_walker, m)}
+
+
+def time_dominant_kernel(model, B, iters):
+    """HIP-event timing of the dominant kernel on its launch stream: the 64x64-tile fp32-MFMA
+    GEMM instantiation that serves layers 1-4 (per step: one 4096x512x33 and three 4096x512x512
+    launches).  Returns (avg ms per launch, algorithmic FLOP per launch)."""
+    import torch
+    from linna_amd import _lib
+    dev = model.device
+    x0 = torch.randn((B, _lib.ld4(NIN)), device=dev)
+    h = [torch.empty((B, WIDTH), device=dev) for _ in range(2)]
+    sd = model.state_dict()
+    ctx, st = _lib.ctx(dev.index), _lib.stream()
+
+    def four_launches():
+        src, ld, K = x0, x0.stride(0), NIN
+        for i in range(DEPTH):
+            dst = h[i & 1]
+            W = sd["layer%d.weight" % (i + 1)]            # strided view into the packed flat buffer
+            _lib.call("linna_linear_fwd", ctx, _lib.ptr(src), ld, C.c_void_p(W.data_ptr()), W.stride(0),
+                      _lib.ptr(sd["layer%d.bias" % (i + 1)]), _lib.ptr(dst), WIDTH, B, K, WIDTH, 1, 1.0, None, 0, st)
+            src, ld, K = dst, WIDTH, WIDTH
+
+    for _ in range(5):
+        four_launches()
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
+    _lib.call("linna_event_record", e0, st)
+    for _ in range(iters):
+        four_launches()
+    _lib.call("linna_event_record", e1, st)
+    ms = C.c_float()
+    _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+    flop = 2.0 * B * WIDTH * (NIN + (DEPTH - 1) * WIDTH) / DEPTH
+    return ms.value / (iters * DEPTH), flop
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels directly instead of a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from linna_amd import _lib
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    lp, model, consts = build_problem(device)
+    z_host = np.random.RandomState(100 + rank).standard_normal((NWALKERS, NIN)).astype(np.float32)
+    z = torch.as_tensor(z_host, device=device)
+    out = torch.empty(NWALKERS, dtype=torch.float32, device=device)
+    st = _lib.stream()
+
+    def step_direct():
+        lp.evaluate(z, out=out)
+
+    step_direct()
+    torch.cuda.synchronize()
+    graph = None
+    if not args.no_graph:
+        # capture one step on a side stream (hipGraph), replay it on the same stream
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            st_side = _lib.stream()
+            lp.evaluate(z, out=out)                 # allocate workspaces outside capture
+            s.synchronize()
+            _lib.call("linna_graph_begin", st_side)
+            lp.evaluate(z, out=out)
+            g = C.c_void_p()
+            _lib.call("linna_graph_end", st_side, C.byref(g))
+        graph = g
+
+    def step():
+        if graph is not None:
+            _lib.call("linna_graph_launch", graph, st)
+        else:
+            step_direct()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # sanity: the timed path produced finite numbers
+    assert torch.isfinite(out).all(), "non-finite log-probabilities in the timed path"
+
+    if rank == 0:
+        ms_kernel, flop_launch = time_dominant_kernel(model, NWALKERS, max(20, args.steps // 4))
+        achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
+        res = {
+            "metric": "emulator log-likelihood evals/sec",
+            "value": world * NWALKERS * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "33-D Gaussian, 4x512 MLP emulator (33->512x4->33), nwalkers=4096 batched "
+                                   "log-likelihood per GPU (BASELINE configs[1])",
+                       "nwalkers_per_gpu": NWALKERS, "flop_per_eval": 2 * MACS_PER_EVAL + 3 * NOUT,
+                       "launch": "hipGraph replay" if graph is not None else "direct launches",
+                       "parallelism": "walkers sharded, %d rank(s), no data-path collective" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "gemm_kernel<2,2,1,1,0,0,4> (64x64 tile, 4-stage LDS-DMA ring, fp32 MFMA): layers 1-4, 4 launches/step",
+                         "avg_launch_ms": ms_kernel, "flop_per_launch": flop_launch},
+            "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(consts, z_host)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -76,7 +76,13 @@ typedef struct {
     int cexp; const float* cpost; const float* cshift2;
     const float* dotwith; int lddot;
     float* dot_partial; int dot_slots;
+    int flags;   /* 0 in production; see LINNA_GEMM_* below (tile override / ablation for tools/) */
 } linna_gemm_t;
+
+#define LINNA_GEMM_TILE_MASK 0x7        /* 0 = automatic, 1.. = force tile configuration n-1 */
+#define LINNA_GEMM_ABL_NOLOAD 0x10      /* timing only: skip global loads after the first K tile */
+#define LINNA_GEMM_ABL_NOSTAGE 0x20     /* timing only: skip LDS restaging + barrier */
+#define LINNA_GEMM_ABL_NOMFMA 0x40      /* timing only: skip the MFMAs */
 
 int linna_gemm_f32(linna_ctx_t* ctx, const linna_gemm_t* desc, void* stream);
 int linna_gemm_dot_slots(int M, int N);
@@ -87,20 +93,25 @@ int linna_gemm_dot_slots(int M, int N);
  *                     Y = relu(0.1*(T W2^T + b2) + X Ws^T)  (Ws NULL: + X)   nn.py:53-54
  * linna_linear_bwd: dX = (dY W) [* (Xmask>0)], dW = dY^T X, db = colsum dY   autograd of the above,
  *                   predictor_gpu.py:285; any of dX/dW/db may be NULL.       */
-int linna_linear_fwd(linna_ctx_t* ctx, const float* X, int ldx, const float* W, const float* b,
+int linna_linear_fwd(linna_ctx_t* ctx, const float* X, int ldx, const float* W, int ldw, const float* b,
                      float* Y, int ldy, int B, int K, int N, int relu, float alpha,
                      const float* R, int ldr, void* stream);
+/* weights of the block use the packed convention of linna_layer_t (row stride LINNA_LD(K)) */
 int linna_resblock_fwd(linna_ctx_t* ctx, const float* X, int ldx, const float* W1, const float* b1,
                        const float* W2, const float* b2, const float* Ws, float* T, int ldt,
                        float* Y, int ldy, int B, int K, int C, int N, void* stream);
 int linna_linear_bwd(linna_ctx_t* ctx, const float* dY, int lddy, const float* X, int ldx,
-                     const float* W, float* dX, int lddx, const float* Xmask, int ldxm,
-                     float* dW, float* db, int B, int K, int N, float scale, void* stream);
+                     const float* W, int ldw, float* dX, int lddx, const float* Xmask, int ldxm,
+                     float* dW, int lddw, float* db, int B, int K, int N, float scale, void* stream);
 
 /* ------------------------------------------------------------------ whole network
  * A network is an ordered list of ops (nn.py:110-133, 185-198, 351-374).  Parameter
  * pointers reference the caller's flat parameter buffer; gradient pointers (may be NULL)
- * reference the caller's flat gradient buffer with the same layout. */
+ * reference the caller's flat gradient buffer with the same layout.
+ * Packed weight convention: a weight matrix [N][K] is stored row-major with row stride
+ * LINNA_LD(K) = K rounded up to a multiple of 4 floats (pad entries zero), 16-byte aligned,
+ * so every row can be streamed by 16-byte LDS-DMA. */
+#define LINNA_LD(k) (((k) + 3) & ~3)
 #define LINNA_OP_LINEAR 0     /* Y = [relu](X W^T + b)                                         */
 #define LINNA_OP_RESBLOCK 1   /* nn.py:11-56                                                    */
 #define LINNA_OP_INSKIP 2     /* out += alpha*(X0 W^T + b), X0 = network input (nn.py:195)     */

@@ -28,7 +28,8 @@ class Gemm(C.Structure):
                 ("alpha0", C.c_float), ("R", C.c_void_p), ("ldr", C.c_int), ("relu", C.c_int),
                 ("mask", C.c_void_p), ("ldmask", C.c_int), ("cscale", C.c_void_p), ("cshift", C.c_void_p),
                 ("cexp", C.c_int), ("cpost", C.c_void_p), ("cshift2", C.c_void_p),
-                ("dotwith", C.c_void_p), ("lddot", C.c_int), ("dot_partial", C.c_void_p), ("dot_slots", C.c_int)]
+                ("dotwith", C.c_void_p), ("lddot", C.c_int), ("dot_partial", C.c_void_p), ("dot_slots", C.c_int),
+                ("flags", C.c_int)]
 
 
 class Layer(C.Structure):
@@ -79,9 +80,9 @@ _SIGNATURES = {
     "linna_event_destroy": (_I, [_V]),
     "linna_gemm_f32": (_I, [_V, C.POINTER(Gemm), _V]),
     "linna_gemm_dot_slots": (_I, [_I, _I]),
-    "linna_linear_fwd": (_I, [_V, _V, _I, _V, _V, _V, _I, _I, _I, _I, _I, _F, _V, _I, _V]),
+    "linna_linear_fwd": (_I, [_V, _V, _I, _V, _I, _V, _V, _I, _I, _I, _I, _I, _F, _V, _I, _V]),
     "linna_resblock_fwd": (_I, [_V, _V, _I, _V, _V, _V, _V, _V, _V, _I, _V, _I, _I, _I, _I, _I, _V]),
-    "linna_linear_bwd": (_I, [_V, _V, _I, _V, _I, _V, _V, _I, _V, _I, _V, _V, _I, _I, _I, _F, _V]),
+    "linna_linear_bwd": (_I, [_V, _V, _I, _V, _I, _V, _I, _V, _I, _V, _I, _V, _I, _V, _I, _I, _I, _F, _V]),
     "linna_net_create": (_I, [_V, C.POINTER(Layer), _I, _I, _PV]),
     "linna_net_destroy": (_I, [_V]),
     "linna_net_fwd_ws_bytes": (_SZ, [_V, _I]),

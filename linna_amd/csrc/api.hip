@@ -150,10 +150,10 @@ int linna_gemm_f32(linna_ctx_t*, const linna_gemm_t* d, void* stream) {
 int linna_gemm_dot_slots(int M, int N) { return gemm_slots(M, N); }
 
 // ------------------------------------------------------------------ layers
-int linna_linear_fwd(linna_ctx_t*, const float* X, int ldx, const float* W, const float* b, float* Y, int ldy, int B,
-                     int K, int N, int relu, float alpha, const float* R, int ldr, void* stream) {
+int linna_linear_fwd(linna_ctx_t*, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int ldy,
+                     int B, int K, int N, int relu, float alpha, const float* R, int ldr, void* stream) {
     GemmArgs a = gemm_zero();
-    set_pair(a, 0, X, ldx, LAY_K, W, K, LAY_K, K);
+    set_pair(a, 0, X, ldx, LAY_K, W, ldw, LAY_K, K);
     a.M = B; a.N = N; a.C = Y; a.ldc = ldy; a.bias0 = b; a.alpha0 = alpha; a.R = R; a.ldr = ldr; a.relu = relu;
     return gemm_launch(a, S(stream));
 }
@@ -162,28 +162,28 @@ int linna_resblock_fwd(linna_ctx_t*, const float* X, int ldx, const float* W1, c
                        const float* b2, const float* Ws, float* T, int ldt, float* Y, int ldy, int B, int K, int C,
                        int N, void* stream) {
     if (!Ws && K != N) { set_error("resblock: identity skip needs K == N"); return LINNA_ERR_INVALID; }
-    TRY(linna_linear_fwd(nullptr, X, ldx, W1, b1, T, ldt, B, K, C, 1, 1.f, nullptr, 0, stream));
+    TRY(linna_linear_fwd(nullptr, X, ldx, W1, ld4(K), b1, T, ldt, B, K, C, 1, 1.f, nullptr, 0, stream));
     GemmArgs a = gemm_zero();
-    set_pair(a, 0, T, ldt, LAY_K, W2, C, LAY_K, C);
+    set_pair(a, 0, T, ldt, LAY_K, W2, ld4(C), LAY_K, C);
     a.M = B; a.N = N; a.C = Y; a.ldc = ldy; a.bias0 = b2; a.alpha0 = 0.1f; a.relu = 1;
-    if (Ws) { a.npairs = 2; set_pair(a, 1, X, ldx, LAY_K, Ws, K, LAY_K, K); }
+    if (Ws) { a.npairs = 2; set_pair(a, 1, X, ldx, LAY_K, Ws, ld4(K), LAY_K, K); }
     else { a.R = X; a.ldr = ldx; }
     return gemm_launch(a, S(stream));
 }
 
-int linna_linear_bwd(linna_ctx_t*, const float* dY, int lddy, const float* X, int ldx, const float* W, float* dX,
-                     int lddx, const float* Xmask, int ldxm, float* dW, float* db, int B, int K, int N, float scale,
-                     void* stream) {
+int linna_linear_bwd(linna_ctx_t*, const float* dY, int lddy, const float* X, int ldx, const float* W, int ldw,
+                     float* dX, int lddx, const float* Xmask, int ldxm, float* dW, int lddw, float* db, int B, int K,
+                     int N, float scale, void* stream) {
     if (dW) {   // dW[n][k] = scale * sum_b dY[b][n] X[b][k]
         GemmArgs a = gemm_zero();
         set_pair(a, 0, dY, lddy, LAY_MN, X, ldx, LAY_MN, B);
-        a.M = N; a.N = K; a.C = dW; a.ldc = K; a.alpha0 = scale;
+        a.M = N; a.N = K; a.C = dW; a.ldc = lddw; a.alpha0 = scale;
         TRY(gemm_launch(a, S(stream)));
     }
     if (db) TRY(launch_colsum(dY, lddy, B, N, scale, db, S(stream)));
     if (dX) {   // dX[b][k] = scale * sum_n dY[b][n] W[n][k]
         GemmArgs a = gemm_zero();
-        set_pair(a, 0, dY, lddy, LAY_K, W, K, LAY_MN, N);
+        set_pair(a, 0, dY, lddy, LAY_K, W, ldw, LAY_MN, N);
         a.M = B; a.N = K; a.C = dX; a.ldc = lddx; a.alpha0 = scale; a.mask = Xmask; a.ldmask = ldxm;
         TRY(gemm_launch(a, S(stream)));
     }
@@ -253,12 +253,12 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
                 // out = (hin W^T + b) + alpha * (X0 Wl^T + bl): pair 0 carries the scaled input skip
                 const linna_layer_t& s = n->inskip;
                 a.npairs = 2;
-                set_pair(a, 0, X, ldx, LAY_K, s.W, s.K, LAY_K, s.K);
+                set_pair(a, 0, X, ldx, LAY_K, s.W, ld4(s.K), LAY_K, s.K);
                 a.bias0 = s.b; a.alpha0 = s.alpha;
-                set_pair(a, 1, hin, ldh, LAY_K, l.W, l.K, LAY_K, l.K);
+                set_pair(a, 1, hin, ldh, LAY_K, l.W, ld4(l.K), LAY_K, l.K);
                 a.bias1 = l.b;
             } else {
-                set_pair(a, 0, hin, ldh, LAY_K, l.W, l.K, LAY_K, l.K);
+                set_pair(a, 0, hin, ldh, LAY_K, l.W, ld4(l.K), LAY_K, l.K);
                 a.bias0 = l.b;
             }
             if (last && om) {
@@ -288,7 +288,7 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
 
     if (n->has_inskip && pg) {
         const linna_layer_t& s = n->inskip;
-        TRY(linna_linear_bwd(nullptr, dOUT, lddo, X, ldx, s.W, nullptr, 0, nullptr, 0, s.gW, s.gb, B, s.K, s.N, s.alpha, stream));
+        TRY(linna_linear_bwd(nullptr, dOUT, lddo, X, ldx, s.W, ld4(s.K), nullptr, 0, nullptr, 0, s.gW, ld4(s.K), s.gb, B, s.K, s.N, s.alpha, stream));
     }
     const float* dcur = dOUT; int ldd = lddo;
     int flip = 0;
@@ -303,18 +303,18 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         const bool hin_relu = (i > 0) && (n->L[i - 1].op == LINNA_OP_RESBLOCK || n->L[i - 1].relu);
         const float* mask = hin_relu ? hin : nullptr;
         if (l.op == LINNA_OP_LINEAR) {
-            if (pg) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.W, nullptr, 0, nullptr, 0, l.gW, l.gb, B, l.K, l.N, 1.f, stream));
+            if (pg) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.W, ld4(l.K), nullptr, 0, nullptr, 0, l.gW, ld4(l.K), l.gb, B, l.K, l.N, 1.f, stream));
             if (need_dx) {
                 GemmArgs a = gemm_zero();
                 a.M = B; a.N = l.K; a.C = dprev; a.ldc = ldp; a.mask = mask; a.ldmask = ldh;
                 if (i == 0 && n->has_inskip) {
                     const linna_layer_t& s = n->inskip;
                     a.npairs = 2;
-                    set_pair(a, 0, dOUT, lddo, LAY_K, s.W, s.K, LAY_MN, s.N);
+                    set_pair(a, 0, dOUT, lddo, LAY_K, s.W, ld4(s.K), LAY_MN, s.N);
                     a.alpha0 = s.alpha;
-                    set_pair(a, 1, dcur, ldd, LAY_K, l.W, l.K, LAY_MN, l.N);
+                    set_pair(a, 1, dcur, ldd, LAY_K, l.W, ld4(l.K), LAY_MN, l.N);
                 } else {
-                    set_pair(a, 0, dcur, ldd, LAY_K, l.W, l.K, LAY_MN, l.N);
+                    set_pair(a, 0, dcur, ldd, LAY_K, l.W, ld4(l.K), LAY_MN, l.N);
                 }
                 TRY(gemm_launch(a, st));
             }
@@ -323,20 +323,20 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
             const int ldt = ld4(l.C);
             {   // dT = 0.1 * (dcur W2) * (T > 0)
                 GemmArgs a = gemm_zero();
-                set_pair(a, 0, dcur, ldd, LAY_K, l.W2, l.C, LAY_MN, l.N);
+                set_pair(a, 0, dcur, ldd, LAY_K, l.W2, ld4(l.C), LAY_MN, l.N);
                 a.M = B; a.N = l.C; a.C = dT; a.ldc = ldt; a.alpha0 = 0.1f; a.mask = T; a.ldmask = ldt;
                 TRY(gemm_launch(a, st));
             }
             if (pg) {
-                TRY(linna_linear_bwd(nullptr, dcur, ldd, T, ldt, l.W2, nullptr, 0, nullptr, 0, l.gW2, l.gb2, B, l.C, l.N, 0.1f, stream));
-                TRY(linna_linear_bwd(nullptr, dT, ldt, hin, ldh, l.W1, nullptr, 0, nullptr, 0, l.gW1, l.gb1, B, l.K, l.C, 1.f, stream));
-                if (l.Ws) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.Ws, nullptr, 0, nullptr, 0, l.gWs, nullptr, B, l.K, l.N, 1.f, stream));
+                TRY(linna_linear_bwd(nullptr, dcur, ldd, T, ldt, l.W2, ld4(l.C), nullptr, 0, nullptr, 0, l.gW2, ld4(l.C), l.gb2, B, l.C, l.N, 0.1f, stream));
+                TRY(linna_linear_bwd(nullptr, dT, ldt, hin, ldh, l.W1, ld4(l.K), nullptr, 0, nullptr, 0, l.gW1, ld4(l.K), l.gb1, B, l.K, l.C, 1.f, stream));
+                if (l.Ws) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.Ws, ld4(l.K), nullptr, 0, nullptr, 0, l.gWs, ld4(l.K), nullptr, B, l.K, l.N, 1.f, stream));
             }
             if (need_dx) {   // dprev = (dT W1 + dcur Ws [+ dcur]) * (hin > 0)
                 GemmArgs a = gemm_zero();
-                set_pair(a, 0, dT, ldt, LAY_K, l.W1, l.K, LAY_MN, l.C);
+                set_pair(a, 0, dT, ldt, LAY_K, l.W1, ld4(l.K), LAY_MN, l.C);
                 a.M = B; a.N = l.K; a.C = dprev; a.ldc = ldp; a.mask = mask; a.ldmask = ldh;
-                if (l.Ws) { a.npairs = 2; set_pair(a, 1, dcur, ldd, LAY_K, l.Ws, l.K, LAY_MN, l.N); }
+                if (l.Ws) { a.npairs = 2; set_pair(a, 1, dcur, ldd, LAY_K, l.Ws, ld4(l.K), LAY_MN, l.N); }
                 else { a.R = dcur; a.ldr = ldd; }
                 TRY(gemm_launch(a, st));
             }

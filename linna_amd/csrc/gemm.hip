@@ -1,97 +1,140 @@
-// fp32-input MFMA GEMM for gfx950: LDS-tiled, register-staged double buffering, one
-// barrier per K-tile, fused epilogues.  Replaces every torch nn.Linear / F.relu / `@` on
-// the reference hot path (linna/nn.py:53-54,121-130; util.py:1077-1085; autograd of them).
+// fp32-input MFMA GEMM for gfx950 with fused epilogues.  Replaces every torch nn.Linear /
+// F.relu / `@` on the reference hot path (linna/nn.py:53-54,121-130; util.py:1077-1085; and
+// the autograd of those, predictor_gpu.py:285).
 //
-// Arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain), which is the
-// parity path against the reference's fp32 CPU GEMMs.
+// Arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32 == k-ordered fmaf chain): the parity
+// path against the reference's fp32 CPU GEMMs.
 //
-// Tile = (WM*TM*32) x (WN*TN*32) outputs per workgroup, BK = 32.  Within an 8-deep k
-// group, lane half h = lane>>5 owns k = 8g+4h+{0..3}: one ds_read_b128 per operand feeds
-// four MFMA steps (the contraction order is a permutation of k, identical for A and B).
+// Structure (one workgroup = (WM*TM*32) x (WN*TN*32) outputs, BK = 32):
+//  * operand tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+//    wave-instruction) into an NS-deep ring; the only waits in the K loop are a counted
+//    s_waitcnt vmcnt(N) and ONE raw s_barrier per K tile, so NS-1 tiles are always in flight;
+//  * the LDS image is unpadded (DMA writes lane-linear); K-contiguous tiles are XOR-swizzled
+//    on the SOURCE address and on the fragment read (chunk ^= (row>>1)&7) so that the
+//    ds_read_b128 fragment reads are bank-conflict free;
+//  * within an 8-deep k group, lane half h = lane>>5 owns k = 8g+4h+{0..3}: one ds_read_b128
+//    per operand feeds four MFMA steps (a permutation of k, identical for A and B);
+//  * a partial last K tile, and whole operands that are not 16-byte aligned, are staged
+//    through registers with clamped, masked element loads into the same LDS image;
+//  * out-of-range rows/columns of an edge tile read clamped (valid) addresses; their
+//    products are never stored.
 #include "common.h"
 
 namespace linna {
 
 constexpr int BK = 32;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
 
-template <int ROWS, int LAY, int NT>
-struct Stager {
-    // ROWS = tile extent along M (or N); the tile holds ROWS x BK floats.
-    static constexpr int NV = ROWS * BK / 4 / NT;
-    static constexpr int LD = (LAY == LAY_K) ? (BK + 4) : (ROWS + 4);
-    static constexpr int SIZE = (LAY == LAY_K) ? ROWS * LD : BK * LD;
-    f32x4 r[NV];
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else static_assert(N < 0, "add the vmcnt literal");
+}
 
-    __device__ __forceinline__ void load(const float* __restrict__ g, int ld, int row0, int nrows,
-                                         int k0, int K, bool vec, int tid) {
+// One operand tile: ROWS (along M or N) x BK floats, ROWS*128 bytes, staged by NW waves.
+template <int ROWS, int LAY, int NW>
+struct Tile {
+    static constexpr int SIZE = ROWS * BK;                 // floats
+    static constexpr int NI = (ROWS * BK * 4 / 1024) / NW;  // 1 KiB DMA instructions per wave per tile
+    static_assert(NI >= 1 && (ROWS * BK * 4 / 1024) % NW == 0, "tile/wave mismatch");
+
+    // LDS float offset of logical element (row r, k) -- K-contiguous: 16-byte chunk c=k/4 lives
+    // at chunk slot c ^ ((r>>1)&7); k-major: [k][ROWS] plain.
+    __device__ static __forceinline__ int slot(int r, int c) { return r * BK + 4 * (c ^ ((r >> 1) & 7)); }
+
+    // Issue this wave's share of the tile as LDS-DMA.  `row0`/`nrows`: first row of the tile and
+    // the operand's extent along the tiled dimension; `ld` multiple of 4 and base 16-B aligned.
+    __device__ static __forceinline__ void dma(const float* __restrict__ g, int ld, int row0, int nrows, int k0,
+                                               float* stage, int wave, int lane) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int f = tid + i * NT;
+        for (int j = 0; j < NI; ++j) {
+            const int ins = wave * NI + j;
+            const float* src;
             if (LAY == LAY_K) {
-                const int rr = f / (BK / 4), kk = (f % (BK / 4)) * 4;
-                const int gr = row0 + rr, gk = k0 + kk;
-                const float* p = g + (size_t)gr * ld + gk;
-                if (gr < nrows && vec && gk + 3 < K) {
-                    r[i] = *reinterpret_cast<const f32x4*>(p);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r[i][e] = (gr < nrows && gk + e < K) ? p[e] : 0.f;
-                }
+                const int r = ins * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                src = g + (size_t)min(row0 + r, nrows - 1) * ld + k0 + 4 * c;
             } else {
-                constexpr int RQ = ROWS / 4;
-                const int kk = f / RQ, rr = (f % RQ) * 4;
-                const int gk = k0 + kk, gr = row0 + rr;
-                const float* p = g + (size_t)gk * ld + gr;
-                if (gk < K && vec && gr + 3 < nrows) {
-                    r[i] = *reinterpret_cast<const f32x4*>(p);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) r[i][e] = (gk < K && gr + e < nrows) ? p[e] : 0.f;
-                }
+                constexpr int CH = ROWS / 4, KR = 64 / CH;          // chunks per k-row, k-rows per instruction
+                const int k = ins * KR + lane / CH;
+                const int col = min(row0 + 4 * (lane % CH), ld - 4);  // stays inside the (padded) row
+                src = g + (size_t)(k0 + k) * ld + col;
             }
+            __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(stage + ins * 256), 16, 0, 0);
         }
     }
-    __device__ __forceinline__ void store(float* lds, int tid) const {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int f = tid + i * NT;
+
+    // Register-staged fallback for a partial K tile or an unaligned operand: clamped element
+    // loads, zero beyond K / beyond nrows, written into the same LDS image.
+    __device__ static __forceinline__ void stage_slow(const float* __restrict__ g, int ld, int row0, int nrows, int k0,
+                                                      int K, float* stage, int tid) {
+        constexpr int NT = NW * 64;
+        for (int f = tid; f < ROWS * BK / 4; f += NT) {
+            f32x4 v;
+            int dst;
             if (LAY == LAY_K) {
-                const int rr = f / (BK / 4), kk = (f % (BK / 4)) * 4;
-                *reinterpret_cast<f32x4*>(lds + rr * LD + kk) = r[i];
+                const int r = f >> 3, c = f & 7;
+                const int gr = row0 + r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gk = k0 + 4 * c + e;
+                    const float x = g[(size_t)min(gr, nrows - 1) * ld + min(gk, K - 1)];
+                    v[e] = (gr < nrows && gk < K) ? x : 0.f;
+                }
+                dst = slot(r, c);
             } else {
-                constexpr int RQ = ROWS / 4;
-                const int kk = f / RQ, rr = (f % RQ) * 4;
-                *reinterpret_cast<f32x4*>(lds + kk * LD + rr) = r[i];
+                constexpr int CH = ROWS / 4;
+                const int k = f / CH, cc = f % CH;
+                const int gk = k0 + k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gr = row0 + 4 * cc + e;
+                    const float x = g[(size_t)min(gk, K - 1) * ld + min(gr, nrows - 1)];
+                    v[e] = (gr < nrows && gk < K) ? x : 0.f;
+                }
+                dst = k * ROWS + 4 * cc;
             }
+            *reinterpret_cast<f32x4*>(stage + dst) = v;
+        }
+    }
+
+    // Fragment of the 32-row slab starting at `slab0`, k group g: 4 values = 4 MFMA steps.
+    __device__ static __forceinline__ f32x4 frag(const float* stage, int slab0, int g, int lane) {
+        const int i = lane & 31, h = lane >> 5;
+        if (LAY == LAY_K) {
+            return *reinterpret_cast<const f32x4*>(stage + slot(slab0 + i, 2 * g + h));
+        } else {
+            f32x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = stage[(8 * g + 4 * h + s) * ROWS + slab0 + i];
+            return v;
         }
     }
 };
 
-// Fragment for one 32-row (or 32-col) MFMA slab, k group g: 4 values = 4 MFMA steps.
-template <int LAY, int LD>
-__device__ __forceinline__ f32x4 read_frag(const float* lds, int slab0, int g, int lane) {
-    const int i = lane & 31, h = lane >> 5;
-    if (LAY == LAY_K) {
-        return *reinterpret_cast<const f32x4*>(lds + (slab0 + i) * LD + 8 * g + 4 * h);
-    } else {
-        f32x4 v;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = lds[(8 * g + 4 * h + s) * LD + slab0 + i];
-        return v;
-    }
-}
-
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
-    constexpr int NT = WM * WN * 64;
+    constexpr int NW = WM * WN, NT = NW * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    using SA = Stager<BM, ALAY, NT>;
-    using SB = Stager<BN, BLAY, NT>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const lA0 = smem;
-    float* const lB0 = smem + 2 * SA::SIZE;
+    using TA = Tile<BM, ALAY, NW>;
+    using TB = Tile<BN, BLAY, NW>;
+    constexpr int LPT = TA::NI + TB::NI;                      // DMA instructions per wave per K tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // NS x (A tile | B tile)
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (private L2), so give every XCD a
@@ -114,31 +157,68 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk0 = (a.p[0].K + BK - 1) / BK;
-    const int nk1 = a.npairs > 1 ? (a.p[1].K + BK - 1) / BK : 0;
-    const int nk = nk0 + nk1;
-
-    SA sa; SB sb;
-    auto gload = [&](int kt) {
-        const int pi = kt >= nk0 ? 1 : 0;
-        const GemmPair& p = a.p[pi];
-        const int k0 = (pi ? kt - nk0 : kt) * BK;
-        const bool va = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
-        const bool vb = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
-        sa.load(p.A, p.lda, m0, a.M, k0, p.K, va, tid);
-        sb.load(p.B, p.ldb, n0, a.N, k0, p.K, vb, tid);
+    auto compute = [&](const float* st) {
+        const float* cA = st;
+        const float* cB = st + TA::SIZE;
+        f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = TA::frag(cA, (wm * TM + i) * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = TB::frag(cB, (wn * TN + j) * 32, 0, lane);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            if (g + 1 < BK / 8) {        // next k group's fragments under this group's MFMAs
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(g + 1) & 1][i] = TA::frag(cA, (wm * TM + i) * 32, g + 1, lane);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(g + 1) & 1][j] = TB::frag(cB, (wn * TN + j) * 32, g + 1, lane);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j], 0, 0, 0);
+        }
     };
 
-    gload(0);
-    sa.store(lA0, tid);
-    sb.store(lB0, tid);
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);               // issue early, written after the MFMAs
-        if (kt == nk0 && nk1 > 0) {
-            // switch from pair 0 to pair 1: acc <- alpha0 * (acc + bias0)
+    for (int pi = 0; pi < a.npairs; ++pi) {
+        const GemmPair p = a.p[pi];
+        const bool dma_ok = ((p.lda & 3) == 0) && ((p.ldb & 3) == 0) &&
+                            (((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0);
+        const int nfast = dma_ok ? p.K / BK : 0;               // full K tiles streamed by LDS-DMA
+        const int nall = (p.K + BK - 1) / BK;
+        auto issue = [&](int t) {
+            float* st = smem + (t % NS) * STAGE;
+            TA::dma(p.A, p.lda, m0, a.M, t * BK, st, wave, lane);
+            TB::dma(p.B, p.ldb, n0, a.N, t * BK, st + TA::SIZE, wave, lane);
+        };
+        if (nfast > 0) {
+#pragma unroll
+            for (int t = 0; t < NS - 1; ++t)
+                if (t < nfast) issue(t);
+            for (int kt = 0; kt < nfast; ++kt) {
+                // tile kt must have landed; up to NS-2 younger tiles of this wave stay in flight
+                const int younger = min(NS - 2, nfast - 1 - kt);
+                if (NS >= 4 && younger >= 2) wait_vmcnt<2 * LPT>();
+                else if (NS >= 3 && younger == 1) wait_vmcnt<LPT>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();      // all waves' DMA for kt landed; stage (kt-1)%NS is free
+                asm volatile("" ::: "memory");
+                if (kt + NS - 1 < nfast) issue(kt + NS - 1);
+                compute(smem + (kt % NS) * STAGE);
+            }
+            __builtin_amdgcn_s_barrier();          // last tile fully read before anything restages
+        }
+        for (int kt = nfast; kt < nall; ++kt) {    // partial tile / unaligned operand: register path
+            TA::stage_slow(p.A, p.lda, m0, a.M, kt * BK, p.K, smem, tid);
+            TB::stage_slow(p.B, p.ldb, n0, a.N, kt * BK, p.K, smem + TA::SIZE, tid);
+            __syncthreads();
+            compute(smem);
+            __syncthreads();
+        }
+        if (pi == 0 && a.npairs > 1) {             // acc <- alpha0 * (acc + bias0) before pair 1 accumulates
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -149,33 +229,11 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = a.alpha0 * (acc[i][j][e] + b0);
             }
         }
-        const float* cA = lA0 + cur * SA::SIZE;
-        const float* cB = lB0 + cur * SB::SIZE;
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<ALAY, SA::LD>(cA, (wm * TM + i) * 32, g, lane);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = read_frag<BLAY, SB::LD>(cB, (wn * TN + j) * 32, g, lane);
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            sa.store(lA0 + (cur ^ 1) * SA::SIZE, tid);
-            sb.store(lB0 + (cur ^ 1) * SB::SIZE, tid);
-        }
-        __syncthreads();
-        cur ^= 1;
     }
 
     // ---------------------------------------------------------------- epilogue
     // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
+    const bool two = a.npairs > 1;
     const int h = lane >> 5;
     float dot[TM][16];
     if (a.dotwith) {
@@ -190,7 +248,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
         const bool cok = col < a.N;
         float b_first = 0.f, b_last = 0.f, cs = 1.f, ct = 0.f, cp = 1.f, ct2 = 0.f;
         if (cok) {
-            if (nk1 > 0) { b_last = a.bias1 ? a.bias1[col] : 0.f; }
+            if (two) { b_last = a.bias1 ? a.bias1[col] : 0.f; }
             else { b_first = a.bias0 ? a.bias0[col] : 0.f; }
             if (a.cscale) cs = a.cscale[col];
             if (a.cshift) ct = a.cshift[col];
@@ -204,7 +262,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
                 const int row = m0 + (wm * TM + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (!cok || row >= a.M) continue;
                 float v = acc[i][j][e];
-                v = (nk1 > 0) ? (v + b_last) : a.alpha0 * (v + b_first);
+                v = two ? (v + b_last) : a.alpha0 * (v + b_first);
                 if (a.R) v += a.R[(size_t)row * a.ldr + col];
                 if (a.relu) v = fmaxf(v, 0.f);
                 if (a.mask) v = (a.mask[(size_t)row * a.ldmask + col] > 0.f) ? v : 0.f;
@@ -234,14 +292,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
 struct TileCfg { int wm, wn, tm, tn; };
 static const TileCfg kCfgs[3] = {{2, 2, 2, 1}, {2, 2, 1, 1}, {1, 1, 1, 1}};   // 128x64, 64x64, 32x32
 
-static int pick_cfg(int M, int N) {
-    // Largest tile that still gives the chip >= 256 workgroups (one per CU); else the
-    // smallest tile, many single-wave workgroups per CU.
-    for (int c = 0; c < 3; ++c) {
+static int pick_cfg(int M, int N, int flags = 0) {
+    if (flags & LINNA_GEMM_TILE_MASK) return (flags & LINNA_GEMM_TILE_MASK) - 1;
+    auto tiles = [&](int c) {
         const int bm = kCfgs[c].wm * kCfgs[c].tm * 32, bn = kCfgs[c].wn * kCfgs[c].tn * 32;
-        const long t = (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
-        if (t >= 256) return c;
-    }
+        return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
+    };
+    // 64x64 workgroups, two or more per CU, are the default; 128x64 only once that already
+    // oversubscribes the chip; single-wave 32x32 tiles when 64x64 cannot give every CU a block.
+    if (tiles(1) >= 2048) return 0;
+    if (tiles(1) >= 256) return 1;
     return 2;
 }
 
@@ -251,21 +311,28 @@ int gemm_slots(int M, int N) {
     return ((N + bn - 1) / bn) * c.wn;
 }
 
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY>
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS>
 static int launch_one(const GemmArgs& a, hipStream_t stream) {
     constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    const size_t lds = 2 * (Stager<BM, ALAY, NT>::SIZE + Stager<BN, BLAY, NT>::SIZE) * sizeof(float);
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, ALAY, BLAY>), dim3(ntm * ntn), dim3(NT), lds, stream, a);
+    const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set && lds > 65536) {
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
+        if (rc != LINNA_OK) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS>), dim3(ntm * ntn), dim3(NT), lds, stream, a);
     return check_hip(hipGetLastError(), "gemm launch");
 }
 
 template <int ALAY, int BLAY>
 static int launch_lay(const GemmArgs& a, int cfg, hipStream_t stream) {
     switch (cfg) {
-        case 0: return launch_one<2, 2, 2, 1, ALAY, BLAY>(a, stream);
-        case 1: return launch_one<2, 2, 1, 1, ALAY, BLAY>(a, stream);
-        default: return launch_one<1, 1, 1, 1, ALAY, BLAY>(a, stream);
+        case 0: return launch_one<2, 2, 2, 1, ALAY, BLAY, 3>(a, stream);   // 72 KiB LDS: 2 blocks / CU
+        case 1: return launch_one<2, 2, 1, 1, ALAY, BLAY, 4>(a, stream);   // 64 KiB LDS: 2 blocks / CU
+        default: return launch_one<1, 1, 1, 1, ALAY, BLAY, 4>(a, stream);  // 32 KiB LDS: 5 blocks / CU
     }
 }
 
@@ -282,7 +349,7 @@ int gemm_launch(const GemmArgs& a, hipStream_t stream) {
         set_error("gemm: row-dot partial buffer too small");
         return LINNA_ERR_INVALID;
     }
-    const int cfg = pick_cfg(a.M, a.N);
+    const int cfg = pick_cfg(a.M, a.N, a.flags);
     const int al = a.p[0].alay, bl = a.p[0].blay;
     if (al == LAY_K && bl == LAY_K) return launch_lay<LAY_K, LAY_K>(a, cfg, stream);
     if (al == LAY_K && bl == LAY_MN) return launch_lay<LAY_K, LAY_MN>(a, cfg, stream);

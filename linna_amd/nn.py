@@ -60,9 +60,11 @@ class _Emulator(object):
         off = 0
         for op in self.ops:
             for key, shp in op.tensors():
-                n = int(np.prod(shp))
+                # packed convention of include/linna_hip.h: weight rows padded to a multiple of 4
+                # floats (16-byte rows for LDS-DMA), every tensor 16-byte aligned; pads stay zero
+                n = shp[0] * _lib.ld4(shp[1]) if len(shp) == 2 else _lib.ld4(shp[0])
                 self._index[key] = (off, shp)
-                off += (n + 3) & ~3              # 16-byte aligned tensors inside the flat buffer
+                off += n
         self.nflat = off
         self.nparams = sum(int(np.prod(s)) for _, s in self._index.values())
         self._flat = torch.zeros(self.nflat, dtype=torch.float32)
@@ -86,14 +88,18 @@ class _Emulator(object):
     # ------------------------------------------------------------------ parameters
     def _view(self, buf, key):
         off, shp = self._index[key]
-        return buf[off:off + int(np.prod(shp))].view(*shp)
+        if len(shp) == 2:
+            ld = _lib.ld4(shp[1])
+            return buf[off:off + shp[0] * ld].view(shp[0], ld)[:, :shp[1]]
+        return buf[off:off + shp[0]]
 
     def init_weight(self):
         """Xavier-uniform weights, bias 1e-2, skip weights zero (nn.py:38-43, 95-99).  Uses
         torch's global RNG (as the reference does) in state_dict order."""
         host = torch.zeros(self.nflat, dtype=torch.float32)
-        for key, (off, shp) in self._index.items():
-            v = host[off:off + int(np.prod(shp))].view(*shp)
+        for key in self._index:
+            shp = self._index[key][1]
+            v = self._view(host, key)
             if key.endswith("bias"):
                 v.fill_(1e-2)
             elif "skip_layer" in key:
