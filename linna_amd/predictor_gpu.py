@@ -107,6 +107,35 @@ class EarlyStopping(object):
         return 0
 
 
+class BatchLoader(object):
+    """Index-only stand-in for the ``torch.utils.data.DataLoader`` the reference builds at
+    util.py:1285-1286.  The arrays stay resident on the GPU; an epoch is a list of index batches.
+    ``epoch_batches`` consumes torch's global RNG exactly as iterating the DataLoader does (one
+    draw for the iterator's base seed, one for the RandomSampler seed, then ``randperm`` on a
+    private generator), so with ``torch.manual_seed(1234)`` (predictor_gpu.py:221) the sample
+    order matches the reference's."""
+
+    def __init__(self, dataset, batch_size, shuffle=False, drop_last=False):
+        self.dataset, self.batch_size, self.shuffle, self.drop_last = dataset, int(batch_size), shuffle, drop_last
+
+    def __len__(self):
+        n = len(self.dataset)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+    def epoch_batches(self):
+        n = len(self.dataset)
+        torch.empty((), dtype=torch.int64).random_()                     # _BaseDataLoaderIter base seed
+        if self.shuffle:
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            g = torch.Generator()
+            g.manual_seed(seed)
+            order = torch.randperm(n, generator=g)
+        else:
+            order = torch.arange(n)
+        nb = len(self)
+        return [order[i * self.batch_size:(i + 1) * self.batch_size] for i in range(nb)]
+
+
 class _AdamWState(object):
     """AdamW hyper-parameters + moments over the model's flat buffer (device resident);
     (de)serialises to the ``torch.optim.AdamW.state_dict()`` layout the reference stores."""

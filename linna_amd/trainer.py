@@ -1,0 +1,287 @@
+"""HIP training engine behind ``Predictor.train`` (predictor_gpu.py:201-449 of the reference).
+
+Data layout: the whole training / validation set lives in HBM once (``X[n, nin]``,
+``Y[n, nout]`` fp32); a minibatch is an int32 index vector.  One optimiser step is
+
+    gather + input transform -> network forward (activations kept) -> chi^2-ratio loss and its
+    gradient -> network backward (flat gradient buffer) -> [RCCL all-reduce over ranks] -> AdamW
+
+all enqueued on one HIP stream; on a single rank the step is captured once into a hipGraph and
+replayed (learning rate / weight decay are read from a device array, the AdamW step counter
+lives on the device).  The per-epoch controller is the reference's, on the host.
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import nnutils
+from .predictor_gpu import EarlyStopping, _AdamWState, _lower_median
+
+
+class TrainEngine(object):
+    def __init__(self, pred, loader, loss_fn, val_loader, world_size=1, dist_group=None, use_graph=True):
+        self.pred, self.model = pred, pred.model
+        dev = self.model.device
+        if dev.type != "cuda":
+            raise _lib.LinnaHipError("training runs on the GPU only (no CPU fallback)")
+        self.dev, self.ctx = dev, _lib.ctx(dev.index)
+        self.world, self.group = int(world_size), dist_group
+        self.use_graph = use_graph and self.world == 1
+        self.nin, self.nout = self.model.in_size, self.model.out_size
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev)
+        self.X, self.Y = f32(loader.dataset.X), f32(loader.dataset.y)
+        self.B = loader.batch_size
+        self.loader = loader
+        self.k = pred._device_consts()
+        sigma, ymean, ystd, data_norm, cinv = loss_fn.auxileryfunction.arrays()
+        self._keep = dict(sigma=f32(sigma), ymean=f32(ymean), ystd=f32(ystd), data_norm=f32(data_norm), cinv=f32(cinv))
+        d = _lib.LossDesc()
+        d.nout = self.nout
+        d.sigma, d.ymean, d.ystd = (_lib.ptr(self._keep[n]) for n in ("sigma", "ymean", "ystd"))
+        d.data_norm, d.Cinv, d.ldc = _lib.ptr(self._keep["data_norm"]), _lib.ptr(self._keep["cinv"]), self.nout
+        self.desc = d
+        self.den = self._chi2_md(self.Y)
+        self.val = None
+        if val_loader is not None:
+            VX, VY = f32(val_loader.dataset.X), f32(val_loader.dataset.y)
+            self.val = dict(X=VX, Y=VY, den=self._chi2_md(VY), n=VX.shape[0])
+        B, ldx, ldo = self.B, _lib.ld4(self.nin), _lib.ld4(self.nout)
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=dev)
+        self.xb, self.predb, self.dpred = z(B, ldx), z(B, ldo), z(B, ldo)
+        self.scratch = z(_lib.load().linna_loss_scratch_bytes(B, self.nout) // 4 + 4)
+        self.loss_rows, self.loss_mean = z(B), z(1)
+        self.rows = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.graph = None
+        self.inv_batch = 1.0 / (B * self.world)          # the global batch is B per rank x ranks
+
+    def _chi2_md(self, Y):
+        n = Y.shape[0]
+        den = torch.empty(n, dtype=torch.float32, device=self.dev)
+        scratch = torch.empty(_lib.load().linna_loss_scratch_bytes(n, self.nout) // 4 + 4, dtype=torch.float32, device=self.dev)
+        _lib.call("linna_chi2_md", self.ctx, C.byref(self.desc), _lib.ptr(Y), Y.stride(0), n, _lib.ptr(scratch),
+                  _lib.ptr(den), _lib.stream())
+        torch.cuda.current_stream().synchronize()
+        return den
+
+    # ------------------------------------------------------------------ one optimiser step
+    def _forward_loss_backward(self):
+        k, st = self.k, _lib.stream()
+        _lib.call("linna_gather_xform", self.ctx, _lib.ptr(self.X), self.X.stride(0), _lib.iptr(self.rows), self.B, self.nin,
+                  _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]),
+                  _lib.ptr(self.xb), self.xb.stride(0), st)
+        self.model.forward_buffer(self.xb, self.B, out=self.predb)
+        _lib.call("linna_chi2_ratio_loss_fwd_bwd", self.ctx, C.byref(self.desc), _lib.ptr(self.predb), self.predb.stride(0),
+                  _lib.ptr(self.Y), self.Y.stride(0), _lib.ptr(self.den), _lib.iptr(self.rows), self.B,
+                  _lib.ptr(self.scratch), _lib.ptr(self.loss_rows), _lib.ptr(self.loss_mean), _lib.ptr(self.dpred),
+                  self.dpred.stride(0), self.inv_batch, st)
+        self.model.backward(self.dpred[:, :self.nout], param_grads=True)
+
+    def _step_body(self, opt):
+        self._forward_loss_backward()
+        if self.world > 1:
+            import torch.distributed as dist
+            g = self.model.flat_grads()
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)            # RCCL over xGMI
+            dist.all_reduce(self.loss_mean, op=dist.ReduceOp.SUM, group=self.group)
+        opt.apply()
+
+    def step(self, opt, rows_dev):
+        """One optimiser step on the int32 device index vector ``rows_dev[B]``."""
+        self.rows.copy_(rows_dev, non_blocking=True)
+        if self.use_graph and self.graph is not None and self._graph_sig == (self.model.flat_params().data_ptr(), id(opt)):
+            _lib.call("linna_graph_launch", self.graph, _lib.stream())
+        else:
+            self._step_body(opt)
+
+    def prepare_graph(self, opt):
+        """Capture one optimiser step.  Capture does not execute: parameters are untouched."""
+        if not self.use_graph:
+            return
+        self.model.flat_grads()
+        self.model.net_handle(with_grads=True)
+        self.model.workspace(self.B)
+        self.model.workspace(self.B, "bwd")
+        if self.graph is not None:
+            _lib.call("linna_graph_destroy", self.graph)
+            self.graph = None
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            st = _lib.stream()
+            _lib.call("linna_graph_begin", st)
+            self._step_body(opt)
+            g = C.c_void_p()
+            _lib.call("linna_graph_end", st, C.byref(g))
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = g
+        self._graph_sig = (self.model.flat_params().data_ptr(), id(opt))
+
+    # ------------------------------------------------------------------ validation (util.py:1124-1127)
+    def validate(self):
+        v, k, st = self.val, self.k, _lib.stream()
+        n = v["n"]
+        if "xb" not in v:
+            z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
+            v["xb"], v["pred"] = z(n, _lib.ld4(self.nin)), z(n, _lib.ld4(self.nout))
+            v["scratch"] = z(_lib.load().linna_loss_scratch_bytes(n, self.nout) // 4 + 4)
+            v["loss_rows"], v["frac_rows"] = z(n), z(n)
+        _lib.call("linna_gather_xform", self.ctx, _lib.ptr(v["X"]), v["X"].stride(0), None, n, self.nin,
+                  _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]),
+                  _lib.ptr(v["xb"]), v["xb"].stride(0), st)
+        self.model.forward_buffer(v["xb"], n, out=v["pred"])
+        _lib.call("linna_val_rows", self.ctx, C.byref(self.desc), _lib.ptr(v["pred"]), v["pred"].stride(0), _lib.ptr(v["Y"]),
+                  v["Y"].stride(0), _lib.ptr(v["den"]), n, _lib.ptr(v["scratch"]), _lib.ptr(v["loss_rows"]),
+                  _lib.ptr(v["frac_rows"]), st)
+        loss = v["loss_rows"].cpu().numpy()
+        frac = v["frac_rows"].cpu().numpy()
+        return np.array([_lower_median(loss.tolist()), frac.max(), _lower_median(frac.tolist())], dtype=np.float64)
+
+
+def _read_lr(pred, engine, rank):
+    """predictor_gpu.py:222-245: learning rate from lr.npy (rank 0 runs the range test if absent)."""
+    path = os.path.join(pred.outdir, "lr.npy") if pred.outdir is not None else None
+    if path is not None and os.path.isfile(path):
+        return float(np.load(path))
+    if rank == 0:
+        from . import lrfinder
+        lr = lrfinder.range_test(pred, engine)
+        if path is not None:
+            np.save(path, lr)
+        return float(lr)
+    while True:                                    # other ranks wait for rank 0's file
+        try:
+            return float(np.load(path))
+        except Exception:
+            time.sleep(0.05)
+
+
+def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrombest, rank, size, dist_group,
+        checkpoint_every, progress):
+    """The body of ``Predictor.train``; returns (train_losses[steps], val_metrics[epochs, 3])."""
+    torch.manual_seed(1234)                                                     # predictor_gpu.py:221
+    size = max(int(size), 1)
+    model = pred.model
+    engine = TrainEngine(pred, dataset, loss_fn, val_dataset, world_size=size, dist_group=dist_group)
+    if pred.optim == "automatic" or pred.optim is None:
+        lr = _read_lr(pred, engine, rank)
+    else:
+        lr = float(getattr(pred.optim, "lr", 1e-3))
+    lr = lr * size                                                              # :246
+    pred.optim = None
+    if initfrombest and pred.outdir is not None:
+        if not pred.load_checkpoint():
+            print("best.pth.tar does not exsit")
+    opt = _AdamWState(model, lr, weight_decay=1e-4)                             # :267
+    pred.optim = opt
+    engine.prepare_graph(opt)
+    es = EarlyStopping(patience=500)                                            # :256
+    train_losses, val_metrics = [], []
+    old, told = 0.0, 0.0
+    best_state = None
+    nsteps = len(dataset) // size               # every rank consumes its own batch of B rows per step
+    loss_hist = torch.zeros(max(nsteps, 1), dtype=torch.float32, device=engine.dev)
+
+    def new_optimizer(lr_now):
+        nonlocal opt
+        opt = _AdamWState(model, lr_now, weight_decay=1e-4)
+        pred.optim = opt
+        engine.prepare_graph(opt)
+
+    def halve_lr():
+        if opt.lr > 2e-6:
+            print("learning rate too large: {0}".format(opt.lr), flush=True)
+            opt.lr = opt.lr / 2.0
+            opt.push_hyper()
+
+    def reinit():
+        model.init_weight()                       # fresh Xavier weights in place (model_old.init_weight(), :323)
+
+    for i in range(num_epochs):
+        batches = dataset.epoch_batches()          # same order on every rank (same torch seed)
+        perm = torch.stack(batches[:nsteps * size]).to(torch.int32).to(engine.dev) if nsteps else None
+        for s in range(nsteps):
+            engine.step(opt, perm[s * size + rank])                             # :273-288
+            loss_hist[s:s + 1].copy_(engine.loss_mean, non_blocking=True)
+        epoch_losses = loss_hist[:nsteps].cpu().numpy().astype(np.float64)
+        train_losses.extend(epoch_losses.tolist())
+        loss = float(epoch_losses[-1]) if nsteps else float("nan")
+        is_best = False
+        if val_dataset is not None:
+            val_dataset.epoch_batches()                                         # keeps torch's RNG stream aligned
+            vm = engine.validate()
+            val_metrics.append(vm)
+            if progress and rank == 0:
+                print("epoch %d  train %.5e  val %.5e" % (i, loss, vm[0]), flush=True)
+            if pred.outdir is not None:
+                is_best = vm[0] < pred.best_val_loss
+                if is_best:
+                    pred.best_val_loss = vm[0]
+            recent = np.array(val_metrics)[-10:, 0]
+            if np.std(recent) < 0.01 * np.mean(recent) and 10 <= i < 120 and i % 10 == 0:      # :319-335
+                print("bad trainning: {0}".format(i), flush=True)
+                lr_now = opt.lr
+                reinit()
+                new_optimizer(lr_now)
+                if i > 10 and lr_now > 2e-4:
+                    halve_lr()
+            v0 = val_metrics[-1][0]
+            if np.isnan(v0) or v0 > 1e10 or (v0 - old > 5 * old and i != 0) or (loss - told > 5 * told and i != 0):  # :339
+                lr_now = opt.lr
+                restored = False
+                if best_state is not None:
+                    model.flat_params().copy_(best_state)
+                    restored = True
+                elif pred.outdir is not None:
+                    restored = pred.load_checkpoint(ismpi=False)
+                if not restored:
+                    reinit()
+                new_optimizer(lr_now)
+                if np.isnan(v0) or v0 > 1e10 or (v0 - old > 10 * old):
+                    if i > 10:
+                        halve_lr()
+                if not np.isnan(v0) and (v0 - old > 5 * old):
+                    val_metrics[-1][0] = old
+            else:
+                criteria = es.step(v0, loss)                                    # :375-401
+                if criteria == 1:
+                    if opt.lr > 2e-6:
+                        print("\n learning rate too large: {0}\n".format(opt.lr), flush=True)
+                        opt.lr, opt.weight_decay = opt.lr / 2.0, opt.weight_decay / 2
+                        opt.push_hyper()
+                    else:
+                        es.cooling = 0
+                if criteria == 2:
+                    print("early stop", flush=True)
+                    print("learning rate", opt.lr, flush=True)
+                    if rank == 0:
+                        _save(pred, model, opt, i, is_best, rank, checkpoint_every, num_epochs, force=True)
+                        break
+                if criteria == 3:
+                    print("\n weight decay too small: {0}\n".format(opt.weight_decay), flush=True)
+                    if opt.weight_decay < 1e0:
+                        opt.weight_decay = opt.weight_decay * 2
+                        opt.push_hyper()
+            old = val_metrics[-1][0]
+            told = loss
+        if is_best:
+            best_state = model.flat_params().clone()                            # device-resident best.pth.tar
+        _save(pred, model, opt, i, is_best, rank, checkpoint_every, num_epochs)
+    if val_dataset is not None:
+        return np.array(train_losses), np.array(val_metrics)
+    return np.array(train_losses)
+
+
+def _save(pred, model, opt, epoch, is_best, rank, every, num_epochs, force=False):
+    """predictor_gpu.py:405-419: last.pth.tar every epoch (here: every ``every`` epochs, always
+    when it is the best so far or the last), best.pth.tar on improvement."""
+    if pred.outdir is None or rank != 0:
+        return
+    if not (is_best or force or (epoch + 1) % max(every, 1) == 0 or epoch + 1 == num_epochs):
+        return
+    sd = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
+    nnutils.save_checkpoint({"epoch": epoch + 1, "state_dict": sd, "optim_dict": opt.state_dict()}, is_best=is_best,
+                            checkpoint=pred.outdir)

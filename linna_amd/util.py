@@ -411,3 +411,146 @@ class Dlnp(object):
         _, g = self.log_prob.evaluate_with_grad(z)
         g = g.cpu().numpy()
         return g[0] if one else g
+
+
+# ------------------------------------------------------------------ training objects (util.py:383-400, 1055-1127)
+class ArrayDataset(object):
+    """util.py:383-400: float32 views of the training arrays."""
+
+    def __init__(self, X, y):
+        self.X = np.asarray(X).astype(np.float32)
+        self.y = np.asarray(y).astype(np.float32)
+
+    def __len__(self):
+        return self.X.shape[0]
+
+    def __getitem__(self, i):
+        return self.X[i, :], self.y[i, :]
+
+
+class Auxilleryfunc(object):
+    """Constants of the chi^2-ratio loss (util.py:1055-1088): the inverse of the covariance in
+    the network's normalised output space (built in fp64, stored fp32) and the normalised
+    data vector.  The arithmetic itself runs in ``linna_chi2_ratio_loss_fwd_bwd``."""
+
+    def __init__(self, data_in, cov_tensor, inv_cov_tensor, y_transform_data, y_inv_transform, device="cpu"):
+        self.inv_cov_tensor = inv_cov_tensor
+        self.transformed_cov = y_inv_transform.transform_cov(y_transform_data.transform_cov(cov_tensor))
+        inv = torch.inverse(self.transformed_cov)
+        # the reference uses inverse() as is; it is symmetric to ~1 ulp -- symmetrise in fp64 so
+        # that the analytic gradient -2 C delta is exact for the matrix actually used
+        self.inv_transformed_cov = (0.5 * (inv + inv.T)).type(torch.float32).detach()
+        self.y_transform_data = y_transform_data
+        self.y_inv_transform = y_inv_transform
+        self.device = device
+        self.data = data_in
+        d = torch.as_tensor(_np32(data_in))
+        self.data_in = torch.nan_to_num(y_inv_transform(y_transform_data(d)), nan=1e-30).detach().reshape(-1)
+
+    def arrays(self):
+        """(sigma, y_mean, y_std, data_norm, Cinv) as float32 numpy arrays."""
+        return (_np32(self.y_transform_data.sigma), _np32(self.y_inv_transform.y_mean), _np32(self.y_inv_transform.y_std),
+                _np32(self.data_in), _np32(self.inv_transformed_cov))
+
+
+class Loss_fn(object):
+    """Training loss: mean over the batch of chi2(target, pred)/max(chi2(target, data), nout/2)
+    (util.py:1090-1116)."""
+
+    def __init__(self, data_in, cov_tensor, inv_cov_tensor, y_transform_data, y_inv_transform, device="cpu"):
+        self.auxileryfunction = Auxilleryfunc(data_in, cov_tensor, inv_cov_tensor, y_transform_data, y_inv_transform, device)
+
+
+class Val_metric_fn(Loss_fn):
+    """Validation metric [median loss, max |chi2_nnd/chi2_Md - 1|, median of the same] (util.py:1118-1127)."""
+
+
+def median_absolute_deviation(y, median, dim):
+    """util.py:1308-1313 (torch.median: lower middle element)."""
+    return torch.abs(y - median).median(axis=dim).values
+
+
+def _load_samples(outdir_list):
+    """util.py:1342-1373: concatenate the samples of all iterations so far."""
+    tx, ty, vx, vy = [], [], [], []
+    for outdir in outdir_list:
+        for lst, name, loader in ((tx, "train_samples_x.txt", np.loadtxt), (ty, "train_samples_y.npy", np.load),
+                                  (vx, "val_samples_x.txt", np.loadtxt), (vy, "val_samples_y.npy", np.load)):
+            a = loader(os.path.join(outdir, name))
+            if len(a) > 1:
+                lst.append(a)
+    train_x, train_y, val_x, val_y = (np.concatenate(v) for v in (tx, ty, vx, vy))
+    train_y_last = np.load(outdir_list[0] + "train_samples_y.npy")
+    if len(train_y_last) == 0:
+        train_y_last = train_y
+    return train_x, train_y, val_x, val_y, train_y_last
+
+
+def train_nn(outdir, model, train_x, train_y, val_x, val_y, X_transform, y_transform, loss_fn, val_metric_fn, dev="cpu",
+             verbose=False, retrain=True, pool=None, nocpu=False, size=0, rank=0, params=None, dist_group=None):
+    """util.py:1272-1306: wrap the arrays and run ``Predictor.train``."""
+    if not retrain and os.path.isfile(os.path.join(outdir, "best.pth.tar")):
+        return None
+    model = predictor_gpu.Predictor(train_x.shape[-1], train_y.shape[-1], X_transform=X_transform, y_transform=y_transform,
+                                    device=dev, optim="automatic", model=model, scheduler=None, outdir=outdir)
+    loader = predictor_gpu.BatchLoader(ArrayDataset(train_x, train_y), batch_size=params["batch_size"], shuffle=True,
+                                       drop_last=True)
+    val_loader = predictor_gpu.BatchLoader(ArrayDataset(val_x, val_y), batch_size=len(val_y), shuffle=False,
+                                           drop_last=False)
+    model.train_history = model.train(loader, params["num_epochs"], loss_fn, val_loader, val_metric_fn, initfrombest=True,
+                                      pool=None, nocpu=nocpu, rank=rank, size=size, dist_group=dist_group,
+                                      checkpoint_every=params.get("checkpoint_every", 1))
+    return model
+
+
+def train_NN(nnsampler, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog10index=None, ypositive=False, retrain=True,
+             norder=2, temperature=None, docuda=False, pool=None, tsize=1, nnmodel_in=None, params=None, usebest=False,
+             device=None, dist_group=None, rank=0):
+    """Prepare statistics, transforms and loss, then train (util.py:1315-1472).  Same positional
+    signature as the reference (``model_args.pkl`` holds the first 18 arguments, main.py:197).
+    ``docuda`` is accepted for parity; training always runs on the GPU here."""
+    if ypositive:
+        raise NotImplementedError("ypositive=True training (log-space targets) is not on the ml_sampler path (main.py:66)")
+    if usebest:
+        raise NotImplementedError("usebest (optimizer-generated samples, main.py:146-152) is outside the hot path")
+    if device is None:
+        device = "cuda"
+    sigma = np.asarray(sigma)
+    y_transform_data = Y_transform_data(sigma, device="cpu")
+    y_invtransform_data = Y_invtransform_data(sigma, device="cpu")
+    if rank == 0:
+        y_transform_data.pickle(os.path.join(outdir_in, "y_transform_data.pkl"))
+        y_invtransform_data.pickle(os.path.join(outdir_in, "y_invtransform_data.pkl"))
+    data_tensor = torch.from_numpy(np.asarray(data).astype(np.float32))
+    train_x, train_y, val_x, val_y, train_y_last = _load_samples(outdir_list)
+    print(train_x.shape, train_y.shape, val_x.shape, val_y.shape)
+    # sentinel clipping, util.py:1433-1438
+    train_y = np.clip(train_y, -1e5, 1e10)
+    val_y = np.clip(val_y, -1e5, 1e8)
+    train_y_last = np.clip(train_y_last, -1e5, 1e10)
+    X1 = torch.tensor(train_x, dtype=torch.float32)
+    if dolog10index is not None:
+        for ind in dolog10index:
+            X1[:, ind] = torch.log10(X1[:, ind])
+    X_mean, X_std = X1.mean(axis=0), X1.std(axis=0)                                       # util.py:1440-1441
+    X_transform = X_transform_class(X_mean, X_std, "cpu", dolog10index)
+    ys = y_transform_data(torch.tensor(train_y_last, dtype=torch.float32))
+    y_mean = ys.median(axis=0).values                                                     # util.py:1449
+    y_std = median_absolute_deviation(ys, y_mean, 0)
+    y_std[y_std < 1e-10] = 1.0                                                            # util.py:1451
+    y_transform = Y_transform_class(y_mean, y_std, "cpu", ypositive=False)
+    y_inv_transform = Y_invtransform_class(y_mean, y_std, data_tensor, "cpu", ypositive=False)
+    if rank == 0:
+        X_transform.pickle(os.path.join(outdir_in, "X_transform.pkl"))
+        y_transform.pickle(os.path.join(outdir_in, "y_transform.pkl"))
+        y_inv_transform.pickle(os.path.join(outdir_in, "y_invtransform.pkl"))
+    cov_t = torch.tensor(np.asarray(cov), dtype=torch.float64)
+    icov_t = torch.tensor(np.asarray(inv_cov), dtype=torch.float64)
+    loss_fn = Loss_fn(data_tensor, cov_t, icov_t, y_transform_data, y_inv_transform, "cpu")
+    val_metric_fn = Val_metric_fn(data_tensor, cov_t, icov_t, y_transform_data, y_inv_transform, "cpu")
+    nnmodel = nnmodel_in(len(train_x[0]), len(train_y[0]), None, docpu=False)
+    if nnsampler is not None:
+        nnsampler.model = nnmodel
+    return train_nn(outdir_in, nnmodel, train_x, train_y, val_x, val_y, X_transform, y_transform, loss_fn, val_metric_fn,
+                    dev=device, verbose=True, retrain=retrain, pool=pool, nocpu=True, size=tsize, rank=rank, params=params,
+                    dist_group=dist_group)

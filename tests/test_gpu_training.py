@@ -1,0 +1,151 @@
+"""GPU parity of the training path (through the C ABI): loss, gradients, AdamW and the full
+train_NN trajectory against golden vectors captured from the live reference."""
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+import cases
+import synth
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def make_engine(name, steps_as_dataset=True):
+    from linna_amd import nn, util, predictor_gpu, trainer
+    p = cases.training_problem(name)
+    cls = {"ChtoModelv2": nn.ChtoModelv2, "MLP": nn.MLP}[p["kind"]]
+    model = cls(p["nin"], p["nout"], None, **p["kw"])
+    model.load_state_dict(p["weights"])
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    Xt = util.X_transform_class(t(p["X_mean"]), t(p["X_std"]), "cpu", None)
+    Yt = util.Y_transform_class(t(p["y_mean"]), t(p["y_std"]), "cpu")
+    pred = predictor_gpu.Predictor(p["nin"], p["nout"], model=model, X_transform=Xt, y_transform=Yt, device="cuda")
+    ytd = util.Y_transform_data(p["sigma"], "cpu")
+    yinv = util.Y_invtransform_class(t(p["y_mean"]), t(p["y_std"]), t(p["data"]), "cpu")
+    lf = util.Loss_fn(t(p["data"]), torch.tensor(p["cov"], dtype=torch.float64),
+                      torch.tensor(np.linalg.inv(p["cov"]), dtype=torch.float64), ytd, yinv, "cpu")
+    B = p["X"].shape[1]
+    X = p["X"].reshape(3 * B, -1)
+    Y = p["Y"].reshape(3 * B, -1)
+    loader = predictor_gpu.BatchLoader(util.ArrayDataset(X, Y), B, shuffle=False, drop_last=True)
+    eng = trainer.TrainEngine(pred, loader, lf, loader, use_graph=False)
+    return p, model, pred, eng, B
+
+
+@pytest.mark.parametrize("name", [c[0] for c in cases.TRAIN])
+def test_loss_gradients_and_adamw_match_reference(name):
+    from linna_amd.predictor_gpu import _AdamWState
+    g = cases.golden(name)
+    p, model, pred, eng, B = make_engine(name)
+    opt = _AdamWState(model, float(g["lr"]), weight_decay=1e-4)
+    losses = []
+    for s in range(3):
+        rows = torch.arange(s * B, (s + 1) * B, dtype=torch.int32, device="cuda")
+        eng.rows.copy_(rows)
+        eng._forward_loss_backward()
+        if s == 0:
+            pred0 = eng.predb[:, :p["nout"]].cpu().numpy()
+            np.testing.assert_allclose(pred0, g["pred0"], rtol=1e-3, atol=1e-4 * np.abs(g["pred0"]).max())
+            np.testing.assert_allclose(eng.loss_rows.cpu().numpy(), g["loss_rows0"], rtol=2e-3)
+            dp = eng.dpred[:, :p["nout"]].cpu().numpy()
+            np.testing.assert_allclose(dp, g["dpred0"], rtol=2e-3, atol=2e-5 * np.abs(g["dpred0"]).max())
+            for k, gk in model.grad_dict().items():
+                ref = g["grad0/" + k]
+                got = gk.cpu().numpy() if p["full"] else synth.tensor_digest(gk.cpu().numpy())
+                np.testing.assert_allclose(got, ref, rtol=3e-3, atol=3e-5 * np.abs(ref).max() + 1e-9, err_msg=k)
+        losses.append(float(eng.loss_mean.item()))
+        opt.apply()
+        for k, v in model.state_dict().items():
+            ref = g["param%d/%s" % (s + 1, k)]
+            got = v.cpu().numpy() if p["full"] else synth.tensor_digest(v.cpu().numpy())
+            np.testing.assert_allclose(got, ref, rtol=1e-3, atol=3e-4 * np.abs(ref).max() + 1e-7, err_msg=k)
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-3)
+    # validation metric pieces on minibatch 0 (util.py:1124-1127), with the ORIGINAL weights
+    model.load_state_dict(p["weights"])
+    vm = eng.validate()
+    assert vm.shape == (3,) and np.all(np.isfinite(vm))
+
+
+def test_chi2_denominator_and_masks():
+    from oracle import training
+    name = "train_v2_5_3"
+    g = cases.golden(name)
+    p, model, pred, eng, B = make_engine(name)
+    den = eng.den.cpu().numpy()[:B]
+    np.testing.assert_allclose(den, g["chisqMd0"], rtol=2e-4)
+    eng.rows.copy_(torch.arange(B, dtype=torch.int32, device="cuda"))
+    eng._forward_loss_backward()
+    dp = eng.dpred[:, :p["nout"]].cpu().numpy()
+    assert dp[1, 0] == 0.0                 # masked sentinel entry (1e10) carries no gradient (util.py:1072-1084)
+
+
+def test_graph_replay_equals_direct_launches():
+    from linna_amd.predictor_gpu import _AdamWState
+    from linna_amd import trainer
+    res = []
+    for use_graph in (False, True):
+        p, model, pred, eng, B = make_engine("train_mlp_7_5")
+        eng.use_graph = use_graph
+        opt = _AdamWState(model, 1e-3)
+        if use_graph:
+            eng.prepare_graph(opt)
+        for s in range(3):
+            eng.step(opt, torch.arange(s * B, (s + 1) * B, dtype=torch.int32, device="cuda"))
+        torch.cuda.synchronize()
+        res.append(model.flat_params().cpu().numpy().copy())
+    np.testing.assert_array_equal(res[0], res[1])
+
+
+def test_train_NN_trajectory_matches_reference(tmp_path):
+    """The whole util.train_NN -> Predictor.train run of the reference (6 epochs, batch 50,
+    lr.npy = 2e-3, same initial weights through the nnmodel_in plug-in, same sample order from
+    torch.manual_seed(1234)): per-step training losses and per-epoch validation metrics."""
+    from linna_amd import util, nn
+    g = cases.golden("train_nn_run")
+    out = str(tmp_path) + "/"
+    np.savetxt(out + "train_samples_x.txt", g["train_x"]); np.save(out + "train_samples_y.npy", g["train_y"])
+    np.savetxt(out + "val_samples_x.txt", g["val_x"]); np.save(out + "val_samples_y.npy", g["val_y"])
+    np.save(out + "lr.npy", float(g["lr"]))
+    w0 = synth.weights("ChtoModelv2", 5, 3, 301)
+
+    def factory(in_size, out_size, linearmodel, docpu=False):
+        m = nn.ChtoModelv2(in_size, out_size, linearmodel, docpu=docpu)
+        m.load_state_dict(w0)
+        return m
+
+    cov = g["cov"]
+    model = util.train_NN(None, cov, np.linalg.inv(cov), np.sqrt(np.diag(cov)), out, [out], g["data"], None, False, True, 2,
+                          1.0, False, None, 1, factory, {"num_epochs": int(g["num_epochs"]), "batch_size": int(g["batch_size"])},
+                          False)
+    train_losses, val_metrics = model.train_history
+    np.testing.assert_allclose(model.X_transform.X_mean.numpy(), g["X_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(model.y_transform.y_std.numpy(), g["y_std"], rtol=1e-5)
+    assert len(train_losses) == len(g["train_losses"])
+    np.testing.assert_allclose(train_losses, g["train_losses"], rtol=5e-3)
+    np.testing.assert_allclose(val_metrics, g["val_metrics"], rtol=1e-2)
+    # artefacts in the reference's on-disk layout
+    for f in ("best.pth.tar", "last.pth.tar", "X_transform.pkl", "y_transform.pkl", "y_invtransform.pkl",
+              "y_transform_data.pkl", "y_invtransform_data.pkl"):
+        assert os.path.isfile(out + f), f
+    ck = torch.load(out + "best.pth.tar", weights_only=False)
+    assert int(ck["epoch"]) == int(g["best_epoch"])
+    for k, v in ck["state_dict"].items():
+        ref = g["best/" + k]
+        np.testing.assert_allclose(v.numpy(), ref, rtol=2e-2, atol=2e-3 * np.abs(ref).max() + 1e-6, err_msg=k)
+    # and the freshly written directory serves through retrieve_model + Log_prob
+    pm, yinv = util.retrieve_model(out, 5, 3, nn.ChtoModelv2)
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -1.0, "arg2": 1.0} for i in range(5)]
+    lp = util.Log_prob(g["data"], np.linalg.inv(cov), pm, yinv, util.Transform(priors), 1.0)
+    assert np.all(np.isfinite(lp(np.zeros((4, 5), np.float32), returntorch=False)))
+
+
+def test_lr_range_test_runs_and_restores_weights(tmp_path):
+    from linna_amd import lrfinder
+    p, model, pred, eng, B = make_engine("train_mlp_7_5")
+    before = model.flat_params().clone()
+    lr = lrfinder.range_test(pred, eng, num_iter=20)
+    assert 1e-4 <= lr <= 5e-3
+    assert torch.equal(before, model.flat_params())

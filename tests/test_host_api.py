@@ -1,0 +1,153 @@
+"""CPU: host-side logic of the product (no GPU compute): EarlyStopping traces, batch order,
+checkpoint formats, reference-artefact loading, parameter layout."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+import synth
+
+
+def test_early_stopping_matches_reference_traces():
+    from linna_amd.predictor_gpu import EarlyStopping
+    g = cases.golden("early_stopping")
+    names = sorted({k.split("/")[0] for k in g.files if k.endswith("/val")})
+    assert names
+    for name in names:
+        es = EarlyStopping(patience=500)
+        codes = []
+        for a, b in zip(g[name + "/val"], g[name + "/train"]):
+            c = es.step(float(a), float(b))
+            codes.append(int(c))
+            if c == 2:
+                break
+        np.testing.assert_array_equal(codes, g[name + "/codes"], err_msg=name)
+    es = EarlyStopping(patience=40, nqueue=20)
+    codes = []
+    for a, b in zip(g["overfit/val"], g["overfit/train"]):
+        c = es.step(float(a), float(b))
+        codes.append(int(c))
+        if c == 2:
+            break
+    np.testing.assert_array_equal(codes, g["overfit_p40/codes"])
+    assert 2 in codes and 1 in codes
+
+
+def test_batch_order_matches_torch_dataloader_with_seed_1234():
+    from linna_amd.predictor_gpu import BatchLoader
+    from linna_amd.util import ArrayDataset
+    g = cases.golden("loader_order")
+    n, batch = int(g["n"]), int(g["batch"])
+    X = np.zeros((n, 2), np.float32)
+    loader = BatchLoader(ArrayDataset(X, X), batch, shuffle=True, drop_last=True)
+    torch.manual_seed(1234)
+    for ep in range(g["order"].shape[0]):
+        got = torch.cat(loader.epoch_batches()).numpy()
+        np.testing.assert_array_equal(got, g["order"][ep])
+
+
+def test_parameter_layout_and_state_dict_roundtrip():
+    from linna_amd import nn
+    m = nn.ChtoModelv2(33, 33, None)
+    assert m.nparams == 843892 and m.macs_per_eval() == 841339
+    assert nn.MLP(33, 33, None).nparams == 822305
+    keys = list(m.state_dict().keys())
+    assert keys[:2] == ["layer1.weight", "layer1.bias"] and "layer2.skip_layer.weight" in keys
+    assert "layer8.bias" == keys[-1]
+    w = synth.weights("ChtoModelv2", 33, 33, 7)
+    m.load_state_dict(w)
+    for k, v in m.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), w[k])
+    # init: skip weights zero, bias 0.01 (nn.py:38-43)
+    m.init_weight()
+    sd = m.state_dict()
+    assert float(sd["layer3.skip_layer.weight"].abs().max()) == 0.0
+    assert np.allclose(sd["layer6.bias"].numpy(), 1e-2)
+    lin = nn.ChtoModelv2_linear(5, 3, None).state_dict()
+    assert np.allclose(lin["linearlayer.weight"].numpy(), 1e-5) and float(lin["linearlayer.bias"].abs().max()) == 0
+    with pytest.raises(KeyError):
+        m.load_state_dict({"layer1.weight": w["layer1.weight"]})
+
+
+def test_reference_fixture_artefacts_load_on_cpu():
+    """The reference's committed checkpoint + transform pickles (linna.util.* classes) load
+    through the product's readers."""
+    from linna_amd import util, nn, nnutils
+    outdir = os.path.join(cases.GOLDEN, "2dgaussian_Fulltconn/iter_0/")
+    g = cases.golden("fixture2d")
+    ck = nnutils.read_checkpoint(os.path.join(outdir, "best.pth.tar"))
+    assert set(ck) >= {"epoch", "state_dict", "optim_dict"}
+    model, yinv = util.retrieve_model(outdir, 2, 2, nn.ChtoModelv2, device="cpu")
+    assert model.model.nparams == 8016
+    np.testing.assert_allclose(model.X_transform.X_std.numpy(), g["X_std"])
+    np.testing.assert_allclose(model.y_transform.y_mean.numpy(), g["y_mean"])
+    np.testing.assert_allclose(yinv.sigma.detach().numpy(), g["sigma"])
+    for k, v in ck["state_dict"].items():
+        np.testing.assert_array_equal(model.model.state_dict()[k].numpy(), v.numpy())
+
+
+def test_checkpoint_written_in_reference_layout(tmp_path):
+    from linna_amd import nn, nnutils
+    from linna_amd.predictor_gpu import _AdamWState
+    m = nn.ChtoModelv2(4, 2, None)
+    opt = _AdamWState.__new__(_AdamWState)
+    opt.model, opt.lr, opt.weight_decay, opt.betas, opt.eps = m, 1e-3, 1e-4, (0.9, 0.999), 1e-8
+    opt.m, opt.v = torch.zeros_like(m.flat_params()), torch.ones_like(m.flat_params())
+    opt.step_dev, opt.hyper = torch.tensor([7], dtype=torch.int32), torch.zeros(4)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    nnutils.save_checkpoint({"epoch": 3, "state_dict": sd, "optim_dict": opt.state_dict()}, True, str(tmp_path))
+    ck = torch.load(os.path.join(str(tmp_path), "best.pth.tar"), weights_only=False)
+    assert ck["epoch"] == 3 and list(ck["state_dict"]) == list(m.state_dict())
+    pg = ck["optim_dict"]["param_groups"][0]
+    assert pg["lr"] == 1e-3 and pg["weight_decay"] == 1e-4 and len(pg["params"]) == len(sd)
+    assert float(ck["optim_dict"]["state"][0]["step"]) == 7.0
+    # and a torch.optim.AdamW over same-shaped tensors accepts it (what the reference would do)
+    params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    topt = torch.optim.AdamW(params, lr=1.0)
+    topt.load_state_dict(ck["optim_dict"])
+    assert topt.param_groups[0]["lr"] == 1e-3
+
+
+def test_transform_python_path_matches_reference_theta():
+    from linna_amd import util
+    name = "v2lin_5_3_log10"
+    g = cases.golden(name)
+    prob = cases.serving_problem(name)
+    t = util.Transform(prob["priors"])
+    theta = np.stack([t(z) for z in g["z"][:8]])
+    np.testing.assert_allclose(theta, g["theta"][:8], rtol=2e-6, atol=2e-6)
+    back = util.invTransform(prob["priors"])(theta[0].astype(np.float64))
+    np.testing.assert_allclose(back, g["z"][0], rtol=2e-3, atol=2e-3)
+
+
+def test_loss_constants_match_reference():
+    from linna_amd import util
+    g = cases.golden("train_v2_12_40")
+    p = cases.training_problem("train_v2_12_40")
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    ytd = util.Y_transform_data(p["sigma"], "cpu")
+    yinv = util.Y_invtransform_class(t(p["y_mean"]), t(p["y_std"]), t(p["data"]), "cpu")
+    lf = util.Loss_fn(t(p["data"]), torch.tensor(p["cov"], dtype=torch.float64),
+                      torch.tensor(np.linalg.inv(p["cov"]), dtype=torch.float64), ytd, yinv, "cpu")
+    sigma, ymean, ystd, data_norm, cinv = lf.auxileryfunction.arrays()
+    np.testing.assert_allclose(cinv, g["icov_norm"], rtol=1e-5, atol=1e-6 * np.abs(g["icov_norm"]).max())
+    np.testing.assert_allclose(data_norm, g["data_norm"].reshape(-1), rtol=1e-5, atol=1e-6)
+    assert np.array_equal(cinv, cinv.T)
+
+
+def test_missing_library_is_a_loud_error(monkeypatch):
+    from linna_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblinna_hip.so")
+    with pytest.raises(_lib.LinnaHipError):
+        _lib.load()
+
+
+def test_cpu_model_refuses_to_compute():
+    from linna_amd import nn, _lib
+    m = nn.MLP(7, 5, None, width=48, depth=3)
+    with pytest.raises(_lib.LinnaHipError):
+        m.forward(torch.zeros(2, 7))
