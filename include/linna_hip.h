@@ -246,25 +246,29 @@ int linna_adamw_step(linna_ctx_t* ctx, float* p, const float* g, float* m, float
 /* ------------------------------------------------------------------ ensemble / HMC moves
  * Stretch move (emcee StretchMove, called at sampler.py:493-495,530): for the active half
  *   zz = ((a-1)u+1)^2/a ; q = c[r] - (c[r]-s) zz ; factor = (ndim-1) log zz
- * with Philox4x32-10 draws keyed (seed; walker, step, stream).  `S_idx`/`C_idx` are int32
- * device arrays listing the active and complementary walkers. */
+ * with Philox4x32-10 draws keyed (seed; walker, step, stream).  `S_idx` lists the active rows of
+ * `coords`, `C_idx` the complementary rows of `ccoords` (the same array on one GPU; the
+ * all-gathered complement of every rank when walkers are sharded). */
 int linna_stretch_propose(linna_ctx_t* ctx, const float* coords, int ldc, int ndim, const int* S_idx,
-                          int ns, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
-                          int stream_id, float a, float* Q, int ldq, float* factors, void* stream);
+                          int ns, const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed,
+                          const int* step_dev, int stream_id, float a, float* Q, int ldq, float* factors,
+                          void* stream);
 int linna_stretch_accept(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float* logp,
                          const int* S_idx, int ns, const float* Q, int ldq, const float* logp_new,
                          const float* factors, uint64_t seed, const int* step_dev, int stream_id,
                          int* naccept, void* stream);
 /* leapfrog pieces for batched per-walker HMC (HMCSampler.py:26-54, sampler.py:67-98). */
+/* P0 (standard-normal draws [B][ldp0]) and U (uniforms [B]) are optional: NULL = Philox draws. */
 int linna_hmc_init(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint64_t seed,
-                   const int* step_dev, const float* lnp, float* P, int ldp, float* H0, void* stream);
+                   const int* step_dev, const float* lnp, const float* P0, int ldp0, float* P, int ldp,
+                   float* H0, void* stream);
 int linna_hmc_kick_drift(linna_ctx_t* ctx, int B, int ndim, const float* mass, float eps_kick,
                          float eps_drift, const float* G, int ldg, float* P, int ldp, float* Q, int ldq,
                          void* stream);
 int linna_hmc_accept(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint64_t seed,
                      const int* step_dev, const float* H0, const float* P, int ldp, const float* Qnew,
-                     int ldq, const float* lnp_new, const float* Gnew, int ldg, float* X, int ldx,
-                     float* lnp, float* G, int* naccept, void* stream);
+                     int ldq, const float* lnp_new, const float* Gnew, int ldg, const float* U, float* X,
+                     int ldx, float* lnp, float* G, int* naccept, void* stream);
 int linna_step_increment(linna_ctx_t* ctx, int* step_dev, void* stream);
 
 #ifdef __cplusplus

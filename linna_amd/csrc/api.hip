@@ -525,11 +525,12 @@ int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v,
 }
 
 // ------------------------------------------------------------------ moves
-int linna_stretch_propose(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns, const int* C_idx,
-                          int nc, uint64_t seed, const int* step_dev, int stream_id, float a, float* Q, int ldq,
-                          float* factors, void* stream) {
+int linna_stretch_propose(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
+                          const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
+                          int stream_id, float a, float* Q, int ldq, float* factors, void* stream) {
     if (ns < 1 || nc < 1) { set_error("stretch_propose: empty walker set"); return LINNA_ERR_INVALID; }
-    return launch_stretch_propose(coords, ldc, ndim, S_idx, ns, C_idx, nc, seed, step_dev, stream_id, a, Q, ldq, factors, S(stream));
+    return launch_stretch_propose(coords, ldc, ndim, S_idx, ns, ccoords, ldcc, C_idx, nc, seed, step_dev, stream_id, a, Q,
+                                  ldq, factors, S(stream));
 }
 int linna_stretch_accept(linna_ctx_t*, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                          const float* Q, int ldq, const float* logp_new, const float* factors, uint64_t seed,
@@ -537,8 +538,8 @@ int linna_stretch_accept(linna_ctx_t*, float* coords, int ldc, int ndim, float* 
     return launch_stretch_accept(coords, ldc, ndim, logp, S_idx, ns, Q, ldq, logp_new, factors, seed, step_dev, stream_id, naccept, S(stream));
 }
 int linna_hmc_init(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
-                   float* P, int ldp, float* H0, void* stream) {
-    return launch_hmc_init(B, ndim, mass, seed, step_dev, lnp, P, ldp, H0, S(stream));
+                   const float* P0, int ldp0, float* P, int ldp, float* H0, void* stream) {
+    return launch_hmc_init(B, ndim, mass, seed, step_dev, lnp, P0, ldp0, P, ldp, H0, S(stream));
 }
 int linna_hmc_kick_drift(linna_ctx_t*, int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg,
                          float* P, int ldp, float* Q, int ldq, void* stream) {
@@ -546,8 +547,8 @@ int linna_hmc_kick_drift(linna_ctx_t*, int B, int ndim, const float* mass, float
 }
 int linna_hmc_accept(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
                      const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
-                     float* X, int ldx, float* lnp, float* G, int* naccept, void* stream) {
-    return launch_hmc_accept(B, ndim, mass, seed, step_dev, H0, P, ldp, Qn, ldq, lnp_new, Gn, ldg, X, ldx, lnp, G, naccept, S(stream));
+                     const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, void* stream) {
+    return launch_hmc_accept(B, ndim, mass, seed, step_dev, H0, P, ldp, Qn, ldq, lnp_new, Gn, ldg, U, X, ldx, lnp, G, naccept, S(stream));
 }
 int linna_step_increment(linna_ctx_t*, int* step_dev, void* stream) { return launch_step_increment(step_dev, S(stream)); }
 

@@ -50,19 +50,19 @@ int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,
                  float eps, hipStream_t s);
-int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const int* C, int nc,
-                           uint64_t seed, const int* step_dev, int stream_id, float a, float* Q, int ldq, float* factors,
-                           hipStream_t s);
+int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const float* ccoords, int ldcc,
+                           const int* C, int nc, uint64_t seed, const int* step_dev, int stream_id, float a, float* Q,
+                           int ldq, float* factors, hipStream_t s);
 int launch_stretch_accept(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* Q, int ldq,
                           const float* lp_new, const float* factors, uint64_t seed, const int* step_dev, int stream_id,
                           int* naccept, hipStream_t s);
-int launch_hmc_init(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp, float* P,
-                    int ldp, float* H0, hipStream_t s);
+int launch_hmc_init(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
+                    const float* P0, int ldp0, float* P, int ldp, float* H0, hipStream_t s);
 int launch_hmc_kick_drift(int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg, float* P,
                           int ldp, float* Q, int ldq, hipStream_t s);
 int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
                       const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
-                      float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s);
+                      const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write

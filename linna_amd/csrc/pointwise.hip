@@ -264,7 +264,8 @@ __device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t st
 
 // ------------------------------------------------------------------ stretch move (emcee StretchMove / RedBlueMove)
 __global__ void stretch_propose_kernel(const float* __restrict__ coords, int ldc, int ndim, const int* __restrict__ S,
-                                       int ns, const int* __restrict__ C, int nc, uint64_t seed,
+                                       int ns, const float* __restrict__ ccoords, int ldcc, const int* __restrict__ C,
+                                       int nc, uint64_t seed,
                                        const int* __restrict__ step_dev, int stream_id, float a,
                                        float* __restrict__ Q, int ldq, float* __restrict__ factors) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -277,7 +278,7 @@ __global__ void stretch_propose_kernel(const float* __restrict__ coords, int ldc
     const float zz = t * t / a;
     int j = (int)(((uint64_t)r.y * (uint64_t)nc) >> 32);
     const int wc = C[j];
-    const float cr = coords[(size_t)wc * ldc + d], s = coords[(size_t)wk * ldc + d];
+    const float cr = ccoords[(size_t)wc * ldcc + d], s = coords[(size_t)wk * ldc + d];
     Q[idx] = cr - (cr - s) * zz;
     if (d == 0) factors[k] = ((float)ndim - 1.f) * logf(zz);
 }
@@ -308,13 +309,15 @@ __device__ __forceinline__ float normal_draw(uint64_t seed, uint32_t w, uint32_t
 
 __global__ void hmc_init_kernel(int B, int ndim, const float* __restrict__ mass, uint64_t seed,
                                 const int* __restrict__ step_dev, const float* __restrict__ lnp,
+                                const float* __restrict__ P0, int ldp0,
                                 float* __restrict__ P, int ldp, float* __restrict__ H0) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float ke = 0.f;
     for (int d = 0; d < ndim; ++d) {
         const float m = mass[d];
-        const float p = normal_draw(seed, (uint32_t)b, (uint32_t)step_dev[0], 1u, d) * sqrtf(m);
+        const float n01 = P0 ? P0[(size_t)b * ldp0 + d] : normal_draw(seed, (uint32_t)b, (uint32_t)step_dev[0], 1u, d);
+        const float p = n01 * sqrtf(m);
         P[(size_t)b * ldp + d] = p;
         ke += p * p / m;
     }
@@ -337,6 +340,7 @@ __global__ void hmc_accept_kernel(int B, int ndim, const float* __restrict__ mas
                                   const int* __restrict__ step_dev, const float* __restrict__ H0,
                                   const float* __restrict__ P, int ldp, const float* __restrict__ Qn, int ldq,
                                   const float* __restrict__ lnp_new, const float* __restrict__ Gn, int ldg,
+                                  const float* __restrict__ U,
                                   float* __restrict__ X, int ldx, float* __restrict__ lnp, float* __restrict__ G,
                                   int* __restrict__ naccept) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,7 +351,8 @@ __global__ void hmc_accept_kernel(int B, int ndim, const float* __restrict__ mas
     const float H1 = 0.5f * ke - ln;
     const U4 r = walker_bits(seed, (uint32_t)b, (uint32_t)step_dev[0], 2u, 0u);
     const float ratio = expf(fminf(H0[b] - H1, 0.f));
-    if (isfinite(ln) && u01(r.x) < ratio) {
+    const float u = U ? U[b] : u01(r.x);
+    if (isfinite(ln) && u < ratio) {
         for (int d = 0; d < ndim; ++d) {
             X[(size_t)b * ldx + d] = Qn[(size_t)b * ldq + d];
             G[(size_t)b * ldg + d] = Gn[(size_t)b * ldg + d];
@@ -434,11 +439,11 @@ int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* 
     hipLaunchKernelGGL(adamw_kernel, grid1d(n, 256), dim3(256), 0, s, p, g, m, v, n, hyper, b1, b2, eps);
     LAUNCH_CHECK("adamw");
 }
-int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const int* C, int nc,
-                           uint64_t seed, const int* step_dev, int stream_id, float a, float* Q, int ldq, float* factors,
-                           hipStream_t s) {
+int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const float* ccoords, int ldcc,
+                           const int* C, int nc, uint64_t seed, const int* step_dev, int stream_id, float a, float* Q,
+                           int ldq, float* factors, hipStream_t s) {
     hipLaunchKernelGGL(stretch_propose_kernel, grid1d((size_t)ns * ldq, 256), dim3(256), 0, s, coords, ldc, ndim, S, ns,
-                       C, nc, seed, step_dev, stream_id, a, Q, ldq, factors);
+                       ccoords, ldcc, C, nc, seed, step_dev, stream_id, a, Q, ldq, factors);
     LAUNCH_CHECK("stretch_propose");
 }
 int launch_stretch_accept(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* Q, int ldq,
@@ -448,9 +453,10 @@ int launch_stretch_accept(float* coords, int ldc, int ndim, float* logp, const i
                        lp_new, factors, seed, step_dev, stream_id, naccept);
     LAUNCH_CHECK("stretch_accept");
 }
-int launch_hmc_init(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp, float* P,
-                    int ldp, float* H0, hipStream_t s) {
-    hipLaunchKernelGGL(hmc_init_kernel, grid1d(B, 256), dim3(256), 0, s, B, ndim, mass, seed, step_dev, lnp, P, ldp, H0);
+int launch_hmc_init(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
+                    const float* P0, int ldp0, float* P, int ldp, float* H0, hipStream_t s) {
+    hipLaunchKernelGGL(hmc_init_kernel, grid1d(B, 256), dim3(256), 0, s, B, ndim, mass, seed, step_dev, lnp, P0, ldp0, P,
+                       ldp, H0);
     LAUNCH_CHECK("hmc_init");
 }
 int launch_hmc_kick_drift(int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg, float* P,
@@ -461,9 +467,9 @@ int launch_hmc_kick_drift(int B, int ndim, const float* mass, float ek, float ed
 }
 int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
                       const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
-                      float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s) {
+                      const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s) {
     hipLaunchKernelGGL(hmc_accept_kernel, grid1d(B, 256), dim3(256), 0, s, B, ndim, mass, seed, step_dev, H0, P, ldp, Qn,
-                       ldq, lnp_new, Gn, ldg, X, ldx, lnp, G, naccept);
+                       ldq, lnp_new, Gn, ldg, U, X, ldx, lnp, G, naccept);
     LAUNCH_CHECK("hmc_accept");
 }
 int launch_step_increment(int* step, hipStream_t s) {

@@ -1,0 +1,128 @@
+"""LINNA top-level entry points on MI355X: ``ml_sampler`` / ``ml_sampler_core`` with the
+reference's signatures (linna/main.py:22, 77) and the ``theory()`` / ``priors`` callback surface.
+
+Per iteration: design training points -> evaluate the user's theory -> train the emulator
+(HIP kernels, in process; the reference's ``train_gpu.py`` subprocess + ``finish.pkl``
+rendezvous is kept as on-disk artefacts) -> load it back -> run the ensemble sampler on the
+GPU with the fused Log_prob pipeline -> feed the chain to the next iteration.
+"""
+import gc
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .nn import *  # noqa: F401,F403
+from .util import (Transform, invTransform, NN_samplerv1, generate_training_point, train_NN, retrieve_model, Log_prob,
+                   gaussianlogliklihood, run_mcmc, read_chain_and_cut, LogPrior, logp_theory_data)
+from . import nn as lnn
+
+
+def ml_sampler(outdir, theory, priors, data, cov, init, pool, nwalkers, gpunode, omegab2cut=None, nepoch=4500,
+               method="zeus", nbest=None, chisqcut=None, loglikelihoodfunc=None):
+    """main.py:22-75: the hyper-parameter schedule of To et al. 2022."""
+    ntrainArr = [10000, 10000, 10000, 10000]
+    nvalArr = [500, 500, 500, 500]
+    if method == "emcee":
+        nkeepArr, ntimesArr = [2, 2, 5, 4], [5, 5, 10, 15]
+    elif method == "zeus":
+        nkeepArr, ntimesArr = [2, 2, 5, 5], [5, 5, 10, 50]
+    else:
+        raise NotImplementedError(method)
+    ntautolArr = [0.03, 0.03, 0.02, 0.01]
+    temperatureArr = [4.0, 2.0, 1.0, 1.0]
+    meanshiftArr = [0.2, 0.2, 0.2, 0.2]
+    stdshiftArr = [0.15, 0.15, 0.15, 0.15]
+    params = {"trainingoption": 1, "num_epochs": nepoch, "batch_size": 500}
+    return ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshiftArr, stdshiftArr, outdir, theory,
+                           priors, data, cov, init, pool, nwalkers, "cuda", None, False, temperatureArr, omegab2cut, False, 1,
+                           gpunode, lnn.ChtoModelv2, params, method, nbest=nbest, chisqcut=chisqcut,
+                           loglikelihoodfunc=loglikelihoodfunc)
+
+
+def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshiftArr, stdshiftArr, outdir, theory, priors,
+                    data, cov, init, pool, nwalkers, device, dolog10index, ypositive, temperatureArr, omegab2cut=None,
+                    docuda=False, tsize=1, gpunode=None, nnmodel_in=None, params=None, method="emcee", nbest=None,
+                    chisqcut=None, loglikelihoodfunc=None, nsigma=3, externalloglike=None):
+    """main.py:77-335.  Returns ``(chain[nsamp, ndim] in theta space, log_prob)``."""
+    if method == "emcee":
+        filename = "chemcee_256.h5"
+    elif method == "zeus":
+        filename = "zeus_256.h5"
+    else:
+        raise NotImplementedError(method)
+    if nbest is not None and not (isinstance(nbest, list) and all(n <= 0 for n in nbest)):
+        raise NotImplementedError("nbest (optimizer-seeded training points) is outside the hot path")
+    if nnmodel_in is None:
+        nnmodel_in = lnn.ChtoModelv2
+    params = dict(params or {})
+    ndim = len(init)
+    data, cov = np.asarray(data, np.float64), np.asarray(cov, np.float64)
+    sigma = np.sqrt(np.diag(cov))
+    inv_cov = np.linalg.inv(cov)
+    prior_range = []
+    for item in priors:
+        if item["dist"] == "flat":
+            prior_range.append([item["arg1"], item["arg2"]])
+        elif item["dist"] == "gauss":
+            prior_range.append([item["arg1"] - 5 * item["arg2"], item["arg1"] + 5 * item["arg2"]])
+        else:
+            raise ValueError("not implement dist : {0}".format(item["dist"]))
+    transform = Transform(priors)
+    init = invTransform(priors)(np.asarray(init, np.float64))
+    master = pool is None or pool.is_master()
+    store = None
+    nk = ntimes = None
+    for i, (nt, nv, nk, ntimes, tautol, temperature, meanshift, stdshift) in enumerate(
+            zip(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, temperatureArr, meanshiftArr, stdshiftArr)):
+        temperature = temperature ** 2                                           # main.py:153
+        print("#" * 100)
+        print("iteration: {0}".format(i), flush=True)
+        print("#" * 100)
+        outdir_in = os.path.join(outdir, "iter_{0}/".format(i))
+        chain = None
+        if i > 0:
+            prev = os.path.join(outdir, "iter_{0}/".format(i - 1), filename[:-3])
+            chain, _, _ = read_chain_and_cut(prev, nk, ntimes, method=method)
+        nnsampler = NN_samplerv1(outdir_in, prior_range)
+        generate_training_point(theory, nnsampler, pool, outdir_in, nt, nv, data, inv_cov, chain, nsigma=nsigma,
+                                omegab2cut=omegab2cut, options=params.get("trainingoption", 0), chisqcut=chisqcut)
+        chain = None
+        gc.collect()
+        if master:
+            outdir_list = [os.path.join(outdir, "iter_{0}/".format(m)) for m in range(i + 1)]
+            args = [None, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog10index, ypositive, False, 2, temperature,
+                    True, None, 1, None, params, False]
+            with open(os.path.join(outdir_in, "model_args.pkl"), "wb") as f:     # main.py:192-198 (artefact parity)
+                pickle.dump(args, f)
+            if not os.path.isfile(os.path.join(outdir_in, "finish.pkl")):
+                args[15] = nnmodel_in
+                train_NN(*args, device=device if str(device).startswith("cuda") else "cuda")
+                with open(os.path.join(outdir_in, "finish.pkl"), "wb") as f:     # train_gpu.py:36-38
+                    pickle.dump([True], f)
+        model, y_invtransform_data = retrieve_model(outdir_in, len(init), len(data), nnmodel_in)
+        if os.path.isfile(os.path.join(outdir_in, filename[:-3] + ".npz")):      # main.py:273-274
+            continue
+        log_prob = Log_prob(data.astype(np.float32), inv_cov.astype(np.float32), model, y_invtransform_data, transform,
+                            temperature, nograd=True, loglikelihoodfunc=loglikelihoodfunc or gaussianlogliklihood,
+                            externalloglike=externalloglike)
+        store = run_mcmc(nnsampler, outdir_in, method, ndim, nwalkers, init, log_prob, pool=pool, transform=transform,
+                         ntimes=ntimes, tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
+    last = os.path.join(outdir, "iter_{0}/".format(len(ntrainArr) - 1), filename[:-3])
+    chain, _, d = read_chain_and_cut(last, nk, ntimes, method=method)
+    log_prob_samples_x = d["log_prob"].reshape(-1)                               # main.py:291
+    if "nimp" in params:                                                         # main.py:297-334
+        select = np.random.randint(0, len(chain), params["nimp"])
+        flat_lp = d["log_prob"][-(len(chain) // d["log_prob"].shape[1]):].reshape(-1)
+        chain_s, lp_s = chain[select], flat_lp[select]
+        nns = NN_samplerv1(os.path.join(outdir, "imp/"), prior_range)
+        os.makedirs(nns.outdir, exist_ok=True)
+        th = nns.generate_training_data(zip(range(len(chain_s)), chain_s), theory, pool=pool, args=[nns.outdir])
+        logp = np.array(logp_theory_data(chain_s, th, data, inv_cov, LogPrior(priors)))
+        w = np.exp(logp - lp_s)
+        lw = np.log(w)
+        w[np.abs(lw - np.mean(lw)) > 2 * np.std(lw)] = 0
+        np.save(os.path.join(outdir, "weight_im.npy"), [lp_s, logp, w / np.sum(w)])
+        np.save(os.path.join(outdir, "samples_im.npy"), chain_s)
+    return chain, log_prob_samples_x

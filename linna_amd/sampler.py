@@ -1,0 +1,427 @@
+"""Ensemble and HMC walkers on MI355X.
+
+Mirrors the sampling layer of the reference: ``linna/sampler.py`` (``HMCSampler`` -- despite
+its name the emcee driver, :389-554; ``checkmeanstd`` :370-387; ``ZeusSampler`` :699-737) and
+the walker loop they delegate to emcee.  Here the ensemble lives on the GPU:
+
+* ``EnsembleSampler``: affine-invariant stretch move (emcee ``StretchMove`` inside
+  ``RedBlueMove``, a = 2, random split of the walkers in two halves every step).  Per half
+  step: ``linna_stretch_propose`` -> fused ``Log_prob`` pipeline on the whole half ->
+  ``linna_stretch_accept``; Philox draws keyed (seed; walker, step, stream).
+* ``BatchedHMC``: the leapfrog of ``linna/HMCSampler.py`` run independently per walker with
+  the emulator's reverse-mode gradient (``linna_logprob_grad``).
+* walkers shard across ranks (one process per GPU): every rank advances its own
+  sub-ensemble, chain state is gathered with one RCCL all-gather per flush.
+
+The emcee arithmetic itself is third-party code absent from the reference tree: it is
+restated from the published algorithm (see oracle/sampling.py) and checked statistically.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+
+__all__ = ["EnsembleSampler", "BatchedHMC", "HMCSampler", "ZeusSampler", "checkmeanstd", "integrated_time",
+           "ChainStore", "read_chain_and_cut"]
+
+
+# ------------------------------------------------------------------ convergence statistics (host)
+def _next_pow_two(n):
+    i = 1
+    while i < n:
+        i <<= 1
+    return i
+
+
+def _autocorr_1d(x):
+    n = _next_pow_two(len(x))
+    f = np.fft.fft(x - np.mean(x), n=2 * n)
+    acf = np.fft.ifft(f * np.conjugate(f))[:len(x)].real
+    if acf[0] == 0:
+        return np.full(len(x), np.nan)
+    return acf / acf[0]
+
+
+def integrated_time(x, c=5.0):
+    """Integrated autocorrelation time per parameter of a chain ``x[nstep, nwalker, ndim]``
+    (emcee's estimator as called at sampler.py:538 with tol=0: FFT autocorrelation averaged over
+    walkers, Sokal window with c = 5)."""
+    x = np.atleast_1d(x)
+    if x.ndim == 1:
+        x = x[:, None, None]
+    if x.ndim == 2:
+        x = x[:, :, None]
+    nt, nw, nd = x.shape
+    tau = np.empty(nd)
+    for d in range(nd):
+        f = np.zeros(nt)
+        for k in range(nw):
+            f += _autocorr_1d(x[:, k, d])
+        f /= nw
+        taus = 2.0 * np.cumsum(f) - 1.0
+        m = np.arange(len(taus)) < c * taus
+        win = int(np.argmin(m)) if np.any(m) and not np.all(m) else len(taus) - 1
+        tau[d] = taus[win]
+    return tau
+
+
+def checkmeanstd(samples, meanshift, stdshift):
+    """sampler.py:370-387: first-half / second-half drift of mean and standard deviation."""
+    half = int(len(samples) / 2)
+    a = samples[:half].reshape(-1, samples.shape[-1])
+    b = samples[half:].reshape(-1, samples.shape[-1])
+    meanshifte = np.median(np.abs(np.mean(a, axis=0) - np.mean(b, axis=0)) / np.std(b, axis=0))
+    stdshifte = np.median((np.std(a, axis=0) - np.std(b, axis=0)) / np.std(b, axis=0))
+    print(meanshifte, stdshifte, flush=True)
+    return (meanshifte < meanshift) & (stdshifte < stdshift)
+
+
+# ------------------------------------------------------------------ chain storage
+class ChainStore(object):
+    """Chain backend.  The reference stores emcee/zeus HDF5 files (``chemcee_256.h5`` with
+    ``chain``, ``chain_transformed``, ``log_prob``, ``accepted``; sampler.py:322-368); h5py is not
+    available here, so the same arrays go to ``<name>.npz`` plus the ``<name>.txt`` layout that
+    the reference's own reader accepts as a fallback (main.py:166-167, 293-295: rows of
+    ``theta..., log_prob``)."""
+
+    def __init__(self, filename, transform=None):
+        self.base = filename[:-3] if filename.endswith(".h5") else filename
+        self.transform = transform
+        self.chain, self.chain_transformed, self.log_prob = [], [], []
+        self.accepted = None
+
+    @property
+    def npz(self):
+        return self.base + ".npz"
+
+    def exists(self):
+        return os.path.isfile(self.npz)
+
+    def append(self, z_block, theta_block, logp_block, accepted):
+        self.chain.append(np.asarray(z_block, np.float64))
+        self.chain_transformed.append(np.asarray(theta_block, np.float64))
+        self.log_prob.append(np.asarray(logp_block, np.float64))
+        self.accepted = np.asarray(accepted, np.float64)
+
+    def arrays(self):
+        return (np.concatenate(self.chain), np.concatenate(self.chain_transformed), np.concatenate(self.log_prob))
+
+    def flush(self):
+        z, th, lp = self.arrays()
+        np.savez(self.npz, chain=z, chain_transformed=th, log_prob=lp, accepted=self.accepted, iteration=len(z))
+        flat = np.concatenate([th.reshape(-1, th.shape[-1]), lp.reshape(-1, 1)], axis=1)
+        np.savetxt(self.base + ".txt", flat[-100000:])
+
+    @staticmethod
+    def load(filename):
+        base = filename[:-3] if filename.endswith(".h5") else filename
+        d = np.load(base + ".npz")
+        return {k: d[k] for k in d.files}
+
+    def get_last_sample(self):
+        return self.load(self.base)["chain"][-1]
+
+
+def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee", flat=False):
+    """util.py:68-94: last ``nk`` autocorrelation times of the stored chain (theta space)."""
+    d = ChainStore.load(chainname)
+    if nk > ntimes:
+        print("Error: keep number greater then chain samples. nk: {0}, ntimes: {1}. This will lead to inclusion of all "
+              "burn in step".format(nk, ntimes))
+    tau = integrated_time(d["chain"])
+    nkeep = int(np.nanmedian(tau) * nk)
+    chain = d["chain_transformed"]
+    lp = d["log_prob"]
+    chain = chain[-nkeep:].reshape(-1, chain.shape[-1])
+    lp = lp[-nkeep:]
+    if flat:
+        lp = lp.reshape(-1, 1)
+    return chain, lp, d
+
+
+# ------------------------------------------------------------------ stretch-move ensemble on the device
+class EnsembleSampler(object):
+    """Affine-invariant ensemble sampler with every walker evaluated in one batched GPU call.
+
+    ``log_prob`` is a ``linna_amd.util.Log_prob`` (device pipeline).  ``nwalkers`` is the number
+    of walkers OWNED BY THIS RANK; with ``exchange='allgather'`` and a process group the
+    complementary set of a half step is drawn from the walkers of all ranks (one all-gather of
+    ``[nwalkers, ndim]`` per half step), otherwise ranks run independent sub-ensembles and only
+    chain state is gathered.
+    """
+
+    def __init__(self, nwalkers, ndim, log_prob, a=2.0, seed=0, randomize_split=True, dist_group=None,
+                 exchange="none"):
+        self.nw, self.ndim, self.lp, self.a, self.seed = int(nwalkers), int(ndim), log_prob, float(a), int(seed)
+        if self.nw < 2 or self.nw % 2:
+            raise ValueError("need an even number of walkers >= 2")
+        self.randomize_split = randomize_split
+        self.group, self.exchange = dist_group, exchange
+        p = log_prob._ensure()
+        self.dev = p["dev"]
+        self.ctx = _lib.ctx(self.dev.index)
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
+        self.ld = _lib.ld4(self.ndim)
+        self.coords, self.logp = z(self.nw, self.ld), z(self.nw)
+        self.half = self.nw // 2
+        self.Q, self.factors, self.lp_new = z(self.half, self.ld), z(self.half), z(self.half)
+        self.naccept = torch.zeros(self.nw, dtype=torch.int32, device=self.dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.iteration = 0
+        self._rs = np.random.RandomState(self.seed ^ 0x5EED)
+        self._split = None
+        self.rank = 0
+        self.world = 1
+        if dist_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            import torch.distributed as dist
+            self.rank, self.world = dist.get_rank(dist_group), dist.get_world_size(dist_group)
+        self._gathered = None
+
+    # -- state
+    def set_state(self, x0):
+        x0 = torch.as_tensor(np.asarray(x0, np.float32), device=self.dev)
+        if x0.shape != (self.nw, self.ndim):
+            raise ValueError("x0 must be [nwalkers, ndim]")
+        self.coords.zero_()
+        self.coords[:, :self.ndim].copy_(x0)
+        self.lp.evaluate(self.coords, out=self.logp)
+        if not bool(torch.isfinite(self.logp).all()):
+            raise ValueError("initial state has non-finite log-probability")   # emcee raises the same way
+
+    def _splits(self):
+        idx = np.arange(self.nw)
+        if self.randomize_split:
+            self._rs.shuffle(idx)
+        halves = idx.reshape(2, self.half)          # random equal split == shuffled (arange % 2) of emcee
+        return torch.as_tensor(halves.astype(np.int32), device=self.dev)
+
+    def step(self):
+        """One ensemble iteration (both halves).  Everything is enqueued on the current stream."""
+        st = _lib.stream()
+        halves = self._splits()
+        lib_seed = C.c_uint64(self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1) & 0xFFFFFFFFFFFFFFFF)
+        for h in (0, 1):
+            S, Cc = halves[h], halves[1 - h]
+            comp, ldc, cidx, nc = self.coords, self.ld, Cc, self.half
+            if self.exchange == "allgather" and self.world > 1:
+                comp, cidx, nc = self._allgather_complement(Cc)
+            _lib.call("linna_stretch_propose", self.ctx, _lib.ptr(self.coords), self.ld, self.ndim, _lib.iptr(S), self.half,
+                      _lib.ptr(comp), ldc, _lib.iptr(cidx), nc, lib_seed, _lib.iptr(self.step_dev), h, self.a,
+                      _lib.ptr(self.Q), self.ld, _lib.ptr(self.factors), st)
+            self.lp.evaluate(self.Q, out=self.lp_new)
+            _lib.call("linna_stretch_accept", self.ctx, _lib.ptr(self.coords), self.ld, self.ndim, _lib.ptr(self.logp),
+                      _lib.iptr(S), self.half, _lib.ptr(self.Q), self.ld, _lib.ptr(self.lp_new), _lib.ptr(self.factors),
+                      lib_seed, _lib.iptr(self.step_dev), h, _lib.iptr(self.naccept), st)
+        _lib.call("linna_step_increment", self.ctx, _lib.iptr(self.step_dev), st)
+        self.iteration += 1
+
+    def _allgather_complement(self, Cc):
+        """Complementary walkers of ALL ranks: gather this rank's complementary half."""
+        from . import dist as ldist
+        gathered = ldist.gather_rows(self.coords[Cc.long()], self.group)
+        if self._gathered is None:
+            self._gidx = torch.arange(gathered.shape[0], dtype=torch.int32, device=self.dev)
+        self._gathered = gathered
+        return gathered, self._gidx, gathered.shape[0]
+
+    def run(self, nsteps, store=True):
+        """Advance ``nsteps``; returns (chain[nsteps, nw, ndim], logp[nsteps, nw]) as device tensors."""
+        chain = torch.empty((nsteps, self.nw, self.ndim), dtype=torch.float32, device=self.dev) if store else None
+        lps = torch.empty((nsteps, self.nw), dtype=torch.float32, device=self.dev) if store else None
+        for i in range(nsteps):
+            self.step()
+            if store:
+                chain[i].copy_(self.coords[:, :self.ndim])
+                lps[i].copy_(self.logp)
+        return chain, lps
+
+    def theta_of(self, z):
+        """Physical parameters of latent points ``z[..., ndim]`` (device), via the prior-map kernel."""
+        p = self.lp._ensure()
+        flat = z.reshape(-1, self.ndim).contiguous()
+        n = flat.shape[0]
+        th = torch.empty_like(flat)
+        x = torch.empty((n, self.ld), dtype=torch.float32, device=self.dev)
+        k, d = p["keep"], p["desc"]
+        _lib.call("linna_prior_map_fwd", self.ctx, _lib.ptr(flat), self.ndim, n, self.ndim, _lib.iptr(k["is_flat"]),
+                  _lib.ptr(k["a1"]), _lib.ptr(k["a2"]), None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]), _lib.ptr(x), self.ld,
+                  _lib.ptr(th), self.ndim, _lib.stream())
+        return th.reshape(z.shape)
+
+    def gather_chain(self, chain, lps):
+        """RCCL all-gather of this rank's chain block: [nsteps, world*nw, ndim] on every rank."""
+        from . import dist as ldist
+        return ldist.gather_chain(chain, lps, self.group)
+
+
+# ------------------------------------------------------------------ batched per-walker HMC
+class BatchedHMC(object):
+    """``linna/HMCSampler.py:19-68`` for B independent chains: p ~ N(0, m); half kick; ``num_steps``
+    x (drift, gradient, kick); final half kick; Metropolis test on H = p^2/2m - lnP."""
+
+    def __init__(self, log_prob, x0, mass=None, seed=0):
+        self.lp = log_prob
+        p = log_prob._ensure()
+        self.dev, self.ctx = p["dev"], _lib.ctx(p["dev"].index)
+        x0 = torch.as_tensor(np.asarray(x0, np.float32), device=self.dev)
+        self.B, self.ndim = x0.shape
+        self.ld = _lib.ld4(self.ndim)
+        z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
+        self.x, self.q, self.p = z(self.B, self.ld), z(self.B, self.ld), z(self.B, self.ld)
+        self.x[:, :self.ndim].copy_(x0)
+        self.mass = torch.ones(self.ndim, dtype=torch.float32, device=self.dev) if mass is None else \
+            torch.as_tensor(np.asarray(mass, np.float32), device=self.dev)
+        self.lnp, self.lnp_new, self.H0 = z(self.B), z(self.B), z(self.B)
+        self.g, self.g_new = z(self.B, self.ld), z(self.B, self.ld)
+        self.naccept = torch.zeros(self.B, dtype=torch.int32, device=self.dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.seed = int(seed)
+        self.lp.evaluate_with_grad(self.x, out=self.lnp, grad=self.g)
+
+    def step(self, num_steps, step_size, p0=None, u=None):
+        """One HMC transition per chain.  ``p0[B, ndim]`` (standard-normal draws) and ``u[B]`` replace
+        the Philox draws when given (replaying HMCSampler.py:26 / :59 streams)."""
+        st, eps = _lib.stream(), float(step_size)
+        seed = C.c_uint64(self.seed)
+        args = (self.ctx, self.B, self.ndim, _lib.ptr(self.mass))
+        p0d = None if p0 is None else torch.as_tensor(np.ascontiguousarray(p0, np.float32), device=self.dev)
+        ud = None if u is None else torch.as_tensor(np.ascontiguousarray(u, np.float32), device=self.dev)
+        _lib.call("linna_hmc_init", *args, seed, _lib.iptr(self.step_dev), _lib.ptr(self.lnp),
+                  _lib.ptr(p0d) if p0d is not None else None, self.ndim, _lib.ptr(self.p), self.ld, _lib.ptr(self.H0), st)
+        self.q.copy_(self.x)
+        g = self.g
+        for i in range(num_steps):
+            ek = 0.5 * eps if i == 0 else eps                     # :35 half kick first, full kicks after
+            _lib.call("linna_hmc_kick_drift", *args, ek, eps, _lib.ptr(g), self.ld, _lib.ptr(self.p), self.ld,
+                      _lib.ptr(self.q), self.ld, st)
+            self.lp.evaluate_with_grad(self.q, out=self.lnp_new, grad=self.g_new)
+            g = self.g_new
+        _lib.call("linna_hmc_kick_drift", *args, 0.5 * eps, 0.0, _lib.ptr(g), self.ld, _lib.ptr(self.p), self.ld,
+                  _lib.ptr(self.q), self.ld, st)                                             # :51
+        _lib.call("linna_hmc_accept", *args, seed, _lib.iptr(self.step_dev), _lib.ptr(self.H0), _lib.ptr(self.p), self.ld,
+                  _lib.ptr(self.q), self.ld, _lib.ptr(self.lnp_new), _lib.ptr(self.g_new), self.ld,
+                  _lib.ptr(ud) if ud is not None else None, _lib.ptr(self.x), self.ld, _lib.ptr(self.lnp), _lib.ptr(self.g),
+                  _lib.iptr(self.naccept), st)
+        _lib.call("linna_step_increment", self.ctx, _lib.iptr(self.step_dev), st)
+
+    def sample(self, num_samps, num_steps, step_size):
+        chain = torch.empty((num_samps, self.B, self.ndim), dtype=torch.float32, device=self.dev)
+        lnps = torch.empty((num_samps, self.B), dtype=torch.float32, device=self.dev)
+        for i in range(num_samps):
+            self.step(num_steps, step_size)
+            chain[i].copy_(self.x[:, :self.ndim])
+            lnps[i].copy_(self.lnp)
+        return chain, lnps
+
+
+# ------------------------------------------------------------------ drivers with the reference's names
+class HMCSampler(object):
+    """The reference's emcee driver (sampler.py:389-554): burn-in, restart from the best region,
+    sample until the integrated autocorrelation time and the mean/std drift have converged."""
+
+    def __init__(self, lnp, dlnp, ddlnp, ndim, nwalkers, x0=None, m=None, transform=None, torchspeed=False, seed=0,
+                 dist_group=None):
+        self.lnp, self.dlnp, self.ddlnp = lnp, dlnp, ddlnp
+        self.transform, self.x0, self.nparams, self.nwalkers = transform, x0, ndim, nwalkers
+        self.m = np.ones(ndim) if m is None else m
+        self.sampler = None
+        self.seed, self.group = seed, dist_group
+
+    def sample(self, pool, nsamp, samp_steps=0, samp_eps=0, Madapt=1000, outdir="./", progress=False, overwrite=False,
+               ntimes=10, tautol=0.01, method="emcee", incremental=True, meanshift=0.1, stdshift=0.1, nk=2, ncheck=100,
+               burnin=100):
+        if method != "emcee":
+            # sampler.py's "hmc"/"nuts" branches are unreachable in the reference
+            raise NotImplementedError(method)
+        filename = os.path.join(outdir, "chemcee_256.h5")
+        store = ChainStore(filename, self.transform)
+        x0 = self.x0
+        resume = False
+        if store.exists():
+            if overwrite:
+                os.remove(store.npz)
+            else:
+                print("init from previous")
+                prev = ChainStore.load(filename)
+                x0, resume = prev["chain"][-1], True
+                store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])
+        ens = EnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
+        self.sampler = ens
+        print("start", flush=True)
+        if not resume:
+            print("burnin...", flush=True)                                   # sampler.py:519-529
+            ens.set_state(x0)
+            c, l = ens.run(burnin)
+            flat, lp = c.reshape(-1, self.nparams).cpu().numpy(), l.reshape(-1).cpu().numpy()
+            pos = flat[np.argsort(lp)[::-1][:int(50 * self.nwalkers)]]
+            x0 = pos[np.random.randint(0, len(pos), self.nwalkers), :]
+            print("burnin done...", flush=True)
+            ens.naccept.zero_()
+        ens.set_state(x0)
+        old_tau = np.inf
+        done = 0 if not resume else sum(len(c) for c in store.chain)
+        while done < nsamp:
+            c, l = ens.run(ncheck)
+            th = ens.theta_of(c)
+            store.append(c.cpu().numpy(), th.cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
+            done += ncheck
+            if incremental:
+                store.flush()
+            chain = np.concatenate(store.chain)
+            tau = integrated_time(chain)                                      # sampler.py:538
+            if np.isnan(np.sum(tau)) and done > 10:
+                break
+            converged = np.all(tau * ntimes < done)                           # :545-547
+            converged &= np.all(np.abs(old_tau - tau) / tau < tautol)
+            converged &= checkmeanstd(chain[-int(nk * np.mean(tau)):], meanshift=meanshift, stdshift=stdshift)
+            print("max, min tau diff, max tau, ninter: {0}, {1}, {2}, {3}\n".format(
+                np.max(np.abs(old_tau - tau) / tau), np.min(np.abs(old_tau - tau) / tau), np.max(tau), done), flush=True)
+            if converged:
+                break
+            old_tau = tau
+        store.flush()
+        self.sampler = None
+        return store
+
+
+class ZeusSampler(object):
+    """sampler.py:699-737 drives zeus' ensemble slice sampler.  The slice move is listed under
+    "next" in SURVEY section 8 f; until it exists this driver runs the stretch-move ensemble with
+    the zeus convergence rule (IAT on the last 80 %, sampler.py:729) and the zeus file names."""
+
+    def __init__(self, lnp, ndim, nwalkers, x0=None, transform=None, seed=0, dist_group=None):
+        self.lnp, self.transform, self.x0, self.nparams, self.nwalkers = lnp, transform, x0, ndim, nwalkers
+        self.sampler = None
+        self.seed, self.group = seed, dist_group
+
+    def sample(self, pool, nsamp, outdir="./", progress=False, overwrite=False, ntimes=10, tautol=0.01, incremental=True,
+               meanshift=0.1, stdshift=0.1, nk=2, ncheck=100):
+        store = ChainStore(os.path.join(outdir, "zeus_256.h5"), self.transform)
+        x0 = self.x0
+        if store.exists() and not overwrite:
+            print("init from previous")
+            prev = ChainStore.load(store.base)
+            x0 = prev["chain"][-1]
+            store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])
+        ens = EnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
+        ens.set_state(x0)
+        old_tau, done = np.inf, sum(len(c) for c in store.chain)
+        while done < min(nsamp, 100000):
+            c, l = ens.run(ncheck)
+            store.append(c.cpu().numpy(), ens.theta_of(c).cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
+            done += ncheck
+            if incremental:
+                store.flush()
+            chain = np.concatenate(store.chain)
+            tau = float(np.mean(integrated_time(chain[int(done * 0.2):])))   # discard=0.2, sampler.py:684,729
+            converged = tau * ntimes < done
+            converged &= abs(old_tau - tau) / tau < tautol
+            converged &= bool(checkmeanstd(chain[-int(nk * tau):], meanshift, stdshift))
+            old_tau = tau
+            if converged:
+                break
+        store.flush()
+        return store

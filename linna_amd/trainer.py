@@ -83,10 +83,8 @@ class TrainEngine(object):
     def _step_body(self, opt):
         self._forward_loss_backward()
         if self.world > 1:
-            import torch.distributed as dist
-            g = self.model.flat_grads()
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)            # RCCL over xGMI
-            dist.all_reduce(self.loss_mean, op=dist.ReduceOp.SUM, group=self.group)
+            from . import dist as ldist
+            ldist.allreduce_grads(self.model.flat_grads(), self.loss_mean, self.group)   # RCCL over xGMI
         opt.apply()
 
     def step(self, opt, rows_dev):
@@ -201,10 +199,11 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
         model.init_weight()                       # fresh Xavier weights in place (model_old.init_weight(), :323)
 
     for i in range(num_epochs):
-        batches = dataset.epoch_batches()          # same order on every rank (same torch seed)
-        perm = torch.stack(batches[:nsteps * size]).to(torch.int32).to(engine.dev) if nsteps else None
+        from . import dist as ldist
+        mine = ldist.rank_batches(dataset.epoch_batches(), rank, size)   # same order on every rank (same seed)
+        perm = torch.stack(mine).to(torch.int32).to(engine.dev) if nsteps else None
         for s in range(nsteps):
-            engine.step(opt, perm[s * size + rank])                             # :273-288
+            engine.step(opt, perm[s])                                           # :273-288
             loss_hist[s:s + 1].copy_(engine.loss_mean, non_blocking=True)
         epoch_losses = loss_hist[:nsteps].cpu().numpy().astype(np.float64)
         train_losses.extend(epoch_losses.tolist())

@@ -554,3 +554,164 @@ def train_NN(nnsampler, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog
     return train_nn(outdir_in, nnmodel, train_x, train_y, val_x, val_y, X_transform, y_transform, loss_fn, val_metric_fn,
                     dev=device, verbose=True, retrain=retrain, pool=pool, nocpu=True, size=tsize, rank=rank, params=params,
                     dist_group=dist_group)
+
+
+# ------------------------------------------------------------------ training-point generation (util.py:736-897, 1167-1270)
+class _FunctionWrapper(object):
+    def __init__(self, f, args, kwargs):
+        self.f, self.args, self.kwargs = f, ([] if args is None else args), ({} if kwargs is None else kwargs)
+
+    def __call__(self, x):
+        return self.f(x, *self.args, **self.kwargs)
+
+
+def _apply_cuts(samples, omegab2cut):
+    """util.py:804-811: optional cut on omega_b h^2 and up to two further parameter ranges."""
+    if omegab2cut is None:
+        return samples
+    ombh2 = samples[:, omegab2cut[0]] * samples[:, omegab2cut[1]] ** 2
+    keep = (ombh2 > omegab2cut[2]) & (ombh2 < omegab2cut[3])
+    if len(omegab2cut) > 4:
+        keep &= (samples[:, omegab2cut[4]] > omegab2cut[5]) & (samples[:, omegab2cut[4]] < omegab2cut[6])
+    if len(omegab2cut) > 6:
+        keep &= (samples[:, omegab2cut[7]] > omegab2cut[8]) & (samples[:, omegab2cut[7]] < omegab2cut[9])
+    return samples[keep]
+
+
+class NN_samplerv1(object):
+    """Per-iteration helper of the reference (util.py:736-951): training-point designs and the
+    MCMC launchers.  The user's ``theory`` callback is evaluated exactly as in the reference
+    (``pool.map`` or ``map`` over ``(index, params)`` tuples)."""
+
+    def __init__(self, outdir, prior_range):
+        self.outdir, self.prior_range = outdir, prior_range
+        self.seed = 123456
+        self.model = None
+
+    def generate_training_data(self, samples, model, pool=None, args=None, kwargs=None):
+        m = _FunctionWrapper(model, args, kwargs)
+        mapper = pool.map if pool is not None else map
+        return np.array(list(mapper(m, samples)))
+
+    def gensample_flat(self, Nsamples, omegab2cut=None):
+        """Centred Latin hypercube over the prior box (util.py:775-814 uses pyDOE2.lhs(criterion=
+        "center"), a third-party package absent here: same design family, own permutations)."""
+        rs = np.random.RandomState(self.seed)
+        n_in, samples = int(Nsamples), np.zeros((0, len(self.prior_range)))
+        while len(samples) < Nsamples:
+            u = np.stack([(rs.permutation(n_in) + 0.5) / n_in for _ in self.prior_range], axis=1)
+            s = np.empty_like(u)
+            for ind, prior in enumerate(self.prior_range):
+                lo, hi = prior
+                if ind == 1 and self.prior_range[1][1] < 1e-5:        # A_s sampled in log (util.py:795-803)
+                    s[:, ind] = np.exp(np.log(lo) + u[:, ind] * (np.log(hi) - np.log(lo)))
+                else:
+                    s[:, ind] = lo + u[:, ind] * (hi - lo)
+            samples = _apply_cuts(s, omegab2cut)
+            n_in += 1000
+        return samples[:Nsamples]
+
+    def gensample_chain_randomsample(self, Nsamples, chain_in, nsigma, omegab2cut=None):
+        """util.py:864-897: uniform random draws (seed 123456) from the previous chain inside the prior box."""
+        chain = _apply_cuts(np.array(chain_in, copy=True), omegab2cut)
+        for i in range(chain.shape[1]):
+            chain = chain[(chain[:, i] > self.prior_range[i][0]) & (chain[:, i] < self.prior_range[i][1])]
+        np.random.seed(self.seed)
+        return chain[np.random.randint(0, len(chain), int(Nsamples))]
+
+    def emcee_sample(self, log_prob, ndim, nwalkers, init, pool, transform, ntimes=50, tautol=0.01, dlnp=None, ddlnp=None,
+                     meanshift=0.1, stdshift=0.1, nk=1, max_n=1000000):
+        from . import sampler
+        x0 = init + 0.1 * np.random.randn(nwalkers, ndim)                 # util.py:915
+        samp = sampler.HMCSampler(log_prob, dlnp, ddlnp, ndim, nwalkers, x0=x0, m=None, transform=transform)
+        return samp.sample(pool, max_n, 0, 0, outdir=self.outdir, overwrite=False, ntimes=ntimes, method="emcee",
+                           incremental=True, progress=False, tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
+
+    def Zeus_sample(self, log_prob, ndim, nwalkers, init, pool, transform, ntimes=50, tautol=0.01, dlnp=None, ddlnp=None,
+                    meanshift=0.1, stdshift=0.1, nk=1, max_n=1000000):
+        from . import sampler
+        x0 = init + 0.001 * np.random.randn(nwalkers, ndim)               # util.py:937
+        samp = sampler.ZeusSampler(log_prob, ndim, nwalkers, x0=x0, transform=transform)
+        return samp.sample(pool, max_n, outdir=self.outdir, overwrite=False, ntimes=ntimes, incremental=True, progress=False,
+                           tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
+
+
+def chisqcut_all(data, invcov, chisqcut, fnamey, fnamex):
+    """util.py:1260-1270."""
+    y, x = np.load(fnamey), np.loadtxt(fnamex)
+    chisq = np.array([y_.dot(invcov).dot(y_) for y_ in y])
+    np.save(fnamey, y[chisq < chisqcut])
+    np.savetxt(fnamex, x[chisq < chisqcut])
+
+
+def generate_training_point(theory, nnsampler, pool, outdir, ntrain, nval, data, invcov, chain=None, nsigma=1,
+                            omegab2cut=None, options=0, negloglike=None, nbest_in=None, chisqcut=None):
+    """util.py:1167-1258: design the training / validation parameters, evaluate the user's theory
+    on them, store ``{train,val}_samples_{x.txt,y.npy}`` (skipping whatever already exists)."""
+    if negloglike is not None:
+        raise NotImplementedError("nbest (optimizer-seeded samples, util.py:1235-1252) is outside the hot path")
+    if not (pool is None or pool.is_master()):
+        return
+    os.makedirs(outdir, exist_ok=True)
+
+    def design(n):
+        if chain is None:
+            return nnsampler.gensample_flat(n, omegab2cut=omegab2cut)
+        if options == 1:
+            return nnsampler.gensample_chain_randomsample(n, chain, nsigma, omegab2cut=omegab2cut)
+        raise NotImplementedError("options=0 needs the third-party sample_generator package (util.py:841)")
+
+    for tag, n in (("train", ntrain), ("val", nval)):
+        fx, fy = os.path.join(outdir, tag + "_samples_x.txt"), os.path.join(outdir, tag + "_samples_y.npy")
+        if not os.path.isfile(fx):
+            np.savetxt(fx, design(n))
+        sub = os.path.join(outdir, tag + "/")
+        os.makedirs(sub, exist_ok=True)
+        if not os.path.isfile(fy):
+            x = np.loadtxt(fx)
+            np.save(fy, nnsampler.generate_training_data(zip(range(len(x)), x), theory, pool=pool, args=[sub]))
+        if chisqcut is not None:
+            chisqcut_all(data, invcov, chisqcut, fy, fx)
+
+
+class LogPrior(object):
+    """util.py:1129-1157 (theta-space prior used by the importance-sampling post step)."""
+
+    def __init__(self, prior):
+        self.prior = prior
+
+    def __call__(self, xlist):
+        logp = 0
+        for ind, x in enumerate(xlist):
+            item = self.prior[ind]
+            if item["dist"] == "flat" and (x < item["arg1"] or x > item["arg2"]):
+                return -np.inf
+            if item["dist"] == "gauss":
+                logp += -0.5 * (x - item["arg1"]) ** 2 / item["arg2"] ** 2
+        return logp
+
+
+def logp_theory_data(samples, theory, data, invcov, logprior):
+    """util.py:1506-1517."""
+    out = []
+    for t, s in zip(theory, samples):
+        d = t[:len(data)] - data
+        out.append(-0.5 * d.dot(invcov.dot(d)) + logprior(s))
+    return out
+
+
+def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee", flat=False):
+    from . import sampler
+    return sampler.read_chain_and_cut(chainname, nk, ntimes, walkercut, method, flat)
+
+
+def run_mcmc(nnsampler, outdir, method, ndim, nwalkers, init, log_prob, dlnp=None, ddlnp=None, pool=None, transform=None,
+             ntimes=50, tautol=0.01, meanshift=0.1, stdshift=0.1, nk=2):
+    """util.py:1474-1504 (the "hmc"/"nuts" branches of the reference are unreachable)."""
+    kw = dict(ntimes=ntimes, tautol=tautol, transform=transform, dlnp=dlnp, ddlnp=ddlnp, meanshift=meanshift,
+              stdshift=stdshift, nk=nk)
+    if method == "emcee":
+        return nnsampler.emcee_sample(log_prob, ndim, nwalkers, init, pool, **kw)
+    if method == "zeus":
+        return nnsampler.Zeus_sample(log_prob, ndim, nwalkers, init, pool, **kw)
+    raise NotImplementedError(method)
