@@ -58,34 +58,69 @@ def build_problem(device):
     return lp, model, consts
 
 
-def cpu_baseline(consts, z, budget_s=12.0):
+def cpu_baseline(consts, z, budget_s=15.0):
     """The numpy oracle (CPU restatement of the reference path) timed on this host: batched
-    BLAS evaluation on all cores (value) and the reference-faithful per-walker loop."""
+    BLAS evaluation (value; the faster of a 32-thread and an all-core BLAS pool) and the
+    reference-faithful per-walker loop (batch 1, one thread)."""
     from oracle import likelihood
+    from threadpoolctl import threadpool_limits
     emu = likelihood.Emulator("MLP", NIN, NOUT, consts["weights"], consts["X_mean"], consts["X_std"], consts["y_mean"],
                               consts["y_std"], consts["sigma"], width=WIDTH, depth=DEPTH)
     invcov = np.linalg.inv(consts["cov"])
     f = lambda zz: likelihood.log_prob(zz, emu, consts["priors"], consts["means"], invcov, 1.0)
-    f(z)                                             # warm up BLAS threads
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s * 0.6:
-        f(z)
-        n += 1
-    batched = n * len(z) / (time.perf_counter() - t0)
-    m, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s * 0.4:
-        f(z[m % len(z)][None, :])
-        m += 1
-    per_walker = m / (time.perf_counter() - t0)
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    return {"value": batched, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": "numpy oracle (oracle/likelihood.log_prob), fp32, %d passes of the same %d-walker batch on all "
-                      "host cores; reference-faithful per-walker loop (batch 1, one core): %.0f evals/s over %d calls"
-                      % (n, len(z), per_walker, m)}
+    best = (0.0, 0, 0)
+    for nthreads in sorted({min(32, cores), cores}):
+        with threadpool_limits(limits=nthreads):
+            f(z)                                     # warm up the BLAS pool
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < budget_s * 0.3:
+                f(z)
+                n += 1
+            rate = n * len(z) / (time.perf_counter() - t0)
+        if rate > best[0]:
+            best = (rate, nthreads, n)
+    with threadpool_limits(limits=1):
+        m, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s * 0.3:
+            f(z[m % len(z)][None, :])
+            m += 1
+        per_walker = m / (time.perf_counter() - t0)
+    return {"value": best[0], "unit": "evals/s", "cores": best[1], "kind": "port",
+            "sample": "numpy oracle (oracle/likelihood.log_prob), fp32: %d passes of the same %d-walker batch with a "
+                      "%d-thread BLAS pool (host has %d cores); reference-faithful per-walker loop (batch 1, one "
+                      "thread): %.0f evals/s over %d calls" % (best[2], len(z), best[1], cores, per_walker, m)}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
+def mcmc_rate(lp, nwalkers, nsteps=60):
+    """Ensemble (stretch-move) iterations per second with every walker advanced once per
+    iteration: 2 half steps x (propose -> fused Log_prob on nwalkers/2 -> accept)."""
+    import torch
+    from linna_amd import sampler
+    ens = sampler.EnsembleSampler(nwalkers, NIN, lp, seed=1)
+    ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nwalkers, NIN)))
+    ens.run(10, store=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ens.run(nsteps, store=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"steps_per_s": nsteps / dt, "walker_updates_per_s": nsteps * nwalkers / dt,
+            "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
 def time_dominant_kernel(model, B, iters):
@@ -100,27 +135,43 @@ def time_dominant_kernel(model, B, iters):
     sd = model.state_dict()
     ctx, st = _lib.ctx(dev.index), _lib.stream()
 
-    def four_launches():
+    def four_launches(wrap):
         src, ld, K = x0, x0.stride(0), NIN
         for i in range(DEPTH):
             dst = h[i & 1]
             W = sd["layer%d.weight" % (i + 1)]            # strided view into the packed flat buffer
-            _lib.call("linna_linear_fwd", ctx, _lib.ptr(src), ld, C.c_void_p(W.data_ptr()), W.stride(0),
-                      _lib.ptr(sd["layer%d.bias" % (i + 1)]), _lib.ptr(dst), WIDTH, B, K, WIDTH, 1, 1.0, None, 0, st)
+            go = lambda src=src, ld=ld, K=K, dst=dst, W=W, i=i: _lib.call(
+                "linna_linear_fwd", ctx, _lib.ptr(src), ld, C.c_void_p(W.data_ptr()), W.stride(0),
+                _lib.ptr(sd["layer%d.bias" % (i + 1)]), _lib.ptr(dst), WIDTH, B, K, WIDTH, 1, 1.0, None, 0, st)
+            if wrap is None:
+                go()
+            else:
+                wrap(go)
             src, ld, K = dst, WIDTH, WIDTH
 
     for _ in range(5):
-        four_launches()
-    e0, e1 = C.c_void_p(), C.c_void_p()
-    _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
-    _lib.call("linna_event_record", e0, st)
+        four_launches(None)
+    # one HIP-event pair around EVERY launch (recorded on the launch stream), so host launch
+    # gaps do not leak into the kernel time; summed after a single synchronisation.
+    pairs = []
+
+    def bracket(launch):
+        e0, e1 = C.c_void_p(), C.c_void_p()
+        _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
+        _lib.call("linna_event_record", e0, st)
+        launch()
+        _lib.call("linna_event_record", e1, st)
+        pairs.append((e0, e1))
+
     for _ in range(iters):
-        four_launches()
-    _lib.call("linna_event_record", e1, st)
-    ms = C.c_float()
-    _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+        four_launches(bracket)
+    total, ms = 0.0, C.c_float()
+    for e0, e1 in pairs:
+        _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+        total += ms.value
+        _lib.call("linna_event_destroy", e0); _lib.call("linna_event_destroy", e1)
     flop = 2.0 * B * WIDTH * (NIN + (DEPTH - 1) * WIDTH) / DEPTH
-    return ms.value / (iters * DEPTH), flop
+    return total / len(pairs), flop
 
 
 def main():
@@ -128,7 +179,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels directly instead of a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph instead of direct launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -159,7 +210,7 @@ def main():
     step_direct()
     torch.cuda.synchronize()
     graph = None
-    if not args.no_graph:
+    if args.graph:
         # capture one step on a side stream (hipGraph), replay it on the same stream
         s = torch.cuda.Stream()
         with torch.cuda.stream(s):
@@ -217,11 +268,13 @@ def main():
                        "launch": "hipGraph replay" if graph is not None else "direct launches",
                        "parallelism": "walkers sharded, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                          "kernel": "gemm_kernel<2,2,1,1,0,0,4> (64x64 tile, 4-stage LDS-DMA ring, fp32 MFMA): layers 1-4, 4 launches/step",
                          "avg_launch_ms": ms_kernel, "flop_per_launch": flop_launch},
             "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
         }
+        res["mcmc"] = mcmc_rate(lp, NWALKERS)
+        res["mcmc"]["steps_per_s_all_gpus"] = res["mcmc"]["steps_per_s"] * world
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(consts, z_host)
         print(json.dumps(res), flush=True)
