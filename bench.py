@@ -123,55 +123,25 @@ def mcmc_rate(lp, nwalkers, nsteps=60):
             "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
-def time_dominant_kernel(model, B, iters):
-    """HIP-event timing of the dominant kernel on its launch stream: the 64x64-tile fp32-MFMA
-    GEMM instantiation that serves layers 1-4 (per step: one 4096x512x33 and three 4096x512x512
-    launches).  Returns (avg ms per launch, algorithmic FLOP per launch)."""
-    import torch
+def time_dominant_kernel(lp, z, out, iters):
+    """HIP-event timing (events recorded on the launch stream) of the dominant kernel: the
+    whole-network serving kernel fused_mlp_kernel<5> -- ONE launch per step evaluates prior map,
+    5 layers and the log-likelihood for all walkers.  Returns (avg ms per launch, algorithmic
+    FLOP per launch = nwalkers x (2 x 820 224 MACs + 99 log-likelihood FLOP))."""
     from linna_amd import _lib
-    dev = model.device
-    x0 = torch.randn((B, _lib.ld4(NIN)), device=dev)
-    h = [torch.empty((B, WIDTH), device=dev) for _ in range(2)]
-    sd = model.state_dict()
-    ctx, st = _lib.ctx(dev.index), _lib.stream()
-
-    def four_launches(wrap):
-        src, ld, K = x0, x0.stride(0), NIN
-        for i in range(DEPTH):
-            dst = h[i & 1]
-            W = sd["layer%d.weight" % (i + 1)]            # strided view into the packed flat buffer
-            go = lambda src=src, ld=ld, K=K, dst=dst, W=W, i=i: _lib.call(
-                "linna_linear_fwd", ctx, _lib.ptr(src), ld, C.c_void_p(W.data_ptr()), W.stride(0),
-                _lib.ptr(sd["layer%d.bias" % (i + 1)]), _lib.ptr(dst), WIDTH, B, K, WIDTH, 1, 1.0, None, 0, st)
-            if wrap is None:
-                go()
-            else:
-                wrap(go)
-            src, ld, K = dst, WIDTH, WIDTH
-
+    st = _lib.stream()
     for _ in range(5):
-        four_launches(None)
-    # one HIP-event pair around EVERY launch (recorded on the launch stream), so host launch
-    # gaps do not leak into the kernel time; summed after a single synchronisation.
-    pairs = []
-
-    def bracket(launch):
-        e0, e1 = C.c_void_p(), C.c_void_p()
-        _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
-        _lib.call("linna_event_record", e0, st)
-        launch()
-        _lib.call("linna_event_record", e1, st)
-        pairs.append((e0, e1))
-
+        lp.evaluate(z, out=out)
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
+    _lib.call("linna_event_record", e0, st)
     for _ in range(iters):
-        four_launches(bracket)
-    total, ms = 0.0, C.c_float()
-    for e0, e1 in pairs:
-        _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
-        total += ms.value
-        _lib.call("linna_event_destroy", e0); _lib.call("linna_event_destroy", e1)
-    flop = 2.0 * B * WIDTH * (NIN + (DEPTH - 1) * WIDTH) / DEPTH
-    return total / len(pairs), flop
+        lp.evaluate(z, out=out)
+    _lib.call("linna_event_record", e1, st)
+    ms = C.c_float()
+    _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+    _lib.call("linna_event_destroy", e0); _lib.call("linna_event_destroy", e1)
+    return ms.value / iters, float(z.shape[0]) * (2.0 * MACS_PER_EVAL + 3 * NOUT)
 
 
 def main():
@@ -252,7 +222,7 @@ def main():
     assert torch.isfinite(out).all(), "non-finite log-probabilities in the timed path"
 
     if rank == 0:
-        ms_kernel, flop_launch = time_dominant_kernel(model, NWALKERS, max(20, args.steps // 4))
+        ms_kernel, flop_launch = time_dominant_kernel(lp, z, out, max(50, args.steps))
         achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
         res = {
             "metric": "emulator log-likelihood evals/sec",
@@ -269,7 +239,7 @@ def main():
                        "parallelism": "walkers sharded, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": "gemm_kernel<2,2,1,1,0,0,4> (64x64 tile, 4-stage LDS-DMA ring, fp32 MFMA): layers 1-4, 4 launches/step",
+                         "kernel": "fused_mlp_kernel<5> (whole network per launch: 16 walkers/workgroup, activations in LDS, weights by wave-private LDS-DMA rings, v_mfma_f32_16x16x4_f32)",
                          "avg_launch_ms": ms_kernel, "flop_per_launch": flop_launch},
             "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
         }

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblinna_hip.so")
-SOURCES = ["gemm.hip", "pointwise.hip", "api.hip"]
+SOURCES = ["gemm.hip", "pointwise.hip", "fused_mlp.hip", "api.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off"]
 
 
@@ -26,7 +26,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + os.environ.get("LINNA_HIPCC_EXTRA", "").split() + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)

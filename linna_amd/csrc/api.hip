@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <stdlib.h>
 
 namespace linna {
 
@@ -404,10 +405,26 @@ static LpLayout lp_layout(const linna_logprob* lp, int B, int with_grad) {
     return L;
 }
 
+static bool fused_enabled() {
+    static const bool on = !(getenv("LINNA_DISABLE_FUSED") && getenv("LINNA_DISABLE_FUSED")[0] == '1');
+    return on;
+}
+
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
-                      float* TH, int ldt, void* stream) {
+                      float* TH, int ldt, void* stream, bool keep_activations) {
     const linna_logprob_desc_t& d = lp->d;
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
+    const linna_net* n = lp->net;
+    if (!keep_activations && fused_enabled() && !n->has_inskip && !d.outmap.cexp &&
+        fused_mlp_eligible(n->L.data(), (int)n->L.size(), n->in_size)) {
+        // whole-network kernel: prior map -> layers -> (diagonal) log-likelihood in one launch
+        TRY(launch_fused_mlp(n->L.data(), (int)n->L.size(), nullptr, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag,
+                             d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, d.w ? lnP : nullptr,
+                             d.w ? nullptr : w + L.d, ldd, TH, ldt, S(stream)));
+        if (d.w) return LINNA_OK;
+        return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
+                                         w + L.part, lnP, stream);
+    }
     TRY(launch_prior_map_fwd(Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag, d.xmean, d.xstd, w + L.x0, ldx, TH,
                              ldt, S(stream)));
     TRY(linna_net_forward(lp->net, w + L.x0, ldx, B, w + L.fwd, w + L.d, ldd, &d.outmap, stream));
@@ -438,7 +455,7 @@ int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void
                        void* stream) {
     if (!lp || !Z || !ws || !lnP || B < 1) { set_error("logprob_eval: bad arguments"); return LINNA_ERR_INVALID; }
     const LpLayout L = lp_layout(lp, B, 0);
-    return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream);
+    return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false);
 }
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
@@ -450,7 +467,7 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
     const LpLayout L = lp_layout(lp, B, 1);
     float* w = static_cast<float*>(ws);
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
-    TRY(lp_forward(lp, Z, ldz, B, w, L, lnP, nullptr, 0, stream));
+    TRY(lp_forward(lp, Z, ldz, B, w, L, lnP, nullptr, 0, stream, true));
     if (d.w) {
         TRY(launch_loglike_diag_grad(w + L.d, ldd, B, d.nout, d.w, d.gscale, d.temperature, w + L.dh, ldd, S(stream)));
     } else {   // dH = -(1/T) * (D Ssym) * gscale

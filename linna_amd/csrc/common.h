@@ -65,6 +65,13 @@ int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const i
                       const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
 
+// fused_mlp.hip
+bool fused_mlp_eligible(const linna_layer_t* layers, int nl, int in_size);
+int launch_fused_mlp(const linna_layer_t* layers, int nl, const float* param_end, const float* Z, int ldz, int B, int nin,
+                     const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
+                     const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
+                     float* D, int ldd, float* TH, int ldt, hipStream_t s);
+
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);
 

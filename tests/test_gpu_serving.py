@@ -185,3 +185,34 @@ def test_nan_maps_to_minus_inf_and_empty_edge():
     assert np.isfinite(out[0]) and out[1] == -np.inf and np.isfinite(out[2])
     with pytest.raises(ValueError):
         lp(np.zeros((2, 5), np.float32))
+
+
+def test_fused_mlp_kernel_edges_and_agreement_with_layered_path():
+    """The whole-network kernel (used by evaluate for eligible MLPs) against the layer-by-layer
+    path (used by evaluate_with_grad) and the oracle: ragged batch, NaN row, theta output."""
+    from oracle import likelihood
+    lp, pred, yinv, prob = build_logprob("mlp_33_33")
+    emu = cases.oracle_emulator(prob)
+    for B in (1, 15, 16, 37, 1000):
+        z = np.random.RandomState(B).standard_normal((B, 33)).astype(np.float32)
+        if B > 2:
+            z[2, 5] = np.nan
+        zd = torch.as_tensor(z, device="cuda")
+        theta = torch.empty_like(zd)
+        fused = lp.evaluate(zd, theta=theta).cpu().numpy()
+        layered, _ = lp.evaluate_with_grad(zd)
+        layered = layered.cpu().numpy()
+        ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0)
+        ok = np.isfinite(ref)
+        np.testing.assert_allclose(fused[ok], ref[ok], rtol=5e-4)
+        np.testing.assert_allclose(fused[ok], layered[ok], rtol=2e-4)
+        assert np.all(fused[~ok] == -np.inf)
+        th_ref = likelihood.prior_map(z, prob["priors"])
+        np.testing.assert_allclose(theta.cpu().numpy()[ok], th_ref[ok], rtol=1e-5, atol=1e-5)
+    # dense inverse covariance goes through the fused network + MFMA row-dot
+    lpd, _, _, probd = build_logprob("mlp_33_33_dense")
+    z = np.random.RandomState(9).standard_normal((300, 33)).astype(np.float32)
+    got = lpd(z, returntorch=False)
+    ref = likelihood.log_prob(z, cases.oracle_emulator(probd), probd["priors"], probd["data"], probd["invcov"], 1.0,
+                              dtype=np.float64)
+    np.testing.assert_allclose(got, ref, rtol=6e-4)
