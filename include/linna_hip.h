@@ -271,6 +271,26 @@ int linna_hmc_accept(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint6
                      int ldx, float* lnp, float* G, int* naccept, void* stream);
 int linna_step_increment(linna_ctx_t* ctx, int* step_dev, void* stream);
 
+/* Ensemble slice sampling (zeus DifferentialMove behind sampler.py:728-735): per active walker a
+ * direction mu*(c_a - c_b) from two distinct complementary walkers, a slice height
+ * Z0 = logp + log u, a unit bracket [L, R] placed at random around 0; stepping out pushes an end
+ * out while the density there exceeds Z0; shrinking draws w ~ U(L, R) and pulls the bracket in to
+ * rejected trials.  flags[3k..3k+2] = {left active, right active, shrinking}; counters[0..2] =
+ * {expansions, contractions, walkers still active after this call} (device int32, caller zeroes). */
+int linna_slice_init(linna_ctx_t* ctx, const float* logp, const int* S_idx, int ns, const float* ccoords, int ldcc,
+                     const int* C_idx, int nc, int ndim, const float* mu_dev, uint64_t seed, const int* step_dev,
+                     int stream_id, float* DIR, int ldd, float* Z0, float* L, float* R, int* flags, void* stream);
+int linna_slice_points(linna_ctx_t* ctx, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
+                       const float* DIR, int ldd, const float* w, float* Q, int ldq, void* stream);
+int linna_slice_expand(linna_ctx_t* ctx, const float* Z0, const float* ZL, const float* ZR, float* L, float* R,
+                       int* flags, int ns, int* counters, void* stream);
+int linna_slice_draw(linna_ctx_t* ctx, const float* L, const float* R, const int* S_idx, float* W, const int* flags,
+                     int ns, uint64_t seed, const int* step_dev, int stream_id, int round, void* stream);
+int linna_slice_shrink(linna_ctx_t* ctx, const float* Z0, const float* Ztrial, float* L, float* R, const float* W,
+                       int* flags, float* Wacc, float* Zacc, int ns, int* counters, void* stream);
+int linna_slice_commit(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
+                       const float* DIR, int ldd, const float* Wacc, const float* Zacc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

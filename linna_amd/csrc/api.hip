@@ -569,4 +569,32 @@ int linna_hmc_accept(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t 
 }
 int linna_step_increment(linna_ctx_t*, int* step_dev, void* stream) { return launch_step_increment(step_dev, S(stream)); }
 
+int linna_slice_init(linna_ctx_t*, const float* logp, const int* S_idx, int ns, const float* cc, int ldcc, const int* C_idx,
+                     int nc, int ndim, const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR,
+                     int ldd, float* Z0, float* L, float* R, int* flags, void* stream) {
+    if (ns < 1 || nc < 2) { set_error("slice_init: need >= 2 complementary walkers"); return LINNA_ERR_INVALID; }
+    return launch_slice_init(logp, S_idx, ns, cc, ldcc, C_idx, nc, ndim, mu, seed, step_dev, stream_id, DIR, ldd, Z0, L, R,
+                             flags, S(stream));
+}
+int linna_slice_points(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns, const float* DIR,
+                       int ldd, const float* w, float* Q, int ldq, void* stream) {
+    return launch_slice_points(coords, ldc, ndim, S_idx, ns, DIR, ldd, w, Q, ldq, S(stream));
+}
+int linna_slice_expand(linna_ctx_t*, const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags,
+                       int ns, int* counters, void* stream) {
+    return launch_slice_expand(Z0, ZL, ZR, L, R, flags, ns, counters, S(stream));
+}
+int linna_slice_draw(linna_ctx_t*, const float* L, const float* R, const int* S_idx, float* W, const int* flags, int ns,
+                     uint64_t seed, const int* step_dev, int stream_id, int round, void* stream) {
+    return launch_slice_draw(L, R, S_idx, W, flags, ns, seed, step_dev, stream_id, round, S(stream));
+}
+int linna_slice_shrink(linna_ctx_t*, const float* Z0, const float* Zt, float* L, float* R, const float* W, int* flags,
+                       float* Wacc, float* Zacc, int ns, int* counters, void* stream) {
+    return launch_slice_shrink(Z0, Zt, L, R, W, flags, Wacc, Zacc, ns, counters, S(stream));
+}
+int linna_slice_commit(linna_ctx_t*, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
+                       const float* DIR, int ldd, const float* Wacc, const float* Zacc, void* stream) {
+    return launch_slice_commit(coords, ldc, ndim, logp, S_idx, ns, DIR, ldd, Wacc, Zacc, S(stream));
+}
+
 }  // extern "C"

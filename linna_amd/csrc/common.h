@@ -63,6 +63,19 @@ int launch_hmc_kick_drift(int B, int ndim, const float* mass, float ek, float ed
 int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
                       const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
                       const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s);
+int launch_slice_init(const float* logp, const int* S, int ns, const float* cc, int ldcc, const int* C, int nc, int ndim,
+                      const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0,
+                      float* L, float* R, int* flags, hipStream_t s);
+int launch_slice_points(const float* coords, int ldc, int ndim, const int* S, int ns, const float* DIR, int ldd,
+                        const float* w, float* Q, int ldq, hipStream_t s);
+int launch_slice_expand(const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags, int ns,
+                        int* counters, hipStream_t s);
+int launch_slice_draw(const float* L, const float* R, const int* S, float* W, const int* flags, int ns, uint64_t seed,
+                      const int* step_dev, int stream_id, int round, hipStream_t s);
+int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, const float* W, int* flags, float* Wacc,
+                        float* Zacc, int ns, int* counters, hipStream_t s);
+int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
+                        const float* Wacc, const float* Zacc, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
 
 // fused_mlp.hip

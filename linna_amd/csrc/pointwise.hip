@@ -364,6 +364,93 @@ __global__ void hmc_accept_kernel(int B, int ndim, const float* __restrict__ mas
 
 __global__ void step_increment_kernel(int* step) { step[0] += 1; }
 
+// ------------------------------------------------------------------ ensemble slice sampling (zeus, Karamanis & Beutler 2021)
+// state per active walker k: direction DIR[k][:], slice height Z0, bracket [L, R] in units of the
+// direction, flags aL/aR (still stepping out) and aS (still shrinking).
+__global__ void slice_init_kernel(const float* __restrict__ logp, const int* __restrict__ S, int ns,
+                                  const float* __restrict__ cc, int ldcc, const int* __restrict__ C, int nc, int ndim,
+                                  const float* __restrict__ mu, uint64_t seed, const int* __restrict__ step_dev,
+                                  int stream_id, float* __restrict__ DIR, int ldd, float* __restrict__ Z0,
+                                  float* __restrict__ L, float* __restrict__ R, int* __restrict__ flags) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ns * ldd) return;
+    const int k = (int)(idx / ldd), d = (int)(idx % ldd);
+    const int wk = S[k];
+    const U4 r = walker_bits(seed, (uint32_t)wk, (uint32_t)step_dev[0], (uint32_t)stream_id, 0u);
+    // differential move: two DISTINCT complementary walkers
+    const int ia = (int)(((uint64_t)r.x * (uint64_t)nc) >> 32);
+    int ib = (int)(((uint64_t)r.y * (uint64_t)(nc - 1)) >> 32);
+    ib += (ib >= ia);
+    if (d < ndim) DIR[idx] = mu[0] * (cc[(size_t)C[ia] * ldcc + d] - cc[(size_t)C[ib] * ldcc + d]);
+    else DIR[idx] = 0.f;
+    if (d == 0) {
+        Z0[k] = logp[wk] + logf(u01(r.z));           // log of a uniform height under the density
+        const float l = -u01(r.w);
+        L[k] = l; R[k] = l + 1.f;
+        flags[3 * k] = 1; flags[3 * k + 1] = 1; flags[3 * k + 2] = 1;
+    }
+}
+
+// Q[row0 + k][:] = X[S[k]][:] + w[k] * DIR[k][:]
+__global__ void slice_points_kernel(const float* __restrict__ coords, int ldc, int ndim, const int* __restrict__ S, int ns,
+                                    const float* __restrict__ DIR, int ldd, const float* __restrict__ w,
+                                    float* __restrict__ Q, int ldq) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ns * ldq) return;
+    const int k = (int)(idx / ldq), d = (int)(idx % ldq);
+    Q[idx] = d < ndim ? coords[(size_t)S[k] * ldc + d] + w[k] * DIR[(size_t)k * ldd + d] : 0.f;
+}
+
+// stepping out: while the density at an end is above the slice, push that end out by one unit
+__global__ void slice_expand_kernel(const float* __restrict__ Z0, const float* __restrict__ ZL, const float* __restrict__ ZR,
+                                    float* __restrict__ L, float* __restrict__ R, int* __restrict__ flags, int ns,
+                                    int* __restrict__ counters) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    int n = 0;
+    if (flags[3 * k]) { if (ZL[k] > Z0[k]) { L[k] -= 1.f; ++n; } else flags[3 * k] = 0; }
+    if (flags[3 * k + 1]) { if (ZR[k] > Z0[k]) { R[k] += 1.f; ++n; } else flags[3 * k + 1] = 0; }
+    if (n) { atomicAdd(counters + 0, n); atomicAdd(counters + 2, 1); }      // [0] expansions, [2] still-active count
+}
+
+__global__ void slice_draw_kernel(const float* __restrict__ L, const float* __restrict__ R, const int* __restrict__ S,
+                                  float* __restrict__ W, const int* __restrict__ flags, int ns, uint64_t seed,
+                                  const int* __restrict__ step_dev, int stream_id, int round) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns || !flags[3 * k + 2]) return;
+    const U4 r = walker_bits(seed, (uint32_t)S[k], (uint32_t)step_dev[0], (uint32_t)stream_id, (uint32_t)(round + 1));
+    W[k] = L[k] + u01(r.x) * (R[k] - L[k]);
+}
+
+// shrinking: accept the trial if it is inside the slice, otherwise pull the bracket in to the trial
+__global__ void slice_shrink_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
+                                    float* __restrict__ R, const float* __restrict__ W, int* __restrict__ flags,
+                                    float* __restrict__ Wacc, float* __restrict__ Zacc, int ns, int* __restrict__ counters) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns || !flags[3 * k + 2]) return;
+    if (Zt[k] < Z0[k] || isnan(Zt[k])) {
+        if (W[k] < 0.f) L[k] = W[k]; else R[k] = W[k];
+        atomicAdd(counters + 1, 1);                       // [1] contractions
+        atomicAdd(counters + 2, 1);
+        if (R[k] - L[k] < 1e-30f) { flags[3 * k + 2] = 0; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
+    } else {
+        flags[3 * k + 2] = 0; Wacc[k] = W[k]; Zacc[k] = Zt[k];
+    }
+}
+
+__global__ void slice_commit_kernel(float* __restrict__ coords, int ldc, int ndim, float* __restrict__ logp,
+                                    const int* __restrict__ S, int ns, const float* __restrict__ DIR, int ldd,
+                                    const float* __restrict__ Wacc, const float* __restrict__ Zacc) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ns * ndim) return;
+    const int k = (int)(idx / ndim), d = (int)(idx % ndim);
+    const int wk = S[k];
+    if (Wacc[k] != 0.f) {
+        coords[(size_t)wk * ldc + d] += Wacc[k] * DIR[(size_t)k * ldd + d];
+        if (d == 0) logp[wk] = Zacc[k];
+    }
+}
+
 // ------------------------------------------------------------------ host-side launchers (namespace-internal)
 #define LAUNCH_CHECK(name) return check_hip(hipGetLastError(), name)
 
@@ -471,6 +558,42 @@ int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const i
     hipLaunchKernelGGL(hmc_accept_kernel, grid1d(B, 256), dim3(256), 0, s, B, ndim, mass, seed, step_dev, H0, P, ldp, Qn,
                        ldq, lnp_new, Gn, ldg, U, X, ldx, lnp, G, naccept);
     LAUNCH_CHECK("hmc_accept");
+}
+int launch_slice_init(const float* logp, const int* S, int ns, const float* cc, int ldcc, const int* C, int nc, int ndim,
+                      const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0,
+                      float* L, float* R, int* flags, hipStream_t s) {
+    hipLaunchKernelGGL(slice_init_kernel, grid1d((size_t)ns * ldd, 256), dim3(256), 0, s, logp, S, ns, cc, ldcc, C, nc, ndim,
+                       mu, seed, step_dev, stream_id, DIR, ldd, Z0, L, R, flags);
+    LAUNCH_CHECK("slice_init");
+}
+int launch_slice_points(const float* coords, int ldc, int ndim, const int* S, int ns, const float* DIR, int ldd,
+                        const float* w, float* Q, int ldq, hipStream_t s) {
+    hipLaunchKernelGGL(slice_points_kernel, grid1d((size_t)ns * ldq, 256), dim3(256), 0, s, coords, ldc, ndim, S, ns, DIR,
+                       ldd, w, Q, ldq);
+    LAUNCH_CHECK("slice_points");
+}
+int launch_slice_expand(const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags, int ns,
+                        int* counters, hipStream_t s) {
+    hipLaunchKernelGGL(slice_expand_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, ZL, ZR, L, R, flags, ns, counters);
+    LAUNCH_CHECK("slice_expand");
+}
+int launch_slice_draw(const float* L, const float* R, const int* S, float* W, const int* flags, int ns, uint64_t seed,
+                      const int* step_dev, int stream_id, int round, hipStream_t s) {
+    hipLaunchKernelGGL(slice_draw_kernel, grid1d(ns, 256), dim3(256), 0, s, L, R, S, W, flags, ns, seed, step_dev,
+                       stream_id, round);
+    LAUNCH_CHECK("slice_draw");
+}
+int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, const float* W, int* flags, float* Wacc,
+                        float* Zacc, int ns, int* counters, hipStream_t s) {
+    hipLaunchKernelGGL(slice_shrink_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, W, flags, Wacc, Zacc, ns,
+                       counters);
+    LAUNCH_CHECK("slice_shrink");
+}
+int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
+                        const float* Wacc, const float* Zacc, hipStream_t s) {
+    hipLaunchKernelGGL(slice_commit_kernel, grid1d((size_t)ns * ndim, 256), dim3(256), 0, s, coords, ldc, ndim, logp, S,
+                       ns, DIR, ldd, Wacc, Zacc);
+    LAUNCH_CHECK("slice_commit");
 }
 int launch_step_increment(int* step, hipStream_t s) {
     hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, step);

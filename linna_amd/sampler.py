@@ -24,7 +24,7 @@ import torch
 
 from . import _lib
 
-__all__ = ["EnsembleSampler", "BatchedHMC", "HMCSampler", "ZeusSampler", "checkmeanstd", "integrated_time",
+__all__ = ["EnsembleSampler", "SliceEnsembleSampler", "BatchedHMC", "HMCSampler", "ZeusSampler", "checkmeanstd", "integrated_time",
            "ChainStore", "read_chain_and_cut"]
 
 
@@ -257,6 +257,93 @@ class EnsembleSampler(object):
         return ldist.gather_chain(chain, lps, self.group)
 
 
+# ------------------------------------------------------------------ ensemble slice sampling (zeus)
+class SliceEnsembleSampler(EnsembleSampler):
+    """zeus' ensemble slice sampler (Karamanis & Beutler 2021; driven by sampler.py:728-735) with
+    every trial point of a half ensemble evaluated in one batched GPU call.
+
+    Per half step: differential-move directions ``mu (c_a - c_b)``, slice height
+    ``Z0 = logp + log u``, stepping out (both bracket ends evaluated together, 2 x nw/2 points per
+    round) and shrinking (nw/2 points per round) until every walker has accepted.  ``mu`` is tuned
+    during the first iterations as zeus does: ``mu *= 2 nexp / (nexp + ncon)`` until the expansion
+    fraction stays within ``tolerance`` of 1/2 for ``patience`` iterations.  Third-party algorithm
+    restated from the publication (zeus-mcmc is not in the reference tree): parity unpinned,
+    checked statistically.
+    """
+
+    def __init__(self, nwalkers, ndim, log_prob, mu=1.0, seed=0, tune=True, tolerance=0.05, patience=5, maxsteps=10000,
+                 maxiter=100000, dist_group=None, exchange="none"):
+        EnsembleSampler.__init__(self, nwalkers, ndim, log_prob, seed=seed, dist_group=dist_group, exchange=exchange)
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=self.dev)
+        ns = self.half
+        self.mu = float(mu)
+        self.mu_dev = torch.full((1,), self.mu, dtype=torch.float32, device=self.dev)
+        self.tune, self.tolerance, self.patience, self.maxsteps, self.maxiter = tune, tolerance, patience, maxsteps, maxiter
+        self._tune_count = 0
+        self.DIR, self.Q2 = z(ns, self.ld), z(2 * ns, self.ld)
+        self.Z0, self.L, self.R, self.W, self.Wacc, self.Zacc = z(ns), z(ns), z(ns), z(ns), z(ns), z(ns)
+        self.Z2 = z(2 * ns)
+        self.flags = torch.zeros(3 * ns, dtype=torch.int32, device=self.dev)
+        self.counters = torch.zeros(3, dtype=torch.int32, device=self.dev)
+        self.neval = 0
+
+    def _active(self):
+        """Walkers still active after the last expand/shrink call (one small device->host read)."""
+        n = int(self.counters[2].item())
+        self.counters[2:3].zero_()
+        return n
+
+    def step(self):
+        st, ns, ndim = _lib.stream(), self.half, self.ndim
+        halves = self._splits()
+        seed = C.c_uint64((self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF)
+        self.counters.zero_()
+        P = _lib.ptr
+        for h in (0, 1):
+            S, Cc = halves[h], halves[1 - h]
+            comp, ldc, cidx, nc = self.coords, self.ld, Cc, self.half
+            if self.exchange == "allgather" and self.world > 1:
+                comp, cidx, nc = self._allgather_complement(Cc)
+            _lib.call("linna_slice_init", self.ctx, P(self.logp), _lib.iptr(S), ns, P(comp), ldc, _lib.iptr(cidx), nc, ndim,
+                      P(self.mu_dev), seed, _lib.iptr(self.step_dev), h, P(self.DIR), self.ld, P(self.Z0), P(self.L),
+                      P(self.R), _lib.iptr(self.flags), st)
+            for _ in range(self.maxsteps):              # stepping out, both ends per round
+                _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
+                          self.ld, P(self.L), P(self.Q2), self.ld, st)
+                _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
+                          self.ld, P(self.R), C.c_void_p(self.Q2.data_ptr() + 4 * ns * self.ld), self.ld, st)
+                self.lp.evaluate(self.Q2, out=self.Z2)
+                self.neval += 2 * ns
+                _lib.call("linna_slice_expand", self.ctx, P(self.Z0), P(self.Z2), C.c_void_p(self.Z2.data_ptr() + 4 * ns),
+                          P(self.L), P(self.R), _lib.iptr(self.flags), ns, _lib.iptr(self.counters), st)
+                if self._active() == 0:
+                    break
+            Q1, Z1 = self.Q2[:ns], self.Z2[:ns]
+            for rnd in range(self.maxsteps):            # shrinking
+                _lib.call("linna_slice_draw", self.ctx, P(self.L), P(self.R), _lib.iptr(S), P(self.W), _lib.iptr(self.flags),
+                          ns, seed, _lib.iptr(self.step_dev), 2 + h, rnd, st)
+                _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
+                          self.ld, P(self.W), P(Q1), self.ld, st)
+                self.lp.evaluate(Q1, out=Z1)
+                self.neval += ns
+                _lib.call("linna_slice_shrink", self.ctx, P(self.Z0), P(Z1), P(self.L), P(self.R), P(self.W),
+                          _lib.iptr(self.flags), P(self.Wacc), P(self.Zacc), ns, _lib.iptr(self.counters), st)
+                if self._active() == 0:
+                    break
+            _lib.call("linna_slice_commit", self.ctx, P(self.coords), self.ld, ndim, P(self.logp), _lib.iptr(S), ns,
+                      P(self.DIR), self.ld, P(self.Wacc), P(self.Zacc), st)
+        _lib.call("linna_step_increment", self.ctx, _lib.iptr(self.step_dev), st)
+        self.iteration += 1
+        if self.tune:                                   # zeus: mu *= 2 nexp / (nexp + ncon)
+            c = self.counters.cpu().numpy()
+            nexp, ncon = max(1, int(c[0])), int(c[1])
+            self.mu *= 2.0 * nexp / (nexp + ncon)
+            self.mu_dev.fill_(self.mu)
+            self._tune_count = self._tune_count + 1 if abs(nexp / (nexp + ncon) - 0.5) < self.tolerance else 0
+            if self._tune_count > self.patience:
+                self.tune = False
+
+
 # ------------------------------------------------------------------ batched per-walker HMC
 class BatchedHMC(object):
     """``linna/HMCSampler.py:19-68`` for B independent chains: p ~ N(0, m); half kick; ``num_steps``
@@ -388,9 +475,8 @@ class HMCSampler(object):
 
 
 class ZeusSampler(object):
-    """sampler.py:699-737 drives zeus' ensemble slice sampler.  The slice move is listed under
-    "next" in SURVEY section 8 f; until it exists this driver runs the stretch-move ensemble with
-    the zeus convergence rule (IAT on the last 80 %, sampler.py:729) and the zeus file names."""
+    """sampler.py:699-737: zeus' ensemble slice sampler (``SliceEnsembleSampler``) with the reference's
+    convergence callback (IAT on the last 80 %, sampler.py:684,729; mean/std drift) and file names."""
 
     def __init__(self, lnp, ndim, nwalkers, x0=None, transform=None, seed=0, dist_group=None):
         self.lnp, self.transform, self.x0, self.nparams, self.nwalkers = lnp, transform, x0, ndim, nwalkers
@@ -406,7 +492,8 @@ class ZeusSampler(object):
             prev = ChainStore.load(store.base)
             x0 = prev["chain"][-1]
             store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])
-        ens = EnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
+        ens = SliceEnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
+        self.sampler = ens
         ens.set_state(x0)
         old_tau, done = np.inf, sum(len(c) for c in store.chain)
         while done < min(nsamp, 100000):

@@ -38,11 +38,13 @@ class TrainEngine(object):
         self.loader = loader
         self.k = pred._device_consts()
         sigma, ymean, ystd, data_norm, cinv = loss_fn.auxileryfunction.arrays()
+        ldc = _lib.ld4(self.nout)         # padded rows: streamable by 16-byte LDS-DMA
+        cinv = np.pad(cinv, ((0, 0), (0, ldc - self.nout)))
         self._keep = dict(sigma=f32(sigma), ymean=f32(ymean), ystd=f32(ystd), data_norm=f32(data_norm), cinv=f32(cinv))
         d = _lib.LossDesc()
         d.nout = self.nout
         d.sigma, d.ymean, d.ystd = (_lib.ptr(self._keep[n]) for n in ("sigma", "ymean", "ystd"))
-        d.data_norm, d.Cinv, d.ldc = _lib.ptr(self._keep["data_norm"]), _lib.ptr(self._keep["cinv"]), self.nout
+        d.data_norm, d.Cinv, d.ldc = _lib.ptr(self._keep["data_norm"]), _lib.ptr(self._keep["cinv"]), ldc
         self.desc = d
         self.den = self._chi2_md(self.Y)
         self.val = None

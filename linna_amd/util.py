@@ -296,9 +296,12 @@ class Log_prob(object):
             k["w"] = f32(np.diagonal(S))
             d.w = _lib.ptr(k["w"])
         else:
-            k["S"] = f32(S)
-            k["Ssym"] = f32(0.5 * (S.astype(np.float64) + S.astype(np.float64).T))
-            d.S, d.lds, d.Ssym = _lib.ptr(k["S"]), nout, _lib.ptr(k["Ssym"])
+            # rows padded to a multiple of 4 floats so the MFMA GEMM streams them by 16-byte LDS-DMA
+            ldS = _lib.ld4(nout)
+            pad = lambda m: np.pad(m, ((0, 0), (0, ldS - nout)))
+            k["S"] = f32(pad(S))
+            k["Ssym"] = f32(pad(0.5 * (S.astype(np.float64) + S.astype(np.float64).T)))
+            d.S, d.lds, d.Ssym = _lib.ptr(k["S"]), ldS, _lib.ptr(k["Ssym"])
         d.gscale = _lib.ptr(k["gscale"])
         d.temperature = self.T
         h = C.c_void_p()

@@ -182,3 +182,41 @@ def test_ml_sampler_core_end_to_end(tmp_path):
     chain2, _ = ml_sampler_core([20], [5], [1], [2], [0.5], [100], [100], out, theory, priors, means, cov, init, None, 4, "cuda",
                                 None, False, [1.0], nnmodel_in=ChtoModelv2, params=params, method="emcee")
     np.testing.assert_array_equal(chain, chain2)
+
+
+def test_slice_ensemble_posterior_33d_gaussian():
+    """zeus-style ensemble slice sampler: posterior of the 33-D Gaussian and mu tuning."""
+    from linna_amd import sampler, util
+    ndim, means, cov, priors = _gaussian_33()
+    lp = identity_emulator_logprob(ndim, means, cov, priors)
+    nw = 512
+    ens = sampler.SliceEnsembleSampler(nw, ndim, lp, seed=5)
+    z0 = util.invTransform(priors)(means)[None, :] + 0.001 * np.random.RandomState(1).standard_normal((nw, ndim))
+    ens.set_state(z0)
+    ens.run(150, store=False)
+    assert not ens.tune and 0.05 < ens.mu < 50.0            # tuning converged
+    c, l = ens.run(250)
+    th = ens.theta_of(c).cpu().numpy().reshape(-1, ndim)
+    sig = np.sqrt(np.diag(cov))
+    assert np.max(np.abs(th.mean(0) - means) / sig) < 0.05
+    np.testing.assert_allclose(th.std(0), sig, rtol=0.06)
+    # every stored log-probability is the log-probability of the stored position
+    z_last = c[-1]
+    np.testing.assert_allclose(lp.evaluate(torch.nn.functional.pad(z_last, (0, ens.ld - ndim))).cpu().numpy(),
+                               l[-1].cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert ens.neval / (ens.iteration * nw) < 25            # batched rounds, inactive lanes included
+
+
+def test_zeus_driver_smoke(tmp_path):
+    """tests/test_sampler.py:4-14 of the reference (``test_zeus``) on the emulator path."""
+    from linna_amd import sampler, util
+    ndim, means, cov, priors = 2, np.array([0.1, 1.0]), np.diag([0.5, 0.2]), \
+        [{"param": "t%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(2)]
+    lp = identity_emulator_logprob(ndim, means, cov, priors)
+    x0 = util.invTransform(priors)(means)[None, :] + 0.001 * np.random.RandomState(3).standard_normal((10, ndim))
+    samp = sampler.ZeusSampler(lp, ndim, 10, x0=x0, transform=util.Transform(priors))
+    store = samp.sample(None, 1000, outdir=str(tmp_path), ntimes=10, tautol=0.01, incremental=True)
+    z, th, l = store.arrays()
+    assert th.shape[1:] == (10, 2) and len(th) >= 100 and np.all(np.isfinite(l))
+    assert os.path.isfile(os.path.join(str(tmp_path), "zeus_256.npz"))
+    assert np.all(np.abs(th.reshape(-1, 2).mean(0) - means) < 0.25)
