@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph instead of direct launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                                                      "rehearse the multi-rank path on a box with fewer GPUs)")
     args = ap.parse_args()
 
     import torch
@@ -163,10 +165,17 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > 1 and local_rank >= ndev:
+        sys.exit("rank %d has no GPU (%d visible): one rank per GPU" % (local_rank, ndev))
+    dev_index = local_rank % max(ndev, 1)           # (gloo rehearsal may share a GPU between ranks)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     lp, model, consts = build_problem(device)
     z_host = np.random.RandomState(100 + rank).standard_normal((NWALKERS, NIN)).astype(np.float32)
@@ -214,7 +223,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

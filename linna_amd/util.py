@@ -416,6 +416,27 @@ class Dlnp(object):
         return g[0] if one else g
 
 
+class Ddlnp(object):
+    """Hessian of ``Log_prob`` wrt the latent position -- the INTENDED semantics of util.py:1037-1051
+    (same broken constructor as ``Dlnp`` in the reference).  The reference differentiates the
+    autograd gradient row by row; here the rows are central differences of the HIP gradient,
+    all 2*ndim displaced points evaluated in ONE batched ``linna_logprob_grad`` call."""
+
+    def __init__(self, data_new, invcov_new, model, y_invtransform_data, transform, temperature, eps=1e-2):
+        self.log_prob = Log_prob(data_new, invcov_new, model, y_invtransform_data, transform, temperature)
+        self.eps = float(eps)
+
+    def __call__(self, x):
+        z, _ = self.log_prob._to_device(x)
+        n = z.shape[1]
+        e = self.eps * torch.eye(n, device=z.device, dtype=torch.float32)
+        pts = torch.cat([z[0:1] + e, z[0:1] - e]).contiguous()
+        _, g = self.log_prob.evaluate_with_grad(pts)
+        g = g.double()
+        hess = (g[:n] - g[n:]) / (2 * self.eps)
+        return (0.5 * (hess + hess.T)).cpu().numpy()
+
+
 # ------------------------------------------------------------------ training objects (util.py:383-400, 1055-1127)
 class ArrayDataset(object):
     """util.py:383-400: float32 views of the training arrays."""

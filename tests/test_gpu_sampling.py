@@ -220,3 +220,25 @@ def test_zeus_driver_smoke(tmp_path):
     assert th.shape[1:] == (10, 2) and len(th) >= 100 and np.all(np.isfinite(l))
     assert os.path.isfile(os.path.join(str(tmp_path), "zeus_256.npz"))
     assert np.all(np.abs(th.reshape(-1, 2).mean(0) - means) < 0.25)
+
+
+def test_hessian_of_log_prob_matches_oracle_fd():
+    """util.py:1037-1051 intended semantics (Ddlnp): Hessian of lnP wrt z."""
+    from oracle import likelihood
+    from linna_amd import util
+    lp, pred, yinv, prob = build_logprob("mlp_7_5_small", 16.0)
+    dd = util.Ddlnp(prob["data"], prob["invcov"], pred, yinv, util.Transform(prob["priors"]), 16.0)
+    z0 = np.array([0.1, -0.2, 0.3, 0.05, -0.1, 0.2, 0.0], np.float32)
+    H = dd(z0)
+    emu = cases.oracle_emulator(prob)
+    eps, n = 1e-2, 7
+    E = eps * np.eye(n)
+    _, gp = likelihood.grad_log_prob(z0[None, :] + E, emu, prob["priors"], prob["data"], prob["invcov"], 16.0, dtype=np.float64)
+    _, gm = likelihood.grad_log_prob(z0[None, :] - E, emu, prob["priors"], prob["data"], prob["invcov"], 16.0, dtype=np.float64)
+    Href = (gp - gm) / (2 * eps)
+    Href = 0.5 * (Href + Href.T)
+    assert H.shape == (n, n)
+    np.testing.assert_allclose(H, Href, rtol=5e-2, atol=5e-2 * np.abs(Href).max())
+    g = util.Dlnp(prob["data"], prob["invcov"], pred, yinv, util.Transform(prob["priors"]), 16.0)(z0)
+    _, gref = likelihood.grad_log_prob(z0[None, :], emu, prob["priors"], prob["data"], prob["invcov"], 16.0)
+    np.testing.assert_allclose(g, gref[0], rtol=3e-3, atol=1e-4 * np.abs(gref).max())

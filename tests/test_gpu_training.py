@@ -149,3 +149,26 @@ def test_lr_range_test_runs_and_restores_weights(tmp_path):
     lr = lrfinder.range_test(pred, eng, num_iter=20)
     assert 1e-4 <= lr <= 5e-3
     assert torch.equal(before, model.flat_params())
+
+
+def test_train_gpu_process_shim(tmp_path):
+    """linna/train_gpu.py:24-38: `python train_gpu.py <outdir> cuda` reads model_args.pkl, trains,
+    writes finish.pkl -- here `python -m linna_amd.train_gpu`."""
+    import pickle
+    import subprocess
+    import sys
+    g = cases.golden("train_nn_run")
+    out = str(tmp_path) + "/"
+    np.savetxt(out + "train_samples_x.txt", g["train_x"]); np.save(out + "train_samples_y.npy", g["train_y"])
+    np.savetxt(out + "val_samples_x.txt", g["val_x"]); np.save(out + "val_samples_y.npy", g["val_y"])
+    np.save(out + "lr.npy", 2e-3)
+    cov = g["cov"]
+    args = [None, cov, np.linalg.inv(cov), np.sqrt(np.diag(cov)), out, [out], g["data"], None, False, False, 2, 1.0, True, None,
+            1, None, {"num_epochs": 2, "batch_size": 50}, False]
+    with open(out + "model_args.pkl", "wb") as f:
+        pickle.dump(args, f)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "linna_amd.train_gpu", out, "cuda"], cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert os.path.isfile(out + "finish.pkl") and os.path.isfile(out + "best.pth.tar")
