@@ -52,7 +52,12 @@ static void set_pair(GemmArgs& a, int i, const float* A, int lda, int alay, cons
 
 using namespace linna;
 
-struct linna_ctx { int device; };
+struct linna_ctx {
+    int device;
+    hipStream_t aux = nullptr;               // second stream: parameter-gradient GEMMs run beside the dX chain
+    std::vector<hipEvent_t> events;          // fork/join markers (no timing)
+    int overlap = -1;                        // -1 unknown, 0 off (env LINNA_BWD_STREAMS=0), 1 on
+};
 struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
 
 struct linna_net {
@@ -101,10 +106,19 @@ int linna_ctx_create(int device, linna_ctx_t** out) {
         set_error("ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return LINNA_ERR_UNSUPPORTED;
     }
-    *out = new (std::nothrow) linna_ctx{device};
-    return *out ? LINNA_OK : LINNA_ERR_INVALID;
+    *out = new (std::nothrow) linna_ctx();
+    if (!*out) return LINNA_ERR_INVALID;
+    (*out)->device = device;
+    return LINNA_OK;
 }
-int linna_ctx_destroy(linna_ctx_t* ctx) { delete ctx; return LINNA_OK; }
+int linna_ctx_destroy(linna_ctx_t* ctx) {
+    if (ctx) {
+        for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+        if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+    }
+    delete ctx;
+    return LINNA_OK;
+}
 int linna_stream_sync(void* stream) { return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize"); }
 
 int linna_graph_begin(void* stream) {
@@ -230,9 +244,18 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
 int linna_net_destroy(linna_net_t* net) { delete net; return LINNA_OK; }
 
 size_t linna_net_fwd_ws_bytes(const linna_net_t* n, int B) { return (fwd_layout(n, B).total + 16) * sizeof(float); }
-size_t linna_net_bwd_ws_bytes(const linna_net_t* n, int B) {
-    return ((size_t)B * (2 * (size_t)ld4(n->max_w) + ld4(n->max_c)) + 16) * sizeof(float);
+// backward scratch: one buffer per op for the gradient wrt that op's input (no reuse: the
+// parameter-gradient GEMMs of an op may still be reading it on the auxiliary stream while the dX
+// chain moves on) + one dT buffer per residual block
+static size_t bwd_floats(const linna_net* n, int B) {
+    size_t f = 0;
+    for (size_t i = 0; i < n->L.size(); ++i) {
+        f += (size_t)B * ld4(n->L[i].K);
+        if (n->L[i].op == LINNA_OP_RESBLOCK) f += (size_t)B * ld4(n->L[i].C);
+    }
+    return f;
 }
+size_t linna_net_bwd_ws_bytes(const linna_net_t* n, int B) { return (bwd_floats(n, B) + 16) * sizeof(float); }
 
 int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, float* OUT, int ldo,
                       const linna_colmap_t* om, void* stream) {
@@ -281,30 +304,59 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
     const FwdLayout f = fwd_layout(n, B);
     const float* w = static_cast<const float*>(fwd_ws);
     float* bw = static_cast<float*>(bwd_ws);
-    const int ldw = ld4(n->max_w);
-    float* buf[2] = {bw, bw + (size_t)B * ldw};
-    float* dT = bw + 2 * (size_t)B * ldw;
     const int nl = (int)n->L.size();
     hipStream_t st = S(stream);
 
+    // ---- auxiliary stream for the parameter gradients (off the dX critical path)
+    linna_ctx* ctx = n->ctx;
+    bool overlap = false;
+    if (pg && ctx) {
+        if (ctx->overlap < 0) {
+            const char* e = getenv("LINNA_BWD_STREAMS");
+            ctx->overlap = (e && e[0] == '0') ? 0 : 1;
+        }
+        if (ctx->overlap == 1) {
+            if (!ctx->aux) TRY(check_hip(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking), "hipStreamCreate"));
+            while ((int)ctx->events.size() < 2 * nl + 4) {
+                hipEvent_t e;
+                TRY(check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"));
+                ctx->events.push_back(e);
+            }
+            overlap = true;
+        }
+    }
+    int next_event = 0;
+    void* aux = overlap ? (void*)ctx->aux : stream;
+    auto fork = [&]() -> int {       // work enqueued on aux after this sees everything enqueued on st so far
+        if (!overlap) return LINNA_OK;
+        hipEvent_t e = ctx->events[next_event++];
+        TRY(check_hip(hipEventRecord(e, st), "hipEventRecord"));
+        return check_hip(hipStreamWaitEvent(ctx->aux, e, 0), "hipStreamWaitEvent");
+    };
+
     if (n->has_inskip && pg) {
         const linna_layer_t& s = n->inskip;
-        TRY(linna_linear_bwd(nullptr, dOUT, lddo, X, ldx, s.W, ld4(s.K), nullptr, 0, nullptr, 0, s.gW, ld4(s.K), s.gb, B, s.K, s.N, s.alpha, stream));
+        TRY(fork());
+        TRY(linna_linear_bwd(nullptr, dOUT, lddo, X, ldx, s.W, ld4(s.K), nullptr, 0, nullptr, 0, s.gW, ld4(s.K), s.gb, B, s.K, s.N, s.alpha, aux));
     }
     const float* dcur = dOUT; int ldd = lddo;
-    int flip = 0;
+    float* cursor = bw;
     for (int i = nl - 1; i >= 0; --i) {
         const linna_layer_t& l = n->L[i];
         const float* hin = (i == 0) ? X : w + f.y_off[i - 1];
         const int ldh = (i == 0) ? ldx : ld4(n->L[i - 1].N);
         const bool need_dx = (i > 0) || (dX != nullptr);
-        float* dprev = (i == 0) ? dX : buf[flip];
-        const int ldp = (i == 0) ? lddx : ldw;
+        float* dprev = (i == 0) ? dX : cursor;
+        const int ldp = (i == 0) ? lddx : ld4(l.K);
+        if (i > 0) cursor += (size_t)B * ld4(l.K);
         // hin went through a ReLU iff the producing op is a resblock or a linear with relu
         const bool hin_relu = (i > 0) && (n->L[i - 1].op == LINNA_OP_RESBLOCK || n->L[i - 1].relu);
         const float* mask = hin_relu ? hin : nullptr;
         if (l.op == LINNA_OP_LINEAR) {
-            if (pg) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.W, ld4(l.K), nullptr, 0, nullptr, 0, l.gW, ld4(l.K), l.gb, B, l.K, l.N, 1.f, stream));
+            if (pg) {                // dW, db need only dcur (already produced on st) and hin
+                TRY(fork());
+                TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.W, ld4(l.K), nullptr, 0, nullptr, 0, l.gW, ld4(l.K), l.gb, B, l.K, l.N, 1.f, aux));
+            }
             if (need_dx) {
                 GemmArgs a = gemm_zero();
                 a.M = B; a.N = l.K; a.C = dprev; a.ldc = ldp; a.mask = mask; a.ldmask = ldh;
@@ -322,6 +374,8 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         } else {
             const float* T = w + f.t_off[i];
             const int ldt = ld4(l.C);
+            float* dT = cursor;
+            cursor += (size_t)B * ldt;
             {   // dT = 0.1 * (dcur W2) * (T > 0)
                 GemmArgs a = gemm_zero();
                 set_pair(a, 0, dcur, ldd, LAY_K, l.W2, ld4(l.C), LAY_MN, l.N);
@@ -329,9 +383,10 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
                 TRY(gemm_launch(a, st));
             }
             if (pg) {
-                TRY(linna_linear_bwd(nullptr, dcur, ldd, T, ldt, l.W2, ld4(l.C), nullptr, 0, nullptr, 0, l.gW2, ld4(l.C), l.gb2, B, l.C, l.N, 0.1f, stream));
-                TRY(linna_linear_bwd(nullptr, dT, ldt, hin, ldh, l.W1, ld4(l.K), nullptr, 0, nullptr, 0, l.gW1, ld4(l.K), l.gb1, B, l.K, l.C, 1.f, stream));
-                if (l.Ws) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.Ws, ld4(l.K), nullptr, 0, nullptr, 0, l.gWs, ld4(l.K), nullptr, B, l.K, l.N, 1.f, stream));
+                TRY(fork());         // after dT
+                TRY(linna_linear_bwd(nullptr, dcur, ldd, T, ldt, l.W2, ld4(l.C), nullptr, 0, nullptr, 0, l.gW2, ld4(l.C), l.gb2, B, l.C, l.N, 0.1f, aux));
+                TRY(linna_linear_bwd(nullptr, dT, ldt, hin, ldh, l.W1, ld4(l.K), nullptr, 0, nullptr, 0, l.gW1, ld4(l.K), l.gb1, B, l.K, l.C, 1.f, aux));
+                if (l.Ws) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.Ws, ld4(l.K), nullptr, 0, nullptr, 0, l.gWs, ld4(l.K), nullptr, B, l.K, l.N, 1.f, aux));
             }
             if (need_dx) {   // dprev = (dT W1 + dcur Ws [+ dcur]) * (hin > 0)
                 GemmArgs a = gemm_zero();
@@ -343,7 +398,11 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
             }
         }
         dcur = dprev; ldd = ldp;
-        flip ^= 1;
+    }
+    if (overlap) {                   // join: the caller's stream continues only after every gradient is written
+        hipEvent_t e = ctx->events[next_event++];
+        TRY(check_hip(hipEventRecord(e, ctx->aux), "hipEventRecord"));
+        TRY(check_hip(hipStreamWaitEvent(st, e, 0), "hipStreamWaitEvent"));
     }
     return LINNA_OK;
 }

@@ -368,6 +368,9 @@ class Log_prob(object):
 
     def __call__(self, x, returntorch=True, inputnumpy=True):
         z, one = self._to_device(x)
+        if z.shape[0] == 0:                              # empty batch: nothing to launch
+            like = torch.empty(0, dtype=torch.float32)
+            return like if returntorch else like.numpy()
         if self.loglikelihoodfunc is not gaussianlogliklihood:
             like = self._generic(z)
         else:

@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no liblinna_hip.so (built artefacts are git-ignored): build it once
+    (hipcc cross-compiles gfx950 without a GPU)."""
+    from linna_amd import _lib, _build
+    if not os.path.exists(_lib.LIB_PATH):
+        _build.build(verbose=False)
+
+
 def _has_gpu():
     try:
         import torch

@@ -185,6 +185,10 @@ def test_nan_maps_to_minus_inf_and_empty_edge():
     assert np.isfinite(out[0]) and out[1] == -np.inf and np.isfinite(out[2])
     with pytest.raises(ValueError):
         lp(np.zeros((2, 5), np.float32))
+    assert lp(np.zeros((0, 6), np.float32), returntorch=False).shape == (0,)      # empty batch
+    from linna_amd import _lib
+    with pytest.raises(_lib.LinnaHipError):                                         # the C ABI rejects B < 1 loudly
+        lp.evaluate(torch.zeros((0, 6), device="cuda"))
 
 
 def test_fused_mlp_kernel_edges_and_agreement_with_layered_path():
