@@ -26,6 +26,7 @@ TRAIN = [
     ("train_mlp_7_5", "MLP", 7, 5, 202, 40, {"width": 48, "depth": 3}, True),
     ("train_v2_33_33", "ChtoModelv2", 33, 33, 203, 100, {}, False),
     ("train_v2_12_40", "ChtoModelv2", 12, 40, 204, 50, {}, False),
+    ("train_v2_26_457", "ChtoModelv2", 26, 457, 205, 64, {}, False),      # BASELINE config 3 shape
 ]
 
 
