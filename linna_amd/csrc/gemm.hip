@@ -183,6 +183,26 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
         }
     };
 
+    // ---- per-column epilogue constants, loaded BEFORE any LDS-DMA is in flight and pinned, so that
+    // their latency hides under the K loop and the compiler's wait for them does not drain the ring
+    const bool two = a.npairs > 1;
+    float e_b[TN], e_cs[TN], e_ct[TN], e_cp[TN], e_ct2[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+        const bool cok = col < a.N;
+        const float* bp = two ? a.bias1 : a.bias0;
+        e_b[j] = (cok && bp) ? bp[col] : 0.f;
+        e_cs[j] = (cok && a.cscale) ? a.cscale[col] : 1.f;
+        e_ct[j] = (cok && a.cshift) ? a.cshift[col] : 0.f;
+        e_cp[j] = (cok && a.cpost) ? a.cpost[col] : 1.f;
+        e_ct2[j] = (cok && a.cshift2) ? a.cshift2[col] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        asm volatile("" : "+v"(e_b[j]), "+v"(e_cs[j]), "+v"(e_ct[j]), "+v"(e_cp[j]), "+v"(e_ct2[j]));
+    }
+
     for (int pi = 0; pi < a.npairs; ++pi) {
         const GemmPair p = a.p[pi];
         const bool dma_ok = ((p.lda & 3) == 0) && ((p.ldb & 3) == 0) &&
@@ -233,7 +253,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
 
     // ---------------------------------------------------------------- epilogue
     // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
-    const bool two = a.npairs > 1;
     const int h = lane >> 5;
     float dot[TM][16];
     if (a.dotwith) {
@@ -246,15 +265,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
         const bool cok = col < a.N;
-        float b_first = 0.f, b_last = 0.f, cs = 1.f, ct = 0.f, cp = 1.f, ct2 = 0.f;
-        if (cok) {
-            if (two) { b_last = a.bias1 ? a.bias1[col] : 0.f; }
-            else { b_first = a.bias0 ? a.bias0[col] : 0.f; }
-            if (a.cscale) cs = a.cscale[col];
-            if (a.cshift) ct = a.cshift[col];
-            if (a.cpost) cp = a.cpost[col];
-            if (a.cshift2) ct2 = a.cshift2[col];
-        }
+        const float b_first = two ? 0.f : e_b[j], b_last = two ? e_b[j] : 0.f;
+        const float cs = e_cs[j], ct = e_ct[j], cp = e_cp[j], ct2 = e_ct2[j];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -298,11 +310,12 @@ static int pick_cfg(int M, int N, int flags = 0) {
         const int bm = kCfgs[c].wm * kCfgs[c].tm * 32, bn = kCfgs[c].wn * kCfgs[c].tn * 32;
         return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     };
-    // 64x64 workgroups, two or more per CU, are the default; 128x64 only once that already
-    // oversubscribes the chip; single-wave 32x32 tiles when 64x64 cannot give every CU a block.
+    // 64x64 workgroups are the default (measured: they beat single-wave 32x32 tiles even when they
+    // leave CUs idle, tools/gemm_bench.py); 128x64 only once 64x64 already oversubscribes the chip;
+    // 32x32 for outputs that fit a single such tile.
     if (tiles(1) >= 2048) return 0;
-    if (tiles(1) >= 256) return 1;
-    return 2;
+    if (M <= 32 && N <= 32) return 2;
+    return 1;
 }
 
 int gemm_slots(int M, int N) {
