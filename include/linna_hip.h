@@ -197,6 +197,13 @@ typedef struct {
 int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc,
                          linna_logprob_t** out);
 int linna_logprob_destroy(linna_logprob_t* lp);
+/* Networks whose hidden layers are all 512 wide are served from a fragment-order copy of the
+ * weights owned by the linna_logprob_t (stream_mlp.hip).  The copy is refreshed automatically
+ * after linna_adamw_step and after any linna_graph_launch; a caller that overwrites parameter
+ * memory by other means (hipMemcpy of a checkpoint, a torch-side copy_) calls this once
+ * afterwards -- the reference has no counterpart because `model.load_state_dict`
+ * (predictor_gpu.py:439-445) rebinds the tensors the forward pass reads. */
+int linna_weights_changed(linna_ctx_t* ctx);
 size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad);
 /* lnP[B]; THETA[B][ldt] optional (physical parameters, for chain_transformed). */
 int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,

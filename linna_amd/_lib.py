@@ -95,6 +95,7 @@ _SIGNATURES = {
     "linna_gauss_loglike_dense": (_I, [_V, _V, _I, _I, _I, _V, _I, _V, _I, _I, _F, _V, _V, _V]),
     "linna_logprob_create": (_I, [_V, _V, C.POINTER(LogprobDesc), _PV]),
     "linna_logprob_destroy": (_I, [_V]),
+    "linna_weights_changed": (_I, [_V]),
     "linna_logprob_ws_bytes": (_SZ, [_V, _I, _I]),
     "linna_logprob_eval": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),
     "linna_logprob_grad": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),

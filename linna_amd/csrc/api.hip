@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <atomic>
 #include <new>
 #include <stdlib.h>
 
@@ -51,6 +52,11 @@ static void set_pair(GemmArgs& a, int i, const float* A, int lda, int alay, cons
 }  // namespace linna
 
 using namespace linna;
+
+// Weight epoch: bumped by every entry that may change network parameters (linna_adamw_step, a
+// graph replay, linna_weights_changed()); a log-probability object re-lays its fragment-order
+// weight copy (stream_mlp.hip) when the epoch moved since the copy was made.
+static std::atomic<unsigned long long> g_weights_epoch{1};
 
 struct linna_ctx {
     int device;
@@ -135,6 +141,7 @@ int linna_graph_end(void* stream, linna_graph_t** out) {
 }
 int linna_graph_launch(linna_graph_t* g, void* stream) {
     if (!g) { set_error("graph_launch: null graph"); return LINNA_ERR_INVALID; }
+    g_weights_epoch.fetch_add(1);            // the graph may hold an AdamW step
     return check_hip(hipGraphLaunch(g->exec, S(stream)), "hipGraphLaunch");
 }
 int linna_graph_destroy(linna_graph_t* g) {
@@ -442,6 +449,8 @@ struct linna_logprob {
     linna_ctx* ctx;
     linna_net* net;
     linna_logprob_desc_t d;
+    float* packed = nullptr;                 // fragment-order weight stream (stream_mlp.hip), or null
+    unsigned long long packed_epoch = 0;     // epoch the copy was made at (0 = never)
 };
 
 struct LpLayout { size_t x0, fwd, d, part, dh, bwd, dx, total; int slots; };
@@ -468,12 +477,37 @@ static bool fused_enabled() {
     static const bool on = !(getenv("LINNA_DISABLE_FUSED") && getenv("LINNA_DISABLE_FUSED")[0] == '1');
     return on;
 }
+static bool stream_enabled() {   // LINNA_DISABLE_STREAM=1: first-generation fused kernel (A/B timing, tests)
+    static const bool on = !(getenv("LINNA_DISABLE_STREAM") && getenv("LINNA_DISABLE_STREAM")[0] == '1');
+    return on;
+}
 
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
                       float* TH, int ldt, void* stream, bool keep_activations) {
     const linna_logprob_desc_t& d = lp->d;
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
     const linna_net* n = lp->net;
+    if (!keep_activations && fused_enabled() && stream_enabled() && lp->packed && !d.outmap.cexp) {
+        // whole-network kernel, weights streamed from the fragment-order copy
+        const unsigned long long epoch = g_weights_epoch.load();
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(S(stream), &cap);
+        if (cap != hipStreamCaptureStatusNone) {
+            // a captured evaluation carries its own re-layout, so that every replay sees the weights
+            // of that moment; the copy is not valid for direct launches until they redo it
+            TRY(launch_pack_weight_stream(n->L.data(), (int)n->L.size(), lp->packed, S(stream)));
+            lp->packed_epoch = 0;
+        } else if (lp->packed_epoch != epoch) {
+            TRY(launch_pack_weight_stream(n->L.data(), (int)n->L.size(), lp->packed, S(stream)));
+            lp->packed_epoch = epoch;
+        }
+        TRY(launch_stream_mlp(n->L.data(), (int)n->L.size(), lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+                              d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
+                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, S(stream)));
+        if (d.w) return LINNA_OK;
+        return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
+                                         w + L.part, lnP, stream);
+    }
     if (!keep_activations && fused_enabled() && !n->has_inskip && !d.outmap.cexp &&
         fused_mlp_eligible(n->L.data(), (int)n->L.size(), n->in_size)) {
         // whole-network kernel: prior map -> layers -> (diagonal) log-likelihood in one launch
@@ -502,10 +536,22 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     }
     if (!desc->w && !desc->S) { set_error("logprob_create: need S (dense) or w (diagonal)"); return LINNA_ERR_INVALID; }
     if (!(desc->temperature > 0.f)) { set_error("logprob_create: temperature must be > 0"); return LINNA_ERR_INVALID; }
-    *out = new linna_logprob{ctx, net, *desc};
+    linna_logprob* lp = new linna_logprob{ctx, net, *desc};
+    if (!net->has_inskip && stream_mlp_eligible(net->L.data(), (int)net->L.size(), net->in_size)) {
+        const size_t nf = stream_mlp_packed_floats(net->L.data(), (int)net->L.size());
+        if (check_hip(hipMalloc(reinterpret_cast<void**>(&lp->packed), nf * sizeof(float)), "hipMalloc(weight stream)") != LINNA_OK) {
+            delete lp; return LINNA_ERR_HIP;
+        }
+    }
+    *out = lp;
     return LINNA_OK;
 }
-int linna_logprob_destroy(linna_logprob_t* lp) { delete lp; return LINNA_OK; }
+int linna_logprob_destroy(linna_logprob_t* lp) {
+    if (lp && lp->packed) (void)hipFree(lp->packed);
+    delete lp;
+    return LINNA_OK;
+}
+int linna_weights_changed(linna_ctx_t*) { g_weights_epoch.fetch_add(1); return LINNA_OK; }
 size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad) {
     return (lp_layout(lp, B, with_grad).total + 16) * sizeof(float);
 }
@@ -597,6 +643,7 @@ int linna_gather_xform(linna_ctx_t*, const float* X, int ldx, const int* ROWS, i
 int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev,
                      float b1, float b2, float eps, void* stream) {
     if (!p || !g || !m || !v || !hyper || !step_dev) { set_error("adamw_step: null pointer"); return LINNA_ERR_INVALID; }
+    g_weights_epoch.fetch_add(1);
     return launch_adamw(p, g, m, v, n, hyper, step_dev, b1, b2, eps, S(stream));
 }
 

@@ -85,6 +85,15 @@ int launch_fused_mlp(const linna_layer_t* layers, int nl, const float* param_end
                      const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                      float* D, int ldd, float* TH, int ldt, hipStream_t s);
 
+// stream_mlp.hip (hidden width 512: weights streamed from a fragment-order copy)
+bool stream_mlp_eligible(const linna_layer_t* layers, int nl, int in_size);
+size_t stream_mlp_packed_floats(const linna_layer_t* layers, int nl);
+int launch_pack_weight_stream(const linna_layer_t* layers, int nl, float* packed, hipStream_t s);
+int launch_stream_mlp(const linna_layer_t* layers, int nl, const float* packed, const float* Z, int ldz, int B, int nin,
+                      const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
+                      const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
+                      float* D, int ldd, float* TH, int ldt, hipStream_t s);
+
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);
 

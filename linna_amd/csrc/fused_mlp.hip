@@ -317,12 +317,20 @@ __global__ __launch_bounds__(64 * FNW, 2) void fused_mlp_kernel(FusedArgs a) {
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             const float* ak = (u1 & 1) ? ao : ae;
             // (u1 == 4 belongs to the next group: 32*4 floats further)
+#if FUSED_ABL & 8
+            asm volatile("" : "+v"(f.a0), "+v"(f.a1));
+#else
             f.a0 = *reinterpret_cast<const f32x4*>(ak + 32 * u1 + aoff0);
+            f.a1 = *reinterpret_cast<const f32x4*>(ak + 32 * u1 + aoff1);
+#endif
+#if FUSED_ABL & 2
+            asm volatile("" : "+v"(f.b00), "+v"(f.b01), "+v"(f.b10), "+v"(f.b11));
+#else
             f.b00 = *reinterpret_cast<const f32x4*>(bp00 + slot * STAGE_F);
             f.b01 = *reinterpret_cast<const f32x4*>(bp01 + slot * STAGE_F);
-            f.a1 = *reinterpret_cast<const f32x4*>(ak + 32 * u1 + aoff1);
             f.b10 = *reinterpret_cast<const f32x4*>(bp10 + slot * STAGE_F);
             f.b11 = *reinterpret_cast<const f32x4*>(bp11 + slot * STAGE_F);
+#endif
         };
         auto mm = [&](auto U, const Frags& f) {                // MFMAs of tile kt+U; refill its slot U with tile +4
             constexpr int u = decltype(U)::value;
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(64 * FNW, 2) void fused_mlp_kernel(FusedArgs a) {
             for (int s4 = 0; s4 < 4; ++s4) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a0[s4], f.b00[s4], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a0[s4], f.b01[s4], acc[1], 0, 0, 0);
-                if (s4 & 1) {
+                if ((s4 & 1) && !(FUSED_ABL & 1)) {
                     const int jj = s4 >> 1;
                     __builtin_amdgcn_global_load_lds((gbl_void_t*)(wb + u * stride_b + rowoff_b[jj]),
                                                      (lds_void_t*)(ring + u * STAGE_F + jj * 256), 16, 0, 0);
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(64 * FNW, 2) void fused_mlp_kernel(FusedArgs a) {
             for (int s4 = 0; s4 < 4; ++s4) {
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1[s4], f.b10[s4], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a1[s4], f.b11[s4], acc[1], 0, 0, 0);
-                if (s4 & 1) {
+                if ((s4 & 1) && !(FUSED_ABL & 1)) {
                     const int jj = 2 + (s4 >> 1);
                     __builtin_amdgcn_global_load_lds((gbl_void_t*)(wb + u * stride_b + rowoff_b[jj]),
                                                      (lds_void_t*)(ring + u * STAGE_F + jj * 256), 16, 0, 0);
