@@ -36,6 +36,9 @@ constexpr int SM_LD = SM_H + 4;         // activation row stride (floats)
 constexpr int SM_ABUF = SM_ROWS * SM_LD;
 constexpr int SM_MAX_LAYERS = 6;
 constexpr int SM_KSLICES = 8;           // K slices of the last layer (64 k each)
+#ifndef SM_PRE
+#define SM_PRE 2                        // ring slots requested before the network input is computed
+#endif
 
 struct StreamArgs {
     const float* Z; int ldz; int B; int nin;
@@ -51,8 +54,9 @@ struct StreamArgs {
 };
 
 __device__ __forceinline__ float sm_prior_theta(float z, int flat, float a1, float a2) {
-    if (flat) return (0.5f * (1.f + erff(z / 1.41421356237309515f))) * a2 + a1;
-    return z * a2 + a1;
+    float u = 0.5f * (1.f + erff(z / 1.41421356237309515f));
+    asm volatile("" : "+v"(u));                    // computed unconditionally: no branch on the loaded flag
+    return (flat ? u : z) * a2 + a1;
 }
 
 // ------------------------------------------------------------------ weight re-layout
@@ -111,34 +115,58 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_mlp_kernel(StreamArgs a) {
     const int li = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.x * SM_ROWS;
 #ifdef SM_STAMPS
+    // stamps are parked in LDS and written out at the very end: a global store inside the step loop
+    // would change the compiler's vmcnt bookkeeping and with it the thing being measured
+    unsigned long long* const lstamp = reinterpret_cast<unsigned long long*>(smem + 2 * SM_ABUF + (SM_MAX_LAYERS - 1) * SM_H) + wave * 16;
     int nstamp = 0;
 #define SM_STAMP() do { const unsigned long long t_ = __builtin_readcyclecounter(); \
-        if (lane == 0) a.stamps[((size_t)blockIdx.x * NW + wave) * 16 + nstamp] = t_; ++nstamp; } while (0)
+        if (lane == 0) lstamp[nstamp] = t_; ++nstamp; } while (0)
 #else
 #define SM_STAMP() do {} while (0)
 #endif
     SM_STAMP();
 
-    // ---- 1. the loads whose values are needed first: biases, and z with its prior/transform
-    // constants for the first ZPRE columns of this thread (one walker row per RG threads)
+    // ---- 1. every small load of the kernel, issued up front in straight-line code (no branch may
+    // depend on a loaded value here: a branch would put a full memory round trip in front of the
+    // weight stream): z and its prior/transform constants for this thread's ZPRE columns (one walker
+    // row per RG threads), the hidden biases, and the constants of the finish.
     const int pr = tid / RG, pc0 = tid % RG;
     const int grow = min(row0 + pr, a.B - 1);
     const int kpad0 = 16 * a.ksteps[0];
+    const int nl = a.nl, nin = a.nin, nout = a.nout;
+    constexpr int ZPRE = 2;
+    float zr[ZPRE], za1[ZPRE], za2[ZPRE], zxm[ZPRE], zxs[ZPRE]; int zfl[ZPRE], zlg[ZPRE];
+    const int* const lgp = a.lg ? a.lg : a.is_flat;            // always a readable pointer
+#pragma unroll
+    for (int i = 0; i < ZPRE; ++i) {
+        const int c = min(pc0 + i * RG, nin - 1);
+        zr[i] = a.Z[(size_t)grow * a.ldz + c];
+        zfl[i] = a.is_flat[c]; za1[i] = a.a1[c]; za2[i] = a.a2[c];
+        zlg[i] = lgp[c]; zxm[i] = a.xmean[c]; zxs[i] = a.xstd[c];
+    }
+    const float* const b0 = a.bias[0]; const float* const b1 = a.bias[1]; const float* const b2 = a.bias[2];
+    const float* const b3 = a.bias[3]; const float* const b4 = a.bias[4];
     constexpr int BMAX = ((SM_MAX_LAYERS - 1) * SM_H + 64 * NW - 1) / (64 * NW);
     float breg[BMAX];
 #pragma unroll
     for (int i = 0; i < BMAX; ++i) {
         const int j = tid + i * 64 * NW, l = j >> 9;
-        breg[i] = (l < a.nl - 1) ? a.bias[l][j & (SM_H - 1)] : 0.f;     // l < nl-1 <= 5 also bounds j
+        const bool ok = l < nl - 1;                           // hidden layer (also bounds j)
+        const float* bp = l == 0 ? b0 : l == 1 ? b1 : l == 2 ? b2 : l == 3 ? b3 : b4;
+        breg[i] = (ok ? bp : b0)[ok ? (j & (SM_H - 1)) : 0];
     }
-    constexpr int ZPRE = 2;
-    float zr[ZPRE], za1[ZPRE], za2[ZPRE], zxm[ZPRE], zxs[ZPRE]; int zfl[ZPRE], zlg[ZPRE];
+    constexpr int FIN = 64 / RG > 0 ? 64 / RG : 1;           // output columns per thread in the finish
+    const float* const blast = a.bias[SM_MAX_LAYERS - 1];    // the host stores the last layer's bias here
+    const float* const csp = a.cscale ? a.cscale : blast;
+    const float* const ctp = a.cshift ? a.cshift : blast;
+    const float* const wtp = a.w ? a.w : blast;
+    float fb[FIN], fcs[FIN], fct[FIN], fw[FIN];
 #pragma unroll
-    for (int i = 0; i < ZPRE; ++i) {
-        const int c = min(pc0 + i * RG, a.nin - 1);
-        zr[i] = a.Z[(size_t)grow * a.ldz + c];
-        zfl[i] = a.is_flat[c]; za1[i] = a.a1[c]; za2[i] = a.a2[c];
-        zlg[i] = a.lg ? a.lg[c] : 0; zxm[i] = a.xmean[c]; zxs[i] = a.xstd[c];
+    for (int i = 0; i < FIN; ++i) {
+        const int c = min(pc0 + i * RG, nout - 1);
+        fb[i] = blast[c];
+        const float cs = csp[c], ct = ctp[c], ww = wtp[c];
+        fcs[i] = a.cscale ? cs : 1.f; fct[i] = a.cshift ? ct : 0.f; fw[i] = a.w ? ww : 0.f;
     }
 
     // ---- 2. start the weight stream: R steps in flight
@@ -151,18 +179,30 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_mlp_kernel(StreamArgs a) {
     auto wload = [&](int t) {
         return *reinterpret_cast<const f32x4*>(wbase + (size_t)(voff + woff) + t * 1024);
     };
+#ifdef SM_NOADVANCE   // timing-only ablation: every load hits the same 4 KiB (L1-resident); results are wrong
+    auto wadvance = [&]() { woff = min(woff, wlast); };
+#else
     auto wadvance = [&]() { woff = min(woff + STEP_B, wlast); };   // past the end: reload the last step (never used)
+#endif
     // (the scheduler must not reorder these: the step loop's counted vmcnt waits are derived from
     // the issue order, and one reversed pair on the entry path degrades every iteration to vmcnt(0))
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
+    // Only the first SM_PRE steps go out before the network input is computed: the compiler waits
+    // for z with vmcnt(0), so everything issued by then is on the critical path of the first MFMA
+    // (all 256 workgroups start together: R steps each would be a 48 MB burst out of the L2s).
+    constexpr int PRE = SM_PRE < R ? SM_PRE : R;
+    auto prefetch = [&](auto Uc) {
+        constexpr int U = decltype(Uc)::value;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            Bq[u][t] = wload(t);
+            Bq[U][t] = wload(t);
             __builtin_amdgcn_sched_barrier(0);
         }
         wadvance();
-    }
+    };
+#define SM_PF(U, LO, HI) if constexpr (U >= LO && U < HI) prefetch(std::integral_constant<int, U>{});
+#define SM_PF_ALL(LO, HI) SM_PF(0, LO, HI) SM_PF(1, LO, HI) SM_PF(2, LO, HI) SM_PF(3, LO, HI) SM_PF(4, LO, HI) SM_PF(5, LO, HI) \
+    SM_PF(6, LO, HI) SM_PF(7, LO, HI) SM_PF(8, LO, HI) SM_PF(9, LO, HI) SM_PF(10, LO, HI) SM_PF(11, LO, HI)
+    SM_PF_ALL(0, PRE)
 
     // ---- 3. prologue: x = X_transform(Transform(z)) into act[0], zero padded to 16*ksteps[0]; biases to LDS.
     // No global store here (theta is written at the very end): a store in flight next to the weight
@@ -172,22 +212,27 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_mlp_kernel(StreamArgs a) {
 #pragma unroll
     for (int i = 0; i < ZPRE; ++i) {
         const int c = pc0 + i * RG;
-        float x = 0.f;
-        theta[i] = 0.f;
-        if (c < a.nin) {
-            zz += zr[i] * zr[i];
-            theta[i] = sm_prior_theta(zr[i], zfl[i], za1[i], za2[i]);
-            const float t = zlg[i] ? log10f(theta[i]) : theta[i];
-            x = (t - zxm[i]) / zxs[i];
-        }
+        const bool in = c < nin;
+        const float z = in ? zr[i] : 0.f;
+        zz += z * z;
+        float th = sm_prior_theta(z, zfl[i], za1[i], za2[i]);
+        float lt = log10f(th);
+        asm volatile("" : "+v"(lt));               // both candidates exist: the select below stays a v_cndmask
+        theta[i] = th;
+        const float t = (a.lg && zlg[i]) ? lt : th;
+        const float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
         if (c < kpad0) act[pr * SM_LD + c] = x;
     }
+    __builtin_amdgcn_sched_barrier(0);
+    SM_PF_ALL(PRE, R)
+#undef SM_PF_ALL
+#undef SM_PF
 #pragma unroll
     for (int o = RG / 2; o >= 1; o >>= 1) zz += __shfl_xor(zz, o, 64);
 #pragma unroll
     for (int i = 0; i < BMAX; ++i) {
         const int j = tid + i * 64 * NW;
-        if ((j >> 9) < a.nl - 1) lbias[j] = breg[i];
+        if ((j >> 9) < nl - 1) lbias[j] = breg[i];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // raw: __syncthreads() would drain the weight stream
@@ -211,7 +256,7 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_mlp_kernel(StreamArgs a) {
         ap += 64;
     };
     auto begin_layer = [&]() {                     // accumulators and A pointer of `layer`
-        const bool last = layer == a.nl - 1;
+        const bool last = layer == nl - 1;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float b = last ? 0.f : lbias[layer * SM_H + colbase + 16 * t + li];
@@ -241,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_mlp_kernel(StreamArgs a) {
             }
         }
         if constexpr (refill) wadvance();
-        if (--kleft == 0 && layer < a.nl - 1) {
+        if (--kleft == 0 && layer < nl - 1) {
             // ---- hidden layer complete: ReLU, publish into the other buffer, one barrier
             float* const nxt = act + (p ^ 1) * SM_ABUF;
 #pragma unroll
@@ -287,18 +332,20 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_mlp_kernel(StreamArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const int N = a.nout;
         const bool rok = row0 + pr < a.B;
-        const float* bl = a.bias[a.nl - 1];
         float chi = 0.f;
-        for (int c = pc0; c < N; c += RG) {
-            float v = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < SM_KSLICES; ++ks) v += part[ks * 1024 + pr * 64 + (c ^ (16 * (pr >> 2)))];
-            v += bl[c];
-            const float d = v * (a.cscale ? a.cscale[c] : 1.f) + (a.cshift ? a.cshift[c] : 0.f);
-            if (a.D && rok) a.D[(size_t)(row0 + pr) * a.ldd + c] = d;
-            if (a.w) chi += (d * a.w[c]) * d;
+        for (int i = 0; i < FIN; ++i) {
+            const int c = pc0 + i * RG;
+            if (c < nout) {
+                float v = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < SM_KSLICES; ++ks) v += part[ks * 1024 + pr * 64 + (c ^ (16 * (pr >> 2)))];
+                v += fb[i];
+                const float d = v * fcs[i] + fct[i];
+                if (a.D && rok) a.D[(size_t)(row0 + pr) * a.ldd + c] = d;
+                chi += (d * fw[i]) * d;
+            }
         }
 #pragma unroll
         for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
@@ -309,10 +356,13 @@ __global__ __launch_bounds__(64 * NW, 1) void stream_mlp_kernel(StreamArgs a) {
         if (a.TH && rok) {
 #pragma unroll
             for (int i = 0; i < ZPRE; ++i)
-                if (pc0 + i * RG < a.nin) a.TH[(size_t)(row0 + pr) * a.ldt + pc0 + i * RG] = theta[i];
+                if (pc0 + i * RG < nin) a.TH[(size_t)(row0 + pr) * a.ldt + pc0 + i * RG] = theta[i];
         }
     }
     SM_STAMP();
+#ifdef SM_STAMPS
+    if (lane < 16) a.stamps[((size_t)blockIdx.x * NW + wave) * 16 + lane] = lane < nstamp ? lstamp[lane] : 0ull;
+#endif
 #undef SM_STAMP
 }
 
@@ -377,8 +427,8 @@ int launch_stream_mlp(const linna_layer_t* layers, int nl, const float* packed, 
     a.is_flat = is_flat; a.a1 = a1; a.a2 = a2; a.lg = lg; a.xmean = xmean; a.xstd = xstd;
     a.packed = packed;
     a.G = stream_steps(layers, nl, a.ksteps);
-    for (int i = 0; i < nl; ++i) a.bias[i] = layers[i].b;
-    for (int i = nl; i < SM_MAX_LAYERS; ++i) { a.bias[i] = layers[nl - 1].b; a.ksteps[i] = 0; }
+    for (int i = 0; i < SM_MAX_LAYERS; ++i) a.bias[i] = layers[i < nl ? i : nl - 1].b;   // [5] is always the last layer's
+    for (int i = nl; i < SM_MAX_LAYERS; ++i) a.ksteps[i] = 0;
     a.nl = nl; a.nout = layers[nl - 1].N;
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
@@ -387,7 +437,11 @@ int launch_stream_mlp(const linna_layer_t* layers, int nl, const float* packed, 
     a.stamps = getenv("LINNA_FUSED_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LINNA_FUSED_STAMPS"), nullptr, 16)) : nullptr;
     if (!a.stamps) { set_error("stream_mlp: SM_STAMPS build needs LINNA_FUSED_STAMPS"); return LINNA_ERR_INVALID; }
 #endif
+#ifdef SM_STAMPS
+    constexpr size_t lds = (size_t)(2 * SM_ABUF + (SM_MAX_LAYERS - 1) * SM_H) * sizeof(float) + SM_NW * 16 * 8;
+#else
     constexpr size_t lds = (size_t)(2 * SM_ABUF + (SM_MAX_LAYERS - 1) * SM_H) * sizeof(float);
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&stream_mlp_kernel<SM_NW, SM_R>),

@@ -109,11 +109,23 @@ class _Emulator(object):
                 v.uniform_(-bound, bound)
         self._post_init(host)
         self._flat.copy_(host)
+        self.weights_changed()
 
     def _post_init(self, host):
         pass
 
+    def weights_changed(self):
+        """Tell the HIP library that parameter memory may have been written from the torch side
+        (`linna_weights_changed`): serving objects re-lay their fragment-order weight copy before
+        their next evaluation.  Every accessor that hands out a WRITABLE view of the parameters
+        calls this, so `model.flat_params().copy_(...)` / `state_dict()[k].copy_(...)` followed by
+        an evaluation is safe; a caller that keeps such a view and writes through it later calls
+        it again after the write."""
+        if self._flat.is_cuda:
+            _lib.call("linna_weights_changed", _lib.ctx(self._flat.device.index))
+
     def state_dict(self):
+        self.weights_changed()
         return collections.OrderedDict((k, self._view(self._flat, k)) for k in self._index)
 
     def load_state_dict(self, sd, strict=True):
@@ -129,15 +141,18 @@ class _Emulator(object):
                 if tuple(src.shape) != tuple(dst.shape):
                     raise ValueError("%s: checkpoint shape %s, model shape %s" % (k, tuple(src.shape), tuple(dst.shape)))
                 dst.copy_(src.detach().to(torch.float32))
+        self.weights_changed()
         return self
 
     def parameters(self):
+        self.weights_changed()
         return [self._flat]
 
     def named_parameters(self):
         return list(self.state_dict().items())
 
     def flat_params(self):
+        self.weights_changed()
         return self._flat
 
     def flat_grads(self):

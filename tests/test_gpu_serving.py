@@ -106,9 +106,9 @@ def test_gemm_rowdot_matches_quadratic_form(M, N, K):
     assert np.all(np.abs(got - ref) <= 1e-6 * scale)
 
 
-def build_logprob(name, temperature=1.0):
+def build_logprob(name, temperature=1.0, prob=None):
     from linna_amd import nn, util, predictor_gpu
-    prob = cases.serving_problem(name)
+    prob = cases.serving_problem(name) if prob is None else prob
     cls = {"ChtoModelv2": nn.ChtoModelv2, "ChtoModelsimple": nn.ChtoModelsimple,
            "ChtoModelv2_linear": nn.ChtoModelv2_linear, "MLP": nn.MLP}[prob["kind"]]
     model = cls(prob["nin"], prob["nout"], None, **prob["kw"])
@@ -220,3 +220,82 @@ def test_fused_mlp_kernel_edges_and_agreement_with_layered_path():
     ref = likelihood.log_prob(z, cases.oracle_emulator(probd), probd["priors"], probd["data"], probd["invcov"], 1.0,
                               dtype=np.float64)
     np.testing.assert_allclose(got, ref, rtol=6e-4)
+
+
+def _custom_problem(nin, nout, seed, width, depth, dense=False):
+    """A serving problem outside cases.SERVING (no golden file: checked against the oracle)."""
+    import synth
+    data, cov, priors = synth.gaussian_problem(nin, nout, seed, dense=dense)
+    X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
+    kw = {"width": width, "depth": depth}
+    return dict(kind="MLP", nin=nin, nout=nout, kw=kw, weights=synth.weights("MLP", nin, nout, seed, **kw),
+                priors=priors, data=data, cov=cov, invcov=np.linalg.inv(cov), sigma=np.sqrt(np.diag(cov)),
+                X_mean=X_mean, X_std=X_std, y_mean=y_mean, y_std=y_std, dolog10=None, ypositive=False)
+
+
+@pytest.mark.parametrize("nin,nout,width,depth,which", [
+    (33, 33, 512, 4, "stream"),      # bench shape: weight-stream kernel
+    (64, 64, 512, 2, "stream"),      # widest input / output the stream kernel takes, 3 linear layers
+    (3, 1, 512, 1, "stream"),        # two linear layers, one output column
+    (65, 40, 512, 3, "ring"),        # 65 inputs: first-generation fused kernel (LDS weight rings)
+    (20, 33, 256, 3, "ring"),        # hidden width 256: first-generation fused kernel
+])
+def test_whole_network_kernels_against_oracle(nin, nout, width, depth, which):
+    """Both whole-network kernels (stream_mlp.hip for hidden width 512 and <= 64 inputs, fused_mlp.hip
+    otherwise) against the oracle and the layer-by-layer path, ragged batches included."""
+    from oracle import likelihood
+    from linna_amd import _lib
+    prob = _custom_problem(nin, nout, 900 + nin + width, width, depth)
+    lp, pred, yinv, _ = build_logprob(None, prob=prob)
+    emu = cases.oracle_emulator(prob)
+    for B in (1, 17, 4096 if which == "stream" else 300):
+        z = (0.7 * np.random.RandomState(B).standard_normal((B, nin))).astype(np.float32)
+        zd = torch.as_tensor(z, device="cuda")
+        theta = torch.empty_like(zd)
+        got = lp.evaluate(zd, theta=theta).cpu().numpy()
+        layered = lp.evaluate_with_grad(zd)[0].cpu().numpy()
+        ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0)
+        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=1e-3)
+        np.testing.assert_allclose(got, layered, rtol=2e-4, atol=1e-3)
+        np.testing.assert_allclose(theta.cpu().numpy(), likelihood.prior_map(z, prob["priors"]), rtol=1e-5, atol=1e-5)
+
+
+def test_stream_kernel_follows_weight_updates():
+    """The weight-stream kernel reads a fragment-order COPY of the weights: the copy must follow an
+    AdamW step (C entry), a torch-side write through flat_params()/state_dict()/load_state_dict(),
+    and a graph replay that holds an AdamW step."""
+    from oracle import likelihood
+    from linna_amd import _lib
+    prob = _custom_problem(33, 33, 77, 512, 4)
+    lp, pred, yinv, _ = build_logprob(None, prob=prob)
+    model = pred.model
+    z = (0.5 * np.random.RandomState(3).standard_normal((64, 33))).astype(np.float32)
+    zd = torch.as_tensor(z, device="cuda")
+
+    def check():
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+        p2 = dict(prob, weights=sd)
+        ref = likelihood.log_prob(z, cases.oracle_emulator(p2), prob["priors"], prob["data"], prob["invcov"], 1.0)
+        got = lp.evaluate(zd).cpu().numpy()
+        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=1e-3)
+        return got
+
+    a = check()
+    model.flat_params().mul_(1.01)                       # torch-side write through the accessor
+    b = check()
+    assert np.abs(a - b).max() > 1e-3
+    sd = {k: 0.98 * v.detach().cpu() for k, v in model.state_dict().items()}
+    model.load_state_dict(sd)
+    c = check()
+    assert np.abs(c - b).max() > 1e-3
+    # AdamW through the C entry (lr large enough to move the output)
+    n = model.flat_params().numel()
+    g = torch.ones(n, device="cuda"); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    hyper = torch.tensor([1e-3, 0.0, 0.0, 0.0], device="cuda"); step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    flat = model.flat_params()
+    lp.evaluate(zd)                                      # copy is fresh here
+    _lib.call("linna_adamw_step", _lib.ctx(0), _lib.ptr(flat), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v),
+              C.c_size_t(n), _lib.ptr(hyper), _lib.iptr(step), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
+              _lib.stream())
+    d = check()
+    assert np.abs(d - c).max() > 1e-3
