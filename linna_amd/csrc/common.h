@@ -94,6 +94,15 @@ int launch_stream_mlp(const linna_layer_t* layers, int nl, const float* packed, 
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, hipStream_t s);
 
+// net_stream.hip (program-driven whole-network kernel: residual blocks, widths up to 1024)
+bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size);
+size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size);
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, hipStream_t s);
+int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
+                      int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
+                      const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
+                      float* D, int ldd, float* TH, int ldt, hipStream_t s);
+
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);
 

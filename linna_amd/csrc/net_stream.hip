@@ -1,0 +1,562 @@
+// Whole-network serving kernel, generalised ("network stream"): the weight-stream design of
+// stream_mlp.hip driven by a small PROGRAM, so that the reference's own architectures run in one
+// launch too -- ChtoModelv2 / ChtoModelsimple (nn.py:59-133, 300-374: Linear + three residual
+// blocks + three Linears) as well as plain MLPs of any width up to 1024.  ONE launch evaluates
+// util.Log_prob.__call__ (util.py:990-1021) for 16 walkers per workgroup.
+//
+// Program = list of segments, each a GEMM over the activation rows held in LDS:
+//   WIDE    N > 64: the N columns are split over the 8 waves in passes of 512 (wave w owns column
+//           tiles 4w..4w+3 of a pass), every wave runs all K steps; epilogue bias(+ReLU) -> the
+//           OTHER activation buffer; one barrier after the last pass.
+//   NARROW  N <= 64: K is split over the 8 waves, every wave computes all 64 columns of its K
+//           slice, partial sums are reduced through LDS, bias(+ReLU) -> the CURRENT buffer at a
+//           column offset (two barriers).
+// A residual block  y = relu(0.1 (W2 relu(W1 x + b1) + b2) + Ws x)  (nn.py:45-56) is NARROW
+// (h = relu(W1 x + b1), written right behind x in the same buffer) + ONE WIDE GEMM over the
+// concatenated K = [x ; h] with the concatenated weight [Ws | 0.1 W2] and bias 0.1 b2.
+// One step = 16 k x 64 columns = 1 ds_read_b128 (A) + 4 coalesced 1-KiB global loads (B, fragment
+// order, see pack below) + 16 v_mfma_f32_16x16x4_f32, exactly as in stream_mlp.hip; every wave
+// owns ONE contiguous weight stream over the whole program, R register sets deep.
+// After the last segment the output row block sits in LDS: output transform, optional store of
+// d, diagonal Gaussian log-likelihood (util.py:953-955) with 32-lane shuffles.
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+#include <vector>
+#include <cstring>
+#include <algorithm>
+
+namespace linna {
+
+constexpr int NS_ROWS = 16;
+constexpr int NS_NW = 8;                 // waves per workgroup
+constexpr int NS_NT = 4;                 // 16-column tiles per wave and step
+constexpr int NS_MAXSEG = 20;
+constexpr int NS_MAXRUN = 40;
+constexpr unsigned NS_STEP_B = NS_NT * 1024;
+constexpr int NS_LDS_BYTES = 160 * 1024;
+#ifndef NS_R
+#define NS_R 6
+#endif
+#ifndef NS_PRE
+#define NS_PRE 2
+#endif
+enum { NS_WIDE = 0, NS_NARROW = 1 };
+
+struct NsSeg {            // kernel-side view of a segment
+    int type, steps, passes, bias_off;
+    int dst_col, relu, kslice, zext;   // kslice: k offset between waves (NARROW) = 16*steps
+};
+
+struct NsArgs {
+    const float* Z; int ldz; int B; int nin;
+    const int* is_flat; const float* a1; const float* a2; const int* lg;
+    const float* xmean; const float* xstd;
+    const float* packed;                // [8 waves][G][4][64 lanes][4] then the packed biases
+    int G, nseg, LD, kpad0, nout, bias_total;
+    const float* cscale; const float* cshift; const float* w; float T;
+    float* lnP; float* D; int ldd; float* TH; int ldt;
+    unsigned long long* stamps;
+    NsSeg seg[NS_MAXSEG];
+};
+
+// ------------------------------------------------------------------ weight re-layout
+struct NsPackSeg {
+    const float* Wa; int lda, Ka, Kapad;          // first K part (Wa NULL: identity)
+    const float* Wb; int ldb, Kb; float alpha;    // second K part, scaled (residual blocks)
+    const float* b; float bscale;
+    int N, type, steps, passes, bias_off, bias_pad;
+};
+struct NsPackArgs {
+    NsPackSeg seg[NS_MAXSEG];
+    int run_seg[NS_MAXRUN], run_pass[NS_MAXRUN], run_first[NS_MAXRUN + 1];
+    int nseg, nrun, G, bias_total;
+    float* out;                                    // weights, then biases
+};
+// stream[w][g][t][lane][e], run r = (segment, pass), s = g - first[r], li = lane & 15, kq = lane >> 4:
+//   WIDE   n = 16 (32 pass + 4 w + t) + li,  k = 16 s + 4 kq + e
+//   NARROW n = 16 t + li,                    k = 16 (w steps + s) + 4 kq + e
+// value = [Wa | alpha Wb](n, k), zero outside.
+__global__ void ns_pack_kernel(NsPackArgs p) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nw4 = (size_t)NS_NW * p.G * NS_NT * 64;
+    if (idx < nw4) {
+        const int lane = (int)(idx & 63);
+        size_t q = idx >> 6;
+        const int t = (int)(q % NS_NT); q /= NS_NT;
+        const int g = (int)(q % p.G);
+        const int w = (int)(q / p.G);
+        int r = 0;
+        while (r + 1 < p.nrun && g >= p.run_first[r + 1]) ++r;
+        const NsPackSeg& S = p.seg[p.run_seg[r]];
+        const int s = g - p.run_first[r], li = lane & 15, kq = lane >> 4;
+        int n, k0;
+        if (S.type == NS_WIDE) { n = 16 * (32 * p.run_pass[r] + 4 * w + t) + li; k0 = 16 * s + 4 * kq; }
+        else { n = 16 * t + li; k0 = 16 * (w * S.steps + s) + 4 * kq; }
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < S.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + e;
+                if (k < S.Kapad) {
+                    if (k < S.Ka) v[e] = S.Wa ? S.Wa[(size_t)n * S.lda + k] : (k == n ? 1.f : 0.f);
+                } else if (k - S.Kapad < S.Kb) {
+                    v[e] = S.alpha * S.Wb[(size_t)n * S.ldb + (k - S.Kapad)];
+                }
+            }
+        }
+        reinterpret_cast<f32x4*>(p.out)[idx] = v;
+        return;
+    }
+    const size_t j = idx - nw4;                       // packed biases, one float per thread
+    if (j >= (size_t)p.bias_total) return;
+    int si = 0;
+    while (si + 1 < p.nseg && (int)j >= p.seg[si + 1].bias_off) ++si;
+    const NsPackSeg& S = p.seg[si];
+    const int c = (int)j - S.bias_off;
+    p.out[nw4 * 4 + j] = (c < S.N && S.b) ? S.bscale * S.b[c] : 0.f;
+}
+
+__device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, float a2) {
+    float u = 0.5f * (1.f + erff(z / 1.41421356237309515f));
+    asm volatile("" : "+v"(u));                    // computed unconditionally: no branch on the loaded flag
+    return (flat ? u : z) * a2 + a1;
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int R>
+__global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
+    constexpr int NT = NS_NT, NW = NS_NW;
+    constexpr int RG = 32;                         // threads per walker row in prologue / reduce / finish
+    static_assert(R % 2 == 0, "the A double buffer alternates with the ring slot parity");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int LD = a.LD, ABUF = NS_ROWS * LD;
+    float* const act = smem;                       // [2][16][LD]
+    float* const lbias = smem + 2 * ABUF;          // packed biases of every segment
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const int row0 = blockIdx.x * NS_ROWS;
+#ifdef NS_STAMPS
+    unsigned long long* const lstamp = reinterpret_cast<unsigned long long*>(lbias + ((a.bias_total + 3) & ~3)) + wave * 32;
+    int nstamp = 0;
+#define NS_STAMP() do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (lane == 0 && nstamp < 32) lstamp[nstamp] = t_; ++nstamp; } while (0)
+#else
+#define NS_STAMP() do {} while (0)
+#endif
+    NS_STAMP();
+
+    // ---- 1. every small load of the kernel, up front, straight-line (no branch on a loaded value)
+    const int pr = tid / RG, pc0 = tid % RG;
+    const int grow = min(row0 + pr, a.B - 1);
+    const int kpad0 = a.kpad0, nin = a.nin, nout = a.nout, nseg = a.nseg;
+    constexpr int ZPRE = 2;
+    float zr[ZPRE], za1[ZPRE], za2[ZPRE], zxm[ZPRE], zxs[ZPRE]; int zfl[ZPRE], zlg[ZPRE];
+    const int* const lgp = a.lg ? a.lg : a.is_flat;
+#pragma unroll
+    for (int i = 0; i < ZPRE; ++i) {
+        const int c = min(pc0 + i * RG, nin - 1);
+        zr[i] = a.Z[(size_t)grow * a.ldz + c];
+        zfl[i] = a.is_flat[c]; za1[i] = a.a1[c]; za2[i] = a.a2[c];
+        zlg[i] = lgp[c]; zxm[i] = a.xmean[c]; zxs[i] = a.xstd[c];
+    }
+    const int nb4 = (a.bias_total + 3) >> 2;       // packed biases, 16 bytes per thread and round
+    const f32x4* const bsrc = reinterpret_cast<const f32x4*>(a.packed + (size_t)NW * a.G * NT * 256);
+    constexpr int BMAX = 3;                        // 3 x 512 x 4 floats >= every eligible network's biases
+    f32x4 breg[BMAX];
+#pragma unroll
+    for (int i = 0; i < BMAX; ++i) {
+        const int j = tid + i * 64 * NW;
+        breg[i] = bsrc[min(j, nb4 - 1)];
+    }
+    constexpr int FIN = 2;
+    const float* const csp = a.cscale ? a.cscale : a.xmean;   // always a readable pointer
+    const float* const ctp = a.cshift ? a.cshift : a.xmean;
+    const float* const wtp = a.w ? a.w : a.xmean;
+    float fcs[FIN], fct[FIN], fw[FIN];
+#pragma unroll
+    for (int i = 0; i < FIN; ++i) {
+        const int cc = min(pc0 + i * RG, nout - 1);
+        const int c1 = a.cscale ? cc : 0, c2 = a.cshift ? cc : 0, c3 = a.w ? cc : 0;
+        const float cs = csp[c1], ct = ctp[c2], ww = wtp[c3];
+        fcs[i] = a.cscale ? cs : 1.f; fct[i] = a.cshift ? ct : 0.f; fw[i] = a.w ? ww : 0.f;
+    }
+
+    // ---- 2. weight stream: wave-uniform base + 32-bit per-lane offset + immediate
+    const char* const wbase = reinterpret_cast<const char*>(a.packed) + (size_t)wave * a.G * NS_STEP_B;
+    const unsigned wlast = (unsigned)(a.G - 1) * NS_STEP_B;
+    unsigned woff = 0;
+    const unsigned voff = 16u * (unsigned)lane;
+    f32x4 Bq[R][NT];
+    auto wload = [&](int t) { return *reinterpret_cast<const f32x4*>(wbase + (size_t)(voff + woff) + t * 1024); };
+    auto wadvance = [&]() { woff = min(woff + NS_STEP_B, wlast); };   // past the end: reload the last step (never used)
+    constexpr int PRE = NS_PRE < R ? NS_PRE : R;
+    auto prefetch = [&](auto Uc) {
+        constexpr int U = decltype(Uc)::value;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            Bq[U][t] = wload(t);
+            __builtin_amdgcn_sched_barrier(0);     // keep the issue order: the loop's counted vmcnt depends on it
+        }
+        wadvance();
+    };
+#define NS_PF(U, LO, HI) if constexpr (U >= LO && U < HI) prefetch(std::integral_constant<int, U>{});
+#define NS_PF_ALL(LO, HI) NS_PF(0, LO, HI) NS_PF(1, LO, HI) NS_PF(2, LO, HI) NS_PF(3, LO, HI) NS_PF(4, LO, HI) NS_PF(5, LO, HI) \
+    NS_PF(6, LO, HI) NS_PF(7, LO, HI)
+    NS_PF_ALL(0, PRE)
+
+    // ---- 3. network input x = X_transform(Transform(z)) into buffer 0, zero padded to kpad0; biases to LDS
+    float zz = 0.f;
+    float theta[ZPRE];
+#pragma unroll
+    for (int i = 0; i < ZPRE; ++i) {
+        const int c = pc0 + i * RG;
+        const bool in = c < nin;
+        const float z = in ? zr[i] : 0.f;
+        zz += z * z;
+        float th = ns_prior_theta(z, zfl[i], za1[i], za2[i]);
+        float lt = log10f(th);
+        asm volatile("" : "+v"(lt));
+        theta[i] = th;
+        const float t = (a.lg && zlg[i]) ? lt : th;
+        const float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
+        if (c < kpad0) act[pr * LD + c] = x;
+    }
+    for (int c = pc0 + ZPRE * RG; c < kpad0; c += RG) act[pr * LD + c] = 0.f;   // NARROW first segment: wider zero pad
+    __builtin_amdgcn_sched_barrier(0);
+    NS_PF_ALL(PRE, R)
+#undef NS_PF_ALL
+#undef NS_PF
+#pragma unroll
+    for (int o = RG / 2; o >= 1; o >>= 1) zz += __shfl_xor(zz, o, 64);
+#pragma unroll
+    for (int i = 0; i < BMAX; ++i) {
+        const int j = tid + i * 64 * NW;
+        if (j < nb4) reinterpret_cast<f32x4*>(lbias)[j] = breg[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // raw: __syncthreads() would drain the weight stream
+    asm volatile("" ::: "memory");
+    NS_STAMP();
+
+    // ---- 4. the step loop
+    const uint32_t act_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)act;
+    f32x4 acc[NT];
+    f32x4 Aq[2];
+    int si = 0, pass = 0, P = 0, kleft;
+    int s_type, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext;
+    uint32_t ap;
+    auto a_read = [&](f32x4& dst) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ap) : "memory");
+        ap += 64;
+    };
+    auto load_seg = [&]() {
+        const NsSeg S = a.seg[si];
+        s_type = S.type; kleft = S.steps; s_passes = S.passes; s_bias = S.bias_off;
+        s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext;
+    };
+    auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
+        if (s_type == NS_WIDE) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float b = lbias[s_bias + 16 * (32 * pass + 4 * wave + t) + li];
+                acc[t] = f32x4{b, b, b, b};
+            }
+            ap = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ap = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq + wave * s_kslice);
+        }
+    };
+    auto lds_barrier = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    load_seg();
+    begin_run();
+    a_read(Aq[0]);
+
+    auto step = [&](auto Uc, auto Refill) {
+        constexpr int U = decltype(Uc)::value;
+        constexpr bool refill = decltype(Refill)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[U & 1]) :: "memory");
+        a_read(Aq[(U + 1) & 1]);                   // next step's A (speculative at a run end)
+        const f32x4 av = Aq[U & 1];
+#pragma unroll
+        for (int h = 0; h < NT; h += 2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][h][s], acc[h], 0, 0, 0);
+                acc[h + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][h + 1][s], acc[h + 1], 0, 0, 0);
+            }
+            if constexpr (refill) {
+                Bq[U][h] = wload(h);
+                Bq[U][h + 1] = wload(h + 1);
+            }
+        }
+        if constexpr (refill) wadvance();
+        if (--kleft == 0) {
+            // ---- end of run (si, pass)
+            if (s_type == NS_WIDE) {
+                float* const nxt = act + (P ^ 1) * ABUF + s_dst + 16 * (32 * pass + 4 * wave) + li;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {  // C/D layout: col = lane&15, row = 4*(lane>>4) + e
+                        const float v = acc[t][e];
+                        nxt[(4 * kq + e) * LD + 16 * t] = s_relu ? fmaxf(v, 0.f) : v;
+                    }
+                if (++pass == s_passes) {
+                    lds_barrier();
+                    NS_STAMP();
+                    P ^= 1; pass = 0; ++si;
+                    if (si < nseg) load_seg();
+                } else {
+                    kleft = a.seg[si].steps;
+                }
+            } else {
+                float* const part = act + (P ^ 1) * ABUF;          // [8 waves][16 rows][64 cols], col ^= 16*(row>>2)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        part[wave * 1024 + (4 * kq + e) * 64 + ((16 * t + li) ^ (16 * kq))] = acc[t][e];
+                lds_barrier();
+                float* const cur = act + P * ABUF + pr * LD + s_dst;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = pc0 + i * RG;
+                    if (c < s_zext) {
+                        float v = 0.f;
+                        if (i < 2) {
+#pragma unroll
+                            for (int ks = 0; ks < NW; ++ks) v += part[ks * 1024 + pr * 64 + (c ^ (16 * (pr >> 2)))];
+                            v += lbias[s_bias + c];
+                            if (s_relu) v = fmaxf(v, 0.f);
+                        }
+                        cur[c] = v;
+                    }
+                }
+                lds_barrier();
+                NS_STAMP();
+                ++si;
+                if (si < nseg) load_seg();
+            }
+            if (si < nseg) {
+                begin_run();
+                a_read(Aq[(U + 1) & 1]);           // replaces the speculative fragment
+            }
+        }
+    };
+    using T_ = std::true_type; using F_ = std::false_type;
+#define NS_STEP(U, RF) if constexpr (U < R) step(std::integral_constant<int, U>{}, RF{});
+    const int ngroups = a.G / R, rem = a.G - ngroups * R;
+#pragma unroll 1
+    for (int it = 0; it < ngroups; ++it) {
+        NS_STEP(0, T_) NS_STEP(1, T_) NS_STEP(2, T_) NS_STEP(3, T_) NS_STEP(4, T_) NS_STEP(5, T_) NS_STEP(6, T_) NS_STEP(7, T_)
+    }
+#define NS_TAIL(U) if constexpr (U < R - 1) { if (rem > U) step(std::integral_constant<int, U>{}, F_{}); }
+    NS_TAIL(0) NS_TAIL(1) NS_TAIL(2) NS_TAIL(3) NS_TAIL(4) NS_TAIL(5) NS_TAIL(6)
+#undef NS_STEP
+#undef NS_TAIL
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the last speculative A read
+    NS_STAMP();
+
+    // ---- 5. output rows are in buffer P (bias added, no ReLU): output transform, d, log-likelihood
+    {
+        const float* const F = act + P * ABUF + pr * LD;
+        const bool rok = row0 + pr < a.B;
+        float chi = 0.f;
+        auto column = [&](int c, float cs, float ct, float ww) {
+            const float d = F[c] * cs + ct;
+            if (a.D && rok) a.D[(size_t)(row0 + pr) * a.ldd + c] = d;
+            chi += (d * ww) * d;
+        };
+#pragma unroll
+        for (int i = 0; i < FIN; ++i)
+            if (pc0 + i * RG < nout) column(pc0 + i * RG, fcs[i], fct[i], fw[i]);
+        for (int c = pc0 + FIN * RG; c < nout; c += RG)        // wide outputs: constants straight from memory
+            column(c, a.cscale ? a.cscale[c] : 1.f, a.cshift ? a.cshift[c] : 0.f, a.w ? a.w[c] : 0.f);
+#pragma unroll
+        for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
+        if (a.lnP && a.w && pc0 == 0 && rok) {
+            const float v = (-0.5f * chi) / a.T + (-0.5f * zz);
+            a.lnP[row0 + pr] = isnan(v) ? -INFINITY : v;
+        }
+        if (a.TH && rok) {
+#pragma unroll
+            for (int j = 0; j < ZPRE; ++j)
+                if (pc0 + j * RG < nin) a.TH[(size_t)(row0 + pr) * a.ldt + pc0 + j * RG] = theta[j];
+        }
+    }
+    NS_STAMP();
+#ifdef NS_STAMPS
+    if (lane < 32) a.stamps[((size_t)blockIdx.x * NW + wave) * 32 + lane] = lane < nstamp ? lstamp[lane] : 0ull;
+#endif
+#undef NS_STAMP
+}
+
+// ---------------------------------------------------------------------------- host side: the program
+struct NsProgram {
+    std::vector<NsPackSeg> pack;
+    std::vector<NsSeg> seg;
+    int G = 0, LD = 0, kpad0 = 0, nout = 0, bias_total = 0;
+    size_t lds_bytes = 0, packed_floats = 0;
+    bool ok = false;
+};
+
+static int ceil16(int k) { return (k + 15) & ~15; }
+
+// Translate the op list into segments; ok = false when something does not fit this kernel.
+static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
+    NsProgram p;
+    if (nl < 1 || in_size < 1 || in_size > 64) return p;
+    struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
+                 int N, relu, dst_col; bool narrow; };
+    std::vector<Lin> lins;
+    int width = in_size;
+    for (int i = 0; i < nl; ++i) {
+        const linna_layer_t& l = layers[i];
+        if (l.K != width) return p;
+        if (l.op == LINNA_OP_LINEAR) {
+            if (l.alpha != 1.f || l.N < 1 || l.N > 1024) return p;
+            lins.push_back(Lin{l.W, (l.K + 3) & ~3, l.K, ceil16(l.K), nullptr, 0, 0, 0.f, l.b, 1.f, l.N, l.relu, 0, l.N <= 64});
+        } else if (l.op == LINNA_OP_RESBLOCK) {
+            if (l.C < 1 || l.C > 64 || l.N <= 64 || l.N > 1024 || (!l.Ws && l.K != l.N)) return p;
+            const int inpad = ceil16(l.K);
+            // h = relu(W1 x + b1) behind x in the same buffer
+            lins.push_back(Lin{l.W1, (l.K + 3) & ~3, l.K, inpad, nullptr, 0, 0, 0.f, l.b1, 1.f, l.C, 1, inpad, true});
+            // y = relu([Ws | 0.1 W2] [x ; h] + 0.1 b2)
+            lins.push_back(Lin{l.Ws, (l.K + 3) & ~3, l.K, inpad, l.W2, (l.C + 3) & ~3, l.C, 0.1f, l.b2, 0.1f, l.N, 1, 0, false});
+        } else {
+            return p;
+        }
+        width = l.N;
+    }
+    if (lins.empty() || lins.back().relu || (int)lins.size() > NS_MAXSEG) return p;
+    int maxext = 64, bias_off = 0, G = 0;
+    for (size_t i = 0; i < lins.size(); ++i) {
+        const Lin& L = lins[i];
+        const int Ktot = L.Kapad + ceil16(L.Kb);           // K extent in the activation row ([x ; h])
+        NsSeg s; NsPackSeg q;
+        s.relu = L.relu; s.dst_col = L.dst_col; s.bias_off = bias_off; s.zext = 0; s.kslice = 0;
+        int in_ext;                                         // columns of its input this segment reads
+        if (!L.narrow) {
+            s.type = NS_WIDE; s.steps = Ktot / 16; s.passes = (L.N + 511) / 512;
+            in_ext = Ktot;
+            maxext = std::max(maxext, 512 * s.passes);
+            q.bias_pad = 512 * s.passes;
+        } else {
+            s.type = NS_NARROW; s.steps = (Ktot / 16 + NS_NW - 1) / NS_NW; s.passes = 1; s.kslice = 16 * s.steps;
+            in_ext = NS_NW * s.kslice;
+            s.zext = 64;
+            maxext = std::max(maxext, L.dst_col + 64);
+            q.bias_pad = 64;
+        }
+        maxext = std::max(maxext, in_ext);
+        if (i == 0) p.kpad0 = in_ext;
+        else {
+            // the producer of this input must have written (zeros at least) every column read here
+            NsSeg& prev = p.seg.back();
+            const Lin& PL = lins[i - 1];
+            if (prev.type == NS_NARROW) {
+                if (PL.dst_col == 0) {                      // plain narrow layer: its output is the whole input
+                    if (in_ext > 128) return p;
+                    prev.zext = std::max(prev.zext, in_ext);
+                }
+                // (residual h: the consumer reads exactly inpad + ceil16(C) <= dst_col + 64 columns, and x was
+                //  written zero-padded by its own producer, checked when that consumer pair was added)
+            }
+            if (prev.type == NS_WIDE && in_ext > 512 * prev.passes) return p;
+        }
+        if (L.narrow && L.dst_col > 0) {
+            // x must be zero-padded up to the read extent of this NARROW segment by ITS producer
+            if (i == 0) p.kpad0 = std::max(p.kpad0, in_ext);
+            else if (p.seg.back().type == NS_WIDE) { if (in_ext > 512 * p.seg.back().passes) return p; }
+            else return p;                                  // residual block fed by a narrow layer: not needed by any model
+        }
+        q.Wa = L.Wa; q.lda = L.lda; q.Ka = L.Ka; q.Kapad = L.Kapad; q.Wb = L.Wb; q.ldb = L.ldb; q.Kb = L.Kb; q.alpha = L.alpha;
+        q.b = L.b; q.bscale = L.bscale; q.N = L.N; q.type = s.type; q.steps = s.steps; q.passes = s.passes; q.bias_off = bias_off;
+        bias_off += q.bias_pad;
+        G += s.steps * s.passes;
+        p.seg.push_back(s); p.pack.push_back(q);
+    }
+    if (p.kpad0 > 128) return p;                            // prologue zero fill covers ZPRE*RG = 64 + loop; keep it small
+    p.nout = lins.back().N;
+    p.G = G; p.bias_total = bias_off;
+    p.LD = ((maxext + 63) & ~63) + 4;
+    if (NS_ROWS * p.LD < 8192 + 64) return p;               // NARROW partials need [8][16][64] floats in one buffer
+    if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
+    p.lds_bytes = (size_t)(2 * NS_ROWS * p.LD + ((bias_off + 3) & ~3)) * sizeof(float);
+#ifdef NS_STAMPS
+    p.lds_bytes += NS_NW * 32 * 8;
+#endif
+    if (p.lds_bytes > (size_t)NS_LDS_BYTES) return p;
+    int nrun = 0;
+    for (const NsSeg& s : p.seg) nrun += s.passes;
+    if (nrun > NS_MAXRUN) return p;
+    p.packed_floats = (size_t)NS_NW * G * NS_NT * 256 + (size_t)((bias_off + 3) & ~3);
+    p.ok = true;
+    return p;
+}
+
+bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size) { return ns_build(layers, nl, in_size).ok; }
+size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size) {
+    return ns_build(layers, nl, in_size).packed_floats;
+}
+
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, hipStream_t s) {
+    const NsProgram p = ns_build(layers, nl, in_size);
+    if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
+    NsPackArgs a;
+    ::memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.nseg = (int)p.seg.size(); a.G = p.G; a.bias_total = p.bias_total; a.out = packed;
+    int nrun = 0, first = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        a.seg[i] = p.pack[i];
+        for (int ps = 0; ps < p.seg[i].passes; ++ps) {
+            a.run_seg[nrun] = i; a.run_pass[nrun] = ps; a.run_first[nrun] = first;
+            first += p.seg[i].steps; ++nrun;
+        }
+    }
+    a.run_first[nrun] = first; a.nrun = nrun;
+    const size_t total = (size_t)NS_NW * p.G * NS_NT * 64 + (size_t)p.bias_total;
+    hipLaunchKernelGGL(ns_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return check_hip(hipGetLastError(), "net_stream pack launch");
+}
+
+int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
+                      int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
+                      const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
+                      float* D, int ldd, float* TH, int ldt, hipStream_t s) {
+    const NsProgram p = ns_build(layers, nl, in_size);
+    if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
+    NsArgs a;
+    ::memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.Z = Z; a.ldz = ldz; a.B = B; a.nin = nin;
+    a.is_flat = is_flat; a.a1 = a1; a.a2 = a2; a.lg = lg; a.xmean = xmean; a.xstd = xstd;
+    a.packed = packed;
+    a.G = p.G; a.nseg = (int)p.seg.size(); a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
+    a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
+    a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
+    for (int i = 0; i < a.nseg; ++i) a.seg[i] = p.seg[i];
+    a.stamps = nullptr;
+#ifdef NS_STAMPS
+    a.stamps = getenv("LINNA_FUSED_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LINNA_FUSED_STAMPS"), nullptr, 16)) : nullptr;
+    if (!a.stamps) { set_error("net_stream: NS_STAMPS build needs LINNA_FUSED_STAMPS"); return LINNA_ERR_INVALID; }
+#endif
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, NS_LDS_BYTES), "hipFuncSetAttribute");
+        if (rc != LINNA_OK) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((net_stream_kernel<NS_R>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), p.lds_bytes, s, a);
+    return check_hip(hipGetLastError(), "net_stream launch");
+}
+
+}  // namespace linna
