@@ -197,8 +197,9 @@ typedef struct {
 int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc,
                          linna_logprob_t** out);
 int linna_logprob_destroy(linna_logprob_t* lp);
-/* Networks whose hidden layers are all 512 wide are served from a fragment-order copy of the
- * weights owned by the linna_logprob_t (stream_mlp.hip).  The copy is refreshed automatically
+/* Networks of LINEAR / RESBLOCK ops up to 1024 wide (every model of nn.py) are served by ONE
+ * whole-network kernel from a fragment-order copy of the weights owned by the linna_logprob_t
+ * (net_stream.hip).  The copy is refreshed automatically
  * after linna_adamw_step and after any linna_graph_launch; a caller that overwrites parameter
  * memory by other means (hipMemcpy of a checkpoint, a torch-side copy_) calls this once
  * afterwards -- the reference has no counterpart because `model.load_state_dict`

@@ -55,7 +55,7 @@ using namespace linna;
 
 // Weight epoch: bumped by every entry that may change network parameters (linna_adamw_step, a
 // graph replay, linna_weights_changed()); a log-probability object re-lays its fragment-order
-// weight copy (stream_mlp.hip) when the epoch moved since the copy was made.
+// weight copy (net_stream.hip) when the epoch moved since the copy was made.
 static std::atomic<unsigned long long> g_weights_epoch{1};
 
 struct linna_ctx {
@@ -449,8 +449,7 @@ struct linna_logprob {
     linna_ctx* ctx;
     linna_net* net;
     linna_logprob_desc_t d;
-    float* packed = nullptr;                 // fragment-order weight stream (stream_mlp.hip / net_stream.hip), or null
-    int packed_kind = 0;                     // 1 stream_mlp.hip, 2 net_stream.hip
+    float* packed = nullptr;                 // fragment-order weight stream (net_stream.hip), or null
     unsigned long long packed_epoch = 0;     // epoch the copy was made at (0 = never)
 };
 
@@ -478,63 +477,30 @@ static bool fused_enabled() {
     static const bool on = !(getenv("LINNA_DISABLE_FUSED") && getenv("LINNA_DISABLE_FUSED")[0] == '1');
     return on;
 }
-static bool stream_enabled() {   // LINNA_DISABLE_STREAM=1: first-generation fused kernel (A/B timing, tests)
-    static const bool on = !(getenv("LINNA_DISABLE_STREAM") && getenv("LINNA_DISABLE_STREAM")[0] == '1');
-    return on;
-}
-static int stream_kind_wanted(const linna_net* n) {   // which weight-stream kernel serves this network (0: none)
-    static const bool force_net = getenv("LINNA_FORCE_NETSTREAM") && getenv("LINNA_FORCE_NETSTREAM")[0] == '1';
-    static const bool no_net = getenv("LINNA_DISABLE_NETSTREAM") && getenv("LINNA_DISABLE_NETSTREAM")[0] == '1';
-    if (n->has_inskip) return 0;
-    const bool net_ok = !no_net && net_stream_eligible(n->L.data(), (int)n->L.size(), n->in_size);
-    if (force_net && net_ok) return 2;
-    if (stream_mlp_eligible(n->L.data(), (int)n->L.size(), n->in_size)) return 1;
-    return net_ok ? 2 : 0;
-}
-
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
                       float* TH, int ldt, void* stream, bool keep_activations) {
     const linna_logprob_desc_t& d = lp->d;
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
     const linna_net* n = lp->net;
-    if (!keep_activations && fused_enabled() && stream_enabled() && lp->packed && !d.outmap.cexp) {
-        // whole-network kernel, weights streamed from the fragment-order copy
+    if (!keep_activations && fused_enabled() && lp->packed && !d.outmap.cexp) {
+        // whole-network kernel (net_stream.hip): prior map -> every layer -> output transform -> diagonal
+        // log-likelihood in ONE launch, weights streamed from the fragment-order copy
         const unsigned long long epoch = g_weights_epoch.load();
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(S(stream), &cap);
         const int nl = (int)n->L.size();
-        auto pack = [&]() {
-            return lp->packed_kind == 1 ? launch_pack_weight_stream(n->L.data(), nl, lp->packed, S(stream))
-                                        : launch_net_stream_pack(n->L.data(), nl, n->in_size, lp->packed, S(stream));
-        };
         if (cap != hipStreamCaptureStatusNone) {
             // a captured evaluation carries its own re-layout, so that every replay sees the weights
             // of that moment; the copy is not valid for direct launches until they redo it
-            TRY(pack());
+            TRY(launch_net_stream_pack(n->L.data(), nl, n->in_size, lp->packed, S(stream)));
             lp->packed_epoch = 0;
         } else if (lp->packed_epoch != epoch) {
-            TRY(pack());
+            TRY(launch_net_stream_pack(n->L.data(), nl, n->in_size, lp->packed, S(stream)));
             lp->packed_epoch = epoch;
         }
-        if (lp->packed_kind == 1) {
-            TRY(launch_stream_mlp(n->L.data(), nl, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
-                                  d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                                  d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, S(stream)));
-        } else {
-            TRY(launch_net_stream(n->L.data(), nl, n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
-                                  d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                                  d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, S(stream)));
-        }
-        if (d.w) return LINNA_OK;
-        return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
-                                         w + L.part, lnP, stream);
-    }
-    if (!keep_activations && fused_enabled() && !n->has_inskip && !d.outmap.cexp &&
-        fused_mlp_eligible(n->L.data(), (int)n->L.size(), n->in_size)) {
-        // whole-network kernel: prior map -> layers -> (diagonal) log-likelihood in one launch
-        TRY(launch_fused_mlp(n->L.data(), (int)n->L.size(), nullptr, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag,
-                             d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, d.w ? lnP : nullptr,
-                             d.w ? nullptr : w + L.d, ldd, TH, ldt, S(stream)));
+        TRY(launch_net_stream(n->L.data(), nl, n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+                              d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
+                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, S(stream)));
         if (d.w) return LINNA_OK;
         return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
@@ -558,10 +524,8 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     if (!desc->w && !desc->S) { set_error("logprob_create: need S (dense) or w (diagonal)"); return LINNA_ERR_INVALID; }
     if (!(desc->temperature > 0.f)) { set_error("logprob_create: temperature must be > 0"); return LINNA_ERR_INVALID; }
     linna_logprob* lp = new linna_logprob{ctx, net, *desc};
-    lp->packed_kind = stream_kind_wanted(net);
-    if (lp->packed_kind) {
-        const size_t nf = lp->packed_kind == 1 ? stream_mlp_packed_floats(net->L.data(), (int)net->L.size())
-                                               : net_stream_packed_floats(net->L.data(), (int)net->L.size(), net->in_size);
+    if (!net->has_inskip && net_stream_eligible(net->L.data(), (int)net->L.size(), net->in_size)) {
+        const size_t nf = net_stream_packed_floats(net->L.data(), (int)net->L.size(), net->in_size);
         if (check_hip(hipMalloc(reinterpret_cast<void**>(&lp->packed), nf * sizeof(float)), "hipMalloc(weight stream)") != LINNA_OK) {
             delete lp; return LINNA_ERR_HIP;
         }

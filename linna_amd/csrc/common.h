@@ -78,22 +78,6 @@ int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int
                         const float* Wacc, const float* Zacc, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
 
-// fused_mlp.hip
-bool fused_mlp_eligible(const linna_layer_t* layers, int nl, int in_size);
-int launch_fused_mlp(const linna_layer_t* layers, int nl, const float* param_end, const float* Z, int ldz, int B, int nin,
-                     const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
-                     const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                     float* D, int ldd, float* TH, int ldt, hipStream_t s);
-
-// stream_mlp.hip (hidden width 512: weights streamed from a fragment-order copy)
-bool stream_mlp_eligible(const linna_layer_t* layers, int nl, int in_size);
-size_t stream_mlp_packed_floats(const linna_layer_t* layers, int nl);
-int launch_pack_weight_stream(const linna_layer_t* layers, int nl, float* packed, hipStream_t s);
-int launch_stream_mlp(const linna_layer_t* layers, int nl, const float* packed, const float* Z, int ldz, int B, int nin,
-                      const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
-                      const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, hipStream_t s);
-
 // net_stream.hip (program-driven whole-network kernel: residual blocks, widths up to 1024)
 bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size);
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size);

@@ -1,22 +1,37 @@
-// Whole-network serving kernel, generalised ("network stream"): the weight-stream design of
-// stream_mlp.hip driven by a small PROGRAM, so that the reference's own architectures run in one
-// launch too -- ChtoModelv2 / ChtoModelsimple (nn.py:59-133, 300-374: Linear + three residual
-// blocks + three Linears) as well as plain MLPs of any width up to 1024.  ONE launch evaluates
-// util.Log_prob.__call__ (util.py:990-1021) for 16 walkers per workgroup.
+// Whole-network serving kernel ("network stream"): ONE launch evaluates util.Log_prob.__call__
+// (util.py:990-1021) for 16 walkers per workgroup -- prior map + input transform (util.py:339-347,
+// 483-497), every layer, the output transform and the diagonal Gaussian log-likelihood
+// (util.py:953-955) -- for the reference's own architectures, ChtoModelv2 / ChtoModelsimple
+// (nn.py:59-133, 300-374: Linear + three residual blocks + three Linears), and for plain MLPs of
+// any width up to 1024 (BASELINE configs 2/5: 33 -> 512 x 4 -> 33).
+//
+// MI355X mapping
+//  * one 512-thread workgroup (8 waves, two per SIMD) per CU owns 16 walker rows; activations stay
+//    in LDS for the whole network, double-buffered [2][16][LD] fp32 (LD = widest row + 4: the
+//    stride makes ds_read_b128 and the epilogue's ds_write_b32 conflict-free);
+//  * weights never touch LDS.  With 16 rows per workgroup no wave shares a weight with another
+//    wave, so they are re-laid ONCE per weight update into MFMA FRAGMENT ORDER (ns_pack_kernel):
+//    the B operand of a step's column tile is 1 KiB contiguous, lane-linear, and one coalesced
+//    global_load_dwordx4 puts it straight into the registers the MFMA reads.  Every wave owns ONE
+//    contiguous stream over the whole network; a ring of R register sets keeps R-1 steps (20 KiB
+//    per wave) in flight across layer boundaries with counted s_waitcnt vmcnt;
+//  * v_mfma_f32_16x16x4_f32 (exact fp32) with the k-permutation trick: lane group kq owns 4
+//    consecutive k, element s of the 128-bit A and B fragments feeds MFMA s;
+//  * ONE copy of the step loop serves every layer: the network is a small PROGRAM of segments.
 //
 // Program = list of segments, each a GEMM over the activation rows held in LDS:
 //   WIDE    N > 64: the N columns are split over the 8 waves in passes of 512 (wave w owns column
 //           tiles 4w..4w+3 of a pass), every wave runs all K steps; epilogue bias(+ReLU) -> the
 //           OTHER activation buffer; one barrier after the last pass.
-//   NARROW  N <= 64: K is split over the 8 waves, every wave computes all 64 columns of its K
-//           slice, partial sums are reduced through LDS, bias(+ReLU) -> the CURRENT buffer at a
-//           column offset (two barriers).
-// A residual block  y = relu(0.1 (W2 relu(W1 x + b1) + b2) + Ws x)  (nn.py:45-56) is NARROW
-// (h = relu(W1 x + b1), written right behind x in the same buffer) + ONE WIDE GEMM over the
+//   SPLIT   N <= 256: the columns form ncg = 1, 2 or 4 groups of 64 and K is split over the
+//           8/ncg waves of a group (wave = kpart*ncg + group), partial sums are reduced through
+//           LDS, bias(+ReLU) -> the CURRENT buffer at a column offset (two barriers).  Keeps all
+//           eight waves on real columns where WIDE would leave most of its 32 tiles empty.
+// A residual block  y = relu(0.1 (W2 relu(W1 x + b1) + b2) + Ws x)  (nn.py:45-56) is SPLIT
+// (h = relu(W1 x + b1), written right behind x in the same buffer) + ONE GEMM over the
 // concatenated K = [x ; h] with the concatenated weight [Ws | 0.1 W2] and bias 0.1 b2.
 // One step = 16 k x 64 columns = 1 ds_read_b128 (A) + 4 coalesced 1-KiB global loads (B, fragment
-// order, see pack below) + 16 v_mfma_f32_16x16x4_f32, exactly as in stream_mlp.hip; every wave
-// owns ONE contiguous weight stream over the whole program, R register sets deep.
+// order, see pack below) + 16 v_mfma_f32_16x16x4_f32.
 // After the last segment the output row block sits in LDS: output transform, optional store of
 // d, diagonal Gaussian log-likelihood (util.py:953-955) with 32-lane shuffles.
 #include "common.h"
@@ -41,11 +56,12 @@ constexpr int NS_LDS_BYTES = 160 * 1024;
 #ifndef NS_PRE
 #define NS_PRE 2
 #endif
-enum { NS_WIDE = 0, NS_NARROW = 1 };
+enum { NS_WIDE = 0, NS_SPLIT = 1 };
 
 struct NsSeg {            // kernel-side view of a segment
     int type, steps, passes, bias_off;
-    int dst_col, relu, kslice, zext;   // kslice: k offset between waves (NARROW) = 16*steps
+    int dst_col, relu, kslice, zext;   // SPLIT: kslice = k offset between K parts (16*steps), zext = columns written
+    int ncg_log2, pad0, pad1, pad2;    // SPLIT: log2 of the number of 64-column groups
 };
 
 struct NsArgs {
@@ -65,7 +81,7 @@ struct NsPackSeg {
     const float* Wa; int lda, Ka, Kapad;          // first K part (Wa NULL: identity)
     const float* Wb; int ldb, Kb; float alpha;    // second K part, scaled (residual blocks)
     const float* b; float bscale;
-    int N, type, steps, passes, bias_off, bias_pad;
+    int N, type, steps, passes, bias_off, bias_pad, ncg;
 };
 struct NsPackArgs {
     NsPackSeg seg[NS_MAXSEG];
@@ -75,7 +91,7 @@ struct NsPackArgs {
 };
 // stream[w][g][t][lane][e], run r = (segment, pass), s = g - first[r], li = lane & 15, kq = lane >> 4:
 //   WIDE   n = 16 (32 pass + 4 w + t) + li,  k = 16 s + 4 kq + e
-//   NARROW n = 16 t + li,                    k = 16 (w steps + s) + 4 kq + e
+//   SPLIT  n = 64 (w % ncg) + 16 t + li,     k = 16 ((w / ncg) steps + s) + 4 kq + e
 // value = [Wa | alpha Wb](n, k), zero outside.
 __global__ void ns_pack_kernel(NsPackArgs p) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,7 +108,7 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
         const int s = g - p.run_first[r], li = lane & 15, kq = lane >> 4;
         int n, k0;
         if (S.type == NS_WIDE) { n = 16 * (32 * p.run_pass[r] + 4 * w + t) + li; k0 = 16 * s + 4 * kq; }
-        else { n = 16 * t + li; k0 = 16 * (w * S.steps + s) + 4 * kq; }
+        else { n = 64 * (w % S.ncg) + 16 * t + li; k0 = 16 * ((w / S.ncg) * S.steps + s) + 4 * kq; }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n < S.N) {
 #pragma unroll
@@ -223,7 +239,20 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         const float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
         if (c < kpad0) act[pr * LD + c] = x;
     }
-    for (int c = pc0 + ZPRE * RG; c < kpad0; c += RG) act[pr * LD + c] = 0.f;   // NARROW first segment: wider zero pad
+    // inputs wider than ZPRE*RG = 64 columns (none of the reference's models; <= 256 supported) and the zero
+    // pad of a SPLIT first segment: plain loop, loads waited in place
+#pragma unroll 1
+    for (int c = pc0 + ZPRE * RG; c < kpad0; c += RG) {
+        float x = 0.f;
+        if (c < nin) {
+            const float z = a.Z[(size_t)grow * a.ldz + c];
+            zz += z * z;
+            const float th = ns_prior_theta(z, a.is_flat[c], a.a1[c], a.a2[c]);
+            const float t = (a.lg && a.lg[c]) ? log10f(th) : th;
+            x = (t - a.xmean[c]) / a.xstd[c];
+        }
+        act[pr * LD + c] = x;
+    }
     __builtin_amdgcn_sched_barrier(0);
     NS_PF_ALL(PRE, R)
 #undef NS_PF_ALL
@@ -245,7 +274,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     f32x4 acc[NT];
     f32x4 Aq[2];
     int si = 0, pass = 0, P = 0, kleft;
-    int s_type, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext;
+    int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl;
     uint32_t ap;
     auto a_read = [&](f32x4& dst) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ap) : "memory");
@@ -253,8 +282,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     };
     auto load_seg = [&]() {
         const NsSeg S = a.seg[si];
-        s_type = S.type; kleft = S.steps; s_passes = S.passes; s_bias = S.bias_off;
-        s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext;
+        s_type = S.type; kleft = s_steps = S.steps; s_passes = S.passes; s_bias = S.bias_off;
+        s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2;
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         if (s_type == NS_WIDE) {
@@ -267,7 +296,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ap = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq + wave * s_kslice);
+            ap = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq + (wave >> s_ncgl) * s_kslice);
         }
     };
     auto lds_barrier = [&]() {
@@ -299,7 +328,15 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         }
         if constexpr (refill) wadvance();
         if (--kleft == 0) {
-            // ---- end of run (si, pass)
+            // ---- end of run (si, pass).  The next segment's descriptor is requested first: the scalar
+            // load's latency then hides under the epilogue stores and the barrier.
+            const NsSeg NX = a.seg[min(si + 1, nseg - 1)];
+            const int cur_steps = s_steps;
+            auto take_next = [&]() {
+                s_type = NX.type; s_steps = NX.steps; s_passes = NX.passes; s_bias = NX.bias_off;
+                s_dst = NX.dst_col; s_relu = NX.relu; s_kslice = NX.kslice; s_zext = NX.zext; s_ncgl = NX.ncg_log2;
+                kleft = NX.steps;
+            };
             if (s_type == NS_WIDE) {
                 float* const nxt = act + (P ^ 1) * ABUF + s_dst + 16 * (32 * pass + 4 * wave) + li;
 #pragma unroll
@@ -313,9 +350,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     lds_barrier();
                     NS_STAMP();
                     P ^= 1; pass = 0; ++si;
-                    if (si < nseg) load_seg();
+                    take_next();
                 } else {
-                    kleft = a.seg[si].steps;
+                    kleft = cur_steps;
                 }
             } else {
                 float* const part = act + (P ^ 1) * ABUF;          // [8 waves][16 rows][64 cols], col ^= 16*(row>>2)
@@ -325,25 +362,28 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     for (int e = 0; e < 4; ++e)
                         part[wave * 1024 + (4 * kq + e) * 64 + ((16 * t + li) ^ (16 * kq))] = acc[t][e];
                 lds_barrier();
+                // thread (row pr, lane pc0 of 32): columns pc0, pc0+32, ...; wave of (K part kp, group cg) = kp*ncg + cg
                 float* const cur = act + P * ABUF + pr * LD + s_dst;
+                const int ncol = 64 << s_ncgl, nkp = NW >> s_ncgl;
+                const int sw = 16 * (pr >> 2);
+                for (int c = pc0; c < s_zext; c += RG) {
+                    float v = 0.f;
+                    if (c < ncol) {
+                        const float* src = part + (c >> 6) * 1024 + pr * 64 + ((c & 63) ^ sw);
+                        float x[NW];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = pc0 + i * RG;
-                    if (c < s_zext) {
-                        float v = 0.f;
-                        if (i < 2) {
+                        for (int kp = 0; kp < NW; ++kp) x[kp] = src[((kp & (nkp - 1)) << s_ncgl) * 1024];   // 8 reads in flight
 #pragma unroll
-                            for (int ks = 0; ks < NW; ++ks) v += part[ks * 1024 + pr * 64 + (c ^ (16 * (pr >> 2)))];
-                            v += lbias[s_bias + c];
-                            if (s_relu) v = fmaxf(v, 0.f);
-                        }
-                        cur[c] = v;
+                        for (int kp = 0; kp < NW; ++kp) v += kp < nkp ? x[kp] : 0.f;
+                        v += lbias[s_bias + c];
+                        if (s_relu) v = fmaxf(v, 0.f);
                     }
+                    cur[c] = v;
                 }
                 lds_barrier();
                 NS_STAMP();
                 ++si;
-                if (si < nseg) load_seg();
+                take_next();
             }
             if (si < nseg) {
                 begin_run();
@@ -390,6 +430,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
             for (int j = 0; j < ZPRE; ++j)
                 if (pc0 + j * RG < nin) a.TH[(size_t)(row0 + pr) * a.ldt + pc0 + j * RG] = theta[j];
+            for (int c = pc0 + ZPRE * RG; c < nin; c += RG)     // wide inputs: theta recomputed rather than kept
+                a.TH[(size_t)(row0 + pr) * a.ldt + c] = ns_prior_theta(a.Z[(size_t)grow * a.ldz + c], a.is_flat[c], a.a1[c], a.a2[c]);
         }
     }
     NS_STAMP();
@@ -413,9 +455,10 @@ static int ceil16(int k) { return (k + 15) & ~15; }
 // Translate the op list into segments; ok = false when something does not fit this kernel.
 static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
     NsProgram p;
-    if (nl < 1 || in_size < 1 || in_size > 64) return p;
+    if (nl < 1 || in_size < 1 || in_size > 256) return p;
+    // 1. linear maps: [Wa | alpha Wb] over K = [Kapad ; Kb], N outputs, written to dst_col (same_buf: into the input's buffer)
     struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
-                 int N, relu, dst_col; bool narrow; };
+                 int N, relu, dst_col; bool same_buf; };
     std::vector<Lin> lins;
     int width = in_size;
     for (int i = 0; i < nl; ++i) {
@@ -423,13 +466,11 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
         if (l.K != width) return p;
         if (l.op == LINNA_OP_LINEAR) {
             if (l.alpha != 1.f || l.N < 1 || l.N > 1024) return p;
-            lins.push_back(Lin{l.W, (l.K + 3) & ~3, l.K, ceil16(l.K), nullptr, 0, 0, 0.f, l.b, 1.f, l.N, l.relu, 0, l.N <= 64});
+            lins.push_back(Lin{l.W, (l.K + 3) & ~3, l.K, ceil16(l.K), nullptr, 0, 0, 0.f, l.b, 1.f, l.N, l.relu, 0, false});
         } else if (l.op == LINNA_OP_RESBLOCK) {
-            if (l.C < 1 || l.C > 64 || l.N <= 64 || l.N > 1024 || (!l.Ws && l.K != l.N)) return p;
+            if (l.C < 1 || l.C > 64 || l.N < 1 || l.N > 1024 || (!l.Ws && l.K != l.N)) return p;
             const int inpad = ceil16(l.K);
-            // h = relu(W1 x + b1) behind x in the same buffer
-            lins.push_back(Lin{l.W1, (l.K + 3) & ~3, l.K, inpad, nullptr, 0, 0, 0.f, l.b1, 1.f, l.C, 1, inpad, true});
-            // y = relu([Ws | 0.1 W2] [x ; h] + 0.1 b2)
+            lins.push_back(Lin{l.W1, (l.K + 3) & ~3, l.K, inpad, nullptr, 0, 0, 0.f, l.b1, 1.f, l.C, 1, inpad, true});   // h behind x
             lins.push_back(Lin{l.Ws, (l.K + 3) & ~3, l.K, inpad, l.W2, (l.C + 3) & ~3, l.C, 0.1f, l.b2, 0.1f, l.N, 1, 0, false});
         } else {
             return p;
@@ -437,46 +478,32 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
         width = l.N;
     }
     if (lins.empty() || lins.back().relu || (int)lins.size() > NS_MAXSEG) return p;
-    int maxext = 64, bias_off = 0, G = 0;
+
+    // 2. segment shapes.  SPLIT when it must write into its own input buffer (h of a residual block) or when
+    //    splitting K over the idle waves saves at least three steps; WIDE otherwise.
+    int bias_off = 0, G = 0;
+    std::vector<int> in_ext(lins.size());
     for (size_t i = 0; i < lins.size(); ++i) {
         const Lin& L = lins[i];
-        const int Ktot = L.Kapad + ceil16(L.Kb);           // K extent in the activation row ([x ; h])
+        const int ksteps = (L.Kapad + ceil16(L.Kb)) / 16;
         NsSeg s; NsPackSeg q;
-        s.relu = L.relu; s.dst_col = L.dst_col; s.bias_off = bias_off; s.zext = 0; s.kslice = 0;
-        int in_ext;                                         // columns of its input this segment reads
-        if (!L.narrow) {
-            s.type = NS_WIDE; s.steps = Ktot / 16; s.passes = (L.N + 511) / 512;
-            in_ext = Ktot;
-            maxext = std::max(maxext, 512 * s.passes);
-            q.bias_pad = 512 * s.passes;
+        std::memset(&s, 0, sizeof(s));
+        s.relu = L.relu; s.dst_col = L.dst_col; s.bias_off = bias_off;
+        const int passes = (L.N + 511) / 512;
+        int ncg = L.N <= 64 ? 1 : L.N <= 128 ? 2 : L.N <= 256 ? 4 : 0;
+        const int split_steps = ncg ? (ksteps + NS_NW / ncg - 1) / (NS_NW / ncg) : 0;
+        const bool split = ncg && (L.same_buf || split_steps + 3 <= ksteps * passes);
+        if (L.same_buf && !ncg) return p;
+        if (split) {
+            s.type = NS_SPLIT; s.steps = split_steps; s.passes = 1; s.kslice = 16 * s.steps;
+            s.ncg_log2 = ncg == 1 ? 0 : ncg == 2 ? 1 : 2;
+            s.zext = 64 * ncg;
+            in_ext[i] = (NS_NW / ncg) * s.kslice;
+            q.bias_pad = 64 * ncg; q.ncg = ncg;
         } else {
-            s.type = NS_NARROW; s.steps = (Ktot / 16 + NS_NW - 1) / NS_NW; s.passes = 1; s.kslice = 16 * s.steps;
-            in_ext = NS_NW * s.kslice;
-            s.zext = 64;
-            maxext = std::max(maxext, L.dst_col + 64);
-            q.bias_pad = 64;
-        }
-        maxext = std::max(maxext, in_ext);
-        if (i == 0) p.kpad0 = in_ext;
-        else {
-            // the producer of this input must have written (zeros at least) every column read here
-            NsSeg& prev = p.seg.back();
-            const Lin& PL = lins[i - 1];
-            if (prev.type == NS_NARROW) {
-                if (PL.dst_col == 0) {                      // plain narrow layer: its output is the whole input
-                    if (in_ext > 128) return p;
-                    prev.zext = std::max(prev.zext, in_ext);
-                }
-                // (residual h: the consumer reads exactly inpad + ceil16(C) <= dst_col + 64 columns, and x was
-                //  written zero-padded by its own producer, checked when that consumer pair was added)
-            }
-            if (prev.type == NS_WIDE && in_ext > 512 * prev.passes) return p;
-        }
-        if (L.narrow && L.dst_col > 0) {
-            // x must be zero-padded up to the read extent of this NARROW segment by ITS producer
-            if (i == 0) p.kpad0 = std::max(p.kpad0, in_ext);
-            else if (p.seg.back().type == NS_WIDE) { if (in_ext > 512 * p.seg.back().passes) return p; }
-            else return p;                                  // residual block fed by a narrow layer: not needed by any model
+            s.type = NS_WIDE; s.steps = ksteps; s.passes = passes;
+            in_ext[i] = 16 * ksteps;
+            q.bias_pad = 512 * passes; q.ncg = 1;
         }
         q.Wa = L.Wa; q.lda = L.lda; q.Ka = L.Ka; q.Kapad = L.Kapad; q.Wb = L.Wb; q.ldb = L.ldb; q.Kb = L.Kb; q.alpha = L.alpha;
         q.b = L.b; q.bscale = L.bscale; q.N = L.N; q.type = s.type; q.steps = s.steps; q.passes = s.passes; q.bias_off = bias_off;
@@ -484,11 +511,38 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
         G += s.steps * s.passes;
         p.seg.push_back(s); p.pack.push_back(q);
     }
-    if (p.kpad0 > 128) return p;                            // prologue zero fill covers ZPRE*RG = 64 + loop; keep it small
+
+    // 3. every column a segment reads must have been WRITTEN (finite; zero where the weights are zero):
+    //    track the defined prefix [0, def) of the current buffer and widen the zero fill of the last
+    //    SPLIT writer (or of the prologue) where a consumer reads further.
+    p.kpad0 = in_ext[0];
+    int def = p.kpad0, writer = -1;                         // writer: segment whose write ends at `def` (-1 prologue, -2 fixed)
+    int maxext = 64;
+    for (size_t i = 0; i < p.seg.size(); ++i) {
+        NsSeg& s = p.seg[i];
+        if (in_ext[i] > def) {
+            if (writer == -1) p.kpad0 = def = in_ext[i];
+            else if (writer >= 0) { NsSeg& w = p.seg[writer]; w.zext = in_ext[i] - w.dst_col; def = in_ext[i]; }
+            else return p;
+        }
+        maxext = std::max(maxext, in_ext[i]);
+        if (s.type == NS_WIDE) {
+            if (s.dst_col != 0) return p;
+            def = 512 * s.passes; writer = -2;
+            maxext = std::max(maxext, def);
+        } else {
+            if (s.dst_col > def) return p;
+            if (s.dst_col == 0) def = s.zext;               // overwrites its input from column 0
+            else def = std::max(def, s.dst_col + s.zext);
+            writer = (int)i;
+        }
+    }
+    for (const NsSeg& s : p.seg) if (s.type == NS_SPLIT) maxext = std::max(maxext, s.dst_col + s.zext);
+    if (p.kpad0 > 256) return p;
     p.nout = lins.back().N;
     p.G = G; p.bias_total = bias_off;
     p.LD = ((maxext + 63) & ~63) + 4;
-    if (NS_ROWS * p.LD < 8192 + 64) return p;               // NARROW partials need [8][16][64] floats in one buffer
+    if (NS_ROWS * p.LD < 8192 + 64) return p;               // SPLIT partials need [8][16][64] floats in one buffer
     if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
     p.lds_bytes = (size_t)(2 * NS_ROWS * p.LD + ((bias_off + 3) & ~3)) * sizeof(float);
 #ifdef NS_STAMPS

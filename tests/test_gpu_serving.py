@@ -191,7 +191,7 @@ def test_nan_maps_to_minus_inf_and_empty_edge():
         lp.evaluate(torch.zeros((0, 6), device="cuda"))
 
 
-def test_fused_mlp_kernel_edges_and_agreement_with_layered_path():
+def test_whole_network_kernel_edges_and_agreement_with_layered_path():
     """The whole-network kernel (used by evaluate for eligible MLPs) against the layer-by-layer
     path (used by evaluate_with_grad) and the oracle: ragged batch, NaN row, theta output."""
     from oracle import likelihood
@@ -234,21 +234,24 @@ def _custom_problem(nin, nout, seed, width, depth, dense=False):
 
 
 @pytest.mark.parametrize("nin,nout,width,depth,which", [
-    (33, 33, 512, 4, "stream"),      # bench shape: weight-stream kernel
-    (64, 64, 512, 2, "stream"),      # widest input / output the stream kernel takes, 3 linear layers
-    (3, 1, 512, 1, "stream"),        # two linear layers, one output column
-    (65, 40, 512, 3, "ring"),        # 65 inputs: first-generation fused kernel (LDS weight rings)
-    (20, 33, 256, 3, "ring"),        # hidden width 256: first-generation fused kernel
+    (33, 33, 512, 4, "big"),         # bench shape: WIDE x4 + SPLIT(8-way K) last layer
+    (64, 64, 512, 2, "big"),         # 64 inputs / outputs, 3 linear layers
+    (3, 1, 512, 1, "big"),           # two linear layers, one output column
+    (65, 40, 512, 3, "small"),       # 65 inputs: the prologue's wide-input loop
+    (200, 33, 512, 1, "small"),      # 200 inputs, theta recomputed at the end
+    (20, 33, 256, 3, "small"),       # hidden width 256: SPLIT with 4 column groups x 2 K parts
+    (12, 100, 128, 2, "small"),      # width 128 and 100 outputs: SPLIT with 2 column groups x 4 K parts
+    (9, 700, 1000, 2, "small"),      # widths > 512: two-pass WIDE segments, wide final layer (d via LDS)
 ])
 def test_whole_network_kernels_against_oracle(nin, nout, width, depth, which):
-    """Both whole-network kernels (stream_mlp.hip for hidden width 512 and <= 64 inputs, fused_mlp.hip
-    otherwise) against the oracle and the layer-by-layer path, ragged batches included."""
+    """The whole-network kernel (net_stream.hip) over the segment shapes its program builder can emit,
+    against the oracle and the layer-by-layer path, ragged batches included."""
     from oracle import likelihood
     from linna_amd import _lib
     prob = _custom_problem(nin, nout, 900 + nin + width, width, depth)
     lp, pred, yinv, _ = build_logprob(None, prob=prob)
     emu = cases.oracle_emulator(prob)
-    for B in (1, 17, 4096 if which == "stream" else 300):
+    for B in (1, 17, 4096 if which == "big" else 300):
         z = (0.7 * np.random.RandomState(B).standard_normal((B, nin))).astype(np.float32)
         zd = torch.as_tensor(z, device="cuda")
         theta = torch.empty_like(zd)
@@ -261,7 +264,7 @@ def test_whole_network_kernels_against_oracle(nin, nout, width, depth, which):
 
 
 def test_stream_kernel_follows_weight_updates():
-    """The weight-stream kernel reads a fragment-order COPY of the weights: the copy must follow an
+    """The whole-network kernel reads a fragment-order COPY of the weights: the copy must follow an
     AdamW step (C entry), a torch-side write through flat_params()/state_dict()/load_state_dict(),
     and a graph replay that holds an AdamW step."""
     from oracle import likelihood

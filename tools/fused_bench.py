@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Time linna_logprob_eval (fused whole-MLP kernel) for the bench problem; env LINNA_FUSED_DBG
-selects timing-only ablations, LINNA_DISABLE_FUSED=1 the layer-by-layer path."""
+"""Time linna_logprob_eval (whole-network kernel) for the bench problem; LINNA_DISABLE_FUSED=1
+selects the layer-by-layer path."""
 import ctypes as C, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,4 +18,4 @@ _lib.call("linna_event_record", e0, st)
 for _ in range(n): lp.evaluate(z, out=out)
 _lib.call("linna_event_record", e1, st)
 ms = C.c_float(); _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
-print("B=%d dbg=%s fused_disabled=%s  %.1f us/step" % (B, os.environ.get("LINNA_FUSED_DBG", "0"), os.environ.get("LINNA_DISABLE_FUSED", "0"), ms.value / n * 1e3))
+print("B=%d fused_disabled=%s  %.1f us/step" % (B, os.environ.get("LINNA_DISABLE_FUSED", "0"), ms.value / n * 1e3))

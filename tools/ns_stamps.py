@@ -1,0 +1,33 @@
+#!/usr/bin/env python
+"""Diagnostic: per-segment cycle stamps of net_stream_kernel (library built with
+LINNA_HIPCC_EXTRA=-DNS_STAMPS).  Usage: python tools/ns_stamps.py [mlp|v2] [B]
+Stamp order: start, after prologue barrier, after every segment's last barrier, after the loop, end."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+which = sys.argv[1] if len(sys.argv) > 1 else "v2"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+nb = (B + 15) // 16
+buf = torch.zeros(nb * 8 * 32, dtype=torch.int64, device="cuda")
+os.environ["LINNA_FUSED_STAMPS"] = "%x" % buf.data_ptr()
+if which == "mlp":
+    import bench
+    lp, model, consts = bench.build_problem(torch.device("cuda", 0))
+    nin = 33
+else:
+    sys.argv = sys.argv[:1]
+    import bench_paths
+    nin, nout = (33, 33) if which == "v2" else (26, 457)
+    p = bench_paths.problem("ChtoModelv2", nin, nout, which != "v2")
+    lp = p["lp"]
+z = torch.randn(B, nin, device="cuda"); out = torch.empty(B, device="cuda")
+for _ in range(5): lp.evaluate(z, out=out)
+torch.cuda.synchronize()
+t = buf.cpu().numpy().reshape(nb, 8, 32).astype(np.float64)
+n = int((t[0, 0] > 0).sum())
+d = np.diff(t[:, :, :n], axis=2)
+print("phase   median cycles   (max over waves, median over blocks)")
+for i in range(n - 1):
+    print("%2d -> %2d %10.0f %10.0f" % (i, i + 1, np.median(d[:, :, i]), np.median(d[:, :, i].max(1))))
+print("total per wave median %.0f cycles" % np.median(t[:, :, n - 1] - t[:, :, 0]))
