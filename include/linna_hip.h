@@ -83,6 +83,7 @@ typedef struct {
 #define LINNA_GEMM_ABL_NOLOAD 0x10      /* timing only: skip global loads after the first K tile */
 #define LINNA_GEMM_ABL_NOSTAGE 0x20     /* timing only: skip LDS restaging + barrier */
 #define LINNA_GEMM_ABL_NOMFMA 0x40      /* timing only: skip the MFMAs */
+#define LINNA_GEMM_NOSPLIT 0x80         /* timing only: no K split inside the workgroup for small grids */
 
 int linna_gemm_f32(linna_ctx_t* ctx, const linna_gemm_t* desc, void* stream);
 int linna_gemm_dot_slots(int M, int N);
@@ -265,6 +266,18 @@ int linna_stretch_accept(linna_ctx_t* ctx, float* coords, int ldc, int ndim, flo
                          const int* S_idx, int ns, const float* Q, int ldq, const float* logp_new,
                          const float* factors, uint64_t seed, const int* step_dev, int stream_id,
                          int* naccept, void* stream);
+/* One ensemble half step in ONE launch: propose + log-probability of the proposals + accept, fused
+ * around the whole-network kernel (net_stream.hip).  Same Philox counters and arithmetic as the
+ * three entries above: bit-identical results.  The Philox step is step_dev[0] + step_offset, so a
+ * host loop can count iterations itself and skip linna_step_increment (one launch less per
+ * iteration); a captured graph passes step_offset = 0 and increments the device counter.  Returns LINNA_ERR_UNSUPPORTED (and launches
+ * nothing) when the log-probability object does not run the whole-network kernel (dense inverse
+ * covariance, ypositive output, more than 64 parameters, a network outside net_stream's reach):
+ * the caller then uses linna_stretch_propose / linna_logprob_eval / linna_stretch_accept. */
+int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp,
+                            const int* S_idx, int ns, const float* ccoords, int ldcc, const int* C_idx,
+                            int nc, uint64_t seed, const int* step_dev, int step_offset, int stream_id,
+                            float a, int* naccept, void* stream);
 /* leapfrog pieces for batched per-walker HMC (HMCSampler.py:26-54, sampler.py:67-98). */
 /* P0 (standard-normal draws [B][ldp0]) and U (uniforms [B]) are optional: NULL = Philox draws. */
 int linna_hmc_init(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint64_t seed,

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "linna_adamw_step": (_I, [_V, _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _V]),
     "linna_stretch_propose": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _F, _V, _I, _V, _V]),
     "linna_stretch_accept": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _V, _U64, _V, _I, _V, _V]),
+    "linna_stretch_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _I, _F, _V, _V]),
     "linna_hmc_init": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V]),
     "linna_hmc_kick_drift": (_I, [_V, _I, _I, _V, _F, _F, _V, _I, _V, _I, _V, _I, _V]),
     "linna_hmc_accept": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V]),
@@ -144,6 +145,9 @@ def load():
         raise LinnaHipError("ABI version mismatch: library %d, binding %d" % (lib.linna_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -3     # LINNA_ERR_UNSUPPORTED (csrc/common.h)
 
 
 def check(rc):

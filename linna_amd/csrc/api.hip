@@ -477,6 +477,24 @@ static bool fused_enabled() {
     static const bool on = !(getenv("LINNA_DISABLE_FUSED") && getenv("LINNA_DISABLE_FUSED")[0] == '1');
     return on;
 }
+// Re-lay the fragment-order weight copy if the weights moved since it was made.
+static int lp_refresh_stream(linna_logprob* lp, void* stream) {
+    const linna_net* n = lp->net;
+    const unsigned long long epoch = g_weights_epoch.load();
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(S(stream), &cap);
+    if (cap != hipStreamCaptureStatusNone) {
+        // a captured evaluation carries its own re-layout, so that every replay sees the weights
+        // of that moment; the copy is not valid for direct launches until they redo it
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, S(stream)));
+        lp->packed_epoch = 0;
+    } else if (lp->packed_epoch != epoch) {
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, S(stream)));
+        lp->packed_epoch = epoch;
+    }
+    return LINNA_OK;
+}
+
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
                       float* TH, int ldt, void* stream, bool keep_activations) {
     const linna_logprob_desc_t& d = lp->d;
@@ -485,22 +503,10 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
     if (!keep_activations && fused_enabled() && lp->packed && !d.outmap.cexp) {
         // whole-network kernel (net_stream.hip): prior map -> every layer -> output transform -> diagonal
         // log-likelihood in ONE launch, weights streamed from the fragment-order copy
-        const unsigned long long epoch = g_weights_epoch.load();
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(S(stream), &cap);
-        const int nl = (int)n->L.size();
-        if (cap != hipStreamCaptureStatusNone) {
-            // a captured evaluation carries its own re-layout, so that every replay sees the weights
-            // of that moment; the copy is not valid for direct launches until they redo it
-            TRY(launch_net_stream_pack(n->L.data(), nl, n->in_size, lp->packed, S(stream)));
-            lp->packed_epoch = 0;
-        } else if (lp->packed_epoch != epoch) {
-            TRY(launch_net_stream_pack(n->L.data(), nl, n->in_size, lp->packed, S(stream)));
-            lp->packed_epoch = epoch;
-        }
-        TRY(launch_net_stream(n->L.data(), nl, n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+        TRY(lp_refresh_stream(lp, stream));
+        TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                               d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, S(stream)));
+                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, S(stream)));
         if (d.w) return LINNA_OK;
         return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
@@ -548,6 +554,26 @@ int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void
     if (!lp || !Z || !ws || !lnP || B < 1) { set_error("logprob_eval: bad arguments"); return LINNA_ERR_INVALID; }
     const LpLayout L = lp_layout(lp, B, 0);
     return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false);
+}
+
+int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
+                            const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
+                            int step_offset, int stream_id, float a, int* naccept, void* stream) {
+    if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !step_dev || ns < 1 || nc < 1) {
+        set_error("stretch_half_step: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    const linna_logprob_desc_t& d = lp->d;
+    if (ndim != d.nin) { set_error("stretch_half_step: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
+    if (!fused_enabled() || !lp->packed || d.outmap.cexp || !d.w || d.nin > 64) {
+        set_error("stretch_half_step: this log-probability does not run the whole-network kernel");
+        return LINNA_ERR_UNSUPPORTED;          // the caller falls back to propose / eval / accept
+    }
+    TRY(lp_refresh_stream(lp, stream));
+    const linna_net* n = lp->net;
+    NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept};
+    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
+                             d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
+                             nullptr, nullptr, 0, nullptr, 0, &mv, S(stream));
 }
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,

@@ -15,6 +15,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace linna {
 
+// ------------------------------------------------------------------ Philox4x32-10 (Salmon et al. 2011)
+struct U4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        U4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ float u01(uint32_t b) { return ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// draws for walker w at (step, stream): counter = (w, step, stream, sub), key = seed
+__device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t step, uint32_t stream, uint32_t sub) {
+    U4 c = {w, step, stream, sub};
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
 
@@ -82,10 +108,16 @@ int launch_step_increment(int* step, hipStream_t s);
 bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size);
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size);
 int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, hipStream_t s);
+// stretch move fused around the evaluation: rows of the batch are the walkers S[0..B)
+struct NsMove {
+    float* coords; int ldc; float* logp; const int* S;
+    const float* cc; int ldcc; const int* C; int nc;
+    unsigned long long seed; const int* step; int step_off; int stream; float a; int* naccept;
+};
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, hipStream_t s);
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, hipStream_t s);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);

@@ -27,19 +27,14 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    else static_assert(N < 0, "add the vmcnt literal");
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));   // vmcnt(N): lgkmcnt/expcnt fields left at max
+    asm volatile("" ::: "memory");
+}
+// s_waitcnt vmcnt(y * LPT) for the runtime y in [0, Y]: a tile with y younger tiles still in flight
+template <int Y, int LPT> __device__ __forceinline__ void wait_younger(int y) {
+    if constexpr (Y == 0) wait_vmcnt<0>();
+    else { if (y >= Y) wait_vmcnt<Y * LPT>(); else wait_younger<Y - 1, LPT>(y); }
 }
 
 // One operand tile: ROWS (along M or N) x BK floats, ROWS*128 bytes, staged by NW waves.
@@ -123,18 +118,24 @@ struct Tile {
     }
 };
 
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
-    constexpr int NW = WM * WN, NT = NW * 64;
+// KS > 1: the workgroup holds KS groups of WM*WN waves; group kg streams K tiles kg, kg+KS, ... through
+// its own slice of every ring stage and the groups' accumulators are summed through LDS in fixed order
+// before the epilogue.  For grids that leave CUs idle: one output tile's K loop is a serial chain of
+// 64-cycle MFMAs on one wave per SIMD, and splitting K inside the workgroup is the parallelism left.
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a) {
+    constexpr int NW = WM * WN, NT = NW * 64;                 // waves / threads of one K group
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using TA = Tile<BM, ALAY, NW>;
     using TB = Tile<BN, BLAY, NW>;
     constexpr int LPT = TA::NI + TB::NI;                      // DMA instructions per wave per K tile
-    extern __shared__ __attribute__((aligned(16))) float smem[];  // NS x (A tile | B tile)
+    extern __shared__ __attribute__((aligned(16))) float smem[];  // NS x KS x (A tile | B tile)
     constexpr int STAGE = TA::SIZE + TB::SIZE;
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int kg = wave_all / NW, wave = wave_all % NW;       // K group, wave within the group
+    const int tid = threadIdx.x % NT;                         // thread within the group
     const int wm = wave / WN, wn = wave % WN;
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (private L2), so give every XCD a
@@ -209,46 +210,74 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs a) {
                             (((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0);
         const int nfast = dma_ok ? p.K / BK : 0;               // full K tiles streamed by LDS-DMA
         const int nall = (p.K + BK - 1) / BK;
-        auto issue = [&](int t) {
-            float* st = smem + (t % NS) * STAGE;
+        const int nmine = (nfast - kg + KS - 1) / KS;           // ... of which this group takes kg, kg+KS, ...
+        const int niter = (nfast + KS - 1) / KS;                // ring turns (same for every group: barriers)
+        auto stage_of = [&](int i) { return smem + ((i % NS) * KS + kg) * STAGE; };
+        auto issue = [&](int i) {
+            float* st = stage_of(i);
+            const int t = kg + i * KS;
             TA::dma(p.A, p.lda, m0, a.M, t * BK, st, wave, lane);
             TB::dma(p.B, p.ldb, n0, a.N, t * BK, st + TA::SIZE, wave, lane);
         };
         if (nfast > 0) {
 #pragma unroll
-            for (int t = 0; t < NS - 1; ++t)
-                if (t < nfast) issue(t);
-            for (int kt = 0; kt < nfast; ++kt) {
-                // tile kt must have landed; up to NS-2 younger tiles of this wave stay in flight
-                const int younger = min(NS - 2, nfast - 1 - kt);
-                if (NS >= 4 && younger >= 2) wait_vmcnt<2 * LPT>();
-                else if (NS >= 3 && younger == 1) wait_vmcnt<LPT>();
-                else wait_vmcnt<0>();
-                __builtin_amdgcn_s_barrier();      // all waves' DMA for kt landed; stage (kt-1)%NS is free
+            for (int i = 0; i < NS - 1; ++i)
+                if (i < nmine) issue(i);
+            for (int it = 0; it < niter; ++it) {
+                // tile `it` of this group must have landed; up to NS-2 younger ones stay in flight
+                if (it < nmine) wait_younger<NS - 2, LPT>(min(NS - 2, nmine - 1 - it));
+                __builtin_amdgcn_s_barrier();      // all waves' DMA for this turn landed; stage (it-1)%NS is free
                 asm volatile("" ::: "memory");
-                if (kt + NS - 1 < nfast) issue(kt + NS - 1);
-                compute(smem + (kt % NS) * STAGE);
+                if (it + NS - 1 < nmine) issue(it + NS - 1);
+                if (it < nmine) compute(stage_of(it));
             }
             __builtin_amdgcn_s_barrier();          // last tile fully read before anything restages
         }
-        for (int kt = nfast; kt < nall; ++kt) {    // partial tile / unaligned operand: register path
-            TA::stage_slow(p.A, p.lda, m0, a.M, kt * BK, p.K, smem, tid);
-            TB::stage_slow(p.B, p.ldb, n0, a.N, kt * BK, p.K, smem + TA::SIZE, tid);
+        for (int kt = nfast; kt < nall; ++kt) {    // partial tile / unaligned operand: register path, group 0
+            if (kg == 0) {
+                TA::stage_slow(p.A, p.lda, m0, a.M, kt * BK, p.K, smem, tid);
+                TB::stage_slow(p.B, p.ldb, n0, a.N, kt * BK, p.K, smem + TA::SIZE, tid);
+            }
             __syncthreads();
-            compute(smem);
+            if (kg == 0) compute(smem);
             __syncthreads();
         }
         if (pi == 0 && a.npairs > 1) {             // acc <- alpha0 * (acc + bias0) before pair 1 accumulates
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-                const float b0 = (a.bias0 && col < a.N) ? a.bias0[col] : 0.f;
+                const float b0 = (kg == 0 && a.bias0 && col < a.N) ? a.bias0[col] : 0.f;   // the bias once, not per K group
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = a.alpha0 * (acc[i][j][e] + b0);
             }
         }
+    }
+
+    // ---------------------------------------------------------------- K groups -> group 0 (fixed order)
+    if constexpr (KS > 1) {
+        __syncthreads();
+        constexpr int E = TM * TN * 16;
+        float* const red = smem;                   // [KS-1][E][NT]: consecutive threads, consecutive floats
+        if (kg > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) red[((kg - 1) * E + (i * TN + j) * 16 + e) * NT + tid] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (kg > 0) return;
+#pragma unroll
+        for (int g = 1; g < KS; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((g - 1) * E + (i * TN + j) * 16 + e) * NT + tid];
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -324,19 +353,19 @@ int gemm_slots(int M, int N) {
     return ((N + bn - 1) / bn) * c.wn;
 }
 
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS>
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS = 1>
 static int launch_one(const GemmArgs& a, hipStream_t stream) {
-    constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int NT = WM * WN * KS * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
+    const size_t lds = (size_t)NS * KS * (BM + BN) * BK * sizeof(float);
     static bool attr_set = false;
     if (!attr_set && lds > 65536) {
-        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS>),
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS, KS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "hipFuncSetAttribute");
         if (rc != LINNA_OK) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS>), dim3(ntm * ntn), dim3(NT), lds, stream, a);
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS, KS>), dim3(ntm * ntn), dim3(NT), lds, stream, a);
     return check_hip(hipGetLastError(), "gemm launch");
 }
 
@@ -344,7 +373,18 @@ template <int ALAY, int BLAY>
 static int launch_lay(const GemmArgs& a, int cfg, hipStream_t stream) {
     switch (cfg) {
         case 0: return launch_one<2, 2, 2, 1, ALAY, BLAY, 3>(a, stream);   // 72 KiB LDS: 2 blocks / CU
-        case 1: return launch_one<2, 2, 1, 1, ALAY, BLAY, 4>(a, stream);   // 64 KiB LDS: 2 blocks / CU
+        case 1: {
+            // A grid that leaves most CUs idle is bound by ONE wave's chain of 64-cycle MFMAs along K
+            // (tools/gemm_small.py: 0.8 us per 32-k tile whatever the ring depth): split K over 4 or 2
+            // wave groups inside the workgroup (16 / 8 waves, 128 KiB LDS, one block per CU).
+            const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
+            const int K = a.npairs > 1 ? (a.p[0].K > a.p[1].K ? a.p[0].K : a.p[1].K) : a.p[0].K;
+            if (!(a.flags & LINNA_GEMM_NOSPLIT) && K >= 128) {
+                if (tiles <= 64) return launch_one<2, 2, 1, 1, ALAY, BLAY, 2, 4>(a, stream);
+                if (tiles <= 128) return launch_one<2, 2, 1, 1, ALAY, BLAY, 4, 2>(a, stream);
+            }
+            return launch_one<2, 2, 1, 1, ALAY, BLAY, 4>(a, stream);       // 64 KiB LDS: 2 blocks / CU
+        }
         default: return launch_one<1, 1, 1, 1, ALAY, BLAY, 4>(a, stream);  // 32 KiB LDS: 5 blocks / CU
     }
 }

@@ -73,6 +73,10 @@ struct NsArgs {
     const float* cscale; const float* cshift; const float* w; float T;
     float* lnP; float* D; int ldd; float* TH; int ldt;
     unsigned long long* stamps;
+    // stretch move fused around the evaluation (MOVE instantiation; emcee StretchMove behind sampler.py:493-495)
+    float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
+    const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
+    unsigned long long mv_seed; const int* mv_step; int mv_step_off; int mv_stream; float mv_a; int* mv_naccept;
     NsSeg seg[NS_MAXSEG];
 };
 
@@ -140,7 +144,12 @@ __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, flo
 }
 
 // ------------------------------------------------------------------ the kernel
-template <int R>
+// MOVE: one ensemble half step in the launch.  Row k of the batch is walker S[k]: the prologue draws the
+// stretch proposal q = c + z (s - c) from the complementary walkers (what linna_stretch_propose writes
+// to memory), the network evaluates lnP(q), the finish applies the Metropolis test of
+// linna_stretch_accept and updates coords / logp / naccept in place.  Same Philox counters, same
+// arithmetic: bit-identical to the three-launch sequence.
+template <int R, bool MOVE>
 __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NT = NS_NT, NW = NS_NW;
     constexpr int RG = 32;                         // threads per walker row in prologue / reduce / finish
@@ -170,10 +179,28 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int ZPRE = 2;
     float zr[ZPRE], za1[ZPRE], za2[ZPRE], zxm[ZPRE], zxs[ZPRE]; int zfl[ZPRE], zlg[ZPRE];
     const int* const lgp = a.lg ? a.lg : a.is_flat;
+    int mv_wk = 0; float mv_factor = 0.f, mv_lnp_old = 0.f, mv_logu = 0.f;
+    if constexpr (MOVE) {
+        mv_wk = a.mv_S[grow];
+        const U4 rb = walker_bits(a.mv_seed, (uint32_t)mv_wk, (uint32_t)(a.mv_step[0] + a.mv_step_off), (uint32_t)a.mv_stream, 0u);
+        const float t = (a.mv_a - 1.f) * u01(rb.x) + 1.f;
+        const float zf = t * t / a.mv_a;
+        const int j = (int)(((uint64_t)rb.y * (uint64_t)a.mv_nc) >> 32);
+        const int wc = a.mv_C[j];
+        mv_factor = ((float)nin - 1.f) * logf(zf);
+        mv_logu = logf(u01(rb.z));
+        mv_lnp_old = a.mv_logp[mv_wk];
+#pragma unroll
+        for (int i = 0; i < ZPRE; ++i) {
+            const int c = min(pc0 + i * RG, nin - 1);
+            const float cr = a.mv_cc[(size_t)wc * a.mv_ldcc + c], sx = a.mv_coords[(size_t)mv_wk * a.mv_ldc + c];
+            zr[i] = cr - (cr - sx) * zf;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ZPRE; ++i) {
         const int c = min(pc0 + i * RG, nin - 1);
-        zr[i] = a.Z[(size_t)grow * a.ldz + c];
+        if constexpr (!MOVE) zr[i] = a.Z[(size_t)grow * a.ldz + c];
         zfl[i] = a.is_flat[c]; za1[i] = a.a1[c]; za2[i] = a.a2[c];
         zlg[i] = lgp[c]; zxm[i] = a.xmean[c]; zxs[i] = a.xstd[c];
     }
@@ -422,9 +449,20 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             column(c, a.cscale ? a.cscale[c] : 1.f, a.cshift ? a.cshift[c] : 0.f, a.w ? a.w[c] : 0.f);
 #pragma unroll
         for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
-        if (a.lnP && a.w && pc0 == 0 && rok) {
-            const float v = (-0.5f * chi) / a.T + (-0.5f * zz);
-            a.lnP[row0 + pr] = isnan(v) ? -INFINITY : v;
+        float lnp_new = (-0.5f * chi) / a.T + (-0.5f * zz);
+        lnp_new = isnan(lnp_new) ? -INFINITY : lnp_new;
+        if (a.lnP && a.w && pc0 == 0 && rok) a.lnP[row0 + pr] = lnp_new;
+        if constexpr (MOVE) {
+            // Metropolis test of the stretch move (linna_stretch_accept); every lane of the row agrees
+            if (rok && mv_factor + lnp_new - mv_lnp_old > mv_logu) {
+#pragma unroll
+                for (int j = 0; j < ZPRE; ++j)
+                    if (pc0 + j * RG < nin) a.mv_coords[(size_t)mv_wk * a.mv_ldc + pc0 + j * RG] = zr[j];
+                if (pc0 == 0) {
+                    a.mv_logp[mv_wk] = lnp_new;
+                    if (a.mv_naccept) a.mv_naccept[mv_wk] += 1;
+                }
+            }
         }
         if (a.TH && rok) {
 #pragma unroll
@@ -582,12 +620,26 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     return check_hip(hipGetLastError(), "net_stream pack launch");
 }
 
+template <bool MOVE>
+static int ns_launch_kernel(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, NS_LDS_BYTES), "hipFuncSetAttribute");
+        if (rc != LINNA_OK) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
+    return check_hip(hipGetLastError(), "net_stream launch");
+}
+
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, hipStream_t s) {
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
+    if (mv && (nin > 64 || !w)) { set_error("net_stream: fused stretch move needs <= 64 parameters and a diagonal covariance"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
     a.Z = Z; a.ldz = ldz; a.B = B; a.nin = nin;
@@ -602,15 +654,13 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     a.stamps = getenv("LINNA_FUSED_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LINNA_FUSED_STAMPS"), nullptr, 16)) : nullptr;
     if (!a.stamps) { set_error("net_stream: NS_STAMPS build needs LINNA_FUSED_STAMPS"); return LINNA_ERR_INVALID; }
 #endif
-    static bool attr_set = false;
-    if (!attr_set) {
-        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, NS_LDS_BYTES), "hipFuncSetAttribute");
-        if (rc != LINNA_OK) return rc;
-        attr_set = true;
+    if (mv) {
+        a.mv_coords = mv->coords; a.mv_ldc = mv->ldc; a.mv_logp = mv->logp; a.mv_S = mv->S;
+        a.mv_cc = mv->cc; a.mv_ldcc = mv->ldcc; a.mv_C = mv->C; a.mv_nc = mv->nc;
+        a.mv_seed = mv->seed; a.mv_step = mv->step; a.mv_step_off = mv->step_off; a.mv_stream = mv->stream; a.mv_a = mv->a; a.mv_naccept = mv->naccept;
+        return ns_launch_kernel<true>(a, B, p.lds_bytes, s);
     }
-    hipLaunchKernelGGL((net_stream_kernel<NS_R>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), p.lds_bytes, s, a);
-    return check_hip(hipGetLastError(), "net_stream launch");
+    return ns_launch_kernel<false>(a, B, p.lds_bytes, s);
 }
 
 }  // namespace linna

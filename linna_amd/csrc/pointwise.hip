@@ -200,17 +200,32 @@ __global__ void gather_xform_kernel(const float* __restrict__ X, int ldx, const 
 }
 
 // ------------------------------------------------------------------ bias gradient: db[n] = scale * sum_b dZ[b][n]
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dZ, int ld, int B, int N, float scale,
-                                                     float* __restrict__ db) {
-    __shared__ float part[4][64];
+// One block per 64 columns, 16 waves: wave w sums rows w, w+16, ... with four independent
+// accumulators (four row loads in flight per lane), then a fixed-order LDS reduction over the
+// waves -- deterministic, and ~30 row loads deep instead of 125.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ dZ, int ld, int B, int N, float scale,
+                                                      float* __restrict__ db) {
+    __shared__ float part[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
-    float acc = 0.f;
-    if (col < N)
-        for (int b = wave; b < B; b += 4) acc += dZ[(size_t)b * ld + col];
-    part[wave][lane] = acc;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < N) {
+        const float* p = dZ + col;
+        int b = wave;
+        for (; b + 48 < B; b += 64) {
+            a0 += p[(size_t)b * ld]; a1 += p[(size_t)(b + 16) * ld];
+            a2 += p[(size_t)(b + 32) * ld]; a3 += p[(size_t)(b + 48) * ld];
+        }
+        for (; b < B; b += 16) a0 += p[(size_t)b * ld];
+    }
+    part[wave][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (wave == 0 && col < N) db[col] = scale * (part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+    if (wave == 0 && col < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][lane];
+        db[col] = scale * t;
+    }
 }
 
 // ------------------------------------------------------------------ AdamW (torch.optim.AdamW single-tensor update)
@@ -237,30 +252,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     p[i] = pi; m[i] = mi; v[i] = vi;
 }
 
-// ------------------------------------------------------------------ Philox4x32-10 (Salmon et al. 2011)
-struct U4 { uint32_t x, y, z, w; };
-__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
-        U4 n;
-        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
-        n.y = (uint32_t)p1;
-        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
-        n.w = (uint32_t)p0;
-        c = n;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c;
-}
-__device__ __forceinline__ float u01(uint32_t b) { return ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
-// draws for walker w at (step, stream): counter = (w, step, stream, sub), key = seed
-__device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t step, uint32_t stream, uint32_t sub) {
-    U4 c = {w, step, stream, sub};
-    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-}
+// Philox4x32-10 and the per-walker counter convention live in common.h (shared with net_stream.hip)
 
 // ------------------------------------------------------------------ stretch move (emcee StretchMove / RedBlueMove)
 __global__ void stretch_propose_kernel(const float* __restrict__ coords, int ldc, int ndim, const int* __restrict__ S,
@@ -517,7 +509,7 @@ int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin
     LAUNCH_CHECK("gather_xform");
 }
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, s, dZ, ld, B, N, scale, db);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, dZ, ld, B, N, scale, db);
     LAUNCH_CHECK("colsum");
 }
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,

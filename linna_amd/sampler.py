@@ -154,12 +154,13 @@ class EnsembleSampler(object):
     """
 
     def __init__(self, nwalkers, ndim, log_prob, a=2.0, seed=0, randomize_split=True, dist_group=None,
-                 exchange="none"):
+                 exchange="none", fused=True):
         self.nw, self.ndim, self.lp, self.a, self.seed = int(nwalkers), int(ndim), log_prob, float(a), int(seed)
         if self.nw < 2 or self.nw % 2:
             raise ValueError("need an even number of walkers >= 2")
         self.randomize_split = randomize_split
         self.group, self.exchange = dist_group, exchange
+        self.fused = None if fused else False        # None: try linna_stretch_half_step on the first half step
         p = log_prob._ensure()
         self.dev = p["dev"]
         self.ctx = _lib.ctx(self.dev.index)
@@ -171,7 +172,9 @@ class EnsembleSampler(object):
         self.naccept = torch.zeros(self.nw, dtype=torch.int32, device=self.dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.iteration = 0
+        self._dev_steps = 0                          # value of the device step counter (== iteration unless fused)
         self._rs = np.random.RandomState(self.seed ^ 0x5EED)
+        self._split_pos, self._split_host, self._split_dev, self._split_evt = 0, None, None, None
         self._split = None
         self.rank = 0
         self.world = 1
@@ -191,12 +194,38 @@ class EnsembleSampler(object):
         if not bool(torch.isfinite(self.logp).all()):
             raise ValueError("initial state has non-finite log-probability")   # emcee raises the same way
 
+    _SPLIT_CHUNK = 64
+
     def _splits(self):
-        idx = np.arange(self.nw)
-        if self.randomize_split:
-            self._rs.shuffle(idx)
-        halves = idx.reshape(2, self.half)          # random equal split == shuffled (arange % 2) of emcee
-        return torch.as_tensor(halves.astype(np.int32), device=self.dev)
+        """Device int32 [2, nw/2]: this iteration's random equal split (== the shuffled ``arange % 2`` of
+        emcee's RedBlueMove).  The host permutations are drawn 64 iterations at a time and shipped in
+        ONE asynchronous copy from pinned memory: a per-iteration blocking copy left the GPU idle for
+        ~25 us of every 150 us iteration."""
+        if not self.randomize_split:
+            if self._split is None:
+                self._split = torch.as_tensor(np.arange(self.nw, dtype=np.int32).reshape(2, self.half), device=self.dev)
+            return self._split
+        n = self._SPLIT_CHUNK
+        k = self._split_pos % n
+        if k == 0:
+            slot = (self._split_pos // n) % 2
+            if self._split_host is None:
+                self._split_host = [torch.empty((n, 2, self.half), dtype=torch.int32).pin_memory() for _ in range(2)]
+                self._split_dev = [torch.empty((n, 2, self.half), dtype=torch.int32, device=self.dev) for _ in range(2)]
+                self._split_evt = [None, None]
+            if self._split_evt[slot] is not None:
+                self._split_evt[slot].synchronize()             # the copy that last read this pinned buffer is done
+            host = self._split_host[slot].numpy()
+            idx = np.arange(self.nw)
+            for i in range(n):
+                self._rs.shuffle(idx)
+                host[i] = idx.reshape(2, self.half)
+            self._split_dev[slot].copy_(self._split_host[slot], non_blocking=True)
+            self._split_evt[slot] = torch.cuda.Event()
+            self._split_evt[slot].record()
+        halves = self._split_dev[(self._split_pos // n) % 2][k]
+        self._split_pos += 1
+        return halves
 
     def step(self):
         """One ensemble iteration (both halves).  Everything is enqueued on the current stream."""
@@ -208,6 +237,18 @@ class EnsembleSampler(object):
             comp, ldc, cidx, nc = self.coords, self.ld, Cc, self.half
             if self.exchange == "allgather" and self.world > 1:
                 comp, cidx, nc = self._allgather_complement(Cc)
+            if self.fused is not False:
+                # propose + log-probability + accept in ONE launch (bit-identical to the three below)
+                rc = _lib.load().linna_stretch_half_step(
+                    self.lp._ensure()["handle"], _lib.ptr(self.coords), self.ld, self.ndim, _lib.ptr(self.logp),
+                    _lib.iptr(S), self.half, _lib.ptr(comp), ldc, _lib.iptr(cidx), nc, lib_seed,
+                    _lib.iptr(self.step_dev), self.iteration - self._dev_steps, h, self.a, _lib.iptr(self.naccept), st)
+                if rc == 0:
+                    self.fused = True
+                    continue
+                if rc != _lib.ERR_UNSUPPORTED or self.fused is True:
+                    _lib.check(rc)
+                self.fused = False                   # this log-probability cannot: three launches from now on
             _lib.call("linna_stretch_propose", self.ctx, _lib.ptr(self.coords), self.ld, self.ndim, _lib.iptr(S), self.half,
                       _lib.ptr(comp), ldc, _lib.iptr(cidx), nc, lib_seed, _lib.iptr(self.step_dev), h, self.a,
                       _lib.ptr(self.Q), self.ld, _lib.ptr(self.factors), st)
@@ -215,7 +256,9 @@ class EnsembleSampler(object):
             _lib.call("linna_stretch_accept", self.ctx, _lib.ptr(self.coords), self.ld, self.ndim, _lib.ptr(self.logp),
                       _lib.iptr(S), self.half, _lib.ptr(self.Q), self.ld, _lib.ptr(self.lp_new), _lib.ptr(self.factors),
                       lib_seed, _lib.iptr(self.step_dev), h, _lib.iptr(self.naccept), st)
-        _lib.call("linna_step_increment", self.ctx, _lib.iptr(self.step_dev), st)
+        if self.fused is not True:                   # the fused entry takes the iteration as an offset instead
+            _lib.call("linna_step_increment", self.ctx, _lib.iptr(self.step_dev), st)
+            self._dev_steps += 1
         self.iteration += 1
 
     def _allgather_complement(self, Cc):

@@ -115,6 +115,30 @@ def _gaussian_33():
     return ndim, means, cov, priors
 
 
+@pytest.mark.parametrize("name,nw", [("mlp_33_33", 200), ("v2_33_33", 64), ("custom_7_5", 34)])
+def test_fused_half_step_is_bit_identical_to_three_launches(name, nw):
+    """linna_stretch_half_step (propose + whole-network log-probability + accept in one launch) against
+    linna_stretch_propose / linna_logprob_eval / linna_stretch_accept: same Philox counters, same
+    arithmetic, so the states must be EQUAL, ragged last workgroup included."""
+    from linna_amd import sampler
+    from test_gpu_serving import _custom_problem
+    custom = _custom_problem(7, 5, 31, 48, 3) if name == "custom_7_5" else None
+    lp, pred, yinv, prob = build_logprob(name, 2.0, prob=custom)
+    nd = prob["nin"]
+    x0 = (0.3 * np.random.RandomState(5).standard_normal((nw, nd))).astype(np.float32)
+    a = sampler.EnsembleSampler(nw, nd, lp, seed=21)
+    b = sampler.EnsembleSampler(nw, nd, lp, seed=21, fused=False)
+    a.set_state(x0); b.set_state(x0)
+    for _ in range(6):
+        a.step(); b.step()
+    torch.cuda.synchronize()
+    assert a.fused is True and b.fused is False
+    assert torch.equal(a.coords, b.coords)
+    assert torch.equal(a.logp, b.logp)
+    assert torch.equal(a.naccept, b.naccept)
+    assert 0 < int(a.naccept.sum()) < 6 * nw
+
+
 def test_ensemble_posterior_33d_gaussian():
     """BASELINE target: posterior mean within 0.05 sigma on the 33-D Gaussian (here against the
     ANALYTIC posterior, which is what the reference CPU path samples for theory = identity)."""
@@ -193,9 +217,9 @@ def test_slice_ensemble_posterior_33d_gaussian():
     ens = sampler.SliceEnsembleSampler(nw, ndim, lp, seed=5)
     z0 = util.invTransform(priors)(means)[None, :] + 0.001 * np.random.RandomState(1).standard_normal((nw, ndim))
     ens.set_state(z0)
-    ens.run(150, store=False)
+    ens.run(300, store=False)                               # the walkers start in a 1e-3 ball: let them spread
     assert not ens.tune and 0.05 < ens.mu < 50.0            # tuning converged
-    c, l = ens.run(250)
+    c, l = ens.run(500)
     th = ens.theta_of(c).cpu().numpy().reshape(-1, ndim)
     sig = np.sqrt(np.diag(cov))
     assert np.max(np.abs(th.mean(0) - means) / sig) < 0.05
