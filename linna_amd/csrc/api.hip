@@ -450,6 +450,7 @@ struct linna_logprob {
     linna_net* net;
     linna_logprob_desc_t d;
     float* packed = nullptr;                 // fragment-order weight stream (net_stream.hip), or null
+    bool grad_fused = false;                 // the stream also holds the backward segments (ReLU MLPs)
     unsigned long long packed_epoch = 0;     // epoch the copy was made at (0 = never)
 };
 
@@ -506,7 +507,7 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
         TRY(lp_refresh_stream(lp, stream));
         TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                               d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, S(stream)));
+                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, S(stream)));
         if (d.w) return LINNA_OK;
         return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
@@ -532,6 +533,8 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     linna_logprob* lp = new linna_logprob{ctx, net, *desc};
     if (!net->has_inskip && net_stream_eligible(net->L.data(), (int)net->L.size(), net->in_size)) {
         const size_t nf = net_stream_packed_floats(net->L.data(), (int)net->L.size(), net->in_size);
+        lp->grad_fused = net_stream_has_grad(net->L.data(), (int)net->L.size(), net->in_size) && !desc->outmap.cexp &&
+                         !(getenv("LINNA_DISABLE_FUSED_GRAD") && getenv("LINNA_DISABLE_FUSED_GRAD")[0] == '1');
         if (check_hip(hipMalloc(reinterpret_cast<void**>(&lp->packed), nf * sizeof(float)), "hipMalloc(weight stream)") != LINNA_OK) {
             delete lp; return LINNA_ERR_HIP;
         }
@@ -573,7 +576,7 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept};
     return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                             nullptr, nullptr, 0, nullptr, 0, &mv, S(stream));
+                             nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, S(stream));
 }
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
@@ -582,6 +585,15 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
     const linna_logprob_desc_t& d = lp->d;
     if (d.outmap.cexp) { set_error("logprob_grad: ypositive (exp) output map has no gradient path"); return LINNA_ERR_UNSUPPORTED; }
     if (!d.gscale || (!d.w && !d.Ssym)) { set_error("logprob_grad: descriptor lacks gscale / Ssym"); return LINNA_ERR_INVALID; }
+    if (fused_enabled() && lp->packed && lp->grad_fused && d.w) {
+        // lnP and d lnP / d z in ONE launch: forward segments, turnaround, backward segments over W^T (net_stream.hip)
+        TRY(lp_refresh_stream(lp, stream));
+        const linna_net* n = lp->net;
+        NsGrad gr{d.gscale, G, ldg};
+        return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+                                 d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP,
+                                 nullptr, 0, nullptr, 0, nullptr, &gr, S(stream));
+    }
     const LpLayout L = lp_layout(lp, B, 1);
     float* w = static_cast<float*>(ws);
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);

@@ -114,10 +114,13 @@ struct NsMove {
     const float* cc; int ldcc; const int* C; int nc;
     unsigned long long seed; const int* step; int step_off; int stream; float a; int* naccept;
 };
+// gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
+struct NsGrad { const float* gscale; float* G; int ldg; };
+bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, hipStream_t s);
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, hipStream_t s);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);

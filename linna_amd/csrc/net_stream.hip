@@ -61,7 +61,8 @@ enum { NS_WIDE = 0, NS_SPLIT = 1 };
 struct NsSeg {            // kernel-side view of a segment
     int type, steps, passes, bias_off;
     int dst_col, relu, kslice, zext;   // SPLIT: kslice = k offset between K parts (16*steps), zext = columns written
-    int ncg_log2, pad0, pad1, pad2;    // SPLIT: log2 of the number of 64-column groups
+    int ncg_log2;                      // SPLIT: log2 of the number of 64-column groups
+    int mask_store, mask_apply, pad2;  // GRAD: 1 + LDS slot of the ReLU sign bits this WIDE segment records / applies (0: none)
 };
 
 struct NsArgs {
@@ -70,6 +71,8 @@ struct NsArgs {
     const float* xmean; const float* xstd;
     const float* packed;                // [8 waves][G][4][64 lanes][4] then the packed biases
     int G, nseg, LD, kpad0, nout, bias_total;
+    int Gstride, nseg_f;                // steps per wave in the packed stream; forward segments (GRAD: the rest is the backward)
+    const float* gscale; float* Gout; int ldg;   // GRAD: d(d)/d(raw output); d lnP / d z
     const float* cscale; const float* cshift; const float* w; float T;
     float* lnP; float* D; int ldd; float* TH; int ldt;
     unsigned long long* stamps;
@@ -86,6 +89,7 @@ struct NsPackSeg {
     const float* Wb; int ldb, Kb; float alpha;    // second K part, scaled (residual blocks)
     const float* b; float bscale;
     int N, type, steps, passes, bias_off, bias_pad, ncg;
+    int transA;                                   // Wa is read transposed: value(n, k) = Wa[k][n] (backward segments)
 };
 struct NsPackArgs {
     NsPackSeg seg[NS_MAXSEG];
@@ -119,7 +123,7 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
             for (int e = 0; e < 4; ++e) {
                 const int k = k0 + e;
                 if (k < S.Kapad) {
-                    if (k < S.Ka) v[e] = S.Wa ? S.Wa[(size_t)n * S.lda + k] : (k == n ? 1.f : 0.f);
+                    if (k < S.Ka) v[e] = !S.Wa ? (k == n ? 1.f : 0.f) : S.transA ? S.Wa[(size_t)k * S.lda + n] : S.Wa[(size_t)n * S.lda + k];
                 } else if (k - S.Kapad < S.Kb) {
                     v[e] = S.alpha * S.Wb[(size_t)n * S.ldb + (k - S.Kapad)];
                 }
@@ -149,7 +153,13 @@ __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, flo
 // to memory), the network evaluates lnP(q), the finish applies the Metropolis test of
 // linna_stretch_accept and updates coords / logp / naccept in place.  Same Philox counters, same
 // arithmetic: bit-identical to the three-launch sequence.
-template <int R, bool MOVE>
+// GRAD: lnP AND d lnP / d z in the launch (what torch.autograd.grad(lnP, x) yields at HMCSampler.py:32,40,48),
+// for ReLU MLPs: every hidden layer records the sign bits of its output in LDS (one word per lane: the
+// backward GEMM of the next layer has the same lane <-> (row, column) map), after the last layer the
+// finish turns the output rows into d lnP / d out in place, and the SAME step loop runs on through the
+// backward segments -- W^T in fragment order, streamed right behind the forward weights -- ending in the
+// prior map's derivative.
+template <int R, bool MOVE, bool GRAD>
 __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NT = NS_NT, NW = NS_NW;
     constexpr int RG = 32;                         // threads per walker row in prologue / reduce / finish
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         zlg[i] = lgp[c]; zxm[i] = a.xmean[c]; zxs[i] = a.xstd[c];
     }
     const int nb4 = (a.bias_total + 3) >> 2;       // packed biases, 16 bytes per thread and round
-    const f32x4* const bsrc = reinterpret_cast<const f32x4*>(a.packed + (size_t)NW * a.G * NT * 256);
+    const f32x4* const bsrc = reinterpret_cast<const f32x4*>(a.packed + (size_t)NW * a.Gstride * NT * 256);
     constexpr int BMAX = 3;                        // 3 x 512 x 4 floats >= every eligible network's biases
     f32x4 breg[BMAX];
 #pragma unroll
@@ -217,17 +227,18 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const float* const csp = a.cscale ? a.cscale : a.xmean;   // always a readable pointer
     const float* const ctp = a.cshift ? a.cshift : a.xmean;
     const float* const wtp = a.w ? a.w : a.xmean;
-    float fcs[FIN], fct[FIN], fw[FIN];
+    float fcs[FIN], fct[FIN], fw[FIN], fgs[FIN];
 #pragma unroll
     for (int i = 0; i < FIN; ++i) {
         const int cc = min(pc0 + i * RG, nout - 1);
+        if constexpr (GRAD) fgs[i] = a.gscale[cc]; else fgs[i] = 0.f;
         const int c1 = a.cscale ? cc : 0, c2 = a.cshift ? cc : 0, c3 = a.w ? cc : 0;
         const float cs = csp[c1], ct = ctp[c2], ww = wtp[c3];
         fcs[i] = a.cscale ? cs : 1.f; fct[i] = a.cshift ? ct : 0.f; fw[i] = a.w ? ww : 0.f;
     }
 
     // ---- 2. weight stream: wave-uniform base + 32-bit per-lane offset + immediate
-    const char* const wbase = reinterpret_cast<const char*>(a.packed) + (size_t)wave * a.G * NS_STEP_B;
+    const char* const wbase = reinterpret_cast<const char*>(a.packed) + (size_t)wave * a.Gstride * NS_STEP_B;
     const unsigned wlast = (unsigned)(a.G - 1) * NS_STEP_B;
     unsigned woff = 0;
     const unsigned voff = 16u * (unsigned)lane;
@@ -301,7 +312,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     f32x4 acc[NT];
     f32x4 Aq[2];
     int si = 0, pass = 0, P = 0, kleft;
-    int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl;
+    int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl, s_mstore = 0, s_mapply = 0;
+    unsigned* const lmask = reinterpret_cast<unsigned*>(lbias + ((a.bias_total + 3) & ~3));   // GRAD: [slot][512 lanes]
+    float lnp_grad = 0.f;                          // GRAD: lnP, stored at the very end (no store next to the weight loads)
     uint32_t ap;
     auto a_read = [&](f32x4& dst) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ap) : "memory");
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         const NsSeg S = a.seg[si];
         s_type = S.type; kleft = s_steps = S.steps; s_passes = S.passes; s_bias = S.bias_off;
         s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2;
+        if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         if (s_type == NS_WIDE) {
@@ -362,15 +376,30 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             auto take_next = [&]() {
                 s_type = NX.type; s_steps = NX.steps; s_passes = NX.passes; s_bias = NX.bias_off;
                 s_dst = NX.dst_col; s_relu = NX.relu; s_kslice = NX.kslice; s_zext = NX.zext; s_ncgl = NX.ncg_log2;
+                if constexpr (GRAD) { s_mstore = NX.mask_store; s_mapply = NX.mask_apply; }
                 kleft = NX.steps;
             };
+            bool seg_done = true;
             if (s_type == NS_WIDE) {
                 float* const nxt = act + (P ^ 1) * ABUF + s_dst + 16 * (32 * pass + 4 * wave) + li;
+                unsigned mbits = 0xFFFFu;
+                if constexpr (GRAD) {
+                    if (s_mapply) mbits = lmask[(s_mapply - 1 + pass) * (64 * NW) + threadIdx.x];   // sign bits of this very (row, col)
+                    if (s_mstore) {
+                        unsigned m = 0;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) m |= (acc[t][e] > 0.f ? 1u : 0u) << (4 * t + e);
+                        lmask[(s_mstore - 1 + pass) * (64 * NW) + threadIdx.x] = m;
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {  // C/D layout: col = lane&15, row = 4*(lane>>4) + e
-                        const float v = acc[t][e];
+                        float v = acc[t][e];
+                        if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
                         nxt[(4 * kq + e) * LD + 16 * t] = s_relu ? fmaxf(v, 0.f) : v;
                     }
                 if (++pass == s_passes) {
@@ -380,6 +409,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     take_next();
                 } else {
                     kleft = cur_steps;
+                    seg_done = false;
                 }
             } else {
                 float* const part = act + (P ^ 1) * ABUF;          // [8 waves][16 rows][64 cols], col ^= 16*(row>>2)
@@ -412,6 +442,27 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 ++si;
                 take_next();
             }
+            if constexpr (GRAD) {
+                if (seg_done && si == a.nseg_f) {   // (seg_done: not again after a pass of the first backward segment)
+                    // ---- turnaround: the output rows (bias added) sit in buffer P.  lnP as in the finish, and
+                    // d lnP / d out = -(d w) gscale / T written over them: the input of the first backward segment
+                    float* const F = act + P * ABUF + pr * LD;
+                    float chi = 0.f;
+#pragma unroll
+                    for (int i = 0; i < FIN; ++i) {
+                        const int c = pc0 + i * RG;
+                        if (c < nout) {
+                            const float d = F[c] * fcs[i] + fct[i];
+                            chi += (d * fw[i]) * d;
+                            F[c] = -(d * fw[i]) * fgs[i] / a.T;
+                        }
+                    }
+#pragma unroll
+                    for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
+                    lnp_grad = (-0.5f * chi) / a.T + (-0.5f * zz);
+                    lds_barrier();
+                }
+            }
             if (si < nseg) {
                 begin_run();
                 a_read(Aq[(U + 1) & 1]);           // replaces the speculative fragment
@@ -432,6 +483,27 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the last speculative A read
     NS_STAMP();
 
+    // ---- 5 (GRAD). d lnP / d x sits in buffer P: the derivative of the input transform and of the prior map
+    // (util.py:339-347, 483-497), minus z for the Gaussian prior term; lnP from the turnaround
+    if constexpr (GRAD) {
+        const float* const F = act + P * ABUF + pr * LD;
+        const bool rok = row0 + pr < a.B;
+        if (rok) {
+#pragma unroll
+            for (int j = 0; j < ZPRE; ++j) {
+                const int c = pc0 + j * RG;
+                if (c < nin) {
+                    float g = F[c] / zxs[j];
+                    if (a.lg && zlg[j]) g = g / (theta[j] * 2.30258509299404568f);
+                    const float z = zr[j];
+                    const float dth = zfl[j] ? za2[j] * (expf(-0.5f * z * z) * 0.398942280401432678f) : za2[j];
+                    a.Gout[(size_t)(row0 + pr) * a.ldg + c] = g * dth - z;
+                }
+            }
+            if (pc0 == 0) a.lnP[row0 + pr] = isnan(lnp_grad) ? -INFINITY : lnp_grad;
+        }
+        return;
+    }
     // ---- 5. output rows are in buffer P (bias added, no ReLU): output transform, d, log-likelihood
     {
         const float* const F = act + P * ABUF + pr * LD;
@@ -484,19 +556,26 @@ struct NsProgram {
     std::vector<NsPackSeg> pack;
     std::vector<NsSeg> seg;
     int G = 0, LD = 0, kpad0 = 0, nout = 0, bias_total = 0;
-    size_t lds_bytes = 0, packed_floats = 0;
-    bool ok = false;
+    int Gstride = 0, nseg_f = 0, mask_slots = 0;            // G: forward steps; Gstride: forward + backward steps
+    size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;
+    bool ok = false, grad_ok = false;                       // grad_ok: backward segments appended (ReLU MLPs)
 };
 
 static int ceil16(int k) { return (k + 15) & ~15; }
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, bool allow_grad);
 static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
+    NsProgram p = ns_build_one(layers, nl, in_size, true);
+    if (!p.ok) p = ns_build_one(layers, nl, in_size, false);      // the backward half may be what did not fit
+    return p;
+}
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, bool allow_grad) {
     NsProgram p;
     if (nl < 1 || in_size < 1 || in_size > 256) return p;
     // 1. linear maps: [Wa | alpha Wb] over K = [Kapad ; Kb], N outputs, written to dst_col (same_buf: into the input's buffer)
     struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
-                 int N, relu, dst_col; bool same_buf; };
+                 int N, relu, dst_col; bool same_buf; int transA = 0; int force_wide = 0; int mask_apply_of = -1; };
     std::vector<Lin> lins;
     int width = in_size;
     for (int i = 0; i < nl; ++i) {
@@ -516,10 +595,28 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
         width = l.N;
     }
     if (lins.empty() || lins.back().relu || (int)lins.size() > NS_MAXSEG) return p;
+    const int nfwd = (int)lins.size();
+    // Backward (d lnP / d z) for plain ReLU MLPs whose hidden layers come out as WIDE segments: the backward
+    // GEMM of layer l is a forward-shaped segment over W_l^T (contraction N_l, K_l outputs); for l >= 1 it is
+    // forced WIDE so that its lane <-> (row, column) map equals that of the layer whose sign bits it applies.
+    bool want_grad = allow_grad && in_size <= 64 && lins.back().N <= 64 && 2 * nfwd <= NS_MAXSEG;
+    for (int i = 0; i < nfwd && want_grad; ++i) {
+        const Lin& L = lins[i];
+        if (L.Wb || L.same_buf || L.dst_col || !L.Wa) want_grad = false;
+        if (i < nfwd - 1 && (!L.relu || L.N <= 256)) want_grad = false;       // hidden layers must be WIDE (N > 256)
+    }
+    if (want_grad) {
+        for (int i = nfwd - 1; i >= 0; --i) {
+            const Lin F = lins[i];
+            Lin Bk{F.Wa, F.lda, F.N, ceil16(F.N), nullptr, 0, 0, 0.f, nullptr, 0.f, F.Ka, 0, 0, false};
+            Bk.transA = 1; Bk.force_wide = i >= 1; Bk.mask_apply_of = i - 1;
+            lins.push_back(Bk);
+        }
+    }
 
     // 2. segment shapes.  SPLIT when it must write into its own input buffer (h of a residual block) or when
     //    splitting K over the idle waves saves at least three steps; WIDE otherwise.
-    int bias_off = 0, G = 0;
+    int bias_off = 0, G = 0, zero_off = -1, zero_pad = 0;
     std::vector<int> in_ext(lins.size());
     for (size_t i = 0; i < lins.size(); ++i) {
         const Lin& L = lins[i];
@@ -530,7 +627,7 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
         const int passes = (L.N + 511) / 512;
         int ncg = L.N <= 64 ? 1 : L.N <= 128 ? 2 : L.N <= 256 ? 4 : 0;
         const int split_steps = ncg ? (ksteps + NS_NW / ncg - 1) / (NS_NW / ncg) : 0;
-        const bool split = ncg && (L.same_buf || split_steps + 3 <= ksteps * passes);
+        const bool split = ncg && !L.force_wide && (L.same_buf || split_steps + 3 <= ksteps * passes);
         if (L.same_buf && !ncg) return p;
         if (split) {
             s.type = NS_SPLIT; s.steps = split_steps; s.passes = 1; s.kslice = 16 * s.steps;
@@ -545,10 +642,40 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
         }
         q.Wa = L.Wa; q.lda = L.lda; q.Ka = L.Ka; q.Kapad = L.Kapad; q.Wb = L.Wb; q.ldb = L.ldb; q.Kb = L.Kb; q.alpha = L.alpha;
         q.b = L.b; q.bscale = L.bscale; q.N = L.N; q.type = s.type; q.steps = s.steps; q.passes = s.passes; q.bias_off = bias_off;
+        q.transA = L.transA;
+        if (L.transA) {                                     // backward segments have no bias: ONE shared block of zeros
+            if (zero_off < 0) { zero_off = bias_off; zero_pad = 0; }
+            s.bias_off = q.bias_off = zero_off;
+            const int grow = std::max(0, q.bias_pad - zero_pad);
+            zero_pad += grow; q.bias_pad = grow;            // (the first backward segment's record carries the block; later ones extend it)
+        }
         bias_off += q.bias_pad;
         G += s.steps * s.passes;
         p.seg.push_back(s); p.pack.push_back(q);
     }
+    if (want_grad) {
+        // sign-bit slots: one per pass of every hidden forward segment; the backward segment of layer i+1 applies them
+        int slot = 0;
+        for (int i = 0; i < nfwd - 1; ++i) {
+            if (p.seg[i].type != NS_WIDE) { want_grad = false; break; }
+            p.seg[i].mask_store = 1 + slot;
+            slot += p.seg[i].passes;
+        }
+        for (size_t j = nfwd; j < lins.size() && want_grad; ++j) {
+            const int of = lins[j].mask_apply_of;
+            if (of < 0) continue;
+            if (p.seg[j].type != NS_WIDE || p.seg[j].passes != p.seg[of].passes) { want_grad = false; break; }
+            p.seg[j].mask_apply = p.seg[of].mask_store;
+        }
+        if (want_grad) p.mask_slots = slot;
+        else {   // drop the backward half again
+            for (size_t j = lins.size(); j-- > (size_t)nfwd;) { G -= p.seg[j].steps * p.seg[j].passes; bias_off -= p.pack[j].bias_pad; }
+            p.seg.resize(nfwd); p.pack.resize(nfwd); lins.resize(nfwd); in_ext.resize(nfwd);
+            for (int i = 0; i < nfwd; ++i) p.seg[i].mask_store = 0;
+        }
+    }
+    int Gf = 0;
+    for (int i = 0; i < nfwd; ++i) Gf += p.seg[i].steps * p.seg[i].passes;
 
     // 3. every column a segment reads must have been WRITTEN (finite; zero where the weights are zero):
     //    track the defined prefix [0, def) of the current buffer and widen the zero fill of the last
@@ -577,8 +704,9 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
     }
     for (const NsSeg& s : p.seg) if (s.type == NS_SPLIT) maxext = std::max(maxext, s.dst_col + s.zext);
     if (p.kpad0 > 256) return p;
-    p.nout = lins.back().N;
-    p.G = G; p.bias_total = bias_off;
+    p.nout = lins[nfwd - 1].N;
+    p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
+    p.bias_total = bias_off;
     p.LD = ((maxext + 63) & ~63) + 4;
     if (NS_ROWS * p.LD < 8192 + 64) return p;               // SPLIT partials need [8][16][64] floats in one buffer
     if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
@@ -587,6 +715,8 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
     p.lds_bytes += NS_NW * 32 * 8;
 #endif
     if (p.lds_bytes > (size_t)NS_LDS_BYTES) return p;
+    p.lds_bytes_grad = p.lds_bytes + (size_t)p.mask_slots * 64 * NS_NW * sizeof(unsigned);
+    if (p.grad_ok && p.lds_bytes_grad > (size_t)NS_LDS_BYTES) return p;   // (never for the eligible shapes)
     int nrun = 0;
     for (const NsSeg& s : p.seg) nrun += s.passes;
     if (nrun > NS_MAXRUN) return p;
@@ -605,7 +735,7 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsPackArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
-    a.nseg = (int)p.seg.size(); a.G = p.G; a.bias_total = p.bias_total; a.out = packed;
+    a.nseg = (int)p.seg.size(); a.G = p.Gstride; a.bias_total = p.bias_total; a.out = packed;
     int nrun = 0, first = 0;
     for (int i = 0; i < a.nseg; ++i) {
         a.seg[i] = p.pack[i];
@@ -615,40 +745,46 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
         }
     }
     a.run_first[nrun] = first; a.nrun = nrun;
-    const size_t total = (size_t)NS_NW * p.G * NS_NT * 64 + (size_t)p.bias_total;
+    const size_t total = (size_t)NS_NW * p.Gstride * NS_NT * 64 + (size_t)p.bias_total;
     hipLaunchKernelGGL(ns_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return check_hip(hipGetLastError(), "net_stream pack launch");
 }
 
-template <bool MOVE>
+template <bool MOVE, bool GRAD>
 static int ns_launch_kernel(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE>),
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE, GRAD>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS_LDS_BYTES), "hipFuncSetAttribute");
         if (rc != LINNA_OK) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
+    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
     return check_hip(hipGetLastError(), "net_stream launch");
 }
+
+bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { return ns_build(layers, nl, in_size).grad_ok; }
 
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, hipStream_t s) {
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     if (mv && (nin > 64 || !w)) { set_error("net_stream: fused stretch move needs <= 64 parameters and a diagonal covariance"); return LINNA_ERR_UNSUPPORTED; }
+    if (gr && (!p.grad_ok || !w || !lnP || !gr->gscale || !gr->G || mv)) { set_error("net_stream: no fused gradient for this network / likelihood"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
     a.Z = Z; a.ldz = ldz; a.B = B; a.nin = nin;
     a.is_flat = is_flat; a.a1 = a1; a.a2 = a2; a.lg = lg; a.xmean = xmean; a.xstd = xstd;
     a.packed = packed;
-    a.G = p.G; a.nseg = (int)p.seg.size(); a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
+    a.Gstride = p.Gstride; a.nseg_f = p.nseg_f;
+    a.G = gr ? p.Gstride : p.G;                        // forward only: stop after the forward segments
+    a.nseg = gr ? (int)p.seg.size() : p.nseg_f;
+    a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
-    for (int i = 0; i < a.nseg; ++i) a.seg[i] = p.seg[i];
+    for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
     a.stamps = nullptr;
 #ifdef NS_STAMPS
     a.stamps = getenv("LINNA_FUSED_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LINNA_FUSED_STAMPS"), nullptr, 16)) : nullptr;
@@ -658,9 +794,13 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         a.mv_coords = mv->coords; a.mv_ldc = mv->ldc; a.mv_logp = mv->logp; a.mv_S = mv->S;
         a.mv_cc = mv->cc; a.mv_ldcc = mv->ldcc; a.mv_C = mv->C; a.mv_nc = mv->nc;
         a.mv_seed = mv->seed; a.mv_step = mv->step; a.mv_step_off = mv->step_off; a.mv_stream = mv->stream; a.mv_a = mv->a; a.mv_naccept = mv->naccept;
-        return ns_launch_kernel<true>(a, B, p.lds_bytes, s);
+        return ns_launch_kernel<true, false>(a, B, p.lds_bytes, s);
     }
-    return ns_launch_kernel<false>(a, B, p.lds_bytes, s);
+    if (gr) {
+        a.gscale = gr->gscale; a.Gout = gr->G; a.ldg = gr->ldg;
+        return ns_launch_kernel<false, true>(a, B, p.lds_bytes_grad, s);
+    }
+    return ns_launch_kernel<false, false>(a, B, p.lds_bytes, s);
 }
 
 }  // namespace linna

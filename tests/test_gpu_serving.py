@@ -302,3 +302,50 @@ def test_stream_kernel_follows_weight_updates():
               _lib.stream())
     d = check()
     assert np.abs(d - c).max() > 1e-3
+
+
+@pytest.mark.parametrize("nin,nout,width,depth", [(33, 33, 512, 4), (5, 3, 300, 2), (64, 64, 1024, 1), (12, 40, 700, 3), (10, 5, 600, 2)])
+def test_fused_gradient_against_layered_path_and_oracle(nin, nout, width, depth, monkeypatch):
+    """lnP and d lnP / d z in one launch (forward segments, turnaround, backward segments over W^T) against the
+    layer-by-layer forward + dX chain and the oracle's analytic gradient; ragged batches, log10 inputs."""
+    from oracle import likelihood
+    prob = _custom_problem(nin, nout, 500 + nin + width, width, depth)
+    prob["dolog10"] = [0] if nin > 4 else None
+    if prob["dolog10"]:
+        prob["priors"][0] = {"param": "p0", "dist": "flat", "arg1": 0.1, "arg2": 2.0}
+    fused = build_logprob(None, 2.0, prob=prob)[0]
+    fused._ensure()                                   # linna_logprob_create reads the switch: create inside the window
+    monkeypatch.setenv("LINNA_DISABLE_FUSED_GRAD", "1")
+    layered = build_logprob(None, 2.0, prob=prob)[0]
+    layered._ensure()
+    monkeypatch.delenv("LINNA_DISABLE_FUSED_GRAD")
+    emu = cases.oracle_emulator(prob)
+    for B in (1, 17, 1000):
+        z = (0.6 * np.random.RandomState(B).standard_normal((B, nin))).astype(np.float32)
+        zd = torch.as_tensor(z, device="cuda")
+        lf, gf = fused.evaluate_with_grad(zd)
+        ll, gl = layered.evaluate_with_grad(zd)
+        lf, gf, ll, gl = lf.cpu().numpy(), gf.cpu().numpy(), ll.cpu().numpy(), gl.cpu().numpy()
+        scale = np.abs(gl).max()
+        np.testing.assert_allclose(lf, ll, rtol=3e-4, atol=1e-3)
+        np.testing.assert_allclose(gf, gl, rtol=2e-3, atol=2e-4 * scale)
+        _, gref = likelihood.grad_log_prob(z.astype(np.float64), emu, prob["priors"], prob["data"], prob["invcov"], 2.0,
+                                           dtype=np.float64)
+        np.testing.assert_allclose(gf, gref, rtol=5e-3, atol=5e-4 * scale)
+    # the two objects really took different routes (meaningful on the big shape only; best of several
+    # short runs: a stray hipFree from garbage collection in the middle of a run costs milliseconds)
+    if width == 512 and depth == 4:
+        import gc, time
+        gc.collect()
+        zd = torch.randn(4096, nin, device="cuda") * 0.5
+        out = torch.empty(4096, device="cuda"); grad = torch.empty(4096, nin, device="cuda")
+
+        def t(lp):
+            best = 1e9
+            for _ in range(6):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(5):
+                    lp.evaluate_with_grad(zd, out=out, grad=grad)
+                torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+            return best
+        assert t(fused) < 0.8 * t(layered)
