@@ -210,6 +210,13 @@ size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad);
 /* lnP[B]; THETA[B][ldt] optional (physical parameters, for chain_transformed). */
 int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
                        float* THETA, int ldt, void* stream);
+/* The same, gated on a device int: when gate[0] == 0 at the time the kernel starts, the whole-network
+ * kernel computes nothing and the contents of lnP are unspecified (the layer-by-layer path ignores
+ * the gate and computes).  For
+ * host loops that queue the next round of a data-dependent iteration before they know whether it is
+ * needed (the ensemble slice sampler's stepping-out / shrinking rounds). */
+int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
+                          float* THETA, int ldt, const int* gate, void* stream);
 /* lnP[B] and d lnP / d z [B][ldg]  (intended semantics of util.py:1023-1035; HMCSampler.py:32). */
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
                        float* G, int ldg, void* stream);
@@ -301,14 +308,22 @@ int linna_step_increment(linna_ctx_t* ctx, int* step_dev, void* stream);
 int linna_slice_init(linna_ctx_t* ctx, const float* logp, const int* S_idx, int ns, const float* ccoords, int ldcc,
                      const int* C_idx, int nc, int ndim, const float* mu_dev, uint64_t seed, const int* step_dev,
                      int stream_id, float* DIR, int ldd, float* Z0, float* L, float* R, int* flags, void* stream);
+/* Q[j*ns + k] = coords[S[k]] + w[j*ns + k] * DIR[k], j < nrep */
 int linna_slice_points(linna_ctx_t* ctx, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
-                       const float* DIR, int ldd, const float* w, float* Q, int ldq, void* stream);
+                       const float* DIR, int ldd, const float* w, float* Q, int ldq, int nrep, void* stream);
+/* counters: [0] expansions, [1] contractions (zeus' mu tuning), [slot] walkers still active after this call */
 int linna_slice_expand(linna_ctx_t* ctx, const float* Z0, const float* ZL, const float* ZR, float* L, float* R,
-                       int* flags, int ns, int* counters, void* stream);
+                       int* flags, int ns, int* counters, int slot, void* stream);
+/* `ntrial` shrink trials per call, placed as the sequential procedure would place them if every
+ * earlier one were rejected (the bracket after a rejection depends on where the trial fell, not on
+ * its density): W[j*ns + k], Ztrial[j*ns + k]; Philox sub-counters round+1 .. round+ntrial.  Two
+ * trials per round fill the GPU (2 x nw/2 points per launch) and halve the number of rounds; the
+ * accepted point is the one the one-trial-per-round procedure accepts. */
 int linna_slice_draw(linna_ctx_t* ctx, const float* L, const float* R, const int* S_idx, float* W, const int* flags,
-                     int ns, uint64_t seed, const int* step_dev, int stream_id, int round, void* stream);
+                     int ns, uint64_t seed, const int* step_dev, int stream_id, int round, int ntrial, void* stream);
 int linna_slice_shrink(linna_ctx_t* ctx, const float* Z0, const float* Ztrial, float* L, float* R, const float* W,
-                       int* flags, float* Wacc, float* Zacc, int ns, int* counters, void* stream);
+                       int* flags, float* Wacc, float* Zacc, int ns, int* counters, int slot, int ntrial,
+                       void* stream);
 int linna_slice_commit(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                        const float* DIR, int ldd, const float* Wacc, const float* Zacc, void* stream);
 

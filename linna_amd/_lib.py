@@ -107,16 +107,17 @@ _SIGNATURES = {
     "linna_adamw_step": (_I, [_V, _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _V]),
     "linna_stretch_propose": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _F, _V, _I, _V, _V]),
     "linna_stretch_accept": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _V, _U64, _V, _I, _V, _V]),
+    "linna_logprob_eval_if": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V, _V]),
     "linna_stretch_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _I, _F, _V, _V]),
     "linna_hmc_init": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V]),
     "linna_hmc_kick_drift": (_I, [_V, _I, _I, _V, _F, _F, _V, _I, _V, _I, _V, _I, _V]),
     "linna_hmc_accept": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V]),
     "linna_step_increment": (_I, [_V, _V, _V]),
     "linna_slice_init": (_I, [_V, _V, _V, _I, _V, _I, _V, _I, _I, _V, _U64, _V, _I, _V, _I, _V, _V, _V, _V, _V]),
-    "linna_slice_points": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _V, _I, _V]),
-    "linna_slice_expand": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _V, _V]),
-    "linna_slice_draw": (_I, [_V, _V, _V, _V, _V, _V, _I, _U64, _V, _I, _I, _V]),
-    "linna_slice_shrink": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _V]),
+    "linna_slice_points": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _V, _I, _I, _V]),
+    "linna_slice_expand": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _V, _I, _V]),
+    "linna_slice_draw": (_I, [_V, _V, _V, _V, _V, _V, _I, _U64, _V, _I, _I, _I, _V]),
+    "linna_slice_shrink": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _I, _I, _V]),
     "linna_slice_commit": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _V, _V]),
 }
 EXPORTED = tuple(_SIGNATURES)

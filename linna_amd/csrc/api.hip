@@ -497,7 +497,7 @@ static int lp_refresh_stream(linna_logprob* lp, void* stream) {
 }
 
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
-                      float* TH, int ldt, void* stream, bool keep_activations) {
+                      float* TH, int ldt, void* stream, bool keep_activations, const int* gate = nullptr) {
     const linna_logprob_desc_t& d = lp->d;
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
     const linna_net* n = lp->net;
@@ -507,7 +507,7 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
         TRY(lp_refresh_stream(lp, stream));
         TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                               d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, S(stream)));
+                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, S(stream)));
         if (d.w) return LINNA_OK;
         return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
@@ -559,6 +559,13 @@ int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void
     return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false);
 }
 
+int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* TH, int ldt,
+                          const int* gate, void* stream) {
+    if (!lp || !Z || !ws || !lnP || B < 1) { set_error("logprob_eval_if: bad arguments"); return LINNA_ERR_INVALID; }
+    const LpLayout L = lp_layout(lp, B, 0);
+    return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false, gate);
+}
+
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                             const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
                             int step_offset, int stream_id, float a, int* naccept, void* stream) {
@@ -576,7 +583,7 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept};
     return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                             nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, S(stream));
+                             nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, S(stream));
 }
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
@@ -592,7 +599,7 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
         NsGrad gr{d.gscale, G, ldg};
         return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                                  d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP,
-                                 nullptr, 0, nullptr, 0, nullptr, &gr, S(stream));
+                                 nullptr, 0, nullptr, 0, nullptr, &gr, nullptr, S(stream));
     }
     const LpLayout L = lp_layout(lp, B, 1);
     float* w = static_cast<float*>(ws);
@@ -708,20 +715,23 @@ int linna_slice_init(linna_ctx_t*, const float* logp, const int* S_idx, int ns, 
                              flags, S(stream));
 }
 int linna_slice_points(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns, const float* DIR,
-                       int ldd, const float* w, float* Q, int ldq, void* stream) {
-    return launch_slice_points(coords, ldc, ndim, S_idx, ns, DIR, ldd, w, Q, ldq, S(stream));
+                       int ldd, const float* w, float* Q, int ldq, int nrep, void* stream) {
+    if (nrep < 1) { set_error("slice_points: nrep < 1"); return LINNA_ERR_INVALID; }
+    return launch_slice_points(coords, ldc, ndim, S_idx, ns, DIR, ldd, w, Q, ldq, nrep, S(stream));
 }
 int linna_slice_expand(linna_ctx_t*, const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags,
-                       int ns, int* counters, void* stream) {
-    return launch_slice_expand(Z0, ZL, ZR, L, R, flags, ns, counters, S(stream));
+                       int ns, int* counters, int slot, void* stream) {
+    return launch_slice_expand(Z0, ZL, ZR, L, R, flags, ns, counters, slot, S(stream));
 }
 int linna_slice_draw(linna_ctx_t*, const float* L, const float* R, const int* S_idx, float* W, const int* flags, int ns,
-                     uint64_t seed, const int* step_dev, int stream_id, int round, void* stream) {
-    return launch_slice_draw(L, R, S_idx, W, flags, ns, seed, step_dev, stream_id, round, S(stream));
+                     uint64_t seed, const int* step_dev, int stream_id, int round, int ntrial, void* stream) {
+    if (ntrial < 1) { set_error("slice_draw: ntrial < 1"); return LINNA_ERR_INVALID; }
+    return launch_slice_draw(L, R, S_idx, W, flags, ns, seed, step_dev, stream_id, round, ntrial, S(stream));
 }
 int linna_slice_shrink(linna_ctx_t*, const float* Z0, const float* Zt, float* L, float* R, const float* W, int* flags,
-                       float* Wacc, float* Zacc, int ns, int* counters, void* stream) {
-    return launch_slice_shrink(Z0, Zt, L, R, W, flags, Wacc, Zacc, ns, counters, S(stream));
+                       float* Wacc, float* Zacc, int ns, int* counters, int slot, int ntrial, void* stream) {
+    if (ntrial < 1) { set_error("slice_shrink: ntrial < 1"); return LINNA_ERR_INVALID; }
+    return launch_slice_shrink(Z0, Zt, L, R, W, flags, Wacc, Zacc, ns, counters, slot, ntrial, S(stream));
 }
 int linna_slice_commit(linna_ctx_t*, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                        const float* DIR, int ldd, const float* Wacc, const float* Zacc, void* stream) {

@@ -93,13 +93,13 @@ int launch_slice_init(const float* logp, const int* S, int ns, const float* cc, 
                       const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0,
                       float* L, float* R, int* flags, hipStream_t s);
 int launch_slice_points(const float* coords, int ldc, int ndim, const int* S, int ns, const float* DIR, int ldd,
-                        const float* w, float* Q, int ldq, hipStream_t s);
+                        const float* w, float* Q, int ldq, int nrep, hipStream_t s);
 int launch_slice_expand(const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags, int ns,
-                        int* counters, hipStream_t s);
+                        int* counters, int slot, hipStream_t s);
 int launch_slice_draw(const float* L, const float* R, const int* S, float* W, const int* flags, int ns, uint64_t seed,
-                      const int* step_dev, int stream_id, int round, hipStream_t s);
+                      const int* step_dev, int stream_id, int round, int ntrial, hipStream_t s);
 int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, const float* W, int* flags, float* Wacc,
-                        float* Zacc, int ns, int* counters, hipStream_t s);
+                        float* Zacc, int ns, int* counters, int slot, int ntrial, hipStream_t s);
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
                         const float* Wacc, const float* Zacc, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
@@ -120,7 +120,7 @@ bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, hipStream_t s);
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, hipStream_t s);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);

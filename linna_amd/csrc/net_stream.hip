@@ -76,6 +76,7 @@ struct NsArgs {
     const float* cscale; const float* cshift; const float* w; float T;
     float* lnP; float* D; int ldd; float* TH; int ldt;
     unsigned long long* stamps;
+    const int* gate;                    // optional: every workgroup leaves at once when gate[0] == 0 (speculatively queued rounds)
     // stretch move fused around the evaluation (MOVE instantiation; emcee StretchMove behind sampler.py:493-495)
     float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.x * NS_ROWS;
+    if (a.gate && a.gate[0] == 0) return;
 #ifdef NS_STAMPS
     unsigned long long* const lstamp = reinterpret_cast<unsigned long long*>(lbias + ((a.bias_total + 3) & ~3)) + wave * 32;
     int nstamp = 0;
@@ -768,7 +770,7 @@ bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { ret
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, hipStream_t s) {
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     if (mv && (nin > 64 || !w)) { set_error("net_stream: fused stretch move needs <= 64 parameters and a diagonal covariance"); return LINNA_ERR_UNSUPPORTED; }
@@ -785,7 +787,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
-    a.stamps = nullptr;
+    a.stamps = nullptr; a.gate = gate;
 #ifdef NS_STAMPS
     a.stamps = getenv("LINNA_FUSED_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LINNA_FUSED_STAMPS"), nullptr, 16)) : nullptr;
     if (!a.stamps) { set_error("net_stream: NS_STAMPS build needs LINNA_FUSED_STAMPS"); return LINNA_ERR_INVALID; }

@@ -383,51 +383,68 @@ __global__ void slice_init_kernel(const float* __restrict__ logp, const int* __r
     }
 }
 
-// Q[row0 + k][:] = X[S[k]][:] + w[k] * DIR[k][:]
+// Q[j*ns + k][:] = X[S[k]][:] + w[j*ns + k] * DIR[k][:]   for j < nrep
 __global__ void slice_points_kernel(const float* __restrict__ coords, int ldc, int ndim, const int* __restrict__ S, int ns,
                                     const float* __restrict__ DIR, int ldd, const float* __restrict__ w,
-                                    float* __restrict__ Q, int ldq) {
+                                    float* __restrict__ Q, int ldq, int nrep) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)ns * ldq) return;
-    const int k = (int)(idx / ldq), d = (int)(idx % ldq);
-    Q[idx] = d < ndim ? coords[(size_t)S[k] * ldc + d] + w[k] * DIR[(size_t)k * ldd + d] : 0.f;
+    if (idx >= (size_t)nrep * ns * ldq) return;
+    const int row = (int)(idx / ldq), d = (int)(idx % ldq), k = row % ns;
+    Q[idx] = d < ndim ? coords[(size_t)S[k] * ldc + d] + w[row] * DIR[(size_t)k * ldd + d] : 0.f;
 }
 
 // stepping out: while the density at an end is above the slice, push that end out by one unit
 __global__ void slice_expand_kernel(const float* __restrict__ Z0, const float* __restrict__ ZL, const float* __restrict__ ZR,
                                     float* __restrict__ L, float* __restrict__ R, int* __restrict__ flags, int ns,
-                                    int* __restrict__ counters) {
+                                    int* __restrict__ counters, int slot) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns) return;
     int n = 0;
     if (flags[3 * k]) { if (ZL[k] > Z0[k]) { L[k] -= 1.f; ++n; } else flags[3 * k] = 0; }
     if (flags[3 * k + 1]) { if (ZR[k] > Z0[k]) { R[k] += 1.f; ++n; } else flags[3 * k + 1] = 0; }
-    if (n) { atomicAdd(counters + 0, n); atomicAdd(counters + 2, 1); }      // [0] expansions, [2] still-active count
+    if (n) { atomicAdd(counters + 0, n); atomicAdd(counters + slot, 1); }   // [0] expansions, [slot] still-active count
 }
 
+// ntrial trials per launch, drawn as the SEQUENTIAL procedure would draw them if every earlier one
+// were rejected: the bracket after a rejection depends on where the trial fell, not on its density,
+// so trial j+1 can be placed before trial j has been evaluated.  W[j*ns + k]; Philox sub-counter
+// round + j + 1 (the stream of single-trial rounds).
 __global__ void slice_draw_kernel(const float* __restrict__ L, const float* __restrict__ R, const int* __restrict__ S,
                                   float* __restrict__ W, const int* __restrict__ flags, int ns, uint64_t seed,
-                                  const int* __restrict__ step_dev, int stream_id, int round) {
+                                  const int* __restrict__ step_dev, int stream_id, int round, int ntrial) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns || !flags[3 * k + 2]) return;
-    const U4 r = walker_bits(seed, (uint32_t)S[k], (uint32_t)step_dev[0], (uint32_t)stream_id, (uint32_t)(round + 1));
-    W[k] = L[k] + u01(r.x) * (R[k] - L[k]);
+    float l = L[k], r = R[k];
+    for (int j = 0; j < ntrial; ++j) {
+        const U4 b = walker_bits(seed, (uint32_t)S[k], (uint32_t)step_dev[0], (uint32_t)stream_id, (uint32_t)(round + j + 1));
+        const float w = l + u01(b.x) * (r - l);
+        W[(size_t)j * ns + k] = w;
+        if (w < 0.f) l = w; else r = w;
+    }
 }
 
-// shrinking: accept the trial if it is inside the slice, otherwise pull the bracket in to the trial
+// shrinking: accept the first trial inside the slice, otherwise pull the bracket in to each rejected trial
 __global__ void slice_shrink_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
                                     float* __restrict__ R, const float* __restrict__ W, int* __restrict__ flags,
-                                    float* __restrict__ Wacc, float* __restrict__ Zacc, int ns, int* __restrict__ counters) {
+                                    float* __restrict__ Wacc, float* __restrict__ Zacc, int ns, int* __restrict__ counters,
+                                    int slot, int ntrial) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns || !flags[3 * k + 2]) return;
-    if (Zt[k] < Z0[k] || isnan(Zt[k])) {
-        if (W[k] < 0.f) L[k] = W[k]; else R[k] = W[k];
-        atomicAdd(counters + 1, 1);                       // [1] contractions
-        atomicAdd(counters + 2, 1);
-        if (R[k] - L[k] < 1e-30f) { flags[3 * k + 2] = 0; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
-    } else {
-        flags[3 * k + 2] = 0; Wacc[k] = W[k]; Zacc[k] = Zt[k];
+    int ncon = 0;
+    bool active = true;
+    for (int j = 0; j < ntrial && active; ++j) {
+        const float zt = Zt[(size_t)j * ns + k], w = W[(size_t)j * ns + k];
+        if (zt < Z0[k] || isnan(zt)) {
+            if (w < 0.f) L[k] = w; else R[k] = w;
+            ++ncon;
+            if (R[k] - L[k] < 1e-30f) { active = false; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
+        } else {
+            active = false; Wacc[k] = w; Zacc[k] = zt;
+        }
     }
+    if (ncon) atomicAdd(counters + 1, ncon);              // [1] contractions
+    if (active) atomicAdd(counters + slot, 1);            // [slot] still-active count
+    else flags[3 * k + 2] = 0;
 }
 
 __global__ void slice_commit_kernel(float* __restrict__ coords, int ldc, int ndim, float* __restrict__ logp,
@@ -559,26 +576,26 @@ int launch_slice_init(const float* logp, const int* S, int ns, const float* cc, 
     LAUNCH_CHECK("slice_init");
 }
 int launch_slice_points(const float* coords, int ldc, int ndim, const int* S, int ns, const float* DIR, int ldd,
-                        const float* w, float* Q, int ldq, hipStream_t s) {
-    hipLaunchKernelGGL(slice_points_kernel, grid1d((size_t)ns * ldq, 256), dim3(256), 0, s, coords, ldc, ndim, S, ns, DIR,
-                       ldd, w, Q, ldq);
+                        const float* w, float* Q, int ldq, int nrep, hipStream_t s) {
+    hipLaunchKernelGGL(slice_points_kernel, grid1d((size_t)nrep * ns * ldq, 256), dim3(256), 0, s, coords, ldc, ndim, S, ns, DIR,
+                       ldd, w, Q, ldq, nrep);
     LAUNCH_CHECK("slice_points");
 }
 int launch_slice_expand(const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags, int ns,
-                        int* counters, hipStream_t s) {
-    hipLaunchKernelGGL(slice_expand_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, ZL, ZR, L, R, flags, ns, counters);
+                        int* counters, int slot, hipStream_t s) {
+    hipLaunchKernelGGL(slice_expand_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, ZL, ZR, L, R, flags, ns, counters, slot);
     LAUNCH_CHECK("slice_expand");
 }
 int launch_slice_draw(const float* L, const float* R, const int* S, float* W, const int* flags, int ns, uint64_t seed,
-                      const int* step_dev, int stream_id, int round, hipStream_t s) {
+                      const int* step_dev, int stream_id, int round, int ntrial, hipStream_t s) {
     hipLaunchKernelGGL(slice_draw_kernel, grid1d(ns, 256), dim3(256), 0, s, L, R, S, W, flags, ns, seed, step_dev,
-                       stream_id, round);
+                       stream_id, round, ntrial);
     LAUNCH_CHECK("slice_draw");
 }
 int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, const float* W, int* flags, float* Wacc,
-                        float* Zacc, int ns, int* counters, hipStream_t s) {
+                        float* Zacc, int ns, int* counters, int slot, int ntrial, hipStream_t s) {
     hipLaunchKernelGGL(slice_shrink_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, W, flags, Wacc, Zacc, ns,
-                       counters);
+                       counters, slot, ntrial);
     LAUNCH_CHECK("slice_shrink");
 }
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,

@@ -324,17 +324,52 @@ class SliceEnsembleSampler(EnsembleSampler):
         self.tune, self.tolerance, self.patience, self.maxsteps, self.maxiter = tune, tolerance, patience, maxsteps, maxiter
         self._tune_count = 0
         self.DIR, self.Q2 = z(ns, self.ld), z(2 * ns, self.ld)
-        self.Z0, self.L, self.R, self.W, self.Wacc, self.Zacc = z(ns), z(ns), z(ns), z(ns), z(ns), z(ns)
+        self.Z0, self.L, self.R, self.Wacc, self.Zacc = z(ns), z(ns), z(ns), z(ns), z(ns)
+        self.ntrial = 2                                  # shrink trials per round (2 x nw/2 points = one full launch)
+        self.W = z(self.ntrial * ns)
         self.Z2 = z(2 * ns)
         self.flags = torch.zeros(3 * ns, dtype=torch.int32, device=self.dev)
-        self.counters = torch.zeros(3, dtype=torch.int32, device=self.dev)
+        self.counters = torch.zeros(4, dtype=torch.int32, device=self.dev)   # expansions, contractions, active (ping-pong)
         self.neval = 0
+        self._cs, self._pin = None, None
 
-    def _active(self):
-        """Walkers still active after the last expand/shrink call (one small device->host read)."""
-        n = int(self.counters[2].item())
-        self.counters[2:3].zero_()
-        return n
+    # -- data-dependent rounds with one round of lookahead ------------------------------------------
+    # A round = a few small kernels + one evaluation + a kernel that counts the walkers still active.
+    # Reading that count on the host every round left the GPU idle while the host came back and queued
+    # the next round (~35 us of every ~110 us).  Instead round r+1 is queued BEFORE the count of round r
+    # is known: its evaluation is gated on the device-side count (linna_logprob_eval_if), so when round
+    # r turns out to have been the last, round r+1 costs a few empty launches.  The count travels over
+    # a second stream into pinned memory, so waiting for it does not wait for round r+1.
+    def _run_rounds(self, enqueue, maxrounds):
+        if self._cs is None:
+            self._cs = torch.cuda.Stream(device=self.dev)
+            self._pin = torch.zeros(2, dtype=torch.int32).pin_memory()
+        main = torch.cuda.current_stream(self.dev)
+        pending = None
+        for r in range(maxrounds):
+            slot = 2 + (r & 1)
+            self.counters[slot:slot + 1].zero_()
+            gate = C.c_void_p(self.counters.data_ptr() + 4 * (2 + ((r - 1) & 1))) if r > 0 else None
+            enqueue(r, slot, gate)
+            done = torch.cuda.Event()
+            done.record(main)
+            with torch.cuda.stream(self._cs):
+                self._cs.wait_event(done)
+                self._pin[r & 1:(r & 1) + 1].copy_(self.counters[slot:slot + 1], non_blocking=True)
+                landed = torch.cuda.Event()
+                landed.record(self._cs)
+            if pending is not None:
+                pending[0].synchronize()
+                if int(self._pin[pending[1]]) == 0:
+                    return                              # round r-1 finished every walker; round r (queued) is gated off
+            pending = (landed, r & 1)
+        pending[0].synchronize()
+
+    def _eval_if(self, Q, Z, gate):
+        p = self.lp._ensure()
+        B = Q.shape[0]
+        _lib.call("linna_logprob_eval_if", p["handle"], _lib.ptr(Q), Q.stride(0), B, _lib.ptr(self.lp._workspace(B, False)),
+                  _lib.ptr(Z), None, 0, gate, _lib.stream())
 
     def step(self):
         st, ns, ndim = _lib.stream(), self.half, self.ndim
@@ -342,6 +377,7 @@ class SliceEnsembleSampler(EnsembleSampler):
         seed = C.c_uint64((self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF)
         self.counters.zero_()
         P = _lib.ptr
+        nt = self.ntrial
         for h in (0, 1):
             S, Cc = halves[h], halves[1 - h]
             comp, ldc, cidx, nc = self.coords, self.ld, Cc, self.half
@@ -350,29 +386,33 @@ class SliceEnsembleSampler(EnsembleSampler):
             _lib.call("linna_slice_init", self.ctx, P(self.logp), _lib.iptr(S), ns, P(comp), ldc, _lib.iptr(cidx), nc, ndim,
                       P(self.mu_dev), seed, _lib.iptr(self.step_dev), h, P(self.DIR), self.ld, P(self.Z0), P(self.L),
                       P(self.R), _lib.iptr(self.flags), st)
-            for _ in range(self.maxsteps):              # stepping out, both ends per round
+
+            def expand_round(r, slot, gate):            # stepping out, both ends per round
                 _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
-                          self.ld, P(self.L), P(self.Q2), self.ld, st)
+                          self.ld, P(self.L), P(self.Q2), self.ld, 1, st)
                 _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
-                          self.ld, P(self.R), C.c_void_p(self.Q2.data_ptr() + 4 * ns * self.ld), self.ld, st)
-                self.lp.evaluate(self.Q2, out=self.Z2)
+                          self.ld, P(self.R), C.c_void_p(self.Q2.data_ptr() + 4 * ns * self.ld), self.ld, 1, st)
+                self._eval_if(self.Q2, self.Z2, gate)
                 self.neval += 2 * ns
                 _lib.call("linna_slice_expand", self.ctx, P(self.Z0), P(self.Z2), C.c_void_p(self.Z2.data_ptr() + 4 * ns),
-                          P(self.L), P(self.R), _lib.iptr(self.flags), ns, _lib.iptr(self.counters), st)
-                if self._active() == 0:
-                    break
-            Q1, Z1 = self.Q2[:ns], self.Z2[:ns]
-            for rnd in range(self.maxsteps):            # shrinking
+                          P(self.L), P(self.R), _lib.iptr(self.flags), ns, _lib.iptr(self.counters), slot, st)
+
+            # shrinking, TWO trials per round: the second is placed as if the first were rejected (the bracket
+            # after a rejection depends on where the trial fell, not on its density), so one launch evaluates
+            # 2 x nw/2 points -- the whole GPU instead of half of it -- and the rounds halve; the accepted
+            # point is the one the one-trial-per-round procedure accepts (same Philox sub-counters).
+            def shrink_round(r, slot, gate):
                 _lib.call("linna_slice_draw", self.ctx, P(self.L), P(self.R), _lib.iptr(S), P(self.W), _lib.iptr(self.flags),
-                          ns, seed, _lib.iptr(self.step_dev), 2 + h, rnd, st)
+                          ns, seed, _lib.iptr(self.step_dev), 2 + h, r * nt, nt, st)
                 _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
-                          self.ld, P(self.W), P(Q1), self.ld, st)
-                self.lp.evaluate(Q1, out=Z1)
-                self.neval += ns
-                _lib.call("linna_slice_shrink", self.ctx, P(self.Z0), P(Z1), P(self.L), P(self.R), P(self.W),
-                          _lib.iptr(self.flags), P(self.Wacc), P(self.Zacc), ns, _lib.iptr(self.counters), st)
-                if self._active() == 0:
-                    break
+                          self.ld, P(self.W), P(self.Q2), self.ld, nt, st)
+                self._eval_if(self.Q2[:nt * ns], self.Z2[:nt * ns], gate)
+                self.neval += nt * ns
+                _lib.call("linna_slice_shrink", self.ctx, P(self.Z0), P(self.Z2), P(self.L), P(self.R), P(self.W),
+                          _lib.iptr(self.flags), P(self.Wacc), P(self.Zacc), ns, _lib.iptr(self.counters), slot, nt, st)
+
+            self._run_rounds(expand_round, self.maxsteps)
+            self._run_rounds(shrink_round, (self.maxsteps + nt - 1) // nt)
             _lib.call("linna_slice_commit", self.ctx, P(self.coords), self.ld, ndim, P(self.logp), _lib.iptr(S), ns,
                       P(self.DIR), self.ld, P(self.Wacc), P(self.Zacc), st)
         _lib.call("linna_step_increment", self.ctx, _lib.iptr(self.step_dev), st)
