@@ -63,6 +63,10 @@ struct linna_ctx {
     hipStream_t aux = nullptr;               // second stream: parameter-gradient GEMMs run beside the dX chain
     std::vector<hipEvent_t> events;          // fork/join markers (no timing)
     int overlap = -1;                        // -1 unknown, 0 off (env LINNA_BWD_STREAMS=0), 1 on
+    void* group_dev = nullptr;               // device table of the grouped parameter-gradient GEMMs (gemm_launch_group)
+    size_t group_cap = 0;
+    std::vector<char> group_host;            // what the device table holds
+    int group = -1;                          // -1 unknown, 0 off (env LINNA_BWD_GROUP=0), 1 on
 };
 struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
 
@@ -121,6 +125,7 @@ int linna_ctx_destroy(linna_ctx_t* ctx) {
     if (ctx) {
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
+        if (ctx->group_dev) (void)hipFree(ctx->group_dev);
     }
     delete ctx;
     return LINNA_OK;
@@ -334,17 +339,42 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
     }
     int next_event = 0;
     void* aux = overlap ? (void*)ctx->aux : stream;
+    // Parameter gradients: the bias column sums go to the auxiliary stream as they become possible; the dW GEMMs
+    // (1-128 tiles each, 251 together for ChtoModelv2(33,33)) are collected and launched as ONE grid after the
+    // dX chain -- 13 launches of ~18 us each on the auxiliary stream were the critical path of the step.
+    if (pg && ctx && ctx->group < 0) {
+        const char* e = getenv("LINNA_BWD_GROUP");
+        ctx->group = (e && e[0] == '0') ? 0 : 1;
+    }
+    const bool grouping = pg && ctx && ctx->group == 1;
+    std::vector<GemmArgs> dwq;
+    std::vector<ColsumProb> csq;
+    int csblocks = 0;
+    bool aux_used = false;
     auto fork = [&]() -> int {       // work enqueued on aux after this sees everything enqueued on st so far
         if (!overlap) return LINNA_OK;
+        aux_used = true;
         hipEvent_t e = ctx->events[next_event++];
         TRY(check_hip(hipEventRecord(e, st), "hipEventRecord"));
         return check_hip(hipStreamWaitEvent(ctx->aux, e, 0), "hipStreamWaitEvent");
     };
+    auto param_grads = [&](const float* dY, int lddy, const float* Xin, int ldxin, float* dW, int lddw, float* db, int K,
+                           int N, float scale) -> int {
+        GemmArgs a = gemm_zero();    // dW[n][k] = scale * sum_b dY[b][n] X[b][k]
+        set_pair(a, 0, dY, lddy, LAY_MN, Xin, ldxin, LAY_MN, B);
+        a.M = N; a.N = K; a.C = dW; a.ldc = lddw; a.alpha0 = scale;
+        if (grouping && gemm_group_ok(a)) dwq.push_back(a);
+        else { TRY(fork()); TRY(gemm_launch(a, S(aux))); }
+        if (db) {
+            if (grouping) { csq.push_back(ColsumProb{dY, db, lddy, N, csblocks, scale}); csblocks += (N + 63) / 64; }
+            else { TRY(fork()); TRY(launch_colsum(dY, lddy, B, N, scale, db, S(aux))); }
+        }
+        return LINNA_OK;
+    };
 
     if (n->has_inskip && pg) {
         const linna_layer_t& s = n->inskip;
-        TRY(fork());
-        TRY(linna_linear_bwd(nullptr, dOUT, lddo, X, ldx, s.W, ld4(s.K), nullptr, 0, nullptr, 0, s.gW, ld4(s.K), s.gb, B, s.K, s.N, s.alpha, aux));
+        TRY(param_grads(dOUT, lddo, X, ldx, s.gW, ld4(s.K), s.gb, s.K, s.N, s.alpha));
     }
     const float* dcur = dOUT; int ldd = lddo;
     float* cursor = bw;
@@ -361,8 +391,7 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         const float* mask = hin_relu ? hin : nullptr;
         if (l.op == LINNA_OP_LINEAR) {
             if (pg) {                // dW, db need only dcur (already produced on st) and hin
-                TRY(fork());
-                TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.W, ld4(l.K), nullptr, 0, nullptr, 0, l.gW, ld4(l.K), l.gb, B, l.K, l.N, 1.f, aux));
+                TRY(param_grads(dcur, ldd, hin, ldh, l.gW, ld4(l.K), l.gb, l.K, l.N, 1.f));
             }
             if (need_dx) {
                 GemmArgs a = gemm_zero();
@@ -390,10 +419,9 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
                 TRY(gemm_launch(a, st));
             }
             if (pg) {
-                TRY(fork());         // after dT
-                TRY(linna_linear_bwd(nullptr, dcur, ldd, T, ldt, l.W2, ld4(l.C), nullptr, 0, nullptr, 0, l.gW2, ld4(l.C), l.gb2, B, l.C, l.N, 0.1f, aux));
-                TRY(linna_linear_bwd(nullptr, dT, ldt, hin, ldh, l.W1, ld4(l.K), nullptr, 0, nullptr, 0, l.gW1, ld4(l.K), l.gb1, B, l.K, l.C, 1.f, aux));
-                if (l.Ws) TRY(linna_linear_bwd(nullptr, dcur, ldd, hin, ldh, l.Ws, ld4(l.K), nullptr, 0, nullptr, 0, l.gWs, ld4(l.K), nullptr, B, l.K, l.N, 1.f, aux));
+                TRY(param_grads(dcur, ldd, T, ldt, l.gW2, ld4(l.C), l.gb2, l.C, l.N, 0.1f));   // (after dT)
+                TRY(param_grads(dT, ldt, hin, ldh, l.gW1, ld4(l.K), l.gb1, l.K, l.C, 1.f));
+                if (l.Ws) TRY(param_grads(dcur, ldd, hin, ldh, l.gWs, ld4(l.K), nullptr, l.K, l.N, 1.f));
             }
             if (need_dx) {   // dprev = (dT W1 + dcur Ws [+ dcur]) * (hin > 0)
                 GemmArgs a = gemm_zero();
@@ -406,7 +434,44 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         }
         dcur = dprev; ldd = ldp;
     }
-    if (overlap) {                   // join: the caller's stream continues only after every gradient is written
+    if (!dwq.empty() || !csq.empty()) {
+        // every dY is on `st` by now: one grid over all the dW tiles.  The descriptor table is uploaded only when
+        // it changed (first step, new batch size); during a capture with a stale table the GEMMs go out one by one.
+        const int np = (int)dwq.size(), nc = (int)csq.size();
+        const size_t cs_off = (gemm_group_table_bytes(np) + 15) & ~(size_t)15;
+        std::vector<char> tab(cs_off + (size_t)nc * sizeof(ColsumProb));
+        std::memcpy(tab.data(), dwq.data(), (size_t)np * sizeof(GemmArgs));
+        int* first = reinterpret_cast<int*>(tab.data() + (size_t)np * sizeof(GemmArgs));
+        int nb = 0;
+        for (int i = 0; i < np; ++i) { first[i] = nb; nb += gemm_group_blocks(dwq[i]); }
+        first[np] = nb;
+        if (nc) std::memcpy(tab.data() + cs_off, csq.data(), (size_t)nc * sizeof(ColsumProb));
+        bool ready = ctx->group_dev && ctx->group_host == tab;
+        if (!ready) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cap);
+            if (cap == hipStreamCaptureStatusNone) {
+                if (ctx->group_cap < tab.size()) {
+                    if (ctx->group_dev) (void)hipFree(ctx->group_dev);
+                    ctx->group_dev = nullptr; ctx->group_cap = 0;
+                    TRY(check_hip(hipMalloc(&ctx->group_dev, tab.size()), "hipMalloc(gemm group table)"));
+                    ctx->group_cap = tab.size();
+                }
+                ctx->group_host = tab;
+                TRY(check_hip(hipMemcpyAsync(ctx->group_dev, ctx->group_host.data(), tab.size(), hipMemcpyHostToDevice, st),
+                              "hipMemcpyAsync(gemm group table)"));
+                ready = true;
+            }
+        }
+        if (ready) {
+            TRY(gemm_launch_group(ctx->group_dev, np, nb, st));
+            if (nc) TRY(launch_colsum_group(reinterpret_cast<const ColsumProb*>(static_cast<const char*>(ctx->group_dev) + cs_off), nc, csblocks, B, st));
+        } else {
+            for (const GemmArgs& a : dwq) TRY(gemm_launch(a, st));
+            for (const ColsumProb& q : csq) TRY(launch_colsum(q.dZ, q.ld, B, q.N, q.scale, q.db, st));
+        }
+    }
+    if (overlap && aux_used) {       // join: the caller's stream continues only after every gradient is written
         hipEvent_t e = ctx->events[next_event++];
         TRY(check_hip(hipEventRecord(e, ctx->aux), "hipEventRecord"));
         TRY(check_hip(hipStreamWaitEvent(st, e, 0), "hipStreamWaitEvent"));

@@ -74,6 +74,8 @@ int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const
 int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg, const float* xmean,
                         const float* xstd, float* XB, int ldxb, hipStream_t s);
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s);
+struct ColsumProb { const float* dZ; float* db; int ld, N, first; float scale; };   // first: first 64-column block of this pair
+int launch_colsum_group(const ColsumProb* probs_dev, int nprob, int nblocks, int B, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,
                  float eps, hipStream_t s);
 int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const float* ccoords, int ldcc,
@@ -124,5 +126,10 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);
+// several independent problems in ONE grid (gemm.hip: gemm_group_kernel)
+size_t gemm_group_table_bytes(int nprob);
+bool gemm_group_ok(const GemmArgs& a);
+int gemm_group_blocks(const GemmArgs& a);
+int gemm_launch_group(const void* table, int nprob, int nblocks, hipStream_t stream);
 
 }  // namespace linna

@@ -123,7 +123,7 @@ struct Tile {
 // before the epilogue.  For grids that leave CUs idle: one output tile's K loop is a serial chain of
 // 64-cycle MFMAs on one wave per SIMD, and splitting K inside the workgroup is the parallelism left.
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block) {
     constexpr int NW = WM * WN, NT = NW * 64;                 // waves / threads of one K group
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using TA = Tile<BM, ALAY, NW>;
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a) {
     const int nwg = ntm * ntn;
     int tile;
     {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        const int b = block, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     }
     const int tm_ = tile / ntn, tn_ = tile % ntn;
@@ -329,6 +329,24 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a) {
     }
 }
 
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a) {
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, blockIdx.x);
+}
+
+// Grouped launch: ONE grid over the tiles of several independent problems that share the tile
+// configuration and the operand layouts (the 13 parameter-gradient GEMMs of a training step: 251
+// tiles that fill the chip once, instead of 13 launches of 1-128 tiles each).  `first[p]` = first
+// block of problem p, `first[nprob]` = grid size; the descriptors live in device memory.
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const GemmArgs* __restrict__ probs,
+                                                                       const int* __restrict__ first, int nprob) {
+    int p = 0;
+    while (p + 1 < nprob && (int)blockIdx.x >= first[p + 1]) ++p;
+    const GemmArgs a = probs[p];
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, (int)blockIdx.x - first[p]);
+}
+
 // ---------------------------------------------------------------------------- launcher
 struct TileCfg { int wm, wn, tm, tn; };
 static const TileCfg kCfgs[3] = {{2, 2, 2, 1}, {2, 2, 1, 1}, {1, 1, 1, 1}};   // 128x64, 64x64, 32x32
@@ -387,6 +405,22 @@ static int launch_lay(const GemmArgs& a, int cfg, hipStream_t stream) {
         }
         default: return launch_one<1, 1, 1, 1, ALAY, BLAY, 4>(a, stream);  // 32 KiB LDS: 5 blocks / CU
     }
+}
+
+// Grouped launch of problems that all take tile configuration 1 (64x64, 4-stage ring) and the k-major /
+// k-major layouts.  `table` is device memory for nprob descriptors followed by nprob+1 ints; the caller
+// has already copied `probs` and `first` there (gemm_group_table_bytes / gemm_group_fill).
+size_t gemm_group_table_bytes(int nprob) { return (size_t)nprob * sizeof(GemmArgs) + (size_t)(nprob + 1) * sizeof(int); }
+bool gemm_group_ok(const GemmArgs& a) {
+    return a.npairs == 1 && a.p[0].alay == LAY_MN && a.p[0].blay == LAY_MN && pick_cfg(a.M, a.N, a.flags) == 1 && !a.dotwith;
+}
+int gemm_group_blocks(const GemmArgs& a) { return ((a.M + 63) / 64) * ((a.N + 63) / 64); }
+int gemm_launch_group(const void* table, int nprob, int nblocks, hipStream_t stream) {
+    const GemmArgs* probs = static_cast<const GemmArgs*>(table);
+    const int* first = reinterpret_cast<const int*>(static_cast<const char*>(table) + (size_t)nprob * sizeof(GemmArgs));
+    constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
+    hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks), dim3(256), lds, stream, probs, first, nprob);
+    return check_hip(hipGetLastError(), "gemm group launch");
 }
 
 int gemm_launch(const GemmArgs& a, hipStream_t stream) {

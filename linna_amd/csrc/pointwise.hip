@@ -525,6 +525,37 @@ int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin
                        xmean, xstd, XB, ldxb);
     LAUNCH_CHECK("gather_xform");
 }
+// Grouped bias gradients: ONE grid over the 64-column blocks of several (dZ, db) pairs of the same batch.
+__global__ __launch_bounds__(1024) void colsum_group_kernel(const ColsumProb* __restrict__ probs, int nprob, int B) {
+    __shared__ float part[16][64];
+    int p = 0;
+    while (p + 1 < nprob && (int)blockIdx.x >= probs[p + 1].first) ++p;
+    const ColsumProb q = probs[p];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = ((int)blockIdx.x - q.first) * 64 + lane;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (col < q.N) {
+        const float* ptr = q.dZ + col;
+        int b = wave;
+        for (; b + 48 < B; b += 64) {
+            a0 += ptr[(size_t)b * q.ld]; a1 += ptr[(size_t)(b + 16) * q.ld];
+            a2 += ptr[(size_t)(b + 32) * q.ld]; a3 += ptr[(size_t)(b + 48) * q.ld];
+        }
+        for (; b < B; b += 16) a0 += ptr[(size_t)b * q.ld];
+    }
+    part[wave][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (wave == 0 && col < q.N) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][lane];
+        q.db[col] = q.scale * t;
+    }
+}
+int launch_colsum_group(const ColsumProb* probs_dev, int nprob, int nblocks, int B, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_group_kernel, dim3(nblocks), dim3(1024), 0, s, probs_dev, nprob, B);
+    LAUNCH_CHECK("colsum_group");
+}
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s) {
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, dZ, ld, B, N, scale, db);
     LAUNCH_CHECK("colsum");

@@ -23,7 +23,7 @@ from .predictor_gpu import EarlyStopping, _AdamWState, _lower_median
 
 
 class TrainEngine(object):
-    def __init__(self, pred, loader, loss_fn, val_loader, world_size=1, dist_group=None, use_graph=True):
+    def __init__(self, pred, loader, loss_fn, val_loader, world_size=1, dist_group=None, use_graph=False):
         self.pred, self.model = pred, pred.model
         dev = self.model.device
         if dev.type != "cuda":
@@ -108,6 +108,9 @@ class TrainEngine(object):
         if self.graph is not None:
             _lib.call("linna_graph_destroy", self.graph)
             self.graph = None
+        # one direct forward/backward first (no optimiser step: gradients and scratch only): the library
+        # uploads the descriptor table of its grouped parameter-gradient GEMMs outside a capture only
+        self._forward_loss_backward()
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
