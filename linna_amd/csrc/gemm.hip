@@ -19,6 +19,9 @@
 //  * out-of-range rows/columns of an edge tile read clamped (valid) addresses; their
 //    products are never stored.
 #include "common.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
 
 namespace linna {
 
@@ -122,8 +125,16 @@ struct Tile {
 // its own slice of every ring stage and the groups' accumulators are summed through LDS in fixed order
 // before the epilogue.  For grids that leave CUs idle: one output tile's K loop is a serial chain of
 // 64-cycle MFMAs on one wave per SIMD, and splitting K inside the workgroup is the parallelism left.
+// kz > 1: K is ALSO split over kz workgroups per output tile (grid = kz x tiles rounded up to a multiple of 8,
+// so that the workgroups of one tile share an XCD).  Every workgroup parks its partial tile in `ks_scratch`
+// and bumps the tile's counter; the LAST one to arrive sums the kz partials in fixed order (its own included,
+// so the result does not depend on who was last), runs the epilogue and resets the counter.  No workgroup
+// ever waits for another.  For the few-tile, long-K GEMMs of a batch-500 training step, which otherwise run
+// as one serial MFMA chain per tile on 8-64 of the 256 CUs.
+struct KSplit { int kz; float* scratch; int* counters; };
+
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all, const KSplit ks) {
     constexpr int NW = WM * WN, NT = NW * 64;                 // waves / threads of one K group
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using TA = Tile<BM, ALAY, NW>;
@@ -142,6 +153,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block) {
     // contiguous run of tiles; consecutive tiles walk N first and therefore share the A panel.
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const int nwg = ntm * ntn;
+    const int nwgp = (nwg + 7) & ~7;                          // blocks per K split (padded: same XCD for every split of a tile)
+    const int kzi = ks.kz > 1 ? block_all / nwgp : 0;         // K split of this workgroup
+    const int block = ks.kz > 1 ? block_all % nwgp : block_all;
+    if (block >= nwg) return;
+    const int gid = kzi * KS + kg, ngrp = ks.kz * KS;         // K group among all groups of this tile
     int tile;
     {
         const int b = block, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
@@ -210,12 +226,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block) {
                             (((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0);
         const int nfast = dma_ok ? p.K / BK : 0;               // full K tiles streamed by LDS-DMA
         const int nall = (p.K + BK - 1) / BK;
-        const int nmine = (nfast - kg + KS - 1) / KS;           // ... of which this group takes kg, kg+KS, ...
-        const int niter = (nfast + KS - 1) / KS;                // ring turns (same for every group: barriers)
+        const int nmine = nfast > gid ? (nfast - gid + ngrp - 1) / ngrp : 0;   // ... of which this group takes gid, gid+ngrp, ...
+        const int niter = (nfast + ngrp - 1) / ngrp;            // ring turns (same for every group of the workgroup: barriers)
         auto stage_of = [&](int i) { return smem + ((i % NS) * KS + kg) * STAGE; };
         auto issue = [&](int i) {
             float* st = stage_of(i);
-            const int t = kg + i * KS;
+            const int t = gid + i * ngrp;
             TA::dma(p.A, p.lda, m0, a.M, t * BK, st, wave, lane);
             TB::dma(p.B, p.ldb, n0, a.N, t * BK, st + TA::SIZE, wave, lane);
         };
@@ -233,20 +249,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block) {
             }
             __builtin_amdgcn_s_barrier();          // last tile fully read before anything restages
         }
-        for (int kt = nfast; kt < nall; ++kt) {    // partial tile / unaligned operand: register path, group 0
-            if (kg == 0) {
-                TA::stage_slow(p.A, p.lda, m0, a.M, kt * BK, p.K, smem, tid);
-                TB::stage_slow(p.B, p.ldb, n0, a.N, kt * BK, p.K, smem + TA::SIZE, tid);
+        if (kzi == 0) {
+            for (int kt = nfast; kt < nall; ++kt) {    // partial tile / unaligned operand: register path, group 0 of split 0
+                if (kg == 0) {
+                    TA::stage_slow(p.A, p.lda, m0, a.M, kt * BK, p.K, smem, tid);
+                    TB::stage_slow(p.B, p.ldb, n0, a.N, kt * BK, p.K, smem + TA::SIZE, tid);
+                }
+                __syncthreads();
+                if (kg == 0) compute(smem);
+                __syncthreads();
             }
-            __syncthreads();
-            if (kg == 0) compute(smem);
-            __syncthreads();
         }
         if (pi == 0 && a.npairs > 1) {             // acc <- alpha0 * (acc + bias0) before pair 1 accumulates
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-                const float b0 = (kg == 0 && a.bias0 && col < a.N) ? a.bias0[col] : 0.f;   // the bias once, not per K group
+                const float b0 = (gid == 0 && a.bias0 && col < a.N) ? a.bias0[col] : 0.f;  // the bias once, not per K group
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -278,6 +296,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block) {
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] += red[((g - 1) * E + (i * TN + j) * 16 + e) * NT + tid];
+    }
+
+    // ---------------------------------------------------------------- K splits -> the last workgroup to arrive
+    if (ks.kz > 1) {
+        constexpr int E = TM * TN * 16;
+        __shared__ int s_last;
+        float* const mine = ks.scratch + ((size_t)tile * ks.kz + kzi) * (E * NT);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mine[((i * TN + j) * 16 + e) * NT + tid] = acc[i][j][e];
+        __threadfence();                               // partial visible device-wide before the counter moves
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(ks.counters + tile, 1) == ks.kz - 1;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();                               // acquire: the other splits' partials
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        for (int z = 0; z < ks.kz; ++z) {
+            const float* src = ks.scratch + ((size_t)tile * ks.kz + z) * (E * NT);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        acc[i][j][e] += __builtin_nontemporal_load(src + ((i * TN + j) * 16 + e) * NT + tid);
+        }
+        if (threadIdx.x == 0) ks.counters[tile] = 0;   // every split has arrived: ready for the next launch
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -330,8 +384,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block) {
 }
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a) {
-    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, blockIdx.x);
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a, KSplit ks) {
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, blockIdx.x, ks);
 }
 
 // Grouped launch: ONE grid over the tiles of several independent problems that share the tile
@@ -344,7 +398,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const Gem
     int p = 0;
     while (p + 1 < nprob && (int)blockIdx.x >= first[p + 1]) ++p;
     const GemmArgs a = probs[p];
-    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, (int)blockIdx.x - first[p]);
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, (int)blockIdx.x - first[p], KSplit{1, nullptr, nullptr});
 }
 
 // ---------------------------------------------------------------------------- launcher
@@ -372,7 +426,7 @@ int gemm_slots(int M, int N) {
 }
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS = 1>
-static int launch_one(const GemmArgs& a, hipStream_t stream) {
+static int launch_one(const GemmArgs& a, hipStream_t stream, KSplit ks = KSplit{1, nullptr, nullptr}) {
     constexpr int NT = WM * WN * KS * 64, BM = WM * TM * 32, BN = WN * TN * 32;
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const size_t lds = (size_t)NS * KS * (BM + BN) * BK * sizeof(float);
@@ -383,8 +437,33 @@ static int launch_one(const GemmArgs& a, hipStream_t stream) {
         if (rc != LINNA_OK) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS, KS>), dim3(ntm * ntn), dim3(NT), lds, stream, a);
+    const int grid = ks.kz > 1 ? ks.kz * ((ntm * ntn + 7) & ~7) : ntm * ntn;
+    hipLaunchKernelGGL((gemm_kernel<WM, WN, TM, TN, ALAY, BLAY, NS, KS>), dim3(grid), dim3(NT), lds, stream, a, ks);
     return check_hip(hipGetLastError(), "gemm launch");
+}
+
+// Per-stream scratch of the cross-workgroup K split: partial tiles + arrival counters (zeroed once; every
+// launch leaves them zero).  Launches on one stream are ordered, so one buffer per stream is enough.
+struct KsScratch { float* scratch = nullptr; int* counters = nullptr; };
+static constexpr int KS_MAX_TILES = 64, KS_MAX_KZ = 8;
+static KSplit ksplit_for(hipStream_t stream, int kz) {
+    static std::mutex mu;
+    static std::map<hipStream_t, KsScratch> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    KsScratch& k = pool[stream];
+    if (!k.scratch) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &cap);
+        if (cap != hipStreamCaptureStatusNone) return KSplit{1, nullptr, nullptr};     // no allocation inside a capture
+        const size_t bytes = (size_t)KS_MAX_TILES * KS_MAX_KZ * 64 * 64 * sizeof(float);
+        if (hipMalloc(reinterpret_cast<void**>(&k.scratch), bytes) != hipSuccess) { k.scratch = nullptr; return KSplit{1, nullptr, nullptr}; }
+        if (hipMalloc(reinterpret_cast<void**>(&k.counters), KS_MAX_TILES * sizeof(int)) != hipSuccess ||
+            hipMemset(k.counters, 0, KS_MAX_TILES * sizeof(int)) != hipSuccess) {
+            (void)hipFree(k.scratch); k.scratch = nullptr; k.counters = nullptr;
+            return KSplit{1, nullptr, nullptr};
+        }
+    }
+    return KSplit{kz, k.scratch, k.counters};
 }
 
 template <int ALAY, int BLAY>
@@ -398,6 +477,15 @@ static int launch_lay(const GemmArgs& a, int cfg, hipStream_t stream) {
             const long tiles = (long)((a.M + 63) / 64) * ((a.N + 63) / 64);
             const int K = a.npairs > 1 ? (a.p[0].K > a.p[1].K ? a.p[0].K : a.p[1].K) : a.p[0].K;
             if (!(a.flags & LINNA_GEMM_NOSPLIT) && K >= 128) {
+                // few tiles and a long K: split K over several workgroups per tile (up to ~128 workgroups in all)
+                const int ktiles = a.p[0].K / BK + (a.npairs > 1 ? a.p[1].K / BK : 0);
+                int kz = std::min(std::min(KS_MAX_KZ, 128 / (int)std::max(1L, tiles)), ktiles / 4);
+                // (measured, tools/gemm_small.py: the device-scope fence + scratch round trip costs 5-10 us, so the
+                //  split pays only when a handful of tiles would otherwise run a >= 16-tile K loop each)
+                if (tiles <= 16 && ktiles >= 12 && kz >= 2 && !a.dotwith) {
+                    const KSplit ks = ksplit_for(stream, kz);
+                    if (ks.kz > 1) return launch_one<2, 2, 1, 1, ALAY, BLAY, 4, 1>(a, stream, ks);
+                }
                 if (tiles <= 64) return launch_one<2, 2, 1, 1, ALAY, BLAY, 2, 4>(a, stream);
                 if (tiles <= 128) return launch_one<2, 2, 1, 1, ALAY, BLAY, 4, 2>(a, stream);
             }
