@@ -25,7 +25,7 @@ import torch
 from . import _lib
 
 __all__ = ["EnsembleSampler", "SliceEnsembleSampler", "BatchedHMC", "HMCSampler", "ZeusSampler", "checkmeanstd", "integrated_time",
-           "ChainStore", "read_chain_and_cut"]
+           "ChainStore", "DeviceChain", "read_chain_and_cut"]
 
 
 # ------------------------------------------------------------------ convergence statistics (host)
@@ -66,6 +66,68 @@ def integrated_time(x, c=5.0):
         win = int(np.argmin(m)) if np.any(m) and not np.all(m) else len(taus) - 1
         tau[d] = taus[win]
     return tau
+
+
+class DeviceChain(object):
+    """The chain blocks of a run kept on the GPU for the convergence statistics: the reference
+    recomputes the autocorrelation time of the WHOLE chain every 100 iterations on the host
+    (sampler.py:538, 684); at 4096 walkers that host pass (135 k FFTs in a Python loop, after
+    concatenating every block again) cost ~200x the 100 iterations it judges.  Same estimators,
+    float64, on the device: per parameter one batched FFT over all walkers (torch.fft is used as
+    plumbing here; nothing of it is on the sampling path)."""
+
+    def __init__(self):
+        self.blocks = []
+
+    def append(self, z_block):
+        z = torch.as_tensor(z_block)
+        self.blocks.append(z if z.is_cuda else z.cuda())
+
+    def __len__(self):
+        return sum(len(b) for b in self.blocks)
+
+    def last(self, n):
+        """The last ``n`` steps as one device tensor [n, nw, nd]."""
+        out, need = [], int(n)
+        for b in reversed(self.blocks):
+            if need <= 0:
+                break
+            out.append(b[-need:] if len(b) > need else b)
+            need -= len(out[-1])
+        return torch.cat(out[::-1]) if len(out) > 1 else out[0]
+
+    def integrated_time(self, discard=0, c=5.0):
+        """emcee's estimator (FFT autocorrelation averaged over walkers, Sokal window, tol=0) per
+        parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %)."""
+        nt_all, nd = len(self), self.blocks[0].shape[2]
+        nt = nt_all - int(discard)
+        n = _next_pow_two(nt)
+        taus = torch.empty(nd, dtype=torch.float64, device=self.blocks[0].device)
+        ar = torch.arange(nt, device=taus.device, dtype=torch.float64)
+        for d in range(nd):
+            x = torch.cat([b[:, :, d] for b in self.blocks])[int(discard):].to(torch.float64)   # [nt, nw]
+            x = x - x.mean(0, keepdim=True)
+            f = torch.fft.rfft(x, n=2 * n, dim=0)
+            acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=0)[:nt]
+            fbar = (acf / acf[0:1]).mean(1)                     # 0/0 -> nan, as the host estimator
+            t = 2.0 * torch.cumsum(fbar, 0) - 1.0
+            m = ar < c * t
+            keep = bool(m.any()) and not bool(m.all())
+            win = int(torch.argmin(m.to(torch.int8))) if keep else nt - 1
+            taus[d] = t[win]
+        return taus.cpu().numpy()
+
+    def checkmeanstd(self, nlast, meanshift, stdshift):
+        """sampler.py:370-387 on the last ``nlast`` steps: first-half / second-half drift."""
+        s = self.last(nlast).to(torch.float64)
+        half = int(len(s) / 2)
+        a = s[:half].reshape(-1, s.shape[-1])
+        b = s[half:].reshape(-1, s.shape[-1])
+        sb = b.std(0, unbiased=False)
+        meanshifte = float(torch.median((a.mean(0) - b.mean(0)).abs() / sb))
+        stdshifte = float(torch.median((a.std(0, unbiased=False) - sb) / sb))
+        print(meanshifte, stdshifte, flush=True)
+        return (meanshifte < meanshift) and (stdshifte < stdshift)
 
 
 def checkmeanstd(samples, meanshift, stdshift):
@@ -533,20 +595,23 @@ class HMCSampler(object):
         ens.set_state(x0)
         old_tau = np.inf
         done = 0 if not resume else sum(len(c) for c in store.chain)
+        dchain = DeviceChain()                                               # convergence statistics stay on the GPU
+        for blk in store.chain:
+            dchain.append(np.asarray(blk, np.float32))
         while done < nsamp:
             c, l = ens.run(ncheck)
             th = ens.theta_of(c)
             store.append(c.cpu().numpy(), th.cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
+            dchain.append(c)
             done += ncheck
             if incremental:
                 store.flush()
-            chain = np.concatenate(store.chain)
-            tau = integrated_time(chain)                                      # sampler.py:538
+            tau = dchain.integrated_time()                                    # sampler.py:538
             if np.isnan(np.sum(tau)) and done > 10:
                 break
             converged = np.all(tau * ntimes < done)                           # :545-547
             converged &= np.all(np.abs(old_tau - tau) / tau < tautol)
-            converged &= checkmeanstd(chain[-int(nk * np.mean(tau)):], meanshift=meanshift, stdshift=stdshift)
+            converged &= dchain.checkmeanstd(max(2, int(nk * np.mean(tau))), meanshift, stdshift)
             print("max, min tau diff, max tau, ninter: {0}, {1}, {2}, {3}\n".format(
                 np.max(np.abs(old_tau - tau) / tau), np.min(np.abs(old_tau - tau) / tau), np.max(tau), done), flush=True)
             if converged:
@@ -579,17 +644,20 @@ class ZeusSampler(object):
         self.sampler = ens
         ens.set_state(x0)
         old_tau, done = np.inf, sum(len(c) for c in store.chain)
+        dchain = DeviceChain()
+        for blk in store.chain:
+            dchain.append(np.asarray(blk, np.float32))
         while done < min(nsamp, 100000):
             c, l = ens.run(ncheck)
             store.append(c.cpu().numpy(), ens.theta_of(c).cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
+            dchain.append(c)
             done += ncheck
             if incremental:
                 store.flush()
-            chain = np.concatenate(store.chain)
-            tau = float(np.mean(integrated_time(chain[int(done * 0.2):])))   # discard=0.2, sampler.py:684,729
+            tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2))))   # discard=0.2, sampler.py:684,729
             converged = tau * ntimes < done
             converged &= abs(old_tau - tau) / tau < tautol
-            converged &= bool(checkmeanstd(chain[-int(nk * tau):], meanshift, stdshift))
+            converged &= bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
             old_tau = tau
             if converged:
                 break
