@@ -154,13 +154,14 @@ class ChainStore(object):
         self.transform = transform
         self.chain, self.chain_transformed, self.log_prob = [], [], []
         self.accepted = None
+        self._flushed = 0
 
     @property
     def npz(self):
         return self.base + ".npz"
 
     def exists(self):
-        return os.path.isfile(self.npz)
+        return os.path.isfile(self.npz) or bool(self._parts(self.base))
 
     def append(self, z_block, theta_block, logp_block, accepted):
         self.chain.append(np.asarray(z_block, np.float64))
@@ -171,15 +172,48 @@ class ChainStore(object):
     def arrays(self):
         return (np.concatenate(self.chain), np.concatenate(self.chain_transformed), np.concatenate(self.log_prob))
 
-    def flush(self):
+    def flush(self, final=True):
+        """``final=True``: the consolidated ``<name>.npz`` + ``<name>.txt``.  ``final=False`` (the
+        incremental flush after every convergence check, sampler.py:359/720): only the blocks that are
+        not on disk yet, as ``<name>.partNNNNN.npz`` -- the reference's HDF5 backend appends, and
+        rewriting the whole chain at every check is quadratic (216 MB per 100 iterations at 4096
+        walkers).  ``load`` reads either form, so a killed run resumes from the parts."""
+        if not final:
+            for k in range(self._flushed, len(self.chain)):
+                np.savez(self._part(k), chain=self.chain[k], chain_transformed=self.chain_transformed[k],
+                         log_prob=self.log_prob[k], accepted=self.accepted)
+            self._flushed = len(self.chain)
+            return
         z, th, lp = self.arrays()
         np.savez(self.npz, chain=z, chain_transformed=th, log_prob=lp, accepted=self.accepted, iteration=len(z))
         flat = np.concatenate([th.reshape(-1, th.shape[-1]), lp.reshape(-1, 1)], axis=1)
         np.savetxt(self.base + ".txt", flat[-100000:])
+        for f in self._parts(self.base):                    # superseded by the consolidated file
+            os.remove(f)
+        self._flushed = len(self.chain)
+
+    def _part(self, k):
+        return "%s.part%05d.npz" % (self.base, k)
+
+    @staticmethod
+    def _parts(base):
+        import glob
+        return sorted(glob.glob(base + ".part*.npz"))
 
     @staticmethod
     def load(filename):
         base = filename[:-3] if filename.endswith(".h5") else filename
+        parts = ChainStore._parts(base)
+        if parts:                                           # an interrupted run: (consolidated file, if any) + parts
+            blocks = [np.load(f) for f in parts]
+            out = {k: np.concatenate([b[k] for b in blocks]) for k in ("chain", "chain_transformed", "log_prob")}
+            out["accepted"] = blocks[-1]["accepted"]
+            if os.path.isfile(base + ".npz"):
+                d = np.load(base + ".npz")
+                for k in ("chain", "chain_transformed", "log_prob"):
+                    out[k] = np.concatenate([d[k], out[k]])
+            out["iteration"] = len(out["chain"])
+            return out
         d = np.load(base + ".npz")
         return {k: d[k] for k in d.files}
 
@@ -580,6 +614,7 @@ class HMCSampler(object):
                 prev = ChainStore.load(filename)
                 x0, resume = prev["chain"][-1], True
                 store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])
+                store.flush()                                                # consolidate: parts written from here on are new
         ens = EnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
         self.sampler = ens
         print("start", flush=True)
@@ -605,7 +640,7 @@ class HMCSampler(object):
             dchain.append(c)
             done += ncheck
             if incremental:
-                store.flush()
+                store.flush(final=False)
             tau = dchain.integrated_time()                                    # sampler.py:538
             if np.isnan(np.sum(tau)) and done > 10:
                 break
@@ -640,6 +675,7 @@ class ZeusSampler(object):
             prev = ChainStore.load(store.base)
             x0 = prev["chain"][-1]
             store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])
+            store.flush()                                                    # consolidate: parts written from here on are new
         ens = SliceEnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
         self.sampler = ens
         ens.set_state(x0)
@@ -653,7 +689,7 @@ class ZeusSampler(object):
             dchain.append(c)
             done += ncheck
             if incremental:
-                store.flush()
+                store.flush(final=False)
             tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2))))   # discard=0.2, sampler.py:684,729
             converged = tau * ntimes < done
             converged &= abs(old_tau - tau) / tau < tautol

@@ -151,3 +151,36 @@ def test_cpu_model_refuses_to_compute():
     m = nn.MLP(7, 5, None, width=48, depth=3)
     with pytest.raises(_lib.LinnaHipError):
         m.forward(torch.zeros(2, 7))
+
+
+def test_chainstore_incremental_parts_roundtrip(tmp_path):
+    """Incremental flushes write only the new blocks; load() sees consolidated file + parts; the final
+    flush consolidates and removes the parts; a resumed store does not duplicate what it loaded."""
+    from linna_amd.sampler import ChainStore
+    rs = np.random.RandomState(0)
+    name = str(tmp_path / "chemcee_256.h5")
+    blocks = [(rs.standard_normal((5, 4, 3)), rs.standard_normal((5, 4, 3)), rs.standard_normal((5, 4))) for _ in range(3)]
+    st = ChainStore(name)
+    assert not st.exists()
+    for i, (z, th, lp) in enumerate(blocks[:2]):
+        st.append(z, th, lp, np.full(4, i + 1.0))
+        st.flush(final=False)
+    assert st.exists() and not os.path.isfile(st.npz) and len(ChainStore._parts(st.base)) == 2
+    d = ChainStore.load(name)
+    np.testing.assert_array_equal(d["chain"], np.concatenate([b[0] for b in blocks[:2]]))
+    np.testing.assert_array_equal(d["log_prob"], np.concatenate([b[2] for b in blocks[:2]]))
+    assert d["iteration"] == 10
+    # resume: load, append as one block, consolidate, continue with a new part
+    st2 = ChainStore(name)
+    st2.append(d["chain"], d["chain_transformed"], d["log_prob"], d["accepted"])
+    st2.flush()
+    assert os.path.isfile(st2.npz) and not ChainStore._parts(st2.base)
+    st2.append(*blocks[2], np.full(4, 3.0))
+    st2.flush(final=False)
+    d2 = ChainStore.load(name)
+    np.testing.assert_array_equal(d2["chain"], np.concatenate([b[0] for b in blocks]))
+    np.testing.assert_array_equal(d2["chain_transformed"], np.concatenate([b[1] for b in blocks]))
+    st2.flush()
+    d3 = ChainStore.load(name)
+    np.testing.assert_array_equal(d3["chain"], d2["chain"])
+    assert not ChainStore._parts(st2.base) and os.path.isfile(st2.base + ".txt")
