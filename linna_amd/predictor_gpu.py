@@ -168,10 +168,11 @@ class _AdamWState(object):
 
     def state_dict(self):
         step = float(self.step_dev.item())
+        m_host, v_host = self.m.detach().cpu(), self.v.detach().cpu()      # one copy each, then host views
         state = {}
         for i, key in enumerate(self.model._index):
-            state[i] = {"step": torch.tensor(step), "exp_avg": self.model._view(self.m, key).detach().cpu().clone(),
-                        "exp_avg_sq": self.model._view(self.v, key).detach().cpu().clone()}
+            state[i] = {"step": torch.tensor(step), "exp_avg": self.model._view(m_host, key).clone(),
+                        "exp_avg_sq": self.model._view(v_host, key).clone()}
         group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "params": list(range(len(self.model._index)))}

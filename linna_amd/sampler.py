@@ -101,21 +101,26 @@ class DeviceChain(object):
         parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %)."""
         nt_all, nd = len(self), self.blocks[0].shape[2]
         nt = nt_all - int(discard)
+        nw = self.blocks[0].shape[1]
         n = _next_pow_two(nt)
-        taus = torch.empty(nd, dtype=torch.float64, device=self.blocks[0].device)
-        ar = torch.arange(nt, device=taus.device, dtype=torch.float64)
-        for d in range(nd):
-            x = torch.cat([b[:, :, d] for b in self.blocks])[int(discard):].to(torch.float64)   # [nt, nw]
+        dev = self.blocks[0].device
+        ar = torch.arange(nt, device=dev, dtype=torch.float64)[:, None]
+        out = torch.empty(nd, dtype=torch.float64, device=dev)
+        # all walkers and as many parameters per FFT as ~1 GiB of complex128 allows; no host round trip inside
+        per = max(1, min(nd, int((1 << 30) // max(1, 16 * 2 * n * nw))))
+        for d0 in range(0, nd, per):
+            x = torch.cat([b[:, :, d0:d0 + per] for b in self.blocks])[int(discard):].to(torch.float64)   # [nt, nw, per]
             x = x - x.mean(0, keepdim=True)
             f = torch.fft.rfft(x, n=2 * n, dim=0)
             acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=0)[:nt]
-            fbar = (acf / acf[0:1]).mean(1)                     # 0/0 -> nan, as the host estimator
+            fbar = (acf / acf[0:1]).mean(1)                     # [nt, per]; 0/0 -> nan, as the host estimator
             t = 2.0 * torch.cumsum(fbar, 0) - 1.0
-            m = ar < c * t
-            keep = bool(m.any()) and not bool(m.all())
-            win = int(torch.argmin(m.to(torch.int8))) if keep else nt - 1
-            taus[d] = t[win]
-        return taus.cpu().numpy()
+            m = ar < c * t                                      # Sokal window: first step with step >= c tau
+            first_false = torch.argmin(m.to(torch.int8), dim=0)
+            keep = m.any(0) & ~m.all(0)
+            win = torch.where(keep, first_false, torch.full_like(first_false, nt - 1))
+            out[d0:d0 + per] = t.gather(0, win[None, :])[0]
+        return out.cpu().numpy()
 
     def checkmeanstd(self, nlast, meanshift, stdshift):
         """sampler.py:370-387 on the last ``nlast`` steps: first-half / second-half drift."""
@@ -227,7 +232,12 @@ def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee"
     if nk > ntimes:
         print("Error: keep number greater then chain samples. nk: {0}, ntimes: {1}. This will lead to inclusion of all "
               "burn in step".format(nk, ntimes))
-    tau = integrated_time(d["chain"])
+    if torch.cuda.is_available():                   # the same estimator, batched on the device (see DeviceChain)
+        dc = DeviceChain()
+        dc.append(np.asarray(d["chain"], np.float32))
+        tau = dc.integrated_time()
+    else:
+        tau = integrated_time(d["chain"])
     nkeep = int(np.nanmedian(tau) * nk)
     chain = d["chain_transformed"]
     lp = d["log_prob"]

@@ -165,6 +165,7 @@ def _read_lr(pred, engine, rank):
 def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrombest, rank, size, dist_group,
         checkpoint_every, progress):
     """The body of ``Predictor.train``; returns (train_losses[steps], val_metrics[epochs, 3])."""
+    progress = progress or os.environ.get("LINNA_TRAIN_PROGRESS", "0") == "1"   # per-epoch train / validation loss
     torch.manual_seed(1234)                                                     # predictor_gpu.py:221
     size = max(int(size), 1)
     model = pred.model
@@ -240,6 +241,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
                     model.flat_params().copy_(best_state)
                     restored = True
                 elif pred.outdir is not None:
+                    drain_checkpoints()
                     restored = pred.load_checkpoint(ismpi=False)
                 if not restored:
                     reinit()
@@ -274,9 +276,54 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
         if is_best:
             best_state = model.flat_params().clone()                            # device-resident best.pth.tar
         _save(pred, model, opt, i, is_best, rank, checkpoint_every, num_epochs)
+    drain_checkpoints()                             # best.pth.tar / last.pth.tar are on disk when train() returns
     if val_dataset is not None:
         return np.array(train_losses), np.array(val_metrics)
     return np.array(train_losses)
+
+
+class _CheckpointWriter(object):
+    """last.pth.tar / best.pth.tar written by ONE background thread, in order: pickling and writing
+    ~10 MB took 17 ms of every 25-50 ms epoch on the training thread (the reference pays the same
+    per epoch, predictor_gpu.py:405-419).  The state handed over is already on the host; ``drain``
+    returns when every file is on disk and is called before anything reads a checkpoint back."""
+
+    def __init__(self):
+        import queue, threading
+        self.q = queue.Queue()
+        self.err = None
+        self.t = threading.Thread(target=self._work, daemon=True)
+        self.t.start()
+
+    def _work(self):
+        while True:
+            item = self.q.get()
+            try:
+                if item is not None and self.err is None:
+                    nnutils.save_checkpoint(*item)
+            except Exception as e:                      # surfaced by drain()
+                self.err = e
+            finally:
+                self.q.task_done()
+            if item is None:
+                return
+
+    def put(self, state, is_best, checkpoint):
+        self.q.put((state, is_best, checkpoint))
+
+    def drain(self):
+        self.q.join()
+        if self.err is not None:
+            err, self.err = self.err, None
+            raise err
+
+
+_writer = None
+
+
+def drain_checkpoints():
+    if _writer is not None:
+        _writer.drain()
 
 
 def _save(pred, model, opt, epoch, is_best, rank, every, num_epochs, force=False):
@@ -286,6 +333,11 @@ def _save(pred, model, opt, epoch, is_best, rank, every, num_epochs, force=False
         return
     if not (is_best or force or (epoch + 1) % max(every, 1) == 0 or epoch + 1 == num_epochs):
         return
-    sd = {k: v.detach().cpu().clone().contiguous() for k, v in model.state_dict().items()}
-    nnutils.save_checkpoint({"epoch": epoch + 1, "state_dict": sd, "optim_dict": opt.state_dict()}, is_best=is_best,
-                            checkpoint=pred.outdir)
+    # ONE device->host copy of the flat parameter buffer (and one each of AdamW's m, v inside opt.state_dict):
+    # a .cpu() per tensor was 58 synchronising copies per epoch
+    host = model._flat.detach().cpu()
+    sd = {k: model._view(host, k).clone().contiguous() for k in model._index}
+    global _writer
+    if _writer is None:
+        _writer = _CheckpointWriter()
+    _writer.put({"epoch": epoch + 1, "state_dict": sd, "optim_dict": opt.state_dict()}, is_best, pred.outdir)
