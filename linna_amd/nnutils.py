@@ -20,6 +20,14 @@ def save_checkpoint(state, is_best, checkpoint):
         shutil.copyfile(filepath, os.path.join(checkpoint, "best.pth.tar"))
 
 
+def save_state(state, filepath):
+    """One checkpoint file (the layout of nnutils.py:109-126: {epoch, state_dict, optim_dict})."""
+    d = os.path.dirname(filepath)
+    if d and not os.path.exists(d):
+        os.makedirs(d)
+    torch.save(state, filepath)
+
+
 def read_checkpoint(path, device=None):
     if not os.path.exists(path):
         raise FileNotFoundError("File doesn't exist {}".format(path))

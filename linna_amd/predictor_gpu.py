@@ -166,14 +166,17 @@ class _AdamWState(object):
                   _lib.ptr(self.model.flat_grads()), _lib.ptr(self.m), _lib.ptr(self.v), n, _lib.ptr(self.hyper),
                   _lib.iptr(self.step_dev), self.betas[0], self.betas[1], self.eps, _lib.stream())
 
-    def state_dict(self):
-        step = float(self.step_dev.item())
-        m_host, v_host = self.m.detach().cpu(), self.v.detach().cpu()      # one copy each, then host views
+    def state_dict(self, snapshot=None):
+        """torch.optim.AdamW-shaped state; ``snapshot`` = (m, v, step_dev, lr, weight_decay) device copies taken at
+        another time (the best epoch) instead of the live state."""
+        m, v, step_dev, lr, wd = snapshot if snapshot is not None else (self.m, self.v, self.step_dev, self.lr, self.weight_decay)
+        step = float(step_dev.item())
+        m_host, v_host = m.detach().cpu(), v.detach().cpu()                # one copy each, then host views
         state = {}
         for i, key in enumerate(self.model._index):
             state[i] = {"step": torch.tensor(step), "exp_avg": self.model._view(m_host, key).clone(),
                         "exp_avg_sq": self.model._view(v_host, key).clone()}
-        group = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay,
+        group = {"lr": lr, "betas": self.betas, "eps": self.eps, "weight_decay": wd,
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "params": list(range(len(self.model._index)))}
         return {"state": state, "param_groups": [group]}

@@ -183,6 +183,8 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     pred.optim = opt
     engine.prepare_graph(opt)
     es = EarlyStopping(patience=500)                                            # :256
+    ckpt = _Checkpoints(pred, model, rank)
+    last_epoch = -1
     train_losses, val_metrics = [], []
     old, told = 0.0, 0.0
     best_state = None
@@ -241,7 +243,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
                     model.flat_params().copy_(best_state)
                     restored = True
                 elif pred.outdir is not None:
-                    drain_checkpoints()
+                    drain_checkpoints()                                         # (no best yet in this run: an older file)
                     restored = pred.load_checkpoint(ismpi=False)
                 if not restored:
                     reinit()
@@ -264,7 +266,8 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
                     print("early stop", flush=True)
                     print("learning rate", opt.lr, flush=True)
                     if rank == 0:
-                        _save(pred, model, opt, i, is_best, rank, checkpoint_every, num_epochs, force=True)
+                        ckpt.record(opt, i, is_best, checkpoint_every, num_epochs, force=True)
+                        last_epoch = i
                         break
                 if criteria == 3:
                     print("\n weight decay too small: {0}\n".format(opt.weight_decay), flush=True)
@@ -275,8 +278,9 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
             told = loss
         if is_best:
             best_state = model.flat_params().clone()                            # device-resident best.pth.tar
-        _save(pred, model, opt, i, is_best, rank, checkpoint_every, num_epochs)
-    drain_checkpoints()                             # best.pth.tar / last.pth.tar are on disk when train() returns
+        ckpt.record(opt, i, is_best, checkpoint_every, num_epochs)
+        last_epoch = i
+    ckpt.finish(opt, last_epoch)                    # best.pth.tar / last.pth.tar are on disk when train() returns
     if val_dataset is not None:
         return np.array(train_losses), np.array(val_metrics)
     return np.array(train_losses)
@@ -300,7 +304,10 @@ class _CheckpointWriter(object):
             item = self.q.get()
             try:
                 if item is not None and self.err is None:
-                    nnutils.save_checkpoint(*item)
+                    if item[0] == "file":
+                        nnutils.save_state(item[1], item[2])
+                    else:
+                        nnutils.save_checkpoint(*item)
             except Exception as e:                      # surfaced by drain()
                 self.err = e
             finally:
@@ -310,6 +317,9 @@ class _CheckpointWriter(object):
 
     def put(self, state, is_best, checkpoint):
         self.q.put((state, is_best, checkpoint))
+
+    def put_file(self, state, path):
+        self.q.put(("file", state, path))
 
     def drain(self):
         self.q.join()
@@ -326,18 +336,59 @@ def drain_checkpoints():
         _writer.drain()
 
 
-def _save(pred, model, opt, epoch, is_best, rank, every, num_epochs, force=False):
-    """predictor_gpu.py:405-419: last.pth.tar every epoch (here: every ``every`` epochs, always
-    when it is the best so far or the last), best.pth.tar on improvement."""
-    if pred.outdir is None or rank != 0:
-        return
-    if not (is_best or force or (epoch + 1) % max(every, 1) == 0 or epoch + 1 == num_epochs):
-        return
-    # ONE device->host copy of the flat parameter buffer (and one each of AdamW's m, v inside opt.state_dict):
-    # a .cpu() per tensor was 58 synchronising copies per epoch
-    host = model._flat.detach().cpu()
-    sd = {k: model._view(host, k).clone().contiguous() for k in model._index}
-    global _writer
-    if _writer is None:
-        _writer = _CheckpointWriter()
-    _writer.put({"epoch": epoch + 1, "state_dict": sd, "optim_dict": opt.state_dict()}, is_best, pred.outdir)
+class _Checkpoints(object):
+    """predictor_gpu.py:405-419 keeps last.pth.tar current every epoch and copies it to best.pth.tar on
+    improvement.  Here every epoch only RECORDS: the best state is a device-side copy (parameters, AdamW m / v,
+    step), and the files are (re)written at most every ``interval`` seconds and when training ends, by the
+    background writer -- pickling ~10 MB per epoch cost a third of the wall time of a training run.  After
+    ``train()`` returns the two files hold exactly what the reference's would (last epoch, best epoch);
+    a crash loses at most ``interval`` seconds (LINNA_CHECKPOINT_INTERVAL, 0 = write every epoch)."""
+
+    def __init__(self, pred, model, rank):
+        self.pred, self.model = pred, model
+        self.on = pred.outdir is not None and rank == 0
+        self.interval = float(os.environ.get("LINNA_CHECKPOINT_INTERVAL", "2.0"))
+        self.t_last = time.time()
+        self.best, self.best_dirty, self.last_epoch_written = None, False, -1
+
+    def record(self, opt, epoch, is_best, every, num_epochs, force=False):
+        if not self.on:
+            return
+        if is_best:
+            self.best = dict(epoch=epoch, p=self.model._flat.detach().clone(),
+                             opt=(opt.m.clone(), opt.v.clone(), opt.step_dev.clone(), opt.lr, opt.weight_decay))
+            self.best_dirty = True
+        due = is_best or force or (epoch + 1) % max(every, 1) == 0 or epoch + 1 == num_epochs
+        if force or epoch + 1 == num_epochs or (due and time.time() - self.t_last >= self.interval):
+            self.write(opt, epoch)
+
+    def _host_state(self, flat, epoch, optim_dict):
+        host = flat.detach().cpu()
+        sd = {k: self.model._view(host, k).clone().contiguous() for k in self.model._index}
+        return {"epoch": epoch + 1, "state_dict": sd, "optim_dict": optim_dict}
+
+    def write(self, opt, epoch):
+        global _writer
+        if _writer is None:
+            _writer = _CheckpointWriter()
+        out = self.pred.outdir
+        last = self._host_state(self.model._flat, epoch, opt.state_dict())
+        if self.best_dirty and self.best["epoch"] == epoch:
+            _writer.put(last, True, out)                                       # last.pth.tar + copy to best.pth.tar
+        else:
+            _writer.put(last, False, out)
+            if self.best_dirty:
+                b = self.best
+                _writer.put_file(self._host_state(b["p"], b["epoch"], opt.state_dict(snapshot=b["opt"])),
+                                 os.path.join(out, "best.pth.tar"))
+        self.best_dirty = False
+        self.t_last = time.time()
+        self.last_epoch_written = epoch
+
+    def finish(self, opt, epoch):
+        if self.on and (self.best_dirty or self.last_epoch_written != epoch) and epoch >= 0:
+            self.write(opt, epoch)
+        drain_checkpoints()
+
+
+
