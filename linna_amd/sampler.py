@@ -96,10 +96,11 @@ class DeviceChain(object):
             need -= len(out[-1])
         return torch.cat(out[::-1]) if len(out) > 1 else out[0]
 
-    def integrated_time(self, discard=0, c=5.0):
+    def integrated_time(self, discard=0, c=5.0, upto=None):
         """emcee's estimator (FFT autocorrelation averaged over walkers, Sokal window, tol=0) per
-        parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %)."""
-        nt_all, nd = len(self), self.blocks[0].shape[2]
+        parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %); ``upto``: only
+        the first ``upto`` steps (the chain as it was at an earlier check)."""
+        nt_all, nd = (len(self) if upto is None else int(upto)), self.blocks[0].shape[2]
         nt = nt_all - int(discard)
         nw = self.blocks[0].shape[1]
         n = _next_pow_two(nt)
@@ -109,7 +110,7 @@ class DeviceChain(object):
         # all walkers and as many parameters per FFT as ~1 GiB of complex128 allows; no host round trip inside
         per = max(1, min(nd, int((1 << 30) // max(1, 16 * 2 * n * nw))))
         for d0 in range(0, nd, per):
-            x = torch.cat([b[:, :, d0:d0 + per] for b in self.blocks])[int(discard):].to(torch.float64)   # [nt, nw, per]
+            x = torch.cat([b[:, :, d0:d0 + per] for b in self.blocks])[int(discard):nt_all].to(torch.float64)   # [nt, nw, per]
             x = x - x.mean(0, keepdim=True)
             f = torch.fft.rfft(x, n=2 * n, dim=0)
             acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=0)[:nt]
@@ -643,6 +644,7 @@ class HMCSampler(object):
         dchain = DeviceChain()                                               # convergence statistics stay on the GPU
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
+        next_check = 0
         while done < nsamp:
             c, l = ens.run(ncheck)
             th = ens.theta_of(c)
@@ -651,7 +653,16 @@ class HMCSampler(object):
             done += ncheck
             if incremental:
                 store.flush(final=False)
+            # The reference evaluates its criterion every `ncheck` iterations on the whole chain -- quadratic in
+            # the chain length (a 270 k-iteration run spent 15 of 17 minutes here).  Same criterion, evaluated at
+            # every check up to 2000 iterations and then whenever the chain has grown by 2 %: tau now against tau
+            # `ncheck` iterations earlier, exactly the pair the reference compares at that iteration.
+            if done > 2000 and done < next_check:
+                continue
+            next_check = int(done * 1.02)
             tau = dchain.integrated_time()                                    # sampler.py:538
+            if done > 2000 + ncheck:
+                old_tau = dchain.integrated_time(upto=done - ncheck)
             if np.isnan(np.sum(tau)) and done > 10:
                 break
             converged = np.all(tau * ntimes < done)                           # :545-547
@@ -693,6 +704,7 @@ class ZeusSampler(object):
         dchain = DeviceChain()
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
+        next_check = 0
         while done < min(nsamp, 100000):
             c, l = ens.run(ncheck)
             store.append(c.cpu().numpy(), ens.theta_of(c).cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
@@ -700,6 +712,12 @@ class ZeusSampler(object):
             done += ncheck
             if incremental:
                 store.flush(final=False)
+            if done > 2000 and done < next_check:           # checks thin out as in HMCSampler.sample (same criterion)
+                continue
+            next_check = int(done * 1.02)
+            if done > 2000 + ncheck:
+                prev = done - ncheck
+                old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev)))
             tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2))))   # discard=0.2, sampler.py:684,729
             converged = tau * ntimes < done
             converged &= abs(old_tau - tau) / tau < tautol

@@ -285,6 +285,8 @@ def test_device_convergence_statistics_match_host_estimators():
     xf = x.astype(np.float32).astype(np.float64)
     np.testing.assert_allclose(dc.integrated_time(), sampler.integrated_time(xf), rtol=1e-8)
     np.testing.assert_allclose(dc.integrated_time(discard=120), sampler.integrated_time(xf[120:]), rtol=1e-8)
+    np.testing.assert_allclose(dc.integrated_time(upto=450), sampler.integrated_time(xf[:450]), rtol=1e-8)
+    np.testing.assert_allclose(dc.integrated_time(discard=90, upto=450), sampler.integrated_time(xf[90:450]), rtol=1e-8)
     assert np.all(np.abs(dc.integrated_time() / ((1 + rho) / (1 - rho)) - 1) < 0.5)    # AR(1): tau = (1+rho)/(1-rho)
     for n in (40, 333):
         assert dc.checkmeanstd(n, 0.3, 0.3) == bool(sampler.checkmeanstd(xf[-n:], 0.3, 0.3))
