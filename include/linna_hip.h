@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 1
+#define LINNA_ABI_VERSION 2
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
