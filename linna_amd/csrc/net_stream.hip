@@ -20,7 +20,7 @@
 //  * ONE copy of the step loop serves every layer: the network is a small PROGRAM of segments.
 //
 // Program = list of segments, each a GEMM over the activation rows held in LDS:
-//   WIDE    N > 64: the N columns are split over the 8 waves in passes of 512 (wave w owns column
+//   WIDE    (N > 256, or a short K): the N columns are split over the 8 waves in passes of 512 (wave w owns column
 //           tiles 4w..4w+3 of a pass), every wave runs all K steps; epilogue bias(+ReLU) -> the
 //           OTHER activation buffer; one barrier after the last pass.
 //   SPLIT   N <= 256: the columns form ncg = 1, 2 or 4 groups of 64 and K is split over the
