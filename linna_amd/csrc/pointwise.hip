@@ -55,31 +55,52 @@ __global__ void prior_map_bwd_kernel(const float* __restrict__ Z, int ldz, int B
 }
 
 // ------------------------------------------------------------------ Gaussian log-likelihood
-// One wavefront per walker row: coalesced reads of d and z, shuffle reduction.
+// LPR lanes per walker row (a power of two: 64 for wide rows, down to 1): a wavefront covers 64/LPR
+// rows, so a 33-wide row costs 16 lanes, not a whole wavefront of mostly idle ones.  Coalesced
+// 16-byte reads of d, w and z when the rows are 16-byte aligned (ld multiple of 4), shuffle
+// reduction over the LPR lanes of a row.
 // out = (-0.5 * sum_j (d_j w_j) d_j)/T - 0.5 sum z^2 ; NaN -> -inf (util.py:953-955,1013-1016,1165)
+template <int LPR>
 __global__ __launch_bounds__(256) void loglike_diag_kernel(const float* __restrict__ D, int ldd, int B, int nout,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ Z, int ldz, int nin,
                                                            float T, float* __restrict__ out) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B) return;
-    const float* d = D + (size_t)row * ldd;
-    float acc = 0.f;
-    if ((ldd & 3) == 0 && (nout & 3) == 0 && ((reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(w)) & 15) == 0) {
-        for (int j = lane * 4; j < nout; j += 256) {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(d + j);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j);
+    constexpr int RPW = 64 / LPR;                                  // rows per wavefront
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool rok = row < B;
+    const int r = rok ? row : B - 1;                               // idle lanes read a valid row, store nothing
+    const float* d = D + (size_t)r * ldd;
+    const float* z = Z + (size_t)r * ldz;
+    float acc = 0.f, zz = 0.f;
+    const bool al = (ldd & 3) == 0 && ((reinterpret_cast<uintptr_t>(D) | reinterpret_cast<uintptr_t>(w)) & 15) == 0;
+    if (al) {
+        for (int j = sub * 4; j < nout; j += LPR * 4) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(d + j);   // (row padded to a multiple of 4: in bounds)
+            if (j + 3 < nout) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + j);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc += (dv[e] * wv[e]) * dv[e];
+                for (int e = 0; e < 4; ++e) acc += (dv[e] * wv[e]) * dv[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (j + e < nout) acc += (dv[e] * w[j + e]) * dv[e];
+            }
         }
     } else {
-        for (int j = lane; j < nout; j += 64) { const float dv = d[j]; acc += (dv * w[j]) * dv; }
+        for (int j = sub; j < nout; j += LPR) { const float dv = d[j]; acc += (dv * w[j]) * dv; }
     }
-    float zz = 0.f;
-    for (int j = lane; j < nin; j += 64) { const float zv = Z[(size_t)row * ldz + j]; zz += zv * zv; }
-    acc = wave_sum(acc);
-    zz = wave_sum(zz);
-    if (lane == 0) {
+    if ((ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(Z) & 15) == 0) {
+        for (int j = sub * 4; j < nin; j += LPR * 4) {
+            const f32x4 zv = *reinterpret_cast<const f32x4*>(z + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (j + e < nin) zz += zv[e] * zv[e];
+        }
+    } else {
+        for (int j = sub; j < nin; j += LPR) { const float zv = z[j]; zz += zv * zv; }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) { acc += __shfl_xor(acc, o, 64); zz += __shfl_xor(zz, o, 64); }
+    if (sub == 0 && rok) {
         const float v = (-0.5f * acc) / T + (-0.5f * zz);
         out[row] = isnan(v) ? -INFINITY : v;
     }
@@ -476,9 +497,21 @@ int launch_prior_map_bwd(const float* Z, int ldz, int B, int nin, const int* is_
                        a2, lg, xstd, dX, lddx, dZ, lddz);
     LAUNCH_CHECK("prior_map_bwd");
 }
+template <int LPR>
+static void launch_loglike_diag_lpr(const float* D, int ldd, int B, int nout, const float* w, const float* Z, int ldz, int nin,
+                                    float T, float* out, hipStream_t s) {
+    constexpr int rows_per_block = 4 * (64 / LPR);
+    hipLaunchKernelGGL(loglike_diag_kernel<LPR>, dim3((B + rows_per_block - 1) / rows_per_block), dim3(256), 0, s, D, ldd, B,
+                       nout, w, Z, ldz, nin, T, out);
+}
 int launch_loglike_diag(const float* D, int ldd, int B, int nout, const float* w, const float* Z, int ldz, int nin,
                         float T, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(loglike_diag_kernel, dim3((B + 3) / 4), dim3(256), 0, s, D, ldd, B, nout, w, Z, ldz, nin, T, out);
+    const int q = ((nout > nin ? nout : nin) + 3) / 4;            // 16-byte chunks of the longer of the two rows
+    if (q > 32) launch_loglike_diag_lpr<64>(D, ldd, B, nout, w, Z, ldz, nin, T, out, s);
+    else if (q > 16) launch_loglike_diag_lpr<32>(D, ldd, B, nout, w, Z, ldz, nin, T, out, s);
+    else if (q > 8) launch_loglike_diag_lpr<16>(D, ldd, B, nout, w, Z, ldz, nin, T, out, s);
+    else if (q > 4) launch_loglike_diag_lpr<8>(D, ldd, B, nout, w, Z, ldz, nin, T, out, s);
+    else launch_loglike_diag_lpr<4>(D, ldd, B, nout, w, Z, ldz, nin, T, out, s);
     LAUNCH_CHECK("loglike_diag");
 }
 int launch_loglike_finish(const float* partial, int slots_ld, int nslots, int B, const float* Z, int ldz, int nin,
