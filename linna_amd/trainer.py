@@ -70,32 +70,40 @@ class TrainEngine(object):
         return den
 
     # ------------------------------------------------------------------ one optimiser step
-    def _forward_loss_backward(self):
+    def _forward_loss_backward(self, rows=None, loss_out=None):
+        """``rows`` / ``loss_out``: device int32 row indices and a 1-float device slot for the mean loss; default the
+        engine's own fixed buffers (what a captured graph needs).  Direct launches pass the caller's tensors and save
+        two copy kernels per step."""
         k, st = self.k, _lib.stream()
-        _lib.call("linna_gather_xform", self.ctx, _lib.ptr(self.X), self.X.stride(0), _lib.iptr(self.rows), self.B, self.nin,
+        rows = self.rows if rows is None else rows
+        loss_out = self.loss_mean if loss_out is None else loss_out
+        _lib.call("linna_gather_xform", self.ctx, _lib.ptr(self.X), self.X.stride(0), _lib.iptr(rows), self.B, self.nin,
                   _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]),
                   _lib.ptr(self.xb), self.xb.stride(0), st)
         self.model.forward_buffer(self.xb, self.B, out=self.predb)
         _lib.call("linna_chi2_ratio_loss_fwd_bwd", self.ctx, C.byref(self.desc), _lib.ptr(self.predb), self.predb.stride(0),
-                  _lib.ptr(self.Y), self.Y.stride(0), _lib.ptr(self.den), _lib.iptr(self.rows), self.B,
-                  _lib.ptr(self.scratch), _lib.ptr(self.loss_rows), _lib.ptr(self.loss_mean), _lib.ptr(self.dpred),
+                  _lib.ptr(self.Y), self.Y.stride(0), _lib.ptr(self.den), _lib.iptr(rows), self.B,
+                  _lib.ptr(self.scratch), _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
                   self.dpred.stride(0), self.inv_batch, st)
         self.model.backward(self.dpred[:, :self.nout], param_grads=True)
 
-    def _step_body(self, opt):
-        self._forward_loss_backward()
+    def _step_body(self, opt, rows=None, loss_out=None):
+        self._forward_loss_backward(rows, loss_out)
         if self.world > 1:
             from . import dist as ldist
-            ldist.allreduce_grads(self.model.flat_grads(), self.loss_mean, self.group)   # RCCL over xGMI
+            ldist.allreduce_grads(self.model.flat_grads(), self.loss_mean if loss_out is None else loss_out, self.group)   # RCCL over xGMI
         opt.apply()
 
-    def step(self, opt, rows_dev):
-        """One optimiser step on the int32 device index vector ``rows_dev[B]``."""
-        self.rows.copy_(rows_dev, non_blocking=True)
+    def step(self, opt, rows_dev, loss_out=None):
+        """One optimiser step on the int32 device index vector ``rows_dev[B]``; the mean loss of the step lands in
+        ``loss_out`` (a 1-float device tensor) when given, in ``self.loss_mean`` otherwise."""
         if self.use_graph and self.graph is not None and self._graph_sig == (self.model.flat_params().data_ptr(), id(opt)):
+            self.rows.copy_(rows_dev, non_blocking=True)
             _lib.call("linna_graph_launch", self.graph, _lib.stream())
+            if loss_out is not None:
+                loss_out.copy_(self.loss_mean, non_blocking=True)
         else:
-            self._step_body(opt)
+            self._step_body(opt, rows_dev.contiguous(), loss_out)
 
     def prepare_graph(self, opt):
         """Capture one optimiser step.  Capture does not execute: parameters are untouched."""
@@ -211,8 +219,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
         mine = ldist.rank_batches(dataset.epoch_batches(), rank, size)   # same order on every rank (same seed)
         perm = torch.stack(mine).to(torch.int32).to(engine.dev) if nsteps else None
         for s in range(nsteps):
-            engine.step(opt, perm[s])                                           # :273-288
-            loss_hist[s:s + 1].copy_(engine.loss_mean, non_blocking=True)
+            engine.step(opt, perm[s], loss_hist[s:s + 1])                       # :273-288
         epoch_losses = loss_hist[:nsteps].cpu().numpy().astype(np.float64)
         train_losses.extend(epoch_losses.tolist())
         loss = float(epoch_losses[-1]) if nsteps else float("nan")
