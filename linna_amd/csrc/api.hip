@@ -72,6 +72,9 @@ struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
 
 struct linna_net {
     linna_ctx* ctx;
+    float* packed = nullptr;                 // fragment-order weight stream for the one-launch training forward, or null
+    unsigned long long packed_epoch = 0;
+    int stream_fwd = -1;                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
     std::vector<linna_layer_t> L;   // without the trailing INSKIP
     int in_size, out_size;
     bool has_inskip;
@@ -253,7 +256,11 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
     *out = n;
     return LINNA_OK;
 }
-int linna_net_destroy(linna_net_t* net) { delete net; return LINNA_OK; }
+int linna_net_destroy(linna_net_t* net) {
+    if (net && net->packed) (void)hipFree(net->packed);
+    delete net;
+    return LINNA_OK;
+}
 
 size_t linna_net_fwd_ws_bytes(const linna_net_t* n, int B) { return (fwd_layout(n, B).total + 16) * sizeof(float); }
 // backward scratch: one buffer per op for the gradient wrt that op's input (no reuse: the
@@ -276,6 +283,36 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
     float* w = static_cast<float*>(ws);
     const int nl = (int)n->L.size();
     if (nl > 1 && !w) { set_error("net_forward: workspace required"); return LINNA_ERR_INVALID; }
+    if (!om && !n->has_inskip) {
+        // ONE launch (net_stream.hip, STORE): at batch 500 the ten layer GEMMs are 10-30 us of latency each.  The
+        // fragment-order weight copy is re-laid whenever the weights moved (every optimiser step: ~10 us).
+        if (n->stream_fwd < 0) {
+            const char* e = getenv("LINNA_FWD_STREAM");
+            n->stream_fwd = !(e && e[0] == '0') && net_stream_eligible(n->L.data(), nl, n->in_size) ? 1 : 0;
+        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(S(stream), &cap);
+        if (n->stream_fwd == 1 && !n->packed && cap == hipStreamCaptureStatusNone) {
+            const size_t nf = net_stream_packed_floats(n->L.data(), nl, n->in_size);
+            if (hipMalloc(reinterpret_cast<void**>(&n->packed), nf * sizeof(float)) != hipSuccess) { n->packed = nullptr; n->stream_fwd = 0; }
+        }
+        if (n->stream_fwd == 1 && n->packed) {
+            const unsigned long long epoch = g_weights_epoch.load();
+            if (cap != hipStreamCaptureStatusNone || n->packed_epoch != epoch) {
+                TRY(launch_net_stream_pack(n->L.data(), nl, n->in_size, n->packed, S(stream)));
+                n->packed_epoch = cap != hipStreamCaptureStatusNone ? 0 : epoch;
+            }
+            std::vector<float*> y(nl), t(nl);
+            std::vector<int> ldy(nl), ldt(nl);
+            for (int i = 0; i < nl; ++i) {
+                const bool last = i == nl - 1;
+                y[i] = last ? OUT : w + f.y_off[i]; ldy[i] = last ? ldo : ld4(n->L[i].N);
+                t[i] = n->L[i].op == LINNA_OP_RESBLOCK ? w + f.t_off[i] : nullptr; ldt[i] = ld4(n->L[i].C);
+            }
+            return launch_net_stream_store(n->L.data(), nl, n->in_size, n->packed, X, ldx, B, y.data(), ldy.data(), t.data(),
+                                           ldt.data(), S(stream));
+        }
+    }
     const float* hin = X; int ldh = ldx;
     for (int i = 0; i < nl; ++i) {
         const linna_layer_t& l = n->L[i];

@@ -77,6 +77,9 @@ struct NsArgs {
     float* lnP; float* D; int ldd; float* TH; int ldt;
     unsigned long long* stamps;
     const int* gate;                    // optional: every workgroup leaves at once when gate[0] == 0 (speculatively queued rounds)
+    // STORE instantiation (training / validation forward, nn.py:110-133): the input rows are taken as they are
+    // (already X-transformed), every segment's output ALSO goes to global memory for the backward, no likelihood
+    float* gout[NS_MAXSEG]; int gld[NS_MAXSEG]; int gn[NS_MAXSEG];
     // stretch move fused around the evaluation (MOVE instantiation; emcee StretchMove behind sampler.py:493-495)
     float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
@@ -160,7 +163,11 @@ __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, flo
 // finish turns the output rows into d lnP / d out in place, and the SAME step loop runs on through the
 // backward segments -- W^T in fragment order, streamed right behind the forward weights -- ending in the
 // prior map's derivative.
-template <int R, bool MOVE, bool GRAD>
+// STORE: the forward pass of a training step in one launch.  The activations the backward needs (every op's
+// output, every residual block's hidden h) are written to global memory from the epilogues with inline-asm
+// stores: the compiler does not see them, so its counted vmcnt waits for the weight stream stay counted
+// (stores only ever make the hardware counter read higher, i.e. the waits conservative).
+template <int R, bool MOVE, bool GRAD, bool STORE>
 __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NT = NS_NT, NW = NS_NW;
     constexpr int RG = 32;                         // threads per walker row in prologue / reduce / finish
@@ -276,7 +283,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         asm volatile("" : "+v"(lt));
         theta[i] = th;
         const float t = (a.lg && zlg[i]) ? lt : th;
-        const float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
+        float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
+        if constexpr (STORE) x = z;                 // rows arrive transformed
         if (c < kpad0) act[pr * LD + c] = x;
     }
     // inputs wider than ZPRE*RG = 64 columns (none of the reference's models; <= 256 supported) and the zero
@@ -290,6 +298,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             const float th = ns_prior_theta(z, a.is_flat[c], a.a1[c], a.a2[c]);
             const float t = (a.lg && a.lg[c]) ? log10f(th) : th;
             x = (t - a.xmean[c]) / a.xstd[c];
+            if constexpr (STORE) x = z;
         }
         act[pr * LD + c] = x;
     }
@@ -317,6 +326,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl, s_mstore = 0, s_mapply = 0;
     unsigned* const lmask = reinterpret_cast<unsigned*>(lbias + ((a.bias_total + 3) & ~3));   // GRAD: [slot][512 lanes]
     float lnp_grad = 0.f;                          // GRAD: lnP, stored at the very end (no store next to the weight loads)
+    float* s_gout = nullptr; int s_gld = 0, s_gn = 0;   // STORE: global destination of the current segment's output
+    auto gstore = [&](float* p, float v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory"); };
     uint32_t ap;
     auto a_read = [&](f32x4& dst) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ap) : "memory");
@@ -327,6 +338,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         s_type = S.type; kleft = s_steps = S.steps; s_passes = S.passes; s_bias = S.bias_off;
         s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2;
         if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
+        if constexpr (STORE) { s_gout = a.gout[si]; s_gld = a.gld[si]; s_gn = a.gn[si]; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         if (s_type == NS_WIDE) {
@@ -374,11 +386,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             // ---- end of run (si, pass).  The next segment's descriptor is requested first: the scalar
             // load's latency then hides under the epilogue stores and the barrier.
             const NsSeg NX = a.seg[min(si + 1, nseg - 1)];
+            float* nx_gout = nullptr; int nx_gld = 0, nx_gn = 0;
+            if constexpr (STORE) { const int j = min(si + 1, nseg - 1); nx_gout = a.gout[j]; nx_gld = a.gld[j]; nx_gn = a.gn[j]; }
             const int cur_steps = s_steps;
             auto take_next = [&]() {
                 s_type = NX.type; s_steps = NX.steps; s_passes = NX.passes; s_bias = NX.bias_off;
                 s_dst = NX.dst_col; s_relu = NX.relu; s_kslice = NX.kslice; s_zext = NX.zext; s_ncgl = NX.ncg_log2;
                 if constexpr (GRAD) { s_mstore = NX.mask_store; s_mapply = NX.mask_apply; }
+                if constexpr (STORE) { s_gout = nx_gout; s_gld = nx_gld; s_gn = nx_gn; }
                 kleft = NX.steps;
             };
             bool seg_done = true;
@@ -402,7 +417,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     for (int e = 0; e < 4; ++e) {  // C/D layout: col = lane&15, row = 4*(lane>>4) + e
                         float v = acc[t][e];
                         if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
-                        nxt[(4 * kq + e) * LD + 16 * t] = s_relu ? fmaxf(v, 0.f) : v;
+                        v = s_relu ? fmaxf(v, 0.f) : v;
+                        nxt[(4 * kq + e) * LD + 16 * t] = v;
+                        if constexpr (STORE) {
+                            const int grow_ = row0 + 4 * kq + e, gcol = 16 * (32 * pass + 4 * wave + t) + li;
+                            if (s_gout && grow_ < a.B && gcol < s_gn) gstore(s_gout + (size_t)grow_ * s_gld + gcol, v);
+                        }
                     }
                 if (++pass == s_passes) {
                     lds_barrier();
@@ -436,6 +456,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         for (int kp = 0; kp < NW; ++kp) v += kp < nkp ? x[kp] : 0.f;
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
+                        if constexpr (STORE) {
+                            if (s_gout && row0 + pr < a.B && c < s_gn) gstore(s_gout + (size_t)(row0 + pr) * s_gld + c, v);
+                        }
                     }
                     cur[c] = v;
                 }
@@ -485,6 +508,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the last speculative A read
     NS_STAMP();
 
+    if constexpr (STORE) return;                    // every output is in global memory already
     // ---- 5 (GRAD). d lnP / d x sits in buffer P: the derivative of the input transform and of the prior map
     // (util.py:339-347, 483-497), minus z for the Gaussian prior term; lnP from the turnaround
     if constexpr (GRAD) {
@@ -561,6 +585,7 @@ struct NsProgram {
     int Gstride = 0, nseg_f = 0, mask_slots = 0;            // G: forward steps; Gstride: forward + backward steps
     size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;
     bool ok = false, grad_ok = false;                       // grad_ok: backward segments appended (ReLU MLPs)
+    std::vector<int> seg_op, seg_hidden;                    // forward segments: op index; 1 = the hidden h of a residual block
 };
 
 static int ceil16(int k) { return (k + 15) & ~15; }
@@ -577,7 +602,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     if (nl < 1 || in_size < 1 || in_size > 256) return p;
     // 1. linear maps: [Wa | alpha Wb] over K = [Kapad ; Kb], N outputs, written to dst_col (same_buf: into the input's buffer)
     struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
-                 int N, relu, dst_col; bool same_buf; int transA = 0; int force_wide = 0; int mask_apply_of = -1; };
+                 int N, relu, dst_col; bool same_buf; int transA = 0; int force_wide = 0; int mask_apply_of = -1; int op = -1; };
     std::vector<Lin> lins;
     int width = in_size;
     for (int i = 0; i < nl; ++i) {
@@ -586,11 +611,14 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         if (l.op == LINNA_OP_LINEAR) {
             if (l.alpha != 1.f || l.N < 1 || l.N > 1024) return p;
             lins.push_back(Lin{l.W, (l.K + 3) & ~3, l.K, ceil16(l.K), nullptr, 0, 0, 0.f, l.b, 1.f, l.N, l.relu, 0, false});
+            lins.back().op = i;
         } else if (l.op == LINNA_OP_RESBLOCK) {
             if (l.C < 1 || l.C > 64 || l.N < 1 || l.N > 1024 || (!l.Ws && l.K != l.N)) return p;
             const int inpad = ceil16(l.K);
             lins.push_back(Lin{l.W1, (l.K + 3) & ~3, l.K, inpad, nullptr, 0, 0, 0.f, l.b1, 1.f, l.C, 1, inpad, true});   // h behind x
+            lins.back().op = i;
             lins.push_back(Lin{l.Ws, (l.K + 3) & ~3, l.K, inpad, l.W2, (l.C + 3) & ~3, l.C, 0.1f, l.b2, 0.1f, l.N, 1, 0, false});
+            lins.back().op = i;
         } else {
             return p;
         }
@@ -708,6 +736,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     if (p.kpad0 > 256) return p;
     p.nout = lins[nfwd - 1].N;
     p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
+    for (int i = 0; i < nfwd; ++i) { p.seg_op.push_back(lins[i].op); p.seg_hidden.push_back(lins[i].same_buf ? 1 : 0); }
     p.bias_total = bias_off;
     p.LD = ((maxext + 63) & ~63) + 4;
     if (NS_ROWS * p.LD < 8192 + 64) return p;               // SPLIT partials need [8][16][64] floats in one buffer
@@ -752,16 +781,16 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     return check_hip(hipGetLastError(), "net_stream pack launch");
 }
 
-template <bool MOVE, bool GRAD>
+template <bool MOVE, bool GRAD, bool STORE = false>
 static int ns_launch_kernel(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE, GRAD>),
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE, GRAD, STORE>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS_LDS_BYTES), "hipFuncSetAttribute");
         if (rc != LINNA_OK) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
+    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD, STORE>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
     return check_hip(hipGetLastError(), "net_stream launch");
 }
 
@@ -803,6 +832,30 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         return ns_launch_kernel<false, true>(a, B, p.lds_bytes_grad, s);
     }
     return ns_launch_kernel<false, false>(a, B, p.lds_bytes, s);
+}
+
+// Training / validation forward: X[B][ldx] (transformed inputs) -> every op's output in global memory.
+// `y[i]`, `ldy[i]`: destination of op i's output; `t[i]`, `ldt[i]`: of the hidden h of residual block i.
+int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
+                            int B, float* const* y, const int* ldy, float* const* t, const int* ldt, hipStream_t s) {
+    const NsProgram p = ns_build(layers, nl, in_size);
+    if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
+    NsArgs a;
+    ::memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.Z = X; a.ldz = ldx; a.B = B; a.nin = in_size;
+    // the prologue's transform constants are loaded (and ignored): any readable arrays of >= in_size entries
+    a.is_flat = reinterpret_cast<const int*>(X); a.a1 = X; a.a2 = X; a.lg = nullptr; a.xmean = X; a.xstd = X;
+    a.packed = packed;
+    a.Gstride = p.Gstride; a.nseg_f = p.nseg_f; a.G = p.G; a.nseg = p.nseg_f;
+    a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
+    a.T = 1.f;
+    for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
+    for (int i = 0; i < p.nseg_f; ++i) {
+        const int op = p.seg_op[i];
+        if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
+        else { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
+    }
+    return ns_launch_kernel<false, false, true>(a, B, p.lds_bytes, s);
 }
 
 }  // namespace linna
