@@ -412,8 +412,10 @@ static int pick_cfg(int M, int N, int flags = 0) {
         return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn);
     };
     // 64x64 workgroups are the default (measured: they beat single-wave 32x32 tiles even when they
-    // leave CUs idle, tools/gemm_bench.py); 128x64 only once 64x64 already oversubscribes the chip;
-    // 32x32 for outputs that fit a single such tile.
+    // leave CUs idle, tools/gemm_bench.py; 32x64 two-wave tiles that double the grid gain nothing either:
+    // a wave's 32x32x32 chain of sixteen 64-cycle MFMAs per K tile is the unit of time, and only a
+    // 16x16x4-based split of the tile over more SIMDs would shorten it); 128x64 only once 64x64 already
+    // oversubscribes the chip; 32x32 for outputs that fit a single such tile.
     if (tiles(1) >= 2048) return 0;
     if (M <= 32 && N <= 32) return 2;
     return 1;

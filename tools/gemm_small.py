@@ -8,8 +8,9 @@ from linna_amd import _lib
 
 
 def time_gemm(M, N, K, alay, blay, flags, iters=50):
-    A = torch.randn((M, K) if alay == 0 else (K, M), device="cuda")
-    W = torch.randn((N, K) if blay == 0 else (K, N), device="cuda")
+    pad = lambda n: (n + 3) & ~3                      # rows padded to 16 bytes as the library's own buffers are
+    A = torch.randn((M, pad(K)) if alay == 0 else (K, pad(M)), device="cuda")
+    W = torch.randn((N, pad(K)) if blay == 0 else (K, pad(N)), device="cuda")
     out = torch.empty((M, _lib.ld4(N)), device="cuda")
     g = _lib.Gemm()
     g.npairs, g.alpha0, g.M, g.N = 1, 1.0, M, N
@@ -34,6 +35,8 @@ shapes = [(500, 1000, 33, 0, 0), (500, 16, 1000, 0, 0), (500, 500, 1016, 0, 0), 
           (500, 500, 128, 0, 0), (500, 33, 500, 0, 0), (500, 33, 33, 0, 0),
           (500, 1000, 500, 0, 1), (500, 1000, 16, 0, 1), (500, 500, 33, 0, 1),
           (500, 1000, 500, 1, 1), (16, 1000, 500, 1, 1), (33, 33, 500, 1, 1), (1000, 33, 500, 1, 1)]
+shapes += [(500, 1000, 512, 0, 1), (500, 512, 256, 0, 1), (500, 256, 128, 0, 1), (500, 500, 1016, 0, 0), (500, 250, 544, 0, 0),
+           (4096, 16, 1000, 0, 0), (4096, 500, 1016, 0, 0)]
 print("%-28s %10s %10s" % ("M, N, K, alay, blay", "no K split", "auto"))
 for sh in shapes:
     a = min(time_gemm(*sh, 0x80) for _ in range(3)); b = min(time_gemm(*sh, 0) for _ in range(3))
