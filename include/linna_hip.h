@@ -217,6 +217,12 @@ int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void
  * needed (the ensemble slice sampler's stepping-out / shrinking rounds). */
 int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
                           float* THETA, int ldt, const int* gate, void* stream);
+/* lnP at the ensemble slice sampler's trial points  coords[S[k]] + w[j*ns + k] * DIR[k]  (j < nrep), in ONE
+ * launch and without writing the points to memory (= linna_slice_points + linna_logprob_eval_if).  lnP[nrep*ns].
+ * LINNA_ERR_UNSUPPORTED under the conditions of linna_stretch_half_step: the caller then uses the two entries. */
+int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx,
+                                    int ns, const float* DIR, int ldd, const float* w, int nrep, float* lnP,
+                                    const int* gate, void* stream);
 /* lnP[B] and d lnP / d z [B][ldg]  (intended semantics of util.py:1023-1035; HMCSampler.py:32). */
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
                        float* G, int ldg, void* stream);

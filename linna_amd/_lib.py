@@ -108,6 +108,7 @@ _SIGNATURES = {
     "linna_stretch_propose": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _F, _V, _I, _V, _V]),
     "linna_stretch_accept": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _V, _U64, _V, _I, _V, _V]),
     "linna_logprob_eval_if": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V, _V]),
+    "linna_logprob_eval_slice_points": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V]),
     "linna_stretch_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _I, _F, _V, _V]),
     "linna_hmc_init": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V]),
     "linna_hmc_kick_drift": (_I, [_V, _I, _I, _V, _F, _F, _V, _I, _V, _I, _V, _I, _V]),

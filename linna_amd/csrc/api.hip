@@ -668,6 +668,26 @@ int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, v
     return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false, gate);
 }
 
+int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
+                                    const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
+                                    void* stream) {
+    if (!lp || !coords || !S_idx || !DIR || !w || !lnP || ns < 1 || nrep < 1) {
+        set_error("logprob_eval_slice_points: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    const linna_logprob_desc_t& d = lp->d;
+    if (ndim != d.nin) { set_error("logprob_eval_slice_points: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
+    if (!fused_enabled() || !lp->packed || d.outmap.cexp || !d.w || d.nin > 64) {
+        set_error("logprob_eval_slice_points: this log-probability does not run the whole-network kernel");
+        return LINNA_ERR_UNSUPPORTED;          // the caller falls back to linna_slice_points + linna_logprob_eval_if
+    }
+    TRY(lp_refresh_stream(lp, stream));
+    const linna_net* n = lp->net;
+    NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, nullptr, ns, 0ull, nullptr, 0, 0, 0.f, nullptr, 1};
+    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
+                             d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
+                             lnP, nullptr, 0, nullptr, 0, &mv, nullptr, gate, S(stream));
+}
+
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                             const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
                             int step_offset, int stream_id, float a, int* naccept, void* stream) {
@@ -682,7 +702,7 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     }
     TRY(lp_refresh_stream(lp, stream));
     const linna_net* n = lp->net;
-    NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept};
+    NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept, 0};
     return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
                              nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, S(stream));

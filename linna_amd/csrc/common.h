@@ -110,11 +110,14 @@ int launch_step_increment(int* step, hipStream_t s);
 bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size);
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size);
 int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, hipStream_t s);
-// stretch move fused around the evaluation: rows of the batch are the walkers S[0..B)
+// sampler moves fused around the evaluation.  slice == 0: stretch half step, rows of the batch are the walkers
+// S[0..B).  slice == 1: rows are the slice sampler's trial points coords[S[k]] + cc[row] * DIR[k], k = row % nc
+// (DIR is passed as the launch's Z / ldz; cc = w[nrep * ns], nc = ns; nothing is written back).
 struct NsMove {
     float* coords; int ldc; float* logp; const int* S;
     const float* cc; int ldcc; const int* C; int nc;
     unsigned long long seed; const int* step; int step_off; int stream; float a; int* naccept;
+    int slice;
 };
 // training / validation forward: every op's output stored for the backward (STORE instantiation)
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,

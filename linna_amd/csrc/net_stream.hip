@@ -167,7 +167,7 @@ __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, flo
 // output, every residual block's hidden h) are written to global memory from the epilogues with inline-asm
 // stores: the compiler does not see them, so its counted vmcnt waits for the weight stream stay counted
 // (stores only ever make the hardware counter read higher, i.e. the waits conservative).
-template <int R, bool MOVE, bool GRAD, bool STORE>
+template <int R, int MOVE, bool GRAD, bool STORE>
 __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NT = NS_NT, NW = NS_NW;
     constexpr int RG = 32;                         // threads per walker row in prologue / reduce / finish
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     float zr[ZPRE], za1[ZPRE], za2[ZPRE], zxm[ZPRE], zxs[ZPRE]; int zfl[ZPRE], zlg[ZPRE];
     const int* const lgp = a.lg ? a.lg : a.is_flat;
     int mv_wk = 0; float mv_factor = 0.f, mv_lnp_old = 0.f, mv_logu = 0.f;
-    if constexpr (MOVE) {
+    if constexpr (MOVE == 1) {
         mv_wk = a.mv_S[grow];
         const U4 rb = walker_bits(a.mv_seed, (uint32_t)mv_wk, (uint32_t)(a.mv_step[0] + a.mv_step_off), (uint32_t)a.mv_stream, 0u);
         const float t = (a.mv_a - 1.f) * u01(rb.x) + 1.f;
@@ -216,10 +216,22 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             zr[i] = cr - (cr - sx) * zf;
         }
     }
+    if constexpr (MOVE == 2) {
+        // trial points of the ensemble slice sampler, never written to memory: row j*ns + k is
+        // coords[S[k]] + w[j*ns + k] * DIR[k]   (what linna_slice_points materialises)
+        const int k = grow % a.mv_nc;                                   // mv_nc: ns (walkers per half ensemble)
+        const int wk = a.mv_S[k];
+        const float wgt = a.mv_cc[grow];                                // mv_cc: w[nrep * ns]
+#pragma unroll
+        for (int i = 0; i < ZPRE; ++i) {
+            const int c = min(pc0 + i * RG, nin - 1);
+            zr[i] = a.mv_coords[(size_t)wk * a.mv_ldc + c] + wgt * a.Z[(size_t)k * a.ldz + c];   // Z: DIR[ns][ldz]
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ZPRE; ++i) {
         const int c = min(pc0 + i * RG, nin - 1);
-        if constexpr (!MOVE) zr[i] = a.Z[(size_t)grow * a.ldz + c];
+        if constexpr (MOVE == 0) zr[i] = a.Z[(size_t)grow * a.ldz + c];
         zfl[i] = a.is_flat[c]; za1[i] = a.a1[c]; za2[i] = a.a2[c];
         zlg[i] = lgp[c]; zxm[i] = a.xmean[c]; zxs[i] = a.xstd[c];
     }
@@ -550,7 +562,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         float lnp_new = (-0.5f * chi) / a.T + (-0.5f * zz);
         lnp_new = isnan(lnp_new) ? -INFINITY : lnp_new;
         if (a.lnP && a.w && pc0 == 0 && rok) a.lnP[row0 + pr] = lnp_new;
-        if constexpr (MOVE) {
+        if constexpr (MOVE == 1) {
             // Metropolis test of the stretch move (linna_stretch_accept); every lane of the row agrees
             if (rok && mv_factor + lnp_new - mv_lnp_old > mv_logu) {
 #pragma unroll
@@ -781,7 +793,7 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     return check_hip(hipGetLastError(), "net_stream pack launch");
 }
 
-template <bool MOVE, bool GRAD, bool STORE = false>
+template <int MOVE, bool GRAD, bool STORE = false>
 static int ns_launch_kernel(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -802,7 +814,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
-    if (mv && (nin > 64 || !w)) { set_error("net_stream: fused stretch move needs <= 64 parameters and a diagonal covariance"); return LINNA_ERR_UNSUPPORTED; }
+    if (mv && (nin > 64 || !w)) { set_error("net_stream: fused sampler moves need <= 64 parameters and a diagonal covariance"); return LINNA_ERR_UNSUPPORTED; }
     if (gr && (!p.grad_ok || !w || !lnP || !gr->gscale || !gr->G || mv)) { set_error("net_stream: no fused gradient for this network / likelihood"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -825,13 +837,14 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         a.mv_coords = mv->coords; a.mv_ldc = mv->ldc; a.mv_logp = mv->logp; a.mv_S = mv->S;
         a.mv_cc = mv->cc; a.mv_ldcc = mv->ldcc; a.mv_C = mv->C; a.mv_nc = mv->nc;
         a.mv_seed = mv->seed; a.mv_step = mv->step; a.mv_step_off = mv->step_off; a.mv_stream = mv->stream; a.mv_a = mv->a; a.mv_naccept = mv->naccept;
-        return ns_launch_kernel<true, false>(a, B, p.lds_bytes, s);
+        if (mv->slice) return ns_launch_kernel<2, false>(a, B, p.lds_bytes, s);
+        return ns_launch_kernel<1, false>(a, B, p.lds_bytes, s);
     }
     if (gr) {
         a.gscale = gr->gscale; a.Gout = gr->G; a.ldg = gr->ldg;
-        return ns_launch_kernel<false, true>(a, B, p.lds_bytes_grad, s);
+        return ns_launch_kernel<0, true>(a, B, p.lds_bytes_grad, s);
     }
-    return ns_launch_kernel<false, false>(a, B, p.lds_bytes, s);
+    return ns_launch_kernel<0, false>(a, B, p.lds_bytes, s);
 }
 
 // Training / validation forward: X[B][ldx] (transformed inputs) -> every op's output in global memory.
@@ -855,7 +868,7 @@ int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, co
         if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
         else { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
     }
-    return ns_launch_kernel<false, false, true>(a, B, p.lds_bytes, s);
+    return ns_launch_kernel<0, false, true>(a, B, p.lds_bytes, s);
 }
 
 }  // namespace linna

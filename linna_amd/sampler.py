@@ -431,7 +431,10 @@ class SliceEnsembleSampler(EnsembleSampler):
         self.tune, self.tolerance, self.patience, self.maxsteps, self.maxiter = tune, tolerance, patience, maxsteps, maxiter
         self._tune_count = 0
         self.DIR, self.Q2 = z(ns, self.ld), z(2 * ns, self.ld)
-        self.Z0, self.L, self.R, self.Wacc, self.Zacc = z(ns), z(ns), z(ns), z(ns), z(ns)
+        self.Z0, self.Wacc, self.Zacc = z(ns), z(ns), z(ns)
+        self.LR = z(2 * ns)                              # bracket ends, contiguous: both evaluated in one launch
+        self.L, self.R = self.LR[:ns], self.LR[ns:]
+        self.fused_points = None                         # None: try linna_logprob_eval_slice_points first
         self.ntrial = 2                                  # shrink trials per round (2 x nw/2 points = one full launch)
         self.W = z(self.ntrial * ns)
         self.Z2 = z(2 * ns)
@@ -478,6 +481,24 @@ class SliceEnsembleSampler(EnsembleSampler):
         _lib.call("linna_logprob_eval_if", p["handle"], _lib.ptr(Q), Q.stride(0), B, _lib.ptr(self.lp._workspace(B, False)),
                   _lib.ptr(Z), None, 0, gate, _lib.stream())
 
+    def _eval_points(self, S, w, nrep, gate):
+        """lnP at coords[S[k]] + w[j*ns + k] DIR[k] into Z2[:nrep*ns]: one launch that never writes the points when
+        the whole-network kernel serves this log-probability, else linna_slice_points + the gated evaluation."""
+        ns, st, P = self.half, _lib.stream(), _lib.ptr
+        if self.fused_points is not False:
+            rc = _lib.load().linna_logprob_eval_slice_points(
+                self.lp._ensure()["handle"], P(self.coords), self.ld, self.ndim, _lib.iptr(S), ns, P(self.DIR), self.ld,
+                P(w), nrep, P(self.Z2), gate, st)
+            if rc == 0:
+                self.fused_points = True
+                return
+            if rc != _lib.ERR_UNSUPPORTED or self.fused_points is True:
+                _lib.check(rc)
+            self.fused_points = False
+        _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, self.ndim, _lib.iptr(S), ns, P(self.DIR), self.ld,
+                  P(w), P(self.Q2), self.ld, nrep, st)
+        self._eval_if(self.Q2[:nrep * ns], self.Z2[:nrep * ns], gate)
+
     def step(self):
         st, ns, ndim = _lib.stream(), self.half, self.ndim
         halves = self._splits()
@@ -495,11 +516,7 @@ class SliceEnsembleSampler(EnsembleSampler):
                       P(self.R), _lib.iptr(self.flags), st)
 
             def expand_round(r, slot, gate):            # stepping out, both ends per round
-                _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
-                          self.ld, P(self.L), P(self.Q2), self.ld, 1, st)
-                _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
-                          self.ld, P(self.R), C.c_void_p(self.Q2.data_ptr() + 4 * ns * self.ld), self.ld, 1, st)
-                self._eval_if(self.Q2, self.Z2, gate)
+                self._eval_points(S, self.LR, 2, gate)
                 self.neval += 2 * ns
                 _lib.call("linna_slice_expand", self.ctx, P(self.Z0), P(self.Z2), C.c_void_p(self.Z2.data_ptr() + 4 * ns),
                           P(self.L), P(self.R), _lib.iptr(self.flags), ns, _lib.iptr(self.counters), slot, st)
@@ -511,9 +528,7 @@ class SliceEnsembleSampler(EnsembleSampler):
             def shrink_round(r, slot, gate):
                 _lib.call("linna_slice_draw", self.ctx, P(self.L), P(self.R), _lib.iptr(S), P(self.W), _lib.iptr(self.flags),
                           ns, seed, _lib.iptr(self.step_dev), 2 + h, r * nt, nt, st)
-                _lib.call("linna_slice_points", self.ctx, P(self.coords), self.ld, ndim, _lib.iptr(S), ns, P(self.DIR),
-                          self.ld, P(self.W), P(self.Q2), self.ld, nt, st)
-                self._eval_if(self.Q2[:nt * ns], self.Z2[:nt * ns], gate)
+                self._eval_points(S, self.W, nt, gate)
                 self.neval += nt * ns
                 _lib.call("linna_slice_shrink", self.ctx, P(self.Z0), P(self.Z2), P(self.L), P(self.R), P(self.W),
                           _lib.iptr(self.flags), P(self.Wacc), P(self.Zacc), ns, _lib.iptr(self.counters), slot, nt, st)

@@ -340,3 +340,22 @@ def test_posterior_matches_cpu_oracle_chain():
     assert np.max(np.abs(qg - qc) / sd) < 0.08, np.abs(qg - qc) / sd
     core = lambda a: a[np.all(np.abs(a - qc[2]) < 5 * sd, axis=1)]
     assert np.abs(np.corrcoef(core(gpu).T) - np.corrcoef(core(cpu).T)).max() < 0.06
+
+
+def test_slice_sampler_fused_trial_points_are_bit_identical():
+    """linna_logprob_eval_slice_points (trial points built in the kernel's prologue, never written) against
+    linna_slice_points + linna_logprob_eval_if: the same arithmetic, so the chains must be EQUAL."""
+    from linna_amd import sampler
+    lp, pred, yinv, prob = build_logprob("mlp_33_33", 2.0)
+    nw, nd = 96, 33
+    x0 = (0.3 * np.random.RandomState(8).standard_normal((nw, nd))).astype(np.float32)
+    a = sampler.SliceEnsembleSampler(nw, nd, lp, seed=4)
+    b = sampler.SliceEnsembleSampler(nw, nd, lp, seed=4)
+    b.fused_points = False
+    a.set_state(x0); b.set_state(x0)
+    for _ in range(5):
+        a.step(); b.step()
+    torch.cuda.synchronize()
+    assert a.fused_points is True and b.fused_points is False
+    assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp)
+    assert a.mu == b.mu and a.neval == b.neval
