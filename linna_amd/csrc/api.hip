@@ -283,7 +283,7 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
     float* w = static_cast<float*>(ws);
     const int nl = (int)n->L.size();
     if (nl > 1 && !w) { set_error("net_forward: workspace required"); return LINNA_ERR_INVALID; }
-    if (!om && !n->has_inskip) {
+    if ((!om || !om->cexp) && !n->has_inskip) {
         // ONE launch (net_stream.hip, STORE): at batch 500 the ten layer GEMMs are 10-30 us of latency each.  The
         // fragment-order weight copy is re-laid whenever the weights moved (every optimiser step: ~10 us).
         if (n->stream_fwd < 0) {
@@ -310,7 +310,7 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
                 t[i] = n->L[i].op == LINNA_OP_RESBLOCK ? w + f.t_off[i] : nullptr; ldt[i] = ld4(n->L[i].C);
             }
             return launch_net_stream_store(n->L.data(), nl, n->in_size, n->packed, X, ldx, B, y.data(), ldy.data(), t.data(),
-                                           ldt.data(), S(stream));
+                                           ldt.data(), om ? om->cscale : nullptr, om ? om->cshift : nullptr, S(stream));
         }
     }
     const float* hin = X; int ldh = ldx;

@@ -121,7 +121,8 @@ struct NsMove {
 };
 // training / validation forward: every op's output stored for the backward (STORE instantiation)
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
-                            int B, float* const* y, const int* ldy, float* const* t, const int* ldt, hipStream_t s);
+                            int B, float* const* y, const int* ldy, float* const* t, const int* ldt, const float* cscale,
+                            const float* cshift, hipStream_t s);
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
 struct NsGrad { const float* gscale; float* G; int ldg; };
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);

@@ -433,7 +433,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         nxt[(4 * kq + e) * LD + 16 * t] = v;
                         if constexpr (STORE) {
                             const int grow_ = row0 + 4 * kq + e, gcol = 16 * (32 * pass + 4 * wave + t) + li;
-                            if (s_gout && grow_ < a.B && gcol < s_gn) gstore(s_gout + (size_t)grow_ * s_gld + gcol, v);
+                            if (s_gout && grow_ < a.B && gcol < s_gn) {
+                                float vs = v;                      // the network's last output carries the column affine
+                                if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[gcol] : 1.f) + (a.cshift ? a.cshift[gcol] : 0.f);
+                                gstore(s_gout + (size_t)grow_ * s_gld + gcol, vs);
+                            }
                         }
                     }
                 if (++pass == s_passes) {
@@ -469,7 +473,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
                         if constexpr (STORE) {
-                            if (s_gout && row0 + pr < a.B && c < s_gn) gstore(s_gout + (size_t)(row0 + pr) * s_gld + c, v);
+                            if (s_gout && row0 + pr < a.B && c < s_gn) {
+                                float vs = v;
+                                if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[c] : 1.f) + (a.cshift ? a.cshift[c] : 0.f);
+                                gstore(s_gout + (size_t)(row0 + pr) * s_gld + c, vs);
+                            }
                         }
                     }
                     cur[c] = v;
@@ -850,7 +858,8 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
 // Training / validation forward: X[B][ldx] (transformed inputs) -> every op's output in global memory.
 // `y[i]`, `ldy[i]`: destination of op i's output; `t[i]`, `ldt[i]`: of the hidden h of residual block i.
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
-                            int B, float* const* y, const int* ldy, float* const* t, const int* ldt, hipStream_t s) {
+                            int B, float* const* y, const int* ldy, float* const* t, const int* ldt, const float* cscale,
+                            const float* cshift, hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
@@ -862,6 +871,7 @@ int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, co
     a.Gstride = p.Gstride; a.nseg_f = p.nseg_f; a.G = p.G; a.nseg = p.nseg_f;
     a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
     a.T = 1.f;
+    a.cscale = cscale; a.cshift = cshift;                   // column affine of the last output (Y transforms), or null
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
     for (int i = 0; i < p.nseg_f; ++i) {
         const int op = p.seg_op[i];

@@ -31,8 +31,14 @@ def problem(kind, nin, nout, dense, seed=1, **kw):
 
 
 def timeit(fn, n, warm=10):
-    for _ in range(warm):
-        fn()
+    # warm up for at least 0.4 s of wall time: after the host-side problem set-up the GPU sits at idle clocks and
+    # the first ~50 ms of work run 2-3x slow (tools/grad_timing.py), which swamps a 50-iteration timing window
+    t_end = time.perf_counter() + 0.4
+    k = 0
+    while k < warm or time.perf_counter() < t_end:
+        fn(); k += 1
+        if k % 16 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
