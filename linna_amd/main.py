@@ -102,7 +102,7 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
                 with open(os.path.join(outdir_in, "finish.pkl"), "wb") as f:     # train_gpu.py:36-38
                     pickle.dump([True], f)
         model, y_invtransform_data = retrieve_model(outdir_in, len(init), len(data), nnmodel_in)
-        if os.path.isfile(os.path.join(outdir_in, filename[:-3] + ".npz")):      # main.py:273-274
+        if any(os.path.isfile(os.path.join(outdir_in, filename[:-3] + ext)) for ext in (".h5", ".npz")):   # main.py:273-274
             continue
         log_prob = Log_prob(data.astype(np.float32), inv_cov.astype(np.float32), model, y_invtransform_data, transform,
                             temperature, nograd=True, loglikelihoodfunc=loglikelihoodfunc or gaussianlogliklihood,

@@ -22,7 +22,7 @@ import os
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, h5lite
 
 __all__ = ["EnsembleSampler", "SliceEnsembleSampler", "BatchedHMC", "HMCSampler", "ZeusSampler", "checkmeanstd", "integrated_time",
            "ChainStore", "DeviceChain", "read_chain_and_cut"]
@@ -149,25 +149,40 @@ def checkmeanstd(samples, meanshift, stdshift):
 
 # ------------------------------------------------------------------ chain storage
 class ChainStore(object):
-    """Chain backend.  The reference stores emcee/zeus HDF5 files (``chemcee_256.h5`` with
-    ``chain``, ``chain_transformed``, ``log_prob``, ``accepted``; sampler.py:322-368); h5py is not
-    available here, so the same arrays go to ``<name>.npz`` plus the ``<name>.txt`` layout that
-    the reference's own reader accepts as a fallback (main.py:166-167, 293-295: rows of
-    ``theta..., log_prob``)."""
+    """Chain backend in the reference's file formats: ``chemcee_256.h5`` as emcee's ``HDFBackend`` /
+    ``Transformbackend`` lay it out (group ``mcmc``: ``chain``, ``chain_transformed``, ``log_prob``,
+    ``accepted`` + attributes ``nwalkers``, ``ndim``, ``iteration``, ``has_blobs``; sampler.py:322-368)
+    and ``zeus_256.h5`` as ``ZeusTransformCallback`` does (root datasets ``samples``,
+    ``chain_transformed``, ``logprob``; sampler.py:556-577), through ``h5lite`` (no h5py in this
+    image), plus the ``<name>.txt`` layout the reference's reader accepts as a fallback
+    (main.py:166-167, 293-295: rows of ``theta..., log_prob``).  Files written by the reference load
+    the same way, so a run directory started there resumes here."""
+
+    GZIP_LIMIT = 64 << 20           # zeus layout: gzip chunks like the reference below this many bytes per dataset
 
     def __init__(self, filename, transform=None):
         self.base = filename[:-3] if filename.endswith(".h5") else filename
+        self.layout = "zeus" if os.path.basename(self.base).startswith("zeus") else "emcee"
         self.transform = transform
         self.chain, self.chain_transformed, self.log_prob = [], [], []
         self.accepted = None
         self._flushed = 0
 
     @property
-    def npz(self):
+    def h5(self):
+        return self.base + ".h5"
+
+    @property
+    def npz(self):                                          # consolidated file of earlier versions of this package
         return self.base + ".npz"
 
     def exists(self):
-        return os.path.isfile(self.npz) or bool(self._parts(self.base))
+        return os.path.isfile(self.h5) or os.path.isfile(self.npz) or bool(self._parts(self.base))
+
+    def remove(self):
+        for f in [self.h5, self.npz, self.base + ".txt"] + self._parts(self.base):
+            if os.path.isfile(f):
+                os.remove(f)
 
     def append(self, z_block, theta_block, logp_block, accepted):
         self.chain.append(np.asarray(z_block, np.float64))
@@ -179,7 +194,7 @@ class ChainStore(object):
         return (np.concatenate(self.chain), np.concatenate(self.chain_transformed), np.concatenate(self.log_prob))
 
     def flush(self, final=True):
-        """``final=True``: the consolidated ``<name>.npz`` + ``<name>.txt``.  ``final=False`` (the
+        """``final=True``: the consolidated ``<name>.h5`` + ``<name>.txt``.  ``final=False`` (the
         incremental flush after every convergence check, sampler.py:359/720): only the blocks that are
         not on disk yet, as ``<name>.partNNNNN.npz`` -- the reference's HDF5 backend appends, and
         rewriting the whole chain at every check is quadratic (216 MB per 100 iterations at 4096
@@ -191,12 +206,49 @@ class ChainStore(object):
             self._flushed = len(self.chain)
             return
         z, th, lp = self.arrays()
-        np.savez(self.npz, chain=z, chain_transformed=th, log_prob=lp, accepted=self.accepted, iteration=len(z))
+        self.write_h5(self.h5, z, th, lp, self.accepted, self.layout)
         flat = np.concatenate([th.reshape(-1, th.shape[-1]), lp.reshape(-1, 1)], axis=1)
         np.savetxt(self.base + ".txt", flat[-100000:])
-        for f in self._parts(self.base):                    # superseded by the consolidated file
-            os.remove(f)
+        for f in self._parts(self.base) + [self.npz]:       # superseded by the consolidated file
+            if os.path.isfile(f):
+                os.remove(f)
         self._flushed = len(self.chain)
+
+    @staticmethod
+    def write_h5(path, z, th, lp, accepted, layout="emcee"):
+        w = h5lite.Writer()
+        if layout == "zeus":
+            for name, a in (("samples", z), ("chain_transformed", th), ("logprob", lp)):
+                w.dataset(None, name, a, compression="gzip" if a.nbytes <= ChainStore.GZIP_LIMIT else None)
+        else:
+            nw, nd = z.shape[1], z.shape[2]
+            g = w.group("mcmc", attrs=dict(version="3.0.2",                  # the emcee release whose layout this is
+                                           nwalkers=np.int64(nw), ndim=np.int64(nd), has_blobs=False,
+                                           iteration=np.int64(len(z))))
+            w.dataset(g, "accepted", np.zeros(nw) if accepted is None else np.asarray(accepted, np.float64))
+            w.dataset(g, "chain", z)
+            w.dataset(g, "chain_transformed", th)
+            w.dataset(g, "log_prob", lp)
+        tmp = path + ".tmp"
+        w.save(tmp)
+        os.replace(tmp, path)
+
+    @staticmethod
+    def read_h5(path):
+        """Either layout, written here or by the reference (h5py)."""
+        with h5lite.File(path) as f:
+            if "mcmc" in f:
+                g = f["mcmc"]
+                n = int(g.attrs["iteration"])
+                out = {"chain": g["chain"].read(nrows=n), "log_prob": g["log_prob"].read(nrows=n),
+                       "accepted": g["accepted"].read()}
+                out["chain_transformed"] = g["chain_transformed"].read(nrows=n) if "chain_transformed" in g else None
+            else:
+                out = {"chain": f["samples"].read(), "chain_transformed": f["chain_transformed"].read(),
+                       "log_prob": f["logprob"].read()}
+                out["accepted"] = np.zeros(out["chain"].shape[1])
+            out["iteration"] = len(out["chain"])
+            return out
 
     def _part(self, k):
         return "%s.part%05d.npz" % (self.base, k)
@@ -207,21 +259,31 @@ class ChainStore(object):
         return sorted(glob.glob(base + ".part*.npz"))
 
     @staticmethod
+    def _load_consolidated(base):
+        if os.path.isfile(base + ".h5"):
+            return ChainStore.read_h5(base + ".h5")
+        if os.path.isfile(base + ".npz"):
+            d = np.load(base + ".npz")
+            return {k: d[k] for k in d.files}
+        return None
+
+    @staticmethod
     def load(filename):
         base = filename[:-3] if filename.endswith(".h5") else filename
         parts = ChainStore._parts(base)
+        d = ChainStore._load_consolidated(base)
         if parts:                                           # an interrupted run: (consolidated file, if any) + parts
             blocks = [np.load(f) for f in parts]
             out = {k: np.concatenate([b[k] for b in blocks]) for k in ("chain", "chain_transformed", "log_prob")}
             out["accepted"] = blocks[-1]["accepted"]
-            if os.path.isfile(base + ".npz"):
-                d = np.load(base + ".npz")
+            if d is not None:
                 for k in ("chain", "chain_transformed", "log_prob"):
                     out[k] = np.concatenate([d[k], out[k]])
             out["iteration"] = len(out["chain"])
             return out
-        d = np.load(base + ".npz")
-        return {k: d[k] for k in d.files}
+        if d is None:
+            raise FileNotFoundError(base + ".h5")
+        return d
 
     def get_last_sample(self):
         return self.load(self.base)["chain"][-1]
@@ -634,7 +696,7 @@ class HMCSampler(object):
         resume = False
         if store.exists():
             if overwrite:
-                os.remove(store.npz)
+                store.remove()
             else:
                 print("init from previous")
                 prev = ChainStore.load(filename)
@@ -706,7 +768,9 @@ class ZeusSampler(object):
                meanshift=0.1, stdshift=0.1, nk=2, ncheck=100):
         store = ChainStore(os.path.join(outdir, "zeus_256.h5"), self.transform)
         x0 = self.x0
-        if store.exists() and not overwrite:
+        if store.exists() and overwrite:
+            store.remove()
+        if store.exists():
             print("init from previous")
             prev = ChainStore.load(store.base)
             x0 = prev["chain"][-1]

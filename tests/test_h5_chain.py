@@ -1,0 +1,183 @@
+"""Chain files in the reference's HDF5 layouts, CPU only.
+
+The fixture ``tests/golden/2dgaussian_Fulltconn/iter_0/chemcee_256.h5`` is the data file the
+reference's own ``tests/test_main.py::test_reading`` reads (written by emcee 3.0.2 through h5py /
+libhdf5); the two numbers asserted there (``test_main.py:50-51``) are the golden values below.
+"""
+import os
+import shutil
+import struct
+
+import numpy as np
+import pytest
+
+import cases
+from linna_amd import h5lite
+from linna_amd.sampler import ChainStore, integrated_time, read_chain_and_cut
+
+FIXTURE = os.path.join(cases.GOLDEN, "2dgaussian_Fulltconn", "iter_0", "chemcee_256.h5")
+REF_MEAN, REF_STD = 0.15151080063411168, 0.9633211647095377       # reference tests/test_main.py:50-51
+
+
+def test_reader_on_reference_fixture():
+    with h5lite.File(FIXTURE) as f:
+        assert f.keys() == ["mcmc"] and "mcmc/chain_transformed" in f and "mcmc/blobs" not in f
+        g = f["mcmc"]
+        assert g.keys() == ["accepted", "chain", "chain_transformed", "log_prob"]
+        a = g.attrs
+        assert a["version"] == "3.0.2" and a["nwalkers"] == 4 and a["ndim"] == 2 and a["iteration"] == 200
+        assert a["has_blobs"] is False or a["has_blobs"] == False      # h5py stores numpy bools as an enum  # noqa: E712
+        assert a["random_state_0"] == "MT19937" and a["random_state_1"].shape == (624,)
+        assert a["random_state_1"].dtype == np.uint32
+        ch = g["chain"]
+        assert ch.shape == (1000000, 4, 2) and ch.maxshape[0] == h5lite.UNDEF and ch.dtype == np.float64
+        z = ch.read(nrows=200)
+        th = g["chain_transformed"].read(nrows=200)
+        lp = g["log_prob"].read(nrows=200)
+        acc = g["accepted"].read()
+    assert z.shape == (200, 4, 2) and lp.shape == (200, 4) and acc.shape == (4,)
+    assert np.all(np.isfinite(z)) and np.all(np.abs(th) <= 2.0) and np.all(lp < 0)
+    # chain_transformed is the prior map of chain (flat priors on [-2, 2]: theta = 2 erf(z / sqrt 2))
+    from scipy.special import erf
+    np.testing.assert_allclose(th, 2.0 * erf(z / np.sqrt(2.0)), rtol=0, atol=2e-6)
+    # the acceptance counters are consistent with the stored moves
+    moved = (np.abs(np.diff(z, axis=0)).sum(-1) > 0).sum(0)
+    assert np.all(moved <= acc) and np.all(acc <= 200)
+    # rows past `iteration` are the unwritten remainder of emcee's pre-grown dataset
+    with h5lite.File(FIXTURE) as f:
+        tail = f["mcmc/log_prob"].read(nrows=260)[200:]
+    assert np.all(tail == 0)
+
+
+def test_read_chain_and_cut_reproduces_reference_test():
+    """tests/test_main.py:47-51 (``test_reading``): mean / std of the kept part of the fixture chain."""
+    chain, lp, d = read_chain_and_cut(FIXTURE, 1, ntimes=2, method="emcee")
+    assert d["iteration"] == 200 and chain.shape[1] == 2
+    np.testing.assert_almost_equal(np.mean(chain), REF_MEAN, decimal=5)
+    np.testing.assert_almost_equal(np.std(chain), REF_STD, decimal=5)
+    tau = integrated_time(d["chain"])
+    assert int(np.median(tau)) * 4 == len(chain) == lp.size
+
+
+def test_ml_sampler_core_reads_a_reference_run_directory(tmp_path):
+    """The whole of ``test_reading``: with every artefact of iteration 0 in place, ``ml_sampler_core``
+    trains nothing, samples nothing and returns the cut chain of the reference's HDF5 file."""
+    import pickle
+    from copy import deepcopy
+    from linna_amd.main import ml_sampler_core
+    from linna_amd.nn import ChtoModelv2
+    out = str(tmp_path / "2dgaussian_Fulltconn")
+    shutil.copytree(os.path.join(cases.GOLDEN, "2dgaussian_Fulltconn"), out)
+    with open(os.path.join(out, "iter_0", "finish.pkl"), "wb") as f:
+        pickle.dump([True], f)
+    ndim = 2
+    priors = [{"param": "test_%d" % i, "dist": "flat", "arg1": -2.0, "arg2": 2.0} for i in range(ndim)]
+
+    def theory(x, outdirs):
+        return deepcopy(x[1])
+
+    params = {"trainingoption": 1, "num_epochs": 10, "batch_size": 5}
+    chain, logprob = ml_sampler_core([20], [5], [1], [2], [0.5], [100], [100], out + "/", theory, priors, np.array([0.1, 1.0]),
+                                     np.diag([0.5, 0.2]), np.random.uniform(size=ndim), None, 4, "cuda", None, False, [1.0],
+                                     omegab2cut=None, docuda=False, tsize=1, gpunode=None, nnmodel_in=ChtoModelv2,
+                                     params=params, method="emcee")
+    np.testing.assert_almost_equal(np.mean(chain), REF_MEAN, decimal=5)
+    np.testing.assert_almost_equal(np.std(chain), REF_STD, decimal=5)
+    assert logprob.shape == (800,)
+
+
+def _blocks(rs, n, nw, nd):
+    return rs.standard_normal((n, nw, nd)), rs.standard_normal((n, nw, nd)), rs.standard_normal((n, nw))
+
+
+def test_emcee_layout_roundtrip_and_structure(tmp_path):
+    rs = np.random.RandomState(0)
+    z, th, lp = _blocks(rs, 37, 6, 3)
+    path = str(tmp_path / "chemcee_256.h5")
+    ChainStore.write_h5(path, z, th, lp, np.arange(6.0), "emcee")
+    with h5lite.File(path) as f:
+        g = f["mcmc"]
+        assert g.keys() == ["accepted", "chain", "chain_transformed", "log_prob"]
+        a = g.attrs
+        assert a["nwalkers"] == 6 and a["ndim"] == 3 and a["iteration"] == 37 and not a["has_blobs"]
+        assert a["nwalkers"].dtype == np.int64 and a["version"] == "3.0.2"
+        for name, want in (("chain", z), ("chain_transformed", th), ("log_prob", lp), ("accepted", np.arange(6.0))):
+            ds = g[name]
+            assert ds.dtype == np.float64 and ds.shape == want.shape
+            np.testing.assert_array_equal(ds.read(), want)
+        np.testing.assert_array_equal(g["chain"].read(nrows=5), z[:5])
+    d = ChainStore.read_h5(path)
+    np.testing.assert_array_equal(d["chain_transformed"], th)
+    assert d["iteration"] == 37
+    # same superblock parameters as the file libhdf5 wrote: versions, offset / length sizes, group K values
+    mine, ref = open(path, "rb").read(), open(FIXTURE, "rb").read(96)
+    assert mine[:32] == ref[:32]
+    assert struct.unpack_from("<Q", mine, 40)[0] == len(mine)             # end-of-file address
+    assert struct.unpack_from("<I", mine, 72)[0] == 1                      # root entry caches B-tree + heap
+    # every structure is 8-byte aligned and inside the file
+    _, ohdr, _, _, bt, hp = struct.unpack_from("<QQIIQQ", mine, 56)
+    for addr, sig in ((bt, b"TREE"), (hp, b"HEAP")):
+        assert addr % 8 == 0 and mine[addr:addr + 4] == sig
+    assert ohdr % 8 == 0 and mine[ohdr] == 1
+
+
+def test_zeus_layout_roundtrip_gzip_chunks(tmp_path):
+    rs = np.random.RandomState(1)
+    z, th, lp = _blocks(rs, 1037, 10, 2)
+    path = str(tmp_path / "zeus_256.h5")
+    ChainStore.write_h5(path, z, th, lp, None, "zeus")
+    with h5lite.File(path) as f:
+        assert f.keys() == ["chain_transformed", "logprob", "samples"]
+        s = f["samples"]
+        assert s.shape == (1037, 10, 2) and s.maxshape == (h5lite.UNDEF, 10, 2)
+        assert s._filters() == [(1, (4,))]                                # deflate, as compression="gzip"
+        np.testing.assert_array_equal(s.read(), z)
+        np.testing.assert_array_equal(f["logprob"].read(), lp)
+        np.testing.assert_array_equal(f["chain_transformed"].read(nrows=100), th[:100])
+    d = ChainStore.read_h5(path)
+    np.testing.assert_array_equal(d["chain"], z)
+    assert d["accepted"].shape == (10,)
+    # shuffle + deflate, and a dataset past the gzip limit stored contiguously
+    w = h5lite.Writer()
+    w.dataset(None, "a", z, compression="gzip", shuffle=True)
+    w.dataset(None, "b", lp.astype(np.float32))
+    w.dataset(None, "c", np.arange(12, dtype=np.int32).reshape(3, 4), attrs={"note": "ints", "k": np.float32(2.5)})
+    w.save(str(tmp_path / "m.h5"))
+    with h5lite.File(str(tmp_path / "m.h5")) as f:
+        assert [fid for fid, _ in f["a"]._filters()] == [2, 1]
+        np.testing.assert_array_equal(f["a"].read(), z)
+        assert f["b"].dtype == np.float32
+        np.testing.assert_array_equal(f["b"].read(), lp.astype(np.float32))
+        assert f["c"].attrs["note"] == "ints" and f["c"].attrs["k"] == np.float32(2.5)
+        np.testing.assert_array_equal(f["c"][1:, ::2], np.arange(12).reshape(3, 4)[1:, ::2])
+
+
+def test_chainstore_resumes_from_reference_file(tmp_path):
+    """A store pointed at a chain the reference wrote picks it up and keeps the file format."""
+    path = str(tmp_path / "chemcee_256.h5")
+    shutil.copy(FIXTURE, path)
+    st = ChainStore(path)
+    assert st.exists() and st.layout == "emcee"
+    d = ChainStore.load(path)
+    assert d["chain"].shape == (200, 4, 2)
+    np.testing.assert_array_equal(st.get_last_sample(), d["chain"][-1])
+    st.append(d["chain"], d["chain_transformed"], d["log_prob"], d["accepted"])
+    rs = np.random.RandomState(2)
+    st.append(*_blocks(rs, 10, 4, 2), d["accepted"] + 1)
+    st.flush()
+    d2 = ChainStore.load(path)
+    assert d2["iteration"] == 210 and os.path.getsize(path) < 40000       # rewritten without the pre-grown tail
+    np.testing.assert_array_equal(d2["chain"][:200], d["chain"])
+    np.testing.assert_array_equal(d2["accepted"], d["accepted"] + 1)
+
+
+def test_reader_rejects_what_it_does_not_implement(tmp_path):
+    p = str(tmp_path / "x.h5")
+    open(p, "wb").write(b"not an hdf5 file at all" * 10)
+    with pytest.raises(h5lite.H5Error):
+        h5lite.File(p)
+    raw = bytearray(open(FIXTURE, "rb").read(4096))
+    raw[8] = 2                                                             # superblock version 2 (libver="latest")
+    open(p, "wb").write(bytes(raw))
+    with pytest.raises(h5lite.H5Error):
+        h5lite.File(p)

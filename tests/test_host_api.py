@@ -165,7 +165,7 @@ def test_chainstore_incremental_parts_roundtrip(tmp_path):
     for i, (z, th, lp) in enumerate(blocks[:2]):
         st.append(z, th, lp, np.full(4, i + 1.0))
         st.flush(final=False)
-    assert st.exists() and not os.path.isfile(st.npz) and len(ChainStore._parts(st.base)) == 2
+    assert st.exists() and not os.path.isfile(st.h5) and len(ChainStore._parts(st.base)) == 2
     d = ChainStore.load(name)
     np.testing.assert_array_equal(d["chain"], np.concatenate([b[0] for b in blocks[:2]]))
     np.testing.assert_array_equal(d["log_prob"], np.concatenate([b[2] for b in blocks[:2]]))
@@ -174,7 +174,7 @@ def test_chainstore_incremental_parts_roundtrip(tmp_path):
     st2 = ChainStore(name)
     st2.append(d["chain"], d["chain_transformed"], d["log_prob"], d["accepted"])
     st2.flush()
-    assert os.path.isfile(st2.npz) and not ChainStore._parts(st2.base)
+    assert os.path.isfile(st2.h5) and not ChainStore._parts(st2.base)
     st2.append(*blocks[2], np.full(4, 3.0))
     st2.flush(final=False)
     d2 = ChainStore.load(name)
