@@ -261,7 +261,7 @@ def main():
         }
         res["mcmc"] = mcmc_rate(lp, NWALKERS)
         res["mcmc"]["steps_per_s_all_gpus"] = res["mcmc"]["steps_per_s"] * world
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
             res["cpu_baseline"] = cpu_baseline(consts, z_host)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -349,3 +349,75 @@ def test_fused_gradient_against_layered_path_and_oracle(nin, nout, width, depth,
                 torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
             return best
         assert t(fused) < 0.8 * t(layered)
+
+
+@pytest.mark.parametrize("name", ["mlp_33_33", "v2_33_33", "v2_26_457", "v2_40_1000"])
+def test_full_size_properties(name):
+    """BASELINE sizes (4096 walkers; configs 2, 3, 4 shapes), checked through properties that do not
+    need the oracle at that size: walkers are independent (a permutation of the rows permutes the
+    outputs bit for bit, a walker's value does not depend on its neighbours or on the batch size), the
+    temperature enters as -chi2/(2T) - |z|^2/2 exactly, and a sample of rows agrees with the oracle."""
+    from oracle import likelihood
+    B = 4096
+    lp1, pred, yinv, prob = build_logprob(name, 1.0)
+    nin = prob["nin"]
+    rs = np.random.RandomState(11)
+    z = rs.standard_normal((B, nin)).astype(np.float32)
+    base = lp1(z, returntorch=False)
+    assert base.shape == (B,) and np.all(np.isfinite(base))
+    perm = rs.permutation(B)
+    np.testing.assert_array_equal(lp1(z[perm], returntorch=False), base[perm])
+    # ragged batch sizes around the 16-row tiles: the same rows give the same bits
+    # (with a dense inverse covariance the row-dot GEMM picks its tiling and K split by batch size, so the
+    # summation order may differ between batch sizes there)
+    for n in (1, 15, 17, 1000, 4095):
+        got = lp1(z[:n], returntorch=False).reshape(-1)
+        if name in ("mlp_33_33", "v2_33_33"):
+            np.testing.assert_array_equal(got, base[:n])
+        else:
+            np.testing.assert_allclose(got, base[:n], rtol=2e-5)
+    # one walker repeated in every row
+    rep = lp1(np.repeat(z[7:8], 257, axis=0), returntorch=False)
+    assert np.all(rep == rep[0])
+    if name in ("mlp_33_33", "v2_33_33"):
+        assert rep[0] == base[7]
+    else:
+        np.testing.assert_allclose(rep[0], base[7], rtol=2e-5)
+    # temperature: lnP_T + |z|^2/2 = (lnP_1 + |z|^2/2) / T
+    half = 0.5 * np.sum(z.astype(np.float64) ** 2, axis=1)
+    for T in (4.0, 16.0):
+        lpT = build_logprob(name, T)[0](z, returntorch=False)
+        np.testing.assert_allclose((lpT + half) * T, base + half, rtol=2e-5, atol=2e-4)
+    # a sample of rows against the oracle (float64 accumulation)
+    idx = rs.choice(B, 96, replace=False)
+    ref = likelihood.log_prob(z[idx], cases.oracle_emulator(prob), prob["priors"], prob["data"], prob["invcov"], 1.0,
+                              dtype=np.float64)
+    np.testing.assert_allclose(base[idx], ref, rtol=6e-4)
+
+
+@pytest.mark.parametrize("name", ["mlp_33_33", "v2_33_33"])
+def test_full_size_gradient_properties(name):
+    """Config 5 shape (4096 chains): the gradient entry returns the same lnP as the evaluation entry, rows
+    are independent, and a sample of rows agrees with the oracle's reverse pass."""
+    B = 4096
+    lp = build_logprob(name)[0]
+    nin = 33
+    rs = np.random.RandomState(12)
+    z = (0.5 * rs.standard_normal((B, nin))).astype(np.float32)
+    zd, _ = lp._to_device(z)
+    lnp, g = lp.evaluate_with_grad(zd)
+    lnp, g = lnp.cpu().numpy().copy(), g.cpu().numpy()[:, :nin].copy()
+    np.testing.assert_allclose(lnp, lp(z, returntorch=False), rtol=1e-4, atol=1e-4)
+    perm = rs.permutation(B)
+    zp, _ = lp._to_device(z[perm])
+    lnp_p, g_p = lp.evaluate_with_grad(zp)
+    np.testing.assert_array_equal(lnp_p.cpu().numpy(), lnp[perm])
+    np.testing.assert_array_equal(g_p.cpu().numpy()[:, :nin], g[perm])
+    # a sample of rows against the oracle's reverse pass
+    from oracle import likelihood
+    prob = cases.serving_problem(name)
+    idx = rs.choice(B, 64, replace=False)
+    lref, gref = likelihood.grad_log_prob(z[idx], cases.oracle_emulator(prob), prob["priors"], prob["data"],
+                                          prob["invcov"], 1.0)
+    np.testing.assert_allclose(lnp[idx], lref, rtol=6e-4)
+    np.testing.assert_allclose(g[idx], gref, rtol=0, atol=3e-3 * np.abs(gref).max())
