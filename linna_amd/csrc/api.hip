@@ -70,10 +70,28 @@ struct linna_ctx {
 };
 struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
 
+// The whole-network kernel (net_stream.hip) reads the weights from a copy in MFMA fragment order.  Its 16-row
+// engine and its small-batch engines (8 / 4 rows per workgroup) read different orders, so there are two copies,
+// each re-laid lazily when the weights moved (g_weights_epoch) since it was made.
+struct StreamCopy {
+    float* buf[2] = {nullptr, nullptr};      // [0]: 16-row engine, [1]: small-batch engines
+    unsigned long long epoch[2] = {0, 0};    // epoch each copy was made at (0 = never)
+    size_t floats = 0;
+    bool ready() const { return buf[0] && buf[1]; }
+    int alloc(size_t nf) {
+        floats = nf;
+        for (int k = 0; k < 2; ++k)
+            if (hipMalloc(reinterpret_cast<void**>(&buf[k]), nf * sizeof(float)) != hipSuccess) { release(); return LINNA_ERR_HIP; }
+        return LINNA_OK;
+    }
+    void release() {
+        for (int k = 0; k < 2; ++k) { if (buf[k]) (void)hipFree(buf[k]); buf[k] = nullptr; epoch[k] = 0; }
+    }
+};
+
 struct linna_net {
     linna_ctx* ctx;
-    float* packed = nullptr;                 // fragment-order weight stream for the one-launch training forward, or null
-    unsigned long long packed_epoch = 0;
+    StreamCopy packed;                       // fragment-order weight streams for the one-launch training forward
     int stream_fwd = -1;                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
     std::vector<linna_layer_t> L;   // without the trailing INSKIP
     int in_size, out_size;
@@ -81,6 +99,8 @@ struct linna_net {
     linna_layer_t inskip;
     int max_w, max_c;
 };
+
+static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out);
 
 struct FwdLayout {
     std::vector<size_t> t_off, y_off;   // float offsets, per op (y_off of the last op unused)
@@ -257,7 +277,7 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
     return LINNA_OK;
 }
 int linna_net_destroy(linna_net_t* net) {
-    if (net && net->packed) (void)hipFree(net->packed);
+    if (net) net->packed.release();
     delete net;
     return LINNA_OK;
 }
@@ -292,16 +312,13 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
         }
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(S(stream), &cap);
-        if (n->stream_fwd == 1 && !n->packed && cap == hipStreamCaptureStatusNone) {
-            const size_t nf = net_stream_packed_floats(n->L.data(), nl, n->in_size);
-            if (hipMalloc(reinterpret_cast<void**>(&n->packed), nf * sizeof(float)) != hipSuccess) { n->packed = nullptr; n->stream_fwd = 0; }
+        if (n->stream_fwd == 1 && !n->packed.ready() && cap == hipStreamCaptureStatusNone) {
+            if (n->packed.alloc(net_stream_packed_floats(n->L.data(), nl, n->in_size)) != LINNA_OK) n->stream_fwd = 0;
         }
-        if (n->stream_fwd == 1 && n->packed) {
-            const unsigned long long epoch = g_weights_epoch.load();
-            if (cap != hipStreamCaptureStatusNone || n->packed_epoch != epoch) {
-                TRY(launch_net_stream_pack(n->L.data(), nl, n->in_size, n->packed, S(stream)));
-                n->packed_epoch = cap != hipStreamCaptureStatusNone ? 0 : epoch;
-            }
+        if (n->stream_fwd == 1 && n->packed.ready()) {
+            const int rows = net_stream_rows(B);
+            const float* packed = nullptr;
+            TRY(stream_copy_refresh(n->packed, n, rows, stream, &packed));
             std::vector<float*> y(nl), t(nl);
             std::vector<int> ldy(nl), ldt(nl);
             for (int i = 0; i < nl; ++i) {
@@ -309,8 +326,8 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
                 y[i] = last ? OUT : w + f.y_off[i]; ldy[i] = last ? ldo : ld4(n->L[i].N);
                 t[i] = n->L[i].op == LINNA_OP_RESBLOCK ? w + f.t_off[i] : nullptr; ldt[i] = ld4(n->L[i].C);
             }
-            return launch_net_stream_store(n->L.data(), nl, n->in_size, n->packed, X, ldx, B, y.data(), ldy.data(), t.data(),
-                                           ldt.data(), om ? om->cscale : nullptr, om ? om->cshift : nullptr, S(stream));
+            return launch_net_stream_store(n->L.data(), nl, n->in_size, packed, X, ldx, B, y.data(), ldy.data(), t.data(),
+                                           ldt.data(), om ? om->cscale : nullptr, om ? om->cshift : nullptr, rows, S(stream));
         }
     }
     const float* hin = X; int ldh = ldx;
@@ -551,9 +568,8 @@ struct linna_logprob {
     linna_ctx* ctx;
     linna_net* net;
     linna_logprob_desc_t d;
-    float* packed = nullptr;                 // fragment-order weight stream (net_stream.hip), or null
-    bool grad_fused = false;                 // the stream also holds the backward segments (ReLU MLPs)
-    unsigned long long packed_epoch = 0;     // epoch the copy was made at (0 = never)
+    StreamCopy packed;                       // fragment-order weight streams (net_stream.hip), or not allocated
+    bool grad_fused = false;                 // the streams also hold the backward segments (ReLU MLPs)
 };
 
 struct LpLayout { size_t x0, fwd, d, part, dh, bwd, dx, total; int slots; };
@@ -580,22 +596,27 @@ static bool fused_enabled() {
     static const bool on = !(getenv("LINNA_DISABLE_FUSED") && getenv("LINNA_DISABLE_FUSED")[0] == '1');
     return on;
 }
-// Re-lay the fragment-order weight copy if the weights moved since it was made.
-static int lp_refresh_stream(linna_logprob* lp, void* stream) {
-    const linna_net* n = lp->net;
+static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out) {
+    const int k = rows < 16 ? 1 : 0;
     const unsigned long long epoch = g_weights_epoch.load();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(S(stream), &cap);
     if (cap != hipStreamCaptureStatusNone) {
-        // a captured evaluation carries its own re-layout, so that every replay sees the weights
-        // of that moment; the copy is not valid for direct launches until they redo it
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, S(stream)));
-        lp->packed_epoch = 0;
-    } else if (lp->packed_epoch != epoch) {
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, S(stream)));
-        lp->packed_epoch = epoch;
+        // a captured launch carries its own re-layout, so that every replay sees the weights of that
+        // moment; the copy is not valid for direct launches until they redo it
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, S(stream)));
+        sc.epoch[k] = 0;
+    } else if (sc.epoch[k] != epoch) {
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, S(stream)));
+        sc.epoch[k] = epoch;
     }
+    *out = sc.buf[k];
     return LINNA_OK;
+}
+// The copy the engine for `B` rows reads, re-laid if the weights moved since it was made; *rows: that engine.
+static int lp_refresh_stream(linna_logprob* lp, int B, void* stream, const float** packed, int* rows) {
+    *rows = net_stream_rows(B);
+    return stream_copy_refresh(lp->packed, lp->net, *rows, stream, packed);
 }
 
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
@@ -603,13 +624,14 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
     const linna_logprob_desc_t& d = lp->d;
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
     const linna_net* n = lp->net;
-    if (!keep_activations && fused_enabled() && lp->packed && !d.outmap.cexp) {
+    if (!keep_activations && fused_enabled() && lp->packed.ready() && !d.outmap.cexp) {
         // whole-network kernel (net_stream.hip): prior map -> every layer -> output transform -> diagonal
         // log-likelihood in ONE launch, weights streamed from the fragment-order copy
-        TRY(lp_refresh_stream(lp, stream));
-        TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+        const float* packed = nullptr; int rows = 16;
+        TRY(lp_refresh_stream(lp, B, stream, &packed, &rows));
+        TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                               d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, S(stream)));
+                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, rows, S(stream)));
         if (d.w) return LINNA_OK;
         return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
@@ -637,7 +659,8 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
         const size_t nf = net_stream_packed_floats(net->L.data(), (int)net->L.size(), net->in_size);
         lp->grad_fused = net_stream_has_grad(net->L.data(), (int)net->L.size(), net->in_size) && !desc->outmap.cexp &&
                          !(getenv("LINNA_DISABLE_FUSED_GRAD") && getenv("LINNA_DISABLE_FUSED_GRAD")[0] == '1');
-        if (check_hip(hipMalloc(reinterpret_cast<void**>(&lp->packed), nf * sizeof(float)), "hipMalloc(weight stream)") != LINNA_OK) {
+        if (lp->packed.alloc(nf) != LINNA_OK) {
+            set_error("logprob_create: hipMalloc(weight stream) failed");
             delete lp; return LINNA_ERR_HIP;
         }
     }
@@ -645,7 +668,7 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     return LINNA_OK;
 }
 int linna_logprob_destroy(linna_logprob_t* lp) {
-    if (lp && lp->packed) (void)hipFree(lp->packed);
+    if (lp) lp->packed.release();
     delete lp;
     return LINNA_OK;
 }
@@ -676,16 +699,17 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
     }
     const linna_logprob_desc_t& d = lp->d;
     if (ndim != d.nin) { set_error("logprob_eval_slice_points: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
-    if (!fused_enabled() || !lp->packed || d.outmap.cexp || !d.w || d.nin > 64) {
+    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || !d.w || d.nin > 64) {
         set_error("logprob_eval_slice_points: this log-probability does not run the whole-network kernel");
         return LINNA_ERR_UNSUPPORTED;          // the caller falls back to linna_slice_points + linna_logprob_eval_if
     }
-    TRY(lp_refresh_stream(lp, stream));
+    const float* packed = nullptr; int rows = 16;
+    TRY(lp_refresh_stream(lp, nrep * ns, stream, &packed, &rows));
     const linna_net* n = lp->net;
     NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, nullptr, ns, 0ull, nullptr, 0, 0, 0.f, nullptr, 1};
-    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
+    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                             lnP, nullptr, 0, nullptr, 0, &mv, nullptr, gate, S(stream));
+                             lnP, nullptr, 0, nullptr, 0, &mv, nullptr, gate, rows, S(stream));
 }
 
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
@@ -696,16 +720,17 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     }
     const linna_logprob_desc_t& d = lp->d;
     if (ndim != d.nin) { set_error("stretch_half_step: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
-    if (!fused_enabled() || !lp->packed || d.outmap.cexp || !d.w || d.nin > 64) {
+    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || !d.w || d.nin > 64) {
         set_error("stretch_half_step: this log-probability does not run the whole-network kernel");
         return LINNA_ERR_UNSUPPORTED;          // the caller falls back to propose / eval / accept
     }
-    TRY(lp_refresh_stream(lp, stream));
+    const float* packed = nullptr; int rows = 16;
+    TRY(lp_refresh_stream(lp, ns, stream, &packed, &rows));
     const linna_net* n = lp->net;
     NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept, 0};
-    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
+    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                             nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, S(stream));
+                             nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, rows, S(stream));
 }
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
@@ -714,14 +739,15 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
     const linna_logprob_desc_t& d = lp->d;
     if (d.outmap.cexp) { set_error("logprob_grad: ypositive (exp) output map has no gradient path"); return LINNA_ERR_UNSUPPORTED; }
     if (!d.gscale || (!d.w && !d.Ssym)) { set_error("logprob_grad: descriptor lacks gscale / Ssym"); return LINNA_ERR_INVALID; }
-    if (fused_enabled() && lp->packed && lp->grad_fused && d.w) {
+    if (fused_enabled() && lp->packed.ready() && lp->grad_fused && d.w) {
         // lnP and d lnP / d z in ONE launch: forward segments, turnaround, backward segments over W^T (net_stream.hip)
-        TRY(lp_refresh_stream(lp, stream));
+        const float* packed = nullptr; int rows = 16;
+        TRY(lp_refresh_stream(lp, B, stream, &packed, &rows));
         const linna_net* n = lp->net;
         NsGrad gr{d.gscale, G, ldg};
-        return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, lp->packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+        return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                                  d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP,
-                                 nullptr, 0, nullptr, 0, nullptr, &gr, nullptr, S(stream));
+                                 nullptr, 0, nullptr, 0, nullptr, &gr, nullptr, rows, S(stream));
     }
     const LpLayout L = lp_layout(lp, B, 1);
     float* w = static_cast<float*>(ws);

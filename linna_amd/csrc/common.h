@@ -109,7 +109,10 @@ int launch_step_increment(int* step, hipStream_t s);
 // net_stream.hip (program-driven whole-network kernel: residual blocks, widths up to 1024)
 bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size);
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size);
-int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, hipStream_t s);
+// rows per workgroup for a batch of B rows: 16 (v_mfma_f32_16x16x4_f32), or 8 / 4 (v_mfma_f32_4x4x1_16b_f32) when 16-row
+// workgroups would leave CUs idle.  The 16-row engine and the small ones read different orders of the weight stream.
+int net_stream_rows(int B);
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, hipStream_t s);
 // sampler moves fused around the evaluation.  slice == 0: stretch half step, rows of the batch are the walkers
 // S[0..B).  slice == 1: rows are the slice sampler's trial points coords[S[k]] + cc[row] * DIR[k], k = row % nc
 // (DIR is passed as the launch's Z / ldz; cc = w[nrep * ns], nc = ns; nothing is written back).
@@ -122,14 +125,15 @@ struct NsMove {
 // training / validation forward: every op's output stored for the backward (STORE instantiation)
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
                             int B, float* const* y, const int* ldy, float* const* t, const int* ldt, const float* cscale,
-                            const float* cshift, hipStream_t s);
+                            const float* cshift, int rows, hipStream_t s);
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
 struct NsGrad { const float* gscale; float* G; int ldg; };
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, hipStream_t s);
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
+                      hipStream_t s);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);

@@ -34,6 +34,19 @@
 // order, see pack below) + 16 v_mfma_f32_16x16x4_f32.
 // After the last segment the output row block sits in LDS: output transform, optional store of
 // d, diagonal Gaussian log-likelihood (util.py:953-955) with 32-lane shuffles.
+//
+// Small batches (ROWS = 8 or 4 instantiations).  With 16 rows per workgroup a batch of B rows occupies B/16 of
+// the 256 CUs and the launch lasts as long as one workgroup needs for the whole network, whatever B is: an
+// ensemble half step of 2048 proposals (128 workgroups), a training batch of 500 (32), the reference's own
+// ensembles of 4..128 walkers (1..8).  The same program runs with 8 or 4 rows per workgroup on
+// v_mfma_f32_4x4x1_16b_f32: one instruction multiplies 4 rows by the wave's 64 columns at k = 1 (lane = column;
+// CBSZ = 4 broadcasts the A values of block ABID to all 16 blocks, so the ONE ds_read_b128 per step still fetches
+// 16 k of every row: block b of the read holds row set b & 3, k chunk b >> 2), at the same flop rate per
+// instruction cycle as 16x16x4 (measured: tools/probe/mfma4_probe.hip).  Four accumulator chains per row set (one
+// per k chunk) keep dependent instructions 32 cycles apart.  The weight stream is the same bytes in another order
+// (lane = column, see ns_pack_kernel), so a workgroup of 8 (4) rows needs 2x (4x) the weight bandwidth per flop:
+// 64 (128) B/clk/CU at full MFMA rate against the 64 B/clk a CU's vector L1 delivers -- the small engines are
+// L1-fill bound, which still halves the time of a launch that cannot fill the chip.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -43,7 +56,7 @@
 
 namespace linna {
 
-constexpr int NS_ROWS = 16;
+constexpr int NS_ROWS = 16;                // rows per workgroup of the large-batch engine (and the LDS layout bound)
 constexpr int NS_NW = 8;                 // waves per workgroup
 constexpr int NS_NT = 4;                 // 16-column tiles per wave and step
 constexpr int NS_MAXSEG = 20;
@@ -99,12 +112,14 @@ struct NsPackArgs {
     NsPackSeg seg[NS_MAXSEG];
     int run_seg[NS_MAXRUN], run_pass[NS_MAXRUN], run_first[NS_MAXRUN + 1];
     int nseg, nrun, G, bias_total;
+    int small;                                     // layout of the 4x4x1 engines: lane = column, load t = k chunk
     float* out;                                    // weights, then biases
 };
 // stream[w][g][t][lane][e], run r = (segment, pass), s = g - first[r], li = lane & 15, kq = lane >> 4:
 //   WIDE   n = 16 (32 pass + 4 w + t) + li,  k = 16 s + 4 kq + e
 //   SPLIT  n = 64 (w % ncg) + 16 t + li,     k = 16 ((w / ncg) steps + s) + 4 kq + e
-// value = [Wa | alpha Wb](n, k), zero outside.
+// value = [Wa | alpha Wb](n, k), zero outside.  Small-batch engines (p.small): the same 64 columns x 16 k per
+// (w, g) with lane = column and load t = k chunk:  n = ... + lane,  k = ... + 4 t + e.
 __global__ void ns_pack_kernel(NsPackArgs p) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t nw4 = (size_t)NS_NW * p.G * NS_NT * 64;
@@ -117,10 +132,11 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
         int r = 0;
         while (r + 1 < p.nrun && g >= p.run_first[r + 1]) ++r;
         const NsPackSeg& S = p.seg[p.run_seg[r]];
-        const int s = g - p.run_first[r], li = lane & 15, kq = lane >> 4;
+        const int s = g - p.run_first[r];
+        const int nl = p.small ? lane : 16 * t + (lane & 15), kl = p.small ? 4 * t : 4 * (lane >> 4);
         int n, k0;
-        if (S.type == NS_WIDE) { n = 16 * (32 * p.run_pass[r] + 4 * w + t) + li; k0 = 16 * s + 4 * kq; }
-        else { n = 64 * (w % S.ncg) + 16 * t + li; k0 = 16 * ((w / S.ncg) * S.steps + s) + 4 * kq; }
+        if (S.type == NS_WIDE) { n = 512 * p.run_pass[r] + 64 * w + nl; k0 = 16 * s + kl; }
+        else { n = 64 * (w % S.ncg) + nl; k0 = 16 * ((w / S.ncg) * S.steps + s) + kl; }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n < S.N) {
 #pragma unroll
@@ -167,19 +183,24 @@ __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, flo
 // output, every residual block's hidden h) are written to global memory from the epilogues with inline-asm
 // stores: the compiler does not see them, so its counted vmcnt waits for the weight stream stay counted
 // (stores only ever make the hardware counter read higher, i.e. the waits conservative).
-template <int R, int MOVE, bool GRAD, bool STORE>
+template <int R, int MOVE, bool GRAD, bool STORE, int ROWS>
 __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NT = NS_NT, NW = NS_NW;
     constexpr int RG = 32;                         // threads per walker row in prologue / reduce / finish
+    constexpr bool SM = ROWS < 16;                 // 4x4x1 engine: ROWS / 4 row sets, lane = column
+    constexpr int RS = SM ? ROWS / 4 : 1;
+    constexpr int NQ = SM ? RS : NT;               // result quads per lane: (row set) or (column tile)
+    constexpr int NACC = SM ? 4 * RS : NT;
+    static_assert(ROWS == 16 || ROWS == 8 || ROWS == 4, "rows per workgroup");
     static_assert(R % 2 == 0, "the A double buffer alternates with the ring slot parity");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int LD = a.LD, ABUF = NS_ROWS * LD;
-    float* const act = smem;                       // [2][16][LD]
+    const int LD = a.LD, ABUF = ROWS * LD;
+    float* const act = smem;                       // [2][ROWS][LD]
     float* const lbias = smem + 2 * ABUF;          // packed biases of every segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
-    const int row0 = blockIdx.x * NS_ROWS;
+    const int row0 = blockIdx.x * ROWS;
     if (a.gate && a.gate[0] == 0) return;
 #ifdef NS_STAMPS
     unsigned long long* const lstamp = reinterpret_cast<unsigned long long*>(lbias + ((a.bias_total + 3) & ~3)) + wave * 32;
@@ -192,7 +213,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     NS_STAMP();
 
     // ---- 1. every small load of the kernel, up front, straight-line (no branch on a loaded value)
-    const int pr = tid / RG, pc0 = tid % RG;
+    const int prt = tid / RG, pc0 = tid % RG;
+    const bool prow = prt < ROWS;                   // (ROWS < 16: the thread rows past ROWS only keep the barriers company)
+    const int pr = SM ? min(prt, ROWS - 1) : prt;
     const int grow = min(row0 + pr, a.B - 1);
     const int kpad0 = a.kpad0, nin = a.nin, nout = a.nout, nseg = a.nseg;
     constexpr int ZPRE = 2;
@@ -297,7 +320,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         const float t = (a.lg && zlg[i]) ? lt : th;
         float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
         if constexpr (STORE) x = z;                 // rows arrive transformed
-        if (c < kpad0) act[pr * LD + c] = x;
+        if (c < kpad0 && prow) act[pr * LD + c] = x;
     }
     // inputs wider than ZPRE*RG = 64 columns (none of the reference's models; <= 256 supported) and the zero
     // pad of a SPLIT first segment: plain loop, loads waited in place
@@ -312,7 +335,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             x = (t - a.xmean[c]) / a.xstd[c];
             if constexpr (STORE) x = z;
         }
-        act[pr * LD + c] = x;
+        if (prow) act[pr * LD + c] = x;
     }
     __builtin_amdgcn_sched_barrier(0);
     NS_PF_ALL(PRE, R)
@@ -332,8 +355,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 
     // ---- 4. the step loop
     const uint32_t act_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)act;
-    f32x4 acc[NT];
+    f32x4 acc[NACC];
     f32x4 Aq[2];
+    // 4x4x1 engine: block b = lane >> 2 of the A read holds row set b & 3 (rows wrap below ROWS: never selected), k chunk b >> 2
+    const int sm_arow = (4 * ((lane >> 2) & 3) + (lane & 3)) % ROWS, sm_achunk = lane >> 4;
     int si = 0, pass = 0, P = 0, kleft;
     int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl, s_mstore = 0, s_mapply = 0;
     unsigned* const lmask = reinterpret_cast<unsigned*>(lbias + ((a.bias_total + 3) & ~3));   // GRAD: [slot][512 lanes]
@@ -353,17 +378,24 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         if constexpr (STORE) { s_gout = a.gout[si]; s_gld = a.gld[si]; s_gn = a.gn[si]; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
+        const int arow = SM ? sm_arow : li, ak = SM ? 4 * sm_achunk : 4 * kq;
+#pragma unroll
+        for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (s_type == NS_WIDE) {
+            if constexpr (SM) {
+                const float b = lbias[s_bias + 512 * pass + 64 * wave + lane];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float b = lbias[s_bias + 16 * (32 * pass + 4 * wave + t) + li];
-                acc[t] = f32x4{b, b, b, b};
+                for (int r = 0; r < RS; ++r) acc[4 * r] = f32x4{b, b, b, b};
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float b = lbias[s_bias + 16 * (32 * pass + 4 * wave + t) + li];
+                    acc[t] = f32x4{b, b, b, b};
+                }
             }
-            ap = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq);
+            ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak);
         } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            ap = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq + (wave >> s_ncgl) * s_kslice);
+            ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (wave >> s_ncgl) * s_kslice);
         }
     };
     auto lds_barrier = [&]() {
@@ -381,16 +413,33 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[U & 1]) :: "memory");
         a_read(Aq[(U + 1) & 1]);                   // next step's A (speculative at a run end)
         const f32x4 av = Aq[U & 1];
+        if constexpr (SM) {
+            // acc[4 r + c] += A(rows of set r, k chunk c, element e) x B(k chunk c = load c, element e); ABID = block 4 c + r
+#define NS_M4(r, c, e) acc[4 * (r) + (c)] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], Bq[U][c][e], acc[4 * (r) + (c)], 4, 4 * (c) + (r), 0);
+#define NS_M4R(r, e) NS_M4(r, 0, e) NS_M4(r, 1, e) NS_M4(r, 2, e) NS_M4(r, 3, e)
 #pragma unroll
-        for (int h = 0; h < NT; h += 2) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][h][s], acc[h], 0, 0, 0);
-                acc[h + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][h + 1][s], acc[h + 1], 0, 0, 0);
+            for (int e = 0; e < 4; ++e) {
+                NS_M4R(0, e)
+                if constexpr (RS > 1) { NS_M4R(1, e) }
             }
+#undef NS_M4R
+#undef NS_M4
             if constexpr (refill) {
-                Bq[U][h] = wload(h);
-                Bq[U][h + 1] = wload(h + 1);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Bq[U][t] = wload(t);
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < NT; h += 2) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][h][s], acc[h], 0, 0, 0);
+                    acc[h + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][h + 1][s], acc[h + 1], 0, 0, 0);
+                }
+                if constexpr (refill) {
+                    Bq[U][h] = wload(h);
+                    Bq[U][h + 1] = wload(h + 1);
+                }
             }
         }
         if constexpr (refill) wadvance();
@@ -409,30 +458,38 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 kleft = NX.steps;
             };
             bool seg_done = true;
+            // result quads: fin[q][e] is (row, column) = SM ? (4 q + e, lane) : (4 kq + e, 16 q + li) of the wave's 64 columns
+            if constexpr (SM) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc[q] = (acc[4 * q] + acc[4 * q + 1]) + (acc[4 * q + 2] + acc[4 * q + 3]);
+            }
+#define fin acc
+#define q_row(q, e) (SM ? 4 * (q) + (e) : 4 * kq + (e))
+#define q_col(q) (SM ? lane : 16 * (q) + li)
             if (s_type == NS_WIDE) {
-                float* const nxt = act + (P ^ 1) * ABUF + s_dst + 16 * (32 * pass + 4 * wave) + li;
+                float* const nxt = act + (P ^ 1) * ABUF + s_dst + 512 * pass + 64 * wave;
                 unsigned mbits = 0xFFFFu;
                 if constexpr (GRAD) {
                     if (s_mapply) mbits = lmask[(s_mapply - 1 + pass) * (64 * NW) + threadIdx.x];   // sign bits of this very (row, col)
                     if (s_mstore) {
                         unsigned m = 0;
 #pragma unroll
-                        for (int t = 0; t < NT; ++t)
+                        for (int t = 0; t < NQ; ++t)
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) m |= (acc[t][e] > 0.f ? 1u : 0u) << (4 * t + e);
+                            for (int e = 0; e < 4; ++e) m |= (fin[t][e] > 0.f ? 1u : 0u) << (4 * t + e);
                         lmask[(s_mstore - 1 + pass) * (64 * NW) + threadIdx.x] = m;
                     }
                 }
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NQ; ++t)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {  // C/D layout: col = lane&15, row = 4*(lane>>4) + e
-                        float v = acc[t][e];
+                    for (int e = 0; e < 4; ++e) {  // 16x16x4 C/D layout: col = lane&15, row = 4*(lane>>4) + e; 4x4x1: col = lane, row = 4 t + e
+                        float v = fin[t][e];
                         if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
                         v = s_relu ? fmaxf(v, 0.f) : v;
-                        nxt[(4 * kq + e) * LD + 16 * t] = v;
+                        nxt[q_row(t, e) * LD + q_col(t)] = v;
                         if constexpr (STORE) {
-                            const int grow_ = row0 + 4 * kq + e, gcol = 16 * (32 * pass + 4 * wave + t) + li;
+                            const int grow_ = row0 + q_row(t, e), gcol = 512 * pass + 64 * wave + q_col(t);
                             if (s_gout && grow_ < a.B && gcol < s_gn) {
                                 float vs = v;                      // the network's last output carries the column affine
                                 if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[gcol] : 1.f) + (a.cshift ? a.cshift[gcol] : 0.f);
@@ -450,24 +507,29 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     seg_done = false;
                 }
             } else {
-                float* const part = act + (P ^ 1) * ABUF;          // [8 waves][16 rows][64 cols], col ^= 16*(row>>2)
+                // [8 waves][ROWS][64 cols]; the column is swizzled per row so that the reduce below reads without bank
+                // conflicts: col ^= 16*(row>>2) (16 rows), col ^= 32*(row&1) (4x4x1 engines)
+                float* const part = act + (P ^ 1) * ABUF;
+                constexpr int PW = ROWS * 64;
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
+                for (int t = 0; t < NQ; ++t)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        part[wave * 1024 + (4 * kq + e) * 64 + ((16 * t + li) ^ (16 * kq))] = acc[t][e];
+                    for (int e = 0; e < 4; ++e) {
+                        const int rr = q_row(t, e);
+                        part[wave * PW + rr * 64 + (q_col(t) ^ (SM ? 32 * (rr & 1) : 16 * kq))] = fin[t][e];
+                    }
                 lds_barrier();
                 // thread (row pr, lane pc0 of 32): columns pc0, pc0+32, ...; wave of (K part kp, group cg) = kp*ncg + cg
                 float* const cur = act + P * ABUF + pr * LD + s_dst;
                 const int ncol = 64 << s_ncgl, nkp = NW >> s_ncgl;
-                const int sw = 16 * (pr >> 2);
-                for (int c = pc0; c < s_zext; c += RG) {
+                const int sw = SM ? 32 * (pr & 1) : 16 * (pr >> 2);
+                for (int c = pc0; c < (prow ? s_zext : 0); c += RG) {
                     float v = 0.f;
                     if (c < ncol) {
-                        const float* src = part + (c >> 6) * 1024 + pr * 64 + ((c & 63) ^ sw);
+                        const float* src = part + (c >> 6) * PW + pr * 64 + ((c & 63) ^ sw);
                         float x[NW];
 #pragma unroll
-                        for (int kp = 0; kp < NW; ++kp) x[kp] = src[((kp & (nkp - 1)) << s_ncgl) * 1024];   // 8 reads in flight
+                        for (int kp = 0; kp < NW; ++kp) x[kp] = src[((kp & (nkp - 1)) << s_ncgl) * PW];   // 8 reads in flight
 #pragma unroll
                         for (int kp = 0; kp < NW; ++kp) v += kp < nkp ? x[kp] : 0.f;
                         v += lbias[s_bias + c];
@@ -496,7 +558,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
                     for (int i = 0; i < FIN; ++i) {
                         const int c = pc0 + i * RG;
-                        if (c < nout) {
+                        if (c < nout && prow) {
                             const float d = F[c] * fcs[i] + fct[i];
                             chi += (d * fw[i]) * d;
                             F[c] = -(d * fw[i]) * fgs[i] / a.T;
@@ -508,6 +570,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     lds_barrier();
                 }
             }
+#undef fin
+#undef q_row
+#undef q_col
             if (si < nseg) {
                 begin_run();
                 a_read(Aq[(U + 1) & 1]);           // replaces the speculative fragment
@@ -525,7 +590,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     NS_TAIL(0) NS_TAIL(1) NS_TAIL(2) NS_TAIL(3) NS_TAIL(4) NS_TAIL(5) NS_TAIL(6)
 #undef NS_STEP
 #undef NS_TAIL
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the last speculative A read
+    // The last speculative A read.  Both fragments are operands of the wait: the compiler does not know that the
+    // inline-asm ds_read lands later, and a fragment nobody reads again would otherwise be dead at once -- its
+    // registers could be handed to an accumulator of the final step, which the returning LDS data then overwrites.
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[0]), "+v"(Aq[1]) :: "memory");
     NS_STAMP();
 
     if constexpr (STORE) return;                    // every output is in global memory already
@@ -533,7 +601,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // (util.py:339-347, 483-497), minus z for the Gaussian prior term; lnP from the turnaround
     if constexpr (GRAD) {
         const float* const F = act + P * ABUF + pr * LD;
-        const bool rok = row0 + pr < a.B;
+        const bool rok = prow && row0 + pr < a.B;
         if (rok) {
 #pragma unroll
             for (int j = 0; j < ZPRE; ++j) {
@@ -553,7 +621,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // ---- 5. output rows are in buffer P (bias added, no ReLU): output transform, d, log-likelihood
     {
         const float* const F = act + P * ABUF + pr * LD;
-        const bool rok = row0 + pr < a.B;
+        const bool rok = prow && row0 + pr < a.B;
         float chi = 0.f;
         auto column = [&](int c, float cs, float ct, float ww) {
             const float d = F[c] * cs + ct;
@@ -603,7 +671,14 @@ struct NsProgram {
     std::vector<NsSeg> seg;
     int G = 0, LD = 0, kpad0 = 0, nout = 0, bias_total = 0;
     int Gstride = 0, nseg_f = 0, mask_slots = 0;            // G: forward steps; Gstride: forward + backward steps
-    size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;
+    size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;   // LDS of the 16-row engine (lds_for: any engine)
+    size_t lds_for(int rows, bool grad) const {
+        size_t b = (size_t)(2 * rows * LD + ((bias_total + 3) & ~3)) * sizeof(float);
+#ifdef NS_STAMPS
+        b += NS_NW * 32 * 8;
+#endif
+        return b + (grad ? (size_t)mask_slots * 64 * NS_NW * sizeof(unsigned) : 0);
+    }
     bool ok = false, grad_ok = false;                       // grad_ok: backward segments appended (ReLU MLPs)
     std::vector<int> seg_op, seg_hidden;                    // forward segments: op index; 1 = the hidden h of a residual block
 };
@@ -781,12 +856,27 @@ size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size
     return ns_build(layers, nl, in_size).packed_floats;
 }
 
-int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, hipStream_t s) {
+// Engine for a batch of B rows: the fewest rows per workgroup that still fit the batch into one workgroup per CU.
+int net_stream_rows(int B) {
+    const char* const env = getenv("LINNA_NS_ROWS");         // tests and measurements: force an engine
+    const int forced = env ? atoi(env) : 0;
+    if (forced == 4 || forced == 8 || forced == 16) return forced;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+                  ? pr.multiProcessorCount : 256;
+    }
+    return B <= 4 * ncu ? 4 : B <= 8 * ncu ? 8 : 16;
+}
+
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsPackArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
     a.nseg = (int)p.seg.size(); a.G = p.Gstride; a.bias_total = p.bias_total; a.out = packed;
+    a.small = rows < 16;
     int nrun = 0, first = 0;
     for (int i = 0; i < a.nseg; ++i) {
         a.seg[i] = p.pack[i];
@@ -801,17 +891,26 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     return check_hip(hipGetLastError(), "net_stream pack launch");
 }
 
-template <int MOVE, bool GRAD, bool STORE = false>
-static int ns_launch_kernel(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
+template <int MOVE, bool GRAD, bool STORE, int ROWS>
+static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE, GRAD, STORE>),
+        const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE, GRAD, STORE, ROWS>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, NS_LDS_BYTES), "hipFuncSetAttribute");
         if (rc != LINNA_OK) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD, STORE>), dim3((B + NS_ROWS - 1) / NS_ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
+    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD, STORE, ROWS>), dim3((B + ROWS - 1) / ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
     return check_hip(hipGetLastError(), "net_stream launch");
+}
+template <int MOVE, bool GRAD, bool STORE = false>
+static int ns_launch_kernel(const NsArgs& a, int B, const NsProgram& p, int rows, hipStream_t s) {
+    const size_t lds = p.lds_for(rows, GRAD);
+    if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s);
+    if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s);
+    if (rows == 16) return ns_launch_rows<MOVE, GRAD, STORE, 16>(a, B, lds, s);
+    set_error("net_stream: %d rows per workgroup", rows);
+    return LINNA_ERR_INVALID;
 }
 
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { return ns_build(layers, nl, in_size).grad_ok; }
@@ -819,7 +918,8 @@ bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { ret
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
-                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, hipStream_t s) {
+                      float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
+                      hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     if (mv && (nin > 64 || !w)) { set_error("net_stream: fused sampler moves need <= 64 parameters and a diagonal covariance"); return LINNA_ERR_UNSUPPORTED; }
@@ -845,21 +945,21 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         a.mv_coords = mv->coords; a.mv_ldc = mv->ldc; a.mv_logp = mv->logp; a.mv_S = mv->S;
         a.mv_cc = mv->cc; a.mv_ldcc = mv->ldcc; a.mv_C = mv->C; a.mv_nc = mv->nc;
         a.mv_seed = mv->seed; a.mv_step = mv->step; a.mv_step_off = mv->step_off; a.mv_stream = mv->stream; a.mv_a = mv->a; a.mv_naccept = mv->naccept;
-        if (mv->slice) return ns_launch_kernel<2, false>(a, B, p.lds_bytes, s);
-        return ns_launch_kernel<1, false>(a, B, p.lds_bytes, s);
+        if (mv->slice) return ns_launch_kernel<2, false>(a, B, p, rows, s);
+        return ns_launch_kernel<1, false>(a, B, p, rows, s);
     }
     if (gr) {
         a.gscale = gr->gscale; a.Gout = gr->G; a.ldg = gr->ldg;
-        return ns_launch_kernel<0, true>(a, B, p.lds_bytes_grad, s);
+        return ns_launch_kernel<0, true>(a, B, p, rows, s);
     }
-    return ns_launch_kernel<0, false>(a, B, p.lds_bytes, s);
+    return ns_launch_kernel<0, false>(a, B, p, rows, s);
 }
 
 // Training / validation forward: X[B][ldx] (transformed inputs) -> every op's output in global memory.
 // `y[i]`, `ldy[i]`: destination of op i's output; `t[i]`, `ldt[i]`: of the hidden h of residual block i.
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
                             int B, float* const* y, const int* ldy, float* const* t, const int* ldt, const float* cscale,
-                            const float* cshift, hipStream_t s) {
+                            const float* cshift, int rows, hipStream_t s) {
     const NsProgram p = ns_build(layers, nl, in_size);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
@@ -878,7 +978,7 @@ int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, co
         if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
         else { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
     }
-    return ns_launch_kernel<0, false, true>(a, B, p.lds_bytes, s);
+    return ns_launch_kernel<0, false, true>(a, B, p, rows, s);
 }
 
 }  // namespace linna
