@@ -67,8 +67,22 @@ struct linna_ctx {
     size_t group_cap = 0;
     std::vector<char> group_host;            // what the device table holds
     int group = -1;                          // -1 unknown, 0 off (env LINNA_BWD_GROUP=0), 1 on
+    unsigned* counters = nullptr;            // zeroed, self-resetting arrival counters (fused loss)
+    int loss_fused = -1;                     // -1 unknown, 0 off (env LINNA_LOSS_FUSED=0), 1 on
 };
 struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
+// zeroed arrival counters of the context (allocated on first use, never while the stream is capturing)
+static unsigned* ctx_counters(linna_ctx* ctx, hipStream_t st) {
+    if (!ctx) return nullptr;
+    if (!ctx->counters) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&ctx->counters), 64) != hipSuccess) { ctx->counters = nullptr; return nullptr; }
+        if (hipMemsetAsync(ctx->counters, 0, 64, st) != hipSuccess) { (void)hipFree(ctx->counters); ctx->counters = nullptr; return nullptr; }
+    }
+    return ctx->counters;
+}
 
 // The whole-network kernel (net_stream.hip) reads the weights from a copy in MFMA fragment order.  Its 16-row
 // engine and its small-batch engines (8 / 4 rows per workgroup) read different orders, so there are two copies,
@@ -92,7 +106,9 @@ struct StreamCopy {
 struct linna_net {
     linna_ctx* ctx;
     StreamCopy packed;                       // fragment-order weight streams for the one-launch training forward
-    int stream_fwd = -1;                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
+    int stream_fwd = -1;
+    StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
+    int stream_bwd[2] = {-1, -1};            // -1 unknown, 0 no (network out of reach / LINNA_BWD_STREAM=0), 1 yes                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
     std::vector<linna_layer_t> L;   // without the trailing INSKIP
     int in_size, out_size;
     bool has_inskip;
@@ -100,7 +116,7 @@ struct linna_net {
     int max_w, max_c;
 };
 
-static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out);
+static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog = 0);
 
 struct FwdLayout {
     std::vector<size_t> t_off, y_off;   // float offsets, per op (y_off of the last op unused)
@@ -149,6 +165,7 @@ int linna_ctx_destroy(linna_ctx_t* ctx) {
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
         if (ctx->group_dev) (void)hipFree(ctx->group_dev);
+        if (ctx->counters) (void)hipFree(ctx->counters);
     }
     delete ctx;
     return LINNA_OK;
@@ -277,7 +294,7 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
     return LINNA_OK;
 }
 int linna_net_destroy(linna_net_t* net) {
-    if (net) net->packed.release();
+    if (net) { net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release(); }
     delete net;
     return LINNA_OK;
 }
@@ -430,6 +447,46 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         const linna_layer_t& s = n->inskip;
         TRY(param_grads(dOUT, lddo, X, ldx, s.gW, ld4(s.K), s.gb, s.K, s.N, s.alpha));
     }
+    // The dX chain -- one GEMM per op, each waiting for the one before (140 us of 300 at batch 500) -- as ONE launch of
+    // the whole-network kernel over the transposed weights (net_stream.hip, STORE == 2), when the network has such a
+    // program.  The loop below then only collects the parameter gradients.
+    bool fused_dx = false;
+    const int wi = dX ? 1 : 0;
+    if (!n->has_inskip && (nl >= 2 || dX)) {
+        if (n->stream_bwd[wi] < 0) {
+            const char* e = getenv("LINNA_BWD_STREAM");
+            n->stream_bwd[wi] = !(e && e[0] == '0') && net_stream_dx_eligible(n->L.data(), nl, n->in_size, wi) ? 1 : 0;
+        }
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        StreamCopy& sc = n->packed_dx[wi];
+        if (n->stream_bwd[wi] == 1 && !sc.ready() && cap == hipStreamCaptureStatusNone) {
+            if (sc.alloc(net_stream_dx_packed_floats(n->L.data(), nl, n->in_size, wi)) != LINNA_OK) n->stream_bwd[wi] = 0;
+        }
+        if (n->stream_bwd[wi] == 1 && sc.ready()) {
+            const int rows = net_stream_rows(B);
+            const float* packed = nullptr;
+            TRY(stream_copy_refresh(sc, n, rows, stream, &packed, 1 + wi));
+            std::vector<float*> dprev(nl, nullptr), dt(nl, nullptr);
+            std::vector<const float*> hinp(nl, nullptr), tp(nl, nullptr);
+            std::vector<int> ldpv(nl, 0), ldhv(nl, 0), lddt(nl, 0), ldtv(nl, 0);
+            float* cur = bw;
+            for (int i = nl - 1; i >= (wi ? 0 : 1); --i) {                 // the same workspace walk as the loop below
+                const linna_layer_t& l = n->L[i];
+                dprev[i] = (i == 0) ? dX : cur; ldpv[i] = (i == 0) ? lddx : ld4(l.K);
+                if (i > 0) cur += (size_t)B * ld4(l.K);
+                const bool hin_relu = (i > 0) && (n->L[i - 1].op == LINNA_OP_RESBLOCK || n->L[i - 1].relu);
+                hinp[i] = hin_relu ? w + f.y_off[i - 1] : nullptr; ldhv[i] = (i == 0) ? ldx : ld4(n->L[i - 1].N);
+                if (l.op == LINNA_OP_RESBLOCK) {
+                    dt[i] = cur; lddt[i] = ld4(l.C); cur += (size_t)B * ld4(l.C);
+                    tp[i] = w + f.t_off[i]; ldtv[i] = ld4(l.C);
+                }
+            }
+            TRY(launch_net_stream_dx(n->L.data(), nl, n->in_size, packed, dOUT, lddo, B, dprev.data(), ldpv.data(), hinp.data(),
+                                     ldhv.data(), dt.data(), lddt.data(), tp.data(), ldtv.data(), wi, rows, st));
+            fused_dx = true;
+        }
+    }
     const float* dcur = dOUT; int ldd = lddo;
     float* cursor = bw;
     for (int i = nl - 1; i >= 0; --i) {
@@ -447,7 +504,7 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
             if (pg) {                // dW, db need only dcur (already produced on st) and hin
                 TRY(param_grads(dcur, ldd, hin, ldh, l.gW, ld4(l.K), l.gb, l.K, l.N, 1.f));
             }
-            if (need_dx) {
+            if (need_dx && !fused_dx) {
                 GemmArgs a = gemm_zero();
                 a.M = B; a.N = l.K; a.C = dprev; a.ldc = ldp; a.mask = mask; a.ldmask = ldh;
                 if (i == 0 && n->has_inskip) {
@@ -466,7 +523,7 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
             const int ldt = ld4(l.C);
             float* dT = cursor;
             cursor += (size_t)B * ldt;
-            {   // dT = 0.1 * (dcur W2) * (T > 0)
+            if (!fused_dx) {   // dT = 0.1 * (dcur W2) * (T > 0)
                 GemmArgs a = gemm_zero();
                 set_pair(a, 0, dcur, ldd, LAY_K, l.W2, ld4(l.C), LAY_MN, l.N);
                 a.M = B; a.N = l.C; a.C = dT; a.ldc = ldt; a.alpha0 = 0.1f; a.mask = T; a.ldmask = ldt;
@@ -477,7 +534,7 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
                 TRY(param_grads(dT, ldt, hin, ldh, l.gW1, ld4(l.K), l.gb1, l.K, l.C, 1.f));
                 if (l.Ws) TRY(param_grads(dcur, ldd, hin, ldh, l.gWs, ld4(l.K), nullptr, l.K, l.N, 1.f));
             }
-            if (need_dx) {   // dprev = (dT W1 + dcur Ws [+ dcur]) * (hin > 0)
+            if (need_dx && !fused_dx) {   // dprev = (dT W1 + dcur Ws [+ dcur]) * (hin > 0)
                 GemmArgs a = gemm_zero();
                 set_pair(a, 0, dT, ldt, LAY_K, l.W1, ld4(l.K), LAY_MN, l.C);
                 a.M = B; a.N = l.K; a.C = dprev; a.ldc = ldp; a.mask = mask; a.ldmask = ldh;
@@ -596,7 +653,7 @@ static bool fused_enabled() {
     static const bool on = !(getenv("LINNA_DISABLE_FUSED") && getenv("LINNA_DISABLE_FUSED")[0] == '1');
     return on;
 }
-static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out) {
+static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog) {
     const int k = rows < 16 ? 1 : 0;
     const unsigned long long epoch = g_weights_epoch.load();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -604,10 +661,10 @@ static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, voi
     if (cap != hipStreamCaptureStatusNone) {
         // a captured launch carries its own re-layout, so that every replay sees the weights of that
         // moment; the copy is not valid for direct launches until they redo it
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, S(stream)));
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, S(stream)));
         sc.epoch[k] = 0;
     } else if (sc.epoch[k] != epoch) {
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, S(stream)));
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, S(stream)));
         sc.epoch[k] = epoch;
     }
     *out = sc.buf[k];
@@ -793,11 +850,22 @@ int linna_chi2_md(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int 
                             0.5f * (float)d->nout, den, S(stream));
 }
 
-int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t*, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y,
+int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y,
                                   int ldy, const float* den, const int* ROWS, int B, float* scratch, float* loss_rows,
                                   float* loss_mean, float* dPRED, int lddp, float inv_batch, void* stream) {
     const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
     hipStream_t st = S(stream);
+    if (ctx && d->nout <= 64 && lddp >= 0) {
+        // five launches of 5-14 us each (delta, U = delta Cinv, row sums, mean, gradient) for 2 MFLOP: one kernel
+        if (ctx->loss_fused < 0) {
+            const char* e = getenv("LINNA_LOSS_FUSED");
+            ctx->loss_fused = (e && e[0] == '0') ? 0 : 1;
+        }
+        unsigned* const cnt = ctx->loss_fused == 1 ? ctx_counters(ctx, st) : nullptr;
+        if (cnt)
+            return launch_loss_fused_small(PRED, ldp, Y, ldy, ROWS, B, *d, den, inv_batch, loss_rows, loss_mean, dPRED, lddp,
+                                           cnt, st);
+    }
     TRY(chi2_partials(d, 0, PRED, ldp, Y, ldy, ROWS, B, scratch, dPRED != nullptr, st));
     TRY(launch_loss_rows(1, scratch + 2 * (size_t)B * ld, slots, slots, B, den, ROWS, 0.f, loss_rows, st));
     if (loss_mean) TRY(launch_sum_scale(loss_rows, B, inv_batch, loss_mean, st));
@@ -824,6 +892,8 @@ int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v,
                      float b1, float b2, float eps, void* stream) {
     if (!p || !g || !m || !v || !hyper || !step_dev) { set_error("adamw_step: null pointer"); return LINNA_ERR_INVALID; }
     g_weights_epoch.fetch_add(1);
+    // (The step counter and the bias corrections stay in a launch of their own: folding them into the update with an
+    //  arrival counter measured 5 us slower than the extra launch.)
     return launch_adamw(p, g, m, v, n, hyper, step_dev, b1, b2, eps, S(stream));
 }
 

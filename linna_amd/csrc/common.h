@@ -65,6 +65,9 @@ int launch_loglike_diag_grad(const float* D, int ldd, int B, int nout, const flo
                              float* dH, int lddh, hipStream_t s);
 int launch_loss_delta(int mode, const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
                       const linna_loss_desc_t& d, float* DELTA, int ldd, hipStream_t s);
+int launch_loss_fused_small(const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
+                            const linna_loss_desc_t& d, const float* den, float inv_batch, float* loss_rows, float* loss_mean,
+                            float* dP, int lddp, unsigned* counter, hipStream_t s);
 int launch_loss_rows(int mode, const float* partial, int slots_ld, int nslots, int B, const float* den, const int* ROWS,
                      float floorv, float* out, hipStream_t s);
 int launch_loss_grad(const float* U, int ldu, const float* Y, int ldy, const int* ROWS, int B, int nout,
@@ -112,7 +115,14 @@ size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size
 // rows per workgroup for a batch of B rows: 16 (v_mfma_f32_16x16x4_f32), or 8 / 4 (v_mfma_f32_4x4x1_16b_f32) when 16-row
 // workgroups would leave CUs idle.  The 16-row engine and the small ones read different orders of the weight stream.
 int net_stream_rows(int B);
-int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, hipStream_t s);
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog, hipStream_t s);
+// the dX chain of a training step as a program of the same kernel (prog 1: ops nl-1..1, prog 2: down to op 0)
+bool net_stream_dx_eligible(const linna_layer_t* layers, int nl, int in_size, int with_input);
+size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_size, int with_input);
+int launch_net_stream_dx(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* dOUT, int lddo,
+                         int B, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
+                         float* const* dt, const int* lddt, const float* const* t, const int* ldt, int with_input, int rows,
+                         hipStream_t s);
 // sampler moves fused around the evaluation.  slice == 0: stretch half step, rows of the batch are the walkers
 // S[0..B).  slice == 1: rows are the slice sampler's trial points coords[S[k]] + cc[row] * DIR[k], k = row % nc
 // (DIR is passed as the launch's Z / ldz; cc = w[nrep * ns], nc = ns; nothing is written back).

@@ -93,6 +93,9 @@ struct NsArgs {
     // STORE instantiation (training / validation forward, nn.py:110-133): the input rows are taken as they are
     // (already X-transformed), every segment's output ALSO goes to global memory for the backward, no likelihood
     float* gout[NS_MAXSEG]; int gld[NS_MAXSEG]; int gn[NS_MAXSEG];
+    // STORE == 2 (the dX chain of a training step): a segment's output is zeroed where gmask (the stored forward
+    // activation whose gradient it is) is not positive, before it is stored and handed to the next segment
+    const float* gmask[NS_MAXSEG]; int gmld[NS_MAXSEG];
     // stretch move fused around the evaluation (MOVE instantiation; emcee StretchMove behind sampler.py:493-495)
     float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
@@ -107,6 +110,7 @@ struct NsPackSeg {
     const float* b; float bscale;
     int N, type, steps, passes, bias_off, bias_pad, ncg;
     int transA;                                   // Wa is read transposed: value(n, k) = Wa[k][n] (backward segments)
+    int transB;                                   // the same for Wb
 };
 struct NsPackArgs {
     NsPackSeg seg[NS_MAXSEG];
@@ -145,7 +149,7 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
                 if (k < S.Kapad) {
                     if (k < S.Ka) v[e] = !S.Wa ? (k == n ? 1.f : 0.f) : S.transA ? S.Wa[(size_t)k * S.lda + n] : S.Wa[(size_t)n * S.lda + k];
                 } else if (k - S.Kapad < S.Kb) {
-                    v[e] = S.alpha * S.Wb[(size_t)n * S.ldb + (k - S.Kapad)];
+                    v[e] = S.alpha * (S.transB ? S.Wb[(size_t)(k - S.Kapad) * S.ldb + n] : S.Wb[(size_t)n * S.ldb + (k - S.Kapad)]);
                 }
             }
         }
@@ -183,7 +187,7 @@ __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, flo
 // output, every residual block's hidden h) are written to global memory from the epilogues with inline-asm
 // stores: the compiler does not see them, so its counted vmcnt waits for the weight stream stay counted
 // (stores only ever make the hardware counter read higher, i.e. the waits conservative).
-template <int R, int MOVE, bool GRAD, bool STORE, int ROWS>
+template <int R, int MOVE, bool GRAD, int STORE, int ROWS>
 __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NT = NS_NT, NW = NS_NW;
     constexpr int RG = 32;                         // threads per walker row in prologue / reduce / finish
@@ -364,6 +368,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     unsigned* const lmask = reinterpret_cast<unsigned*>(lbias + ((a.bias_total + 3) & ~3));   // GRAD: [slot][512 lanes]
     float lnp_grad = 0.f;                          // GRAD: lnP, stored at the very end (no store next to the weight loads)
     float* s_gout = nullptr; int s_gld = 0, s_gn = 0;   // STORE: global destination of the current segment's output
+    const float* s_gmask = nullptr; int s_gmld = 0;     // STORE == 2: forward activation gating it
     auto gstore = [&](float* p, float v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory"); };
     uint32_t ap;
     auto a_read = [&](f32x4& dst) {
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2;
         if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
         if constexpr (STORE) { s_gout = a.gout[si]; s_gld = a.gld[si]; s_gn = a.gn[si]; }
+        if constexpr (STORE == 2) { s_gmask = a.gmask[si]; s_gmld = a.gmld[si]; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         const int arow = SM ? sm_arow : li, ak = SM ? 4 * sm_achunk : 4 * kq;
@@ -448,13 +454,16 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             // load's latency then hides under the epilogue stores and the barrier.
             const NsSeg NX = a.seg[min(si + 1, nseg - 1)];
             float* nx_gout = nullptr; int nx_gld = 0, nx_gn = 0;
+            const float* nx_gmask = nullptr; int nx_gmld = 0;
             if constexpr (STORE) { const int j = min(si + 1, nseg - 1); nx_gout = a.gout[j]; nx_gld = a.gld[j]; nx_gn = a.gn[j]; }
+            if constexpr (STORE == 2) { const int j = min(si + 1, nseg - 1); nx_gmask = a.gmask[j]; nx_gmld = a.gmld[j]; }
             const int cur_steps = s_steps;
             auto take_next = [&]() {
                 s_type = NX.type; s_steps = NX.steps; s_passes = NX.passes; s_bias = NX.bias_off;
                 s_dst = NX.dst_col; s_relu = NX.relu; s_kslice = NX.kslice; s_zext = NX.zext; s_ncgl = NX.ncg_log2;
                 if constexpr (GRAD) { s_mstore = NX.mask_store; s_mapply = NX.mask_apply; }
                 if constexpr (STORE) { s_gout = nx_gout; s_gld = nx_gld; s_gn = nx_gn; }
+                if constexpr (STORE == 2) { s_gmask = nx_gmask; s_gmld = nx_gmld; }
                 kleft = NX.steps;
             };
             bool seg_done = true;
@@ -487,12 +496,19 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         float v = fin[t][e];
                         if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
                         v = s_relu ? fmaxf(v, 0.f) : v;
+                        if constexpr (STORE == 2) {
+                            if (s_gmask) {
+                                const int mr = min(row0 + q_row(t, e), a.B - 1), mc = min(512 * pass + 64 * wave + q_col(t), s_gn - 1);
+                                if (!(s_gmask[(size_t)mr * s_gmld + mc] > 0.f)) v = 0.f;
+                            }
+                        }
                         nxt[q_row(t, e) * LD + q_col(t)] = v;
                         if constexpr (STORE) {
                             const int grow_ = row0 + q_row(t, e), gcol = 512 * pass + 64 * wave + q_col(t);
                             if (s_gout && grow_ < a.B && gcol < s_gn) {
                                 float vs = v;                      // the network's last output carries the column affine
-                                if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[gcol] : 1.f) + (a.cshift ? a.cshift[gcol] : 0.f);
+                                if constexpr (STORE == 1)
+                                    if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[gcol] : 1.f) + (a.cshift ? a.cshift[gcol] : 0.f);
                                 gstore(s_gout + (size_t)grow_ * s_gld + gcol, vs);
                             }
                         }
@@ -534,10 +550,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         for (int kp = 0; kp < NW; ++kp) v += kp < nkp ? x[kp] : 0.f;
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
+                        if constexpr (STORE == 2) {
+                            if (s_gmask && !(s_gmask[(size_t)min(row0 + pr, a.B - 1) * s_gmld + min(c, s_gn - 1)] > 0.f)) v = 0.f;
+                        }
                         if constexpr (STORE) {
                             if (s_gout && row0 + pr < a.B && c < s_gn) {
                                 float vs = v;
-                                if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[c] : 1.f) + (a.cshift ? a.cshift[c] : 0.f);
+                                if constexpr (STORE == 1)
+                                    if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[c] : 1.f) + (a.cshift ? a.cshift[c] : 0.f);
                                 gstore(s_gout + (size_t)(row0 + pr) * s_gld + c, vs);
                             }
                         }
@@ -681,26 +701,61 @@ struct NsProgram {
     }
     bool ok = false, grad_ok = false;                       // grad_ok: backward segments appended (ReLU MLPs)
     std::vector<int> seg_op, seg_hidden;                    // forward segments: op index; 1 = the hidden h of a residual block
+                                                            // (dX-chain program: 1 = d/dh of a residual block, else d/d(input) of the op)
 };
 
 static int ceil16(int k) { return (k + 15) & ~15; }
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
-static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, bool allow_grad);
+enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3 };
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode);
 static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
-    NsProgram p = ns_build_one(layers, nl, in_size, true);
-    if (!p.ok) p = ns_build_one(layers, nl, in_size, false);      // the backward half may be what did not fit
+    NsProgram p = ns_build_one(layers, nl, in_size, NS_PROG_FWD);
+    if (!p.ok) p = ns_build_one(layers, nl, in_size, NS_PROG_FWD_NOGRAD);      // the backward half may be what did not fit
     return p;
 }
-static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, bool allow_grad) {
+// mode NS_PROG_DX: the dX chain of a training step as a program of its own (linna_net_backward's order): the rows are
+// d loss / d output, the segments run over the transposed weights from the last op down to op 1 (NS_PROG_DX_INPUT: op 0).
+// A residual block y = relu(0.1 (W2 h + b2) + Ws x), h = relu(W1 x + b1) comes back as  dh = 0.1 (dy W2) [h > 0],
+// written behind dy, and ONE GEMM over [dy ; dh] with [Ws^T | W1^T]; the gate of every output (the stored forward
+// activation) is applied by the kernel's STORE == 2 epilogue.
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode) {
     NsProgram p;
+    const bool allow_grad = mode == NS_PROG_FWD, dx_prog = mode >= NS_PROG_DX;
     if (nl < 1 || in_size < 1 || in_size > 256) return p;
     // 1. linear maps: [Wa | alpha Wb] over K = [Kapad ; Kb], N outputs, written to dst_col (same_buf: into the input's buffer)
     struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
-                 int N, relu, dst_col; bool same_buf; int transA = 0; int force_wide = 0; int mask_apply_of = -1; int op = -1; };
+                 int N, relu, dst_col; bool same_buf; int transA = 0; int force_wide = 0; int mask_apply_of = -1; int op = -1;
+                 int transB = 0; };
     std::vector<Lin> lins;
     int width = in_size;
-    for (int i = 0; i < nl; ++i) {
+    for (int i = 0; i < nl && dx_prog; ++i) {                   // shape checks as in the forward program
+        const linna_layer_t& l = layers[i];
+        if (l.K != width || l.N < 1 || l.N > 1024 || l.K > 1024) return p;
+        if (l.op == LINNA_OP_LINEAR) { if (l.alpha != 1.f) return p; }
+        else if (l.op == LINNA_OP_RESBLOCK) { if (l.C < 1 || l.C > 64 || (!l.Ws && l.K != l.N)) return p; }
+        else return p;
+        width = l.N;
+    }
+    std::vector<int> lin_hidden;
+    for (int i = nl - 1; i >= (mode == NS_PROG_DX_INPUT ? 0 : 1) && dx_prog; --i) {
+        const linna_layer_t& l = layers[i];
+        const int npad = ceil16(l.N);
+        if (l.op == LINNA_OP_LINEAR) {
+            Lin B{l.W, (l.K + 3) & ~3, l.N, npad, nullptr, 0, 0, 0.f, nullptr, 0.f, l.K, 0, 0, false};
+            B.transA = 1; B.op = i;
+            lins.push_back(B); lin_hidden.push_back(0);
+        } else {
+            Lin A{nullptr, 0, 0, 0, l.W2, (l.C + 3) & ~3, l.N, 0.1f, nullptr, 0.f, l.C, 0, npad, true};     // dh behind dy
+            A.transB = 1; A.op = i;
+            lins.push_back(A); lin_hidden.push_back(1);
+            Lin B{l.Ws, (l.K + 3) & ~3, l.N, npad, l.W1, (l.K + 3) & ~3, l.C, 1.f, nullptr, 0.f, l.K, 0, 0, false};
+            B.transA = 1; B.transB = 1; B.op = i;
+            lins.push_back(B); lin_hidden.push_back(0);
+        }
+    }
+    width = in_size;
+    for (int i = 0; i < nl && !dx_prog; ++i) {
         const linna_layer_t& l = layers[i];
         if (l.K != width) return p;
         if (l.op == LINNA_OP_LINEAR) {
@@ -719,6 +774,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         }
         width = l.N;
     }
+    if (dx_prog) in_size = layers[nl - 1].N;                   // the rows of this program are d loss / d output
     if (lins.empty() || lins.back().relu || (int)lins.size() > NS_MAXSEG) return p;
     const int nfwd = (int)lins.size();
     // Backward (d lnP / d z) for plain ReLU MLPs whose hidden layers come out as WIDE segments: the backward
@@ -767,8 +823,8 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         }
         q.Wa = L.Wa; q.lda = L.lda; q.Ka = L.Ka; q.Kapad = L.Kapad; q.Wb = L.Wb; q.ldb = L.ldb; q.Kb = L.Kb; q.alpha = L.alpha;
         q.b = L.b; q.bscale = L.bscale; q.N = L.N; q.type = s.type; q.steps = s.steps; q.passes = s.passes; q.bias_off = bias_off;
-        q.transA = L.transA;
-        if (L.transA) {                                     // backward segments have no bias: ONE shared block of zeros
+        q.transA = L.transA; q.transB = L.transB;
+        if (L.transA && !dx_prog) {                                     // backward segments have no bias: ONE shared block of zeros
             if (zero_off < 0) { zero_off = bias_off; zero_pad = 0; }
             s.bias_off = q.bias_off = zero_off;
             const int grow = std::max(0, q.bias_pad - zero_pad);
@@ -828,10 +884,11 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         }
     }
     for (const NsSeg& s : p.seg) if (s.type == NS_SPLIT) maxext = std::max(maxext, s.dst_col + s.zext);
-    if (p.kpad0 > 256) return p;
+    if (p.kpad0 > (dx_prog ? 1024 : 256)) return p;
     p.nout = lins[nfwd - 1].N;
     p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
     for (int i = 0; i < nfwd; ++i) { p.seg_op.push_back(lins[i].op); p.seg_hidden.push_back(lins[i].same_buf ? 1 : 0); }
+    (void)lin_hidden;
     p.bias_total = bias_off;
     p.LD = ((maxext + 63) & ~63) + 4;
     if (NS_ROWS * p.LD < 8192 + 64) return p;               // SPLIT partials need [8][16][64] floats in one buffer
@@ -870,8 +927,19 @@ int net_stream_rows(int B) {
     return B <= 4 * ncu ? 4 : B <= 8 * ncu ? 8 : 16;
 }
 
-int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, hipStream_t s) {
-    const NsProgram p = ns_build(layers, nl, in_size);
+static NsProgram ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog) {
+    return prog == 0 ? ns_build(layers, nl, in_size) : ns_build_one(layers, nl, in_size, prog == 2 ? NS_PROG_DX_INPUT : NS_PROG_DX);
+}
+bool net_stream_dx_eligible(const linna_layer_t* layers, int nl, int in_size, int with_input) {
+    return nl >= (with_input ? 1 : 2) && ns_build_prog(layers, nl, in_size, with_input ? 2 : 1).ok;
+}
+size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_size, int with_input) {
+    return ns_build_prog(layers, nl, in_size, with_input ? 2 : 1).packed_floats;
+}
+
+// prog: 0 the forward program (+ the fused gradient's backward half), 1 / 2 the dX chain without / with op 0
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog, hipStream_t s) {
+    const NsProgram p = ns_build_prog(layers, nl, in_size, prog);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsPackArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -891,7 +959,7 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     return check_hip(hipGetLastError(), "net_stream pack launch");
 }
 
-template <int MOVE, bool GRAD, bool STORE, int ROWS>
+template <int MOVE, bool GRAD, int STORE, int ROWS>
 static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -903,7 +971,7 @@ static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t 
     hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD, STORE, ROWS>), dim3((B + ROWS - 1) / ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
     return check_hip(hipGetLastError(), "net_stream launch");
 }
-template <int MOVE, bool GRAD, bool STORE = false>
+template <int MOVE, bool GRAD, int STORE = 0>
 static int ns_launch_kernel(const NsArgs& a, int B, const NsProgram& p, int rows, hipStream_t s) {
     const size_t lds = p.lds_for(rows, GRAD);
     if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s);
@@ -978,7 +1046,37 @@ int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, co
         if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
         else { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
     }
-    return ns_launch_kernel<0, false, true>(a, B, p, rows, s);
+    return ns_launch_kernel<0, false, 1>(a, B, p, rows, s);
 }
 
+}  // namespace linna
+
+namespace linna {
+// The dX chain of a training step in one launch (what linna_net_backward otherwise runs as one GEMM per op):
+// dOUT[B][lddo] -> for every op i >= first (1, or 0 with_input) the gradient with respect to its input, gated by the
+// stored forward activation hin[i] (null: no gate), into dprev[i]; for residual blocks also d/dh into dt[i], gated by
+// the stored h (t[i]).
+int launch_net_stream_dx(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* dOUT, int lddo,
+                         int B, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
+                         float* const* dt, const int* lddt, const float* const* t, const int* ldt, int with_input, int rows,
+                         hipStream_t s) {
+    const NsProgram p = ns_build_prog(layers, nl, in_size, with_input ? 2 : 1);
+    if (!p.ok) { set_error("net_stream: no dX-chain program for this network"); return LINNA_ERR_UNSUPPORTED; }
+    NsArgs a;
+    ::memset(static_cast<void*>(&a), 0, sizeof(a));
+    const int nout = layers[nl - 1].N;
+    a.Z = dOUT; a.ldz = lddo; a.B = B; a.nin = nout;
+    a.is_flat = reinterpret_cast<const int*>(dOUT); a.a1 = dOUT; a.a2 = dOUT; a.lg = nullptr; a.xmean = dOUT; a.xstd = dOUT;
+    a.packed = packed;
+    a.Gstride = p.Gstride; a.nseg_f = p.nseg_f; a.G = p.G; a.nseg = p.nseg_f;
+    a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
+    a.T = 1.f;
+    for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
+    for (int i = 0; i < p.nseg_f; ++i) {
+        const int op = p.seg_op[i];
+        if (p.seg_hidden[i]) { a.gout[i] = dt[op]; a.gld[i] = lddt[op]; a.gn[i] = layers[op].C; a.gmask[i] = t[op]; a.gmld[i] = ldt[op]; }
+        else { a.gout[i] = dprev[op]; a.gld[i] = ldp[op]; a.gn[i] = layers[op].K; a.gmask[i] = hin[op]; a.gmld[i] = ldh[op]; }
+    }
+    return ns_launch_kernel<0, false, 2>(a, B, p, rows, s);
+}
 }  // namespace linna

@@ -181,6 +181,54 @@ __global__ void loss_grad_kernel(const float* __restrict__ U, int ldu, const flo
     dP[idx] = masked ? 0.f : (-2.f * U[(size_t)i * ldu + j]) * inv_batch / den[r];
 }
 
+// The whole chi2-ratio loss of a minibatch (util.py:1070-1116) for nout <= 64 in ONE launch: one wave per row, lane j
+// owns column j.  delta (loss_delta_kernel, mode 0), U = delta Cinv from a copy of Cinv in LDS (k-loop, delta_k by
+// shuffle), chi2 = delta . U (wave sum), loss_b = chi2 / den, d loss / d pred (loss_grad_kernel), and the batch mean:
+// the block that arrives last sums loss_rows in index order (same value whatever the arrival order).
+// `counter` is a zeroed int that wraps back to zero by itself (atomicInc).
+__global__ __launch_bounds__(256) void loss_fused_small_kernel(
+        const float* __restrict__ PRED, int ldp, const float* __restrict__ Y, int ldy, const int* __restrict__ ROWS, int B,
+        int nout, const float* __restrict__ sigma, const float* __restrict__ ymean, const float* __restrict__ ystd,
+        const float* __restrict__ data_norm, const float* __restrict__ Cinv, int ldc, const float* __restrict__ den,
+        float inv_batch, float* __restrict__ loss_rows, float* __restrict__ loss_mean, float* __restrict__ dP, int lddp,
+        unsigned* counter) {
+    __shared__ float C[64 * 65];
+    __shared__ float part[4];
+    __shared__ int last;
+    for (int i = threadIdx.x; i < nout * nout; i += 256) C[(i / nout) * 65 + (i % nout)] = Cinv[(size_t)(i / nout) * ldc + (i % nout)];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b < B) {
+        const int r = ROWS ? ROWS[b] : b;
+        const bool in = lane < nout;
+        const int j = in ? lane : 0;
+        const float y = Y[(size_t)r * ldy + j], dn = data_norm[j];
+        const bool masked = !in | (y == 1e-30f) | (y == 1e10f) | (dn == 1e-30f);
+        const float yn = (y / sigma[j] - ymean[j]) / ystd[j];
+        const float delta = masked ? 0.f : yn - PRED[(size_t)b * ldp + j];
+        float u = 0.f;
+        for (int k = 0; k < nout; ++k) u += __shfl(delta, k, 64) * C[k * 65 + j];
+        const float chi = wave_sum(in ? delta * u : 0.f);
+        const float dr = den[r];
+        if (lane == 0) loss_rows[b] = chi / dr;
+        if (dP && lane < lddp) dP[(size_t)b * lddp + lane] = masked ? 0.f : (-2.f * u) * inv_batch / dr;
+    }
+    if (!loss_mean) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicInc(counter, gridDim.x - 1) == gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += 256) acc += __builtin_nontemporal_load(loss_rows + i);
+    acc = wave_sum(acc);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_mean[0] = (((part[0] + part[1]) + part[2]) + part[3]) * inv_batch;
+}
+
 // deterministic single-block sum: out[0] = scale * sum_i v[i]
 __global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out) {
     __shared__ float part[16];
@@ -531,6 +579,13 @@ int launch_loss_delta(int mode, const float* PRED, int ldp, const float* Y, int 
     hipLaunchKernelGGL(loss_delta_kernel, grid1d((size_t)B * ldd, 256), dim3(256), 0, s, mode, PRED, ldp, Y, ldy, ROWS,
                        B, d.nout, d.sigma, d.ymean, d.ystd, d.data_norm, DELTA, ldd);
     LAUNCH_CHECK("loss_delta");
+}
+int launch_loss_fused_small(const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
+                            const linna_loss_desc_t& d, const float* den, float inv_batch, float* loss_rows, float* loss_mean,
+                            float* dP, int lddp, unsigned* counter, hipStream_t s) {
+    hipLaunchKernelGGL(loss_fused_small_kernel, dim3((B + 3) / 4), dim3(256), 0, s, PRED, ldp, Y, ldy, ROWS, B, d.nout, d.sigma,
+                       d.ymean, d.ystd, d.data_norm, d.Cinv, d.ldc, den, inv_batch, loss_rows, loss_mean, dP, lddp, counter);
+    LAUNCH_CHECK("loss_fused_small");
 }
 int launch_loss_rows(int mode, const float* partial, int slots_ld, int nslots, int B, const float* den, const int* ROWS,
                      float floorv, float* out, hipStream_t s) {
