@@ -151,6 +151,11 @@ int linna_net_forward(linna_net_t* net, const float* X, int ldx, int B, void* ws
  * NULL).  torch autograd at predictor_gpu.py:285 / HMCSampler.py:32. */
 int linna_net_backward(linna_net_t* net, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws,
                        const float* dOUT, int lddo, float* dX, int lddx, int param_grads, void* stream);
+/* Diagnostics: which parts of this network's forward / backward ran (or will run) as ONE launch of the
+ * whole-network kernel instead of one GEMM per op.  Each flag is -1 (not decided yet: decided at the first
+ * call of that kind), 0 or 1.  fwd: linna_net_forward; dx: the dX chain of linna_net_backward with dX == NULL
+ * (training); dx_input: with dX != NULL (gradient with respect to the network input).  Any pointer may be NULL. */
+int linna_net_stream_state(const linna_net_t* net, int* fwd, int* dx, int* dx_input);
 
 /* ------------------------------------------------------------------ prior map + input transform
  * util.py:339-347 (Transform) fused with util.py:483-497 (X_transform_class):

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "linna_net_bwd_ws_bytes": (_SZ, [_V, _I]),
     "linna_net_forward": (_I, [_V, _V, _I, _I, _V, _V, _I, C.POINTER(ColMap), _V]),
     "linna_net_backward": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V, _I, _I, _V]),
+    "linna_net_stream_state": (_I, [_V, _V, _V, _V]),
     "linna_prior_map_fwd": (_I, [_V, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _V, _I, _V, _I, _V]),
     "linna_prior_map_bwd": (_I, [_V, _V, _I, _I, _I, _V, _V, _V, _V, _V, _V, _I, _V, _I, _V]),
     "linna_gauss_loglike_diag": (_I, [_V, _V, _I, _I, _I, _V, _V, _I, _I, _F, _V, _V]),

@@ -381,6 +381,14 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
     return LINNA_OK;
 }
 
+int linna_net_stream_state(const linna_net_t* n, int* fwd, int* dx, int* dx_input) {
+    if (!n) { set_error("net_stream_state: null network"); return LINNA_ERR_INVALID; }
+    if (fwd) *fwd = n->stream_fwd;
+    if (dx) *dx = n->stream_bwd[0];
+    if (dx_input) *dx_input = n->stream_bwd[1];
+    return LINNA_OK;
+}
+
 int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
                        int lddo, float* dX, int lddx, int pg, void* stream) {
     if (!n || !X || !dOUT || !bwd_ws || B < 1) { set_error("net_backward: bad arguments"); return LINNA_ERR_INVALID; }

@@ -281,6 +281,16 @@ class _Emulator(object):
 
     __call__ = forward
 
+    def stream_state(self):
+        """(forward, dX chain, dX chain down to the input): 1 where that part runs as one launch of the
+        whole-network kernel, 0 where it runs as one GEMM per op, -1 before its first call."""
+        f, d, di = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        _lib.call("linna_net_stream_state", self.net_handle(), C.byref(f), C.byref(d), C.byref(di))
+        return f.value, d.value, di.value
+
+    def uses_dx_stream(self):
+        return 1 in self.stream_state()[1:]
+
     def backward(self, dout, param_grads=True, need_dx=False):
         """Reverse pass for the most recent ``forward`` (same batch): fills ``flat_grads()``
         and/or returns d/d(input)."""

@@ -172,3 +172,49 @@ def test_train_gpu_process_shim(tmp_path):
                        timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert os.path.isfile(out + "finish.pkl") and os.path.isfile(out + "best.pth.tar")
+
+
+@pytest.mark.parametrize("kind,nin,nout,kw", [("ChtoModelv2", 33, 33, {}), ("ChtoModelv2", 26, 457, {}), ("ChtoModelsimple", 6, 4, {}),
+                                              ("MLP", 33, 33, {"width": 512, "depth": 4})])
+def test_one_launch_dx_chain_equals_gemm_chain(kind, nin, nout, kw, monkeypatch):
+    """The backward's dX chain as ONE launch of the whole-network kernel over the transposed weights
+    (net_stream.hip, STORE == 2) against the GEMM-per-op chain it replaces: every parameter gradient and the
+    gradient with respect to the input, with each of the kernel's three engines and a ragged batch."""
+    from linna_amd import nn
+    cls = {"ChtoModelv2": nn.ChtoModelv2, "ChtoModelsimple": nn.ChtoModelsimple, "MLP": nn.MLP}[kind]
+    torch.manual_seed(5)
+    fused = cls(nin, nout, None, **kw)
+    fused.init_weight()
+    # give the zero-initialised skip weights of the residual blocks something to propagate
+    sd = {k: (v if "skip" not in k else 0.05 * torch.randn_like(v)) for k, v in fused.state_dict().items()}
+    fused.load_state_dict(sd)
+    chain = cls(nin, nout, None, **kw)
+    chain.load_state_dict(sd)
+    fused.cuda(); chain.cuda()
+    B = 301
+    x = torch.randn(B, nin, device="cuda")
+    dout = torch.randn(B, nout, device="cuda") / B
+    monkeypatch.setenv("LINNA_BWD_STREAM", "0")           # read at the network's first backward
+    chain.forward(x)
+    dx_ref = chain.backward(dout, param_grads=True, need_dx=True)[:, :nin].clone()
+    g_ref = {k: v.clone() for k, v in chain.grad_dict().items()}
+    monkeypatch.delenv("LINNA_BWD_STREAM")
+    for rows in (None, "4", "8", "16"):
+        if rows is None:
+            monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+        else:
+            monkeypatch.setenv("LINNA_NS_ROWS", rows)
+        for need_dx in (True, False):
+            fused.flat_grads().zero_()
+            fused.forward(x)
+            dx = fused.backward(dout, param_grads=True, need_dx=need_dx)
+            if need_dx:
+                np.testing.assert_allclose(dx[:, :nin].cpu().numpy(), dx_ref.cpu().numpy(), rtol=2e-3,
+                                           atol=2e-5 * float(dx_ref.abs().max()), err_msg="dX rows %s" % rows)
+            for k, gk in fused.grad_dict().items():
+                ref = g_ref[k].cpu().numpy()
+                np.testing.assert_allclose(gk.cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max() + 1e-9,
+                                           err_msg="%s rows %s" % (k, rows))
+    monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+    # the two objects took different routes: the fused one holds a weight stream for the dX chain
+    assert fused.uses_dx_stream() and not chain.uses_dx_stream()
