@@ -116,7 +116,8 @@ struct linna_net {
     int max_w, max_c;
 };
 
-static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog = 0);
+static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog = 0,
+                               const NsDense* dn = nullptr);
 
 struct FwdLayout {
     std::vector<size_t> t_off, y_off;   // float offsets, per op (y_off of the last op unused)
@@ -635,6 +636,8 @@ struct linna_logprob {
     linna_logprob_desc_t d;
     StreamCopy packed;                       // fragment-order weight streams (net_stream.hip), or not allocated
     bool grad_fused = false;                 // the streams also hold the backward segments (ReLU MLPs)
+    bool dense_fused = false;                // the streams end in the dense inverse covariance (output map folded in)
+    NsDense dense() const { return NsDense{d.S, d.lds, d.outmap.cscale, d.outmap.cshift}; }
 };
 
 struct LpLayout { size_t x0, fwd, d, part, dh, bwd, dx, total; int slots; };
@@ -661,7 +664,8 @@ static bool fused_enabled() {
     static const bool on = !(getenv("LINNA_DISABLE_FUSED") && getenv("LINNA_DISABLE_FUSED")[0] == '1');
     return on;
 }
-static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog) {
+static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog,
+                               const NsDense* dn) {
     const int k = rows < 16 ? 1 : 0;
     const unsigned long long epoch = g_weights_epoch.load();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -669,10 +673,10 @@ static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, voi
     if (cap != hipStreamCaptureStatusNone) {
         // a captured launch carries its own re-layout, so that every replay sees the weights of that
         // moment; the copy is not valid for direct launches until they redo it
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, S(stream)));
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
         sc.epoch[k] = 0;
     } else if (sc.epoch[k] != epoch) {
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, S(stream)));
+        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
         sc.epoch[k] = epoch;
     }
     *out = sc.buf[k];
@@ -681,7 +685,8 @@ static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, voi
 // The copy the engine for `B` rows reads, re-laid if the weights moved since it was made; *rows: that engine.
 static int lp_refresh_stream(linna_logprob* lp, int B, void* stream, const float** packed, int* rows) {
     *rows = net_stream_rows(B);
-    return stream_copy_refresh(lp->packed, lp->net, *rows, stream, packed);
+    const NsDense dn = lp->dense();
+    return stream_copy_refresh(lp->packed, lp->net, *rows, stream, packed, 0, lp->dense_fused ? &dn : nullptr);
 }
 
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
@@ -694,9 +699,18 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
         // log-likelihood in ONE launch, weights streamed from the fragment-order copy
         const float* packed = nullptr; int rows = 16;
         TRY(lp_refresh_stream(lp, B, stream, &packed, &rows));
+        if (lp->dense_fused) {
+            // dense covariance: the output map is folded into the stream's last layer and the inverse covariance is its
+            // last segment -- lnP comes out of the same launch
+            const NsDense dn = lp->dense();
+            return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+                                     d.log10_flag, d.xmean, d.xstd, nullptr, nullptr, nullptr, d.temperature, lnP, nullptr, 0,
+                                     TH, ldt, nullptr, nullptr, gate, rows, &dn, S(stream));
+        }
         TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                               d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, rows, S(stream)));
+                              d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, rows, nullptr,
+                              S(stream)));
         if (d.w) return LINNA_OK;
         return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
@@ -720,7 +734,16 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     if (!desc->w && !desc->S) { set_error("logprob_create: need S (dense) or w (diagonal)"); return LINNA_ERR_INVALID; }
     if (!(desc->temperature > 0.f)) { set_error("logprob_create: temperature must be > 0"); return LINNA_ERR_INVALID; }
     linna_logprob* lp = new linna_logprob{ctx, net, *desc};
-    if (!net->has_inskip && net_stream_eligible(net->L.data(), (int)net->L.size(), net->in_size)) {
+    const NsDense dn = lp->dense();
+    const bool want_dense = !desc->w && desc->S && !desc->outmap.cexp && !net->has_inskip &&
+                            !(getenv("LINNA_DENSE_FUSED") && getenv("LINNA_DENSE_FUSED")[0] == '0');
+    if (want_dense && net_stream_dense_eligible(net->L.data(), (int)net->L.size(), net->in_size, dn)) {
+        lp->dense_fused = true;
+        if (lp->packed.alloc(net_stream_dense_packed_floats(net->L.data(), (int)net->L.size(), net->in_size, dn)) != LINNA_OK) {
+            set_error("logprob_create: hipMalloc(weight stream) failed");
+            delete lp; return LINNA_ERR_HIP;
+        }
+    } else if (!net->has_inskip && net_stream_eligible(net->L.data(), (int)net->L.size(), net->in_size)) {
         const size_t nf = net_stream_packed_floats(net->L.data(), (int)net->L.size(), net->in_size);
         lp->grad_fused = net_stream_has_grad(net->L.data(), (int)net->L.size(), net->in_size) && !desc->outmap.cexp &&
                          !(getenv("LINNA_DISABLE_FUSED_GRAD") && getenv("LINNA_DISABLE_FUSED_GRAD")[0] == '1');
@@ -764,7 +787,7 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
     }
     const linna_logprob_desc_t& d = lp->d;
     if (ndim != d.nin) { set_error("logprob_eval_slice_points: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
-    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || !d.w || d.nin > 64) {
+    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || (!d.w && !lp->dense_fused) || d.nin > 64) {
         set_error("logprob_eval_slice_points: this log-probability does not run the whole-network kernel");
         return LINNA_ERR_UNSUPPORTED;          // the caller falls back to linna_slice_points + linna_logprob_eval_if
     }
@@ -772,9 +795,12 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
     TRY(lp_refresh_stream(lp, nrep * ns, stream, &packed, &rows));
     const linna_net* n = lp->net;
     NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, nullptr, ns, 0ull, nullptr, 0, 0, 0.f, nullptr, 1};
+    const NsDense dn = lp->dense();
+    const bool df = lp->dense_fused;
     return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
-                             d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                             lnP, nullptr, 0, nullptr, 0, &mv, nullptr, gate, rows, S(stream));
+                             d.a2, d.log10_flag, d.xmean, d.xstd, df ? nullptr : d.outmap.cscale, df ? nullptr : d.outmap.cshift,
+                             df ? nullptr : d.w, d.temperature, lnP, nullptr, 0, nullptr, 0, &mv, nullptr, gate, rows,
+                             df ? &dn : nullptr, S(stream));
 }
 
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
@@ -785,7 +811,7 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     }
     const linna_logprob_desc_t& d = lp->d;
     if (ndim != d.nin) { set_error("stretch_half_step: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
-    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || !d.w || d.nin > 64) {
+    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || (!d.w && !lp->dense_fused) || d.nin > 64) {
         set_error("stretch_half_step: this log-probability does not run the whole-network kernel");
         return LINNA_ERR_UNSUPPORTED;          // the caller falls back to propose / eval / accept
     }
@@ -793,9 +819,12 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     TRY(lp_refresh_stream(lp, ns, stream, &packed, &rows));
     const linna_net* n = lp->net;
     NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept, 0};
+    const NsDense dn = lp->dense();
+    const bool df = lp->dense_fused;
     return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
-                             d.a2, d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
-                             nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, rows, S(stream));
+                             d.a2, d.log10_flag, d.xmean, d.xstd, df ? nullptr : d.outmap.cscale, df ? nullptr : d.outmap.cshift,
+                             df ? nullptr : d.w, d.temperature, nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, rows,
+                             df ? &dn : nullptr, S(stream));
 }
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
@@ -812,7 +841,7 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
         NsGrad gr{d.gscale, G, ldg};
         return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                                  d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP,
-                                 nullptr, 0, nullptr, 0, nullptr, &gr, nullptr, rows, S(stream));
+                                 nullptr, 0, nullptr, 0, nullptr, &gr, nullptr, rows, nullptr, S(stream));
     }
     const LpLayout L = lp_layout(lp, B, 1);
     float* w = static_cast<float*>(ws);

@@ -109,13 +109,19 @@ int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int
                         const float* Wacc, const float* Zacc, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
 
+// Dense inverse covariance for the whole-network kernel: the output map d = raw * cscale + cshift is folded into the last
+// layer of the weight stream and S (symmetric, [nout][lds]) is appended as one more segment, chi2 = d . (d S).
+struct NsDense { const float* S; int lds; const float* cscale; const float* cshift; };
 // net_stream.hip (program-driven whole-network kernel: residual blocks, widths up to 1024)
 bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size);
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size);
 // rows per workgroup for a batch of B rows: 16 (v_mfma_f32_16x16x4_f32), or 8 / 4 (v_mfma_f32_4x4x1_16b_f32) when 16-row
 // workgroups would leave CUs idle.  The 16-row engine and the small ones read different orders of the weight stream.
 int net_stream_rows(int B);
-int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog, hipStream_t s);
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog,
+                           const NsDense* dn, hipStream_t s);      // prog 0 + dn: the forward program with the dense segment
+bool net_stream_dense_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn);
+size_t net_stream_dense_packed_floats(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn);
 // the dX chain of a training step as a program of the same kernel (prog 1: ops nl-1..1, prog 2: down to op 0)
 bool net_stream_dx_eligible(const linna_layer_t* layers, int nl, int in_size, int with_input);
 size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_size, int with_input);
@@ -143,7 +149,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
-                      hipStream_t s);
+                      const NsDense* dn, hipStream_t s);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);

@@ -96,6 +96,9 @@ struct NsArgs {
     // STORE == 2 (the dX chain of a training step): a segment's output is zeroed where gmask (the stored forward
     // activation whose gradient it is) is not positive, before it is stored and handed to the next segment
     const float* gmask[NS_MAXSEG]; int gmld[NS_MAXSEG];
+    // dense inverse covariance as the program's last segment: U = d S sits at column u_col of the current buffer
+    // (u_same) or at column 0 with d in the other buffer; the finish takes chi2 = d . U
+    int dense, u_col, u_same;
     // stretch move fused around the evaluation (MOVE instantiation; emcee StretchMove behind sampler.py:493-495)
     float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
@@ -111,6 +114,7 @@ struct NsPackSeg {
     int N, type, steps, passes, bias_off, bias_pad, ncg;
     int transA;                                   // Wa is read transposed: value(n, k) = Wa[k][n] (backward segments)
     int transB;                                   // the same for Wb
+    const float* rscale; const float* rshift;     // per output column: weights and bias * rscale, bias + rshift (folded output map)
 };
 struct NsPackArgs {
     NsPackSeg seg[NS_MAXSEG];
@@ -152,6 +156,7 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
                     v[e] = S.alpha * (S.transB ? S.Wb[(size_t)(k - S.Kapad) * S.ldb + n] : S.Wb[(size_t)n * S.ldb + (k - S.Kapad)]);
                 }
             }
+            if (S.rscale) { const float r = S.rscale[n]; v = f32x4{v[0] * r, v[1] * r, v[2] * r, v[3] * r}; }
         }
         reinterpret_cast<f32x4*>(p.out)[idx] = v;
         return;
@@ -162,7 +167,10 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
     while (si + 1 < p.nseg && (int)j >= p.seg[si + 1].bias_off) ++si;
     const NsPackSeg& S = p.seg[si];
     const int c = (int)j - S.bias_off;
-    p.out[nw4 * 4 + j] = (c < S.N && S.b) ? S.bscale * S.b[c] : 0.f;
+    float bv = (c < S.N && S.b) ? S.bscale * S.b[c] : 0.f;
+    if (c < S.N && S.rscale) bv *= S.rscale[c];
+    if (c < S.N && S.rshift) bv += S.rshift[c];
+    p.out[nw4 * 4 + j] = bv;
 }
 
 __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, float a2) {
@@ -648,16 +656,27 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             if (a.D && rok) a.D[(size_t)(row0 + pr) * a.ldd + c] = d;
             chi += (d * ww) * d;
         };
+        if (a.dense) {
+            // the last segment multiplied d (output map folded into the last layer) by the dense inverse covariance
+            const float* const Dv = a.u_same ? F : act + (P ^ 1) * ABUF + pr * LD;
+            const float* const U = a.u_same ? F + a.u_col : F;
+            for (int c = pc0; c < nout; c += RG) {
+                const float d = Dv[c];
+                if (a.D && rok) a.D[(size_t)(row0 + pr) * a.ldd + c] = d;
+                chi += d * U[c];
+            }
+        } else {
 #pragma unroll
-        for (int i = 0; i < FIN; ++i)
-            if (pc0 + i * RG < nout) column(pc0 + i * RG, fcs[i], fct[i], fw[i]);
-        for (int c = pc0 + FIN * RG; c < nout; c += RG)        // wide outputs: constants straight from memory
-            column(c, a.cscale ? a.cscale[c] : 1.f, a.cshift ? a.cshift[c] : 0.f, a.w ? a.w[c] : 0.f);
+            for (int i = 0; i < FIN; ++i)
+                if (pc0 + i * RG < nout) column(pc0 + i * RG, fcs[i], fct[i], fw[i]);
+            for (int c = pc0 + FIN * RG; c < nout; c += RG)        // wide outputs: constants straight from memory
+                column(c, a.cscale ? a.cscale[c] : 1.f, a.cshift ? a.cshift[c] : 0.f, a.w ? a.w[c] : 0.f);
+        }
 #pragma unroll
         for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
         float lnp_new = (-0.5f * chi) / a.T + (-0.5f * zz);
         lnp_new = isnan(lnp_new) ? -INFINITY : lnp_new;
-        if (a.lnP && a.w && pc0 == 0 && rok) a.lnP[row0 + pr] = lnp_new;
+        if (a.lnP && (a.w || a.dense) && pc0 == 0 && rok) a.lnP[row0 + pr] = lnp_new;
         if constexpr (MOVE == 1) {
             // Metropolis test of the stretch move (linna_stretch_accept); every lane of the row agrees
             if (rok && mv_factor + lnp_new - mv_lnp_old > mv_logu) {
@@ -692,6 +711,7 @@ struct NsProgram {
     int G = 0, LD = 0, kpad0 = 0, nout = 0, bias_total = 0;
     int Gstride = 0, nseg_f = 0, mask_slots = 0;            // G: forward steps; Gstride: forward + backward steps
     size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;   // LDS of the 16-row engine (lds_for: any engine)
+    int dense = 0, u_col = 0, u_same = 0;                   // dense inverse covariance appended as the last segment
     size_t lds_for(int rows, bool grad) const {
         size_t b = (size_t)(2 * rows * LD + ((bias_total + 3) & ~3)) * sizeof(float);
 #ifdef NS_STAMPS
@@ -707,8 +727,8 @@ struct NsProgram {
 static int ceil16(int k) { return (k + 15) & ~15; }
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
-enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3 };
-static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode);
+enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4 };
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn = nullptr);
 static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
     NsProgram p = ns_build_one(layers, nl, in_size, NS_PROG_FWD);
     if (!p.ok) p = ns_build_one(layers, nl, in_size, NS_PROG_FWD_NOGRAD);      // the backward half may be what did not fit
@@ -719,14 +739,18 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
 // A residual block y = relu(0.1 (W2 h + b2) + Ws x), h = relu(W1 x + b1) comes back as  dh = 0.1 (dy W2) [h > 0],
 // written behind dy, and ONE GEMM over [dy ; dh] with [Ws^T | W1^T]; the gate of every output (the stored forward
 // activation) is applied by the kernel's STORE == 2 epilogue.
-static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode) {
+// mode NS_PROG_FWD_DENSE: the forward program with the output map (d = raw * cscale + cshift) folded into the last
+// layer's weights and bias, and the dense inverse covariance appended as one more bias-free segment U = d S -- the
+// Gaussian log-likelihood (util.py:953-955) with a dense covariance then needs no GEMM launch of its own.
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn) {
     NsProgram p;
-    const bool allow_grad = mode == NS_PROG_FWD, dx_prog = mode >= NS_PROG_DX;
+    const bool allow_grad = mode == NS_PROG_FWD, dx_prog = mode == NS_PROG_DX || mode == NS_PROG_DX_INPUT;
+    if (mode == NS_PROG_FWD_DENSE && (!dn || !dn->S)) return p;
     if (nl < 1 || in_size < 1 || in_size > 256) return p;
     // 1. linear maps: [Wa | alpha Wb] over K = [Kapad ; Kb], N outputs, written to dst_col (same_buf: into the input's buffer)
     struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
                  int N, relu, dst_col; bool same_buf; int transA = 0; int force_wide = 0; int mask_apply_of = -1; int op = -1;
-                 int transB = 0; };
+                 int transB = 0; const float* rscale = nullptr; const float* rshift = nullptr; };
     std::vector<Lin> lins;
     int width = in_size;
     for (int i = 0; i < nl && dx_prog; ++i) {                   // shape checks as in the forward program
@@ -776,6 +800,18 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     }
     if (dx_prog) in_size = layers[nl - 1].N;                   // the rows of this program are d loss / d output
     if (lins.empty() || lins.back().relu || (int)lins.size() > NS_MAXSEG) return p;
+    if (mode == NS_PROG_FWD_DENSE) {
+        Lin& last = lins.back();
+        if (last.Wb || last.same_buf || last.dst_col) return p;               // the last op must be a plain linear layer
+        last.rscale = dn->cscale; last.rshift = dn->cshift;
+        const int no = last.N, npad = ceil16(no);
+        if ((int)lins.size() + 1 > NS_MAXSEG) return p;
+        const bool behind = no <= 256;                                          // SPLIT: U behind d in the same buffer
+        Lin Q{dn->S, dn->lds, no, npad, nullptr, 0, 0, 0.f, nullptr, 0.f, no, 0, behind ? npad : 0, behind};
+        Q.op = nl;
+        lins.push_back(Q);
+        p.dense = 1; p.u_col = Q.dst_col; p.u_same = behind ? 1 : 0;
+    }
     const int nfwd = (int)lins.size();
     // Backward (d lnP / d z) for plain ReLU MLPs whose hidden layers come out as WIDE segments: the backward
     // GEMM of layer l is a forward-shaped segment over W_l^T (contraction N_l, K_l outputs); for l >= 1 it is
@@ -823,7 +859,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         }
         q.Wa = L.Wa; q.lda = L.lda; q.Ka = L.Ka; q.Kapad = L.Kapad; q.Wb = L.Wb; q.ldb = L.ldb; q.Kb = L.Kb; q.alpha = L.alpha;
         q.b = L.b; q.bscale = L.bscale; q.N = L.N; q.type = s.type; q.steps = s.steps; q.passes = s.passes; q.bias_off = bias_off;
-        q.transA = L.transA; q.transB = L.transB;
+        q.transA = L.transA; q.transB = L.transB; q.rscale = L.rscale; q.rshift = L.rshift;
         if (L.transA && !dx_prog) {                                     // backward segments have no bias: ONE shared block of zeros
             if (zero_off < 0) { zero_off = bias_off; zero_pad = 0; }
             s.bias_off = q.bias_off = zero_off;
@@ -927,8 +963,15 @@ int net_stream_rows(int B) {
     return B <= 4 * ncu ? 4 : B <= 8 * ncu ? 8 : 16;
 }
 
-static NsProgram ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog) {
+static NsProgram ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn = nullptr) {
+    if (prog == 0 && dn) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DENSE, dn);
     return prog == 0 ? ns_build(layers, nl, in_size) : ns_build_one(layers, nl, in_size, prog == 2 ? NS_PROG_DX_INPUT : NS_PROG_DX);
+}
+bool net_stream_dense_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn) {
+    return ns_build_prog(layers, nl, in_size, 0, &dn).ok;
+}
+size_t net_stream_dense_packed_floats(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn) {
+    return ns_build_prog(layers, nl, in_size, 0, &dn).packed_floats;
 }
 bool net_stream_dx_eligible(const linna_layer_t* layers, int nl, int in_size, int with_input) {
     return nl >= (with_input ? 1 : 2) && ns_build_prog(layers, nl, in_size, with_input ? 2 : 1).ok;
@@ -938,8 +981,9 @@ size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_s
 }
 
 // prog: 0 the forward program (+ the fused gradient's backward half), 1 / 2 the dX chain without / with op 0
-int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog, hipStream_t s) {
-    const NsProgram p = ns_build_prog(layers, nl, in_size, prog);
+int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog,
+                           const NsDense* dn, hipStream_t s) {
+    const NsProgram p = ns_build_prog(layers, nl, in_size, prog, dn);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsPackArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -987,10 +1031,11 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
-                      hipStream_t s) {
-    const NsProgram p = ns_build(layers, nl, in_size);
+                      const NsDense* dn, hipStream_t s) {
+    const NsProgram p = ns_build_prog(layers, nl, in_size, 0, dn);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
-    if (mv && (nin > 64 || !w)) { set_error("net_stream: fused sampler moves need <= 64 parameters and a diagonal covariance"); return LINNA_ERR_UNSUPPORTED; }
+    if (dn && (w || gr || cscale || cshift)) { set_error("net_stream: the dense program carries its own output map and has no fused gradient"); return LINNA_ERR_INVALID; }
+    if (mv && (nin > 64 || (!w && !dn))) { set_error("net_stream: fused sampler moves need <= 64 parameters and a log-likelihood in the launch"); return LINNA_ERR_UNSUPPORTED; }
     if (gr && (!p.grad_ok || !w || !lnP || !gr->gscale || !gr->G || mv)) { set_error("net_stream: no fused gradient for this network / likelihood"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -1002,6 +1047,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     a.nseg = gr ? (int)p.seg.size() : p.nseg_f;
     a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
+    a.dense = p.dense; a.u_col = p.u_col; a.u_same = p.u_same;
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
     a.stamps = nullptr; a.gate = gate;

@@ -433,3 +433,54 @@ def test_full_size_gradient_properties(name):
                                           prob["invcov"], 1.0)
     np.testing.assert_allclose(lnp[idx], lref, rtol=6e-4)
     np.testing.assert_allclose(g[idx], gref, rtol=0, atol=3e-3 * np.abs(gref).max())
+
+
+@pytest.mark.parametrize("nin,nout,width,depth", [
+    (33, 33, 512, 4),        # U = d S as a SPLIT segment behind d (nout <= 64)
+    (12, 100, 128, 2),       # two column groups
+    (20, 250, 256, 3),       # four column groups
+    (9, 457, 512, 2),        # WIDE, one pass: d stays in the other buffer
+    (9, 700, 1000, 2),       # WIDE, two passes
+])
+def test_dense_covariance_as_last_segment(nin, nout, width, depth, monkeypatch):
+    """Dense inverse covariance: the output map folded into the stream's last layer and S appended as the last
+    segment of the whole-network kernel (lnP in one launch), against the oracle and against the network launch +
+    row-dot GEMM it replaces, with each engine and ragged batches; the fused stretch move runs on it too."""
+    from oracle import likelihood
+    from linna_amd import sampler
+    prob = _custom_problem(nin, nout, 300 + nin + nout, width, depth, dense=True)
+    fused = build_logprob(None, 4.0, prob=prob)[0]
+    fused._ensure()
+    monkeypatch.setenv("LINNA_DENSE_FUSED", "0")          # read when the log-probability object is created
+    unfused = build_logprob(None, 4.0, prob=prob)[0]
+    unfused._ensure()
+    monkeypatch.delenv("LINNA_DENSE_FUSED")
+    emu = cases.oracle_emulator(prob)
+    for B in (1, 17, 300):
+        z = (0.7 * np.random.RandomState(B).standard_normal((B, nin))).astype(np.float32)
+        zd = torch.as_tensor(z, device="cuda")
+        ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 4.0, dtype=np.float64)
+        base = unfused.evaluate(zd).cpu().numpy()
+        np.testing.assert_allclose(base, ref, rtol=6e-4)
+        for rows in (None, 4, 8, 16):
+            if rows is None:
+                monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+            else:
+                monkeypatch.setenv("LINNA_NS_ROWS", str(rows))
+            theta = torch.empty_like(zd)
+            got = fused.evaluate(zd, theta=theta).cpu().numpy()
+            np.testing.assert_allclose(got, ref, rtol=6e-4, err_msg="rows %s B %d" % (rows, B))
+            np.testing.assert_allclose(got, base, rtol=3e-4, err_msg="rows %s B %d" % (rows, B))
+            np.testing.assert_allclose(theta.cpu().numpy(), likelihood.prior_map(z, prob["priors"]), rtol=1e-5, atol=1e-5)
+    monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+    # one-launch half step on the dense problem, bit-identical to propose / evaluate / accept
+    nw = 70
+    x0 = (0.3 * np.random.RandomState(5).standard_normal((nw, nin))).astype(np.float32)
+    a = sampler.EnsembleSampler(nw, nin, fused, seed=21)
+    b = sampler.EnsembleSampler(nw, nin, fused, seed=21, fused=False)
+    a.set_state(x0); b.set_state(x0)
+    for _ in range(4):
+        a.step(); b.step()
+    torch.cuda.synchronize()
+    assert a.fused is True
+    assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp) and torch.equal(a.naccept, b.naccept)
