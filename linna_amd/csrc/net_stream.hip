@@ -761,21 +761,20 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         else return p;
         width = l.N;
     }
-    std::vector<int> lin_hidden;
     for (int i = nl - 1; i >= (mode == NS_PROG_DX_INPUT ? 0 : 1) && dx_prog; --i) {
         const linna_layer_t& l = layers[i];
         const int npad = ceil16(l.N);
         if (l.op == LINNA_OP_LINEAR) {
             Lin B{l.W, (l.K + 3) & ~3, l.N, npad, nullptr, 0, 0, 0.f, nullptr, 0.f, l.K, 0, 0, false};
             B.transA = 1; B.op = i;
-            lins.push_back(B); lin_hidden.push_back(0);
+            lins.push_back(B);
         } else {
             Lin A{nullptr, 0, 0, 0, l.W2, (l.C + 3) & ~3, l.N, 0.1f, nullptr, 0.f, l.C, 0, npad, true};     // dh behind dy
             A.transB = 1; A.op = i;
-            lins.push_back(A); lin_hidden.push_back(1);
+            lins.push_back(A);
             Lin B{l.Ws, (l.K + 3) & ~3, l.N, npad, l.W1, (l.K + 3) & ~3, l.C, 1.f, nullptr, 0.f, l.K, 0, 0, false};
             B.transA = 1; B.transB = 1; B.op = i;
-            lins.push_back(B); lin_hidden.push_back(0);
+            lins.push_back(B);
         }
     }
     width = in_size;
@@ -924,7 +923,6 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     p.nout = lins[nfwd - 1].N;
     p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
     for (int i = 0; i < nfwd; ++i) { p.seg_op.push_back(lins[i].op); p.seg_hidden.push_back(lins[i].same_buf ? 1 : 0); }
-    (void)lin_hidden;
     p.bias_total = bias_off;
     p.LD = ((maxext + 63) & ~63) + 4;
     if (NS_ROWS * p.LD < 8192 + 64) return p;               // SPLIT partials need [8][16][64] floats in one buffer

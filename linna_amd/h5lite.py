@@ -17,6 +17,8 @@ datasets, or gzip chunks along axis 0 under a one-node chunk B-tree, in "earlies
 laid out like libhdf5's own (same superblock, node sizes and message versions as the fixture); it is
 checked through the reader only -- libhdf5 is not available here to cross-check it.
 """
+import mmap
+import os
 import struct
 import zlib
 
@@ -179,7 +181,9 @@ class Dataset(_Object):
             addr, size = struct.unpack_from("<QQ", body, 2)
             if addr == UNDEF or count == 0:
                 return np.zeros(self.shape, self.dtype)
-            return np.frombuffer(self.f._at(addr, nbytes), self.dtype, count).reshape(self.shape).copy()
+            if addr + self.f.base + nbytes > len(self.f.buf):
+                raise H5Error("address beyond the end of the file")
+            return np.frombuffer(self.f.buf, self.dtype, count, offset=addr + self.f.base).reshape(self.shape).copy()
         if cls != 2:
             raise H5Error("data layout class %d" % cls)
         ndim = body[2]
@@ -239,8 +243,9 @@ class File(Group):
     """Read-only view of an HDF5 file held in memory (``File(path)['mcmc/chain'].read()``)."""
 
     def __init__(self, path):
-        with open(path, "rb") as fh:
-            self.buf = fh.read()
+        with open(path, "rb") as fh:                                # mapped, not read: a chain file can be gigabytes
+            size = os.fstat(fh.fileno()).st_size
+            self.buf = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) if size else b""
         b = self.buf
         if b[:8] != SIGNATURE:
             raise H5Error("%s: not an HDF5 file" % path)
@@ -299,7 +304,7 @@ class File(Group):
         raise H5Error("object at %d is neither an old-style group nor a dataset" % addr)
 
     def _heap_string(self, heap_data, off):
-        end = self.buf.index(b"\x00", heap_data + off)
+        end = self.buf.find(b"\x00", heap_data + off)
         return self.buf[heap_data + off:end].decode("utf-8")
 
     def _group_entries(self, btree, heap):
@@ -487,12 +492,17 @@ class Writer(object):
         (parent or self.root).children.append((name, (array, dict(attrs or {}), compression, shuffle)))
 
     def save(self, path):
-        self._out = bytearray(96)                                   # superblock + root entry, filled in last
+        # pieces in file order; large arrays go in as memoryviews (no copy), the superblock piece is patched last
+        pieces, pos = [bytearray(96)], [96]
 
         def alloc(data, align=8):
-            self._out += b"\x00" * (-len(self._out) % align)
-            addr = len(self._out)
-            self._out += data
+            pad = -pos[0] % align
+            if pad:
+                pieces.append(b"\x00" * pad)
+                pos[0] += pad
+            addr = pos[0]
+            pieces.append(data)
+            pos[0] += data.nbytes if isinstance(data, memoryview) else len(data)
             return addr
 
         def write_chunked(array, attrs, shuffle):
@@ -538,7 +548,7 @@ class Writer(object):
             if compression and array.ndim >= 1:
                 return write_chunked(array, attrs, shuffle)
             nbytes = array.nbytes
-            daddr = alloc(array.tobytes()) if nbytes else UNDEF
+            daddr = alloc(memoryview(array.reshape(-1)).cast("B")) if nbytes else UNDEF
             msgs = [_message(0x0001, _dataspace_message(array.shape)),
                     _message(0x0003, _dtype_message(array.dtype), flags=1),
                     _message(0x0005, struct.pack("<BBBB", 2, 2, 2, 0)),    # fill value: late allocation, if-set, undefined
@@ -585,10 +595,11 @@ class Writer(object):
             return alloc(_object_header(msgs)), bt_addr, hp_addr
 
         ohdr, bt, hp = write_group(self.root)
-        self._out += b"\x00" * (-len(self._out) % 8)
+        alloc(b"", 8)
         sb = SIGNATURE + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, self.LEAF_K, self.INTERNAL_K, 0)
-        sb += struct.pack("<QQQQ", 0, UNDEF, len(self._out), UNDEF)
+        sb += struct.pack("<QQQQ", 0, UNDEF, pos[0], UNDEF)
         sb += struct.pack("<QQIIQQ", 0, ohdr, 1, 0, bt, hp)
-        self._out[:len(sb)] = sb
+        pieces[0][:len(sb)] = sb
         with open(path, "wb") as fh:
-            fh.write(bytes(self._out))
+            for piece in pieces:
+                fh.write(piece)

@@ -77,50 +77,55 @@ class DeviceChain(object):
     plumbing here; nothing of it is on the sampling path)."""
 
     def __init__(self):
-        self.blocks = []
+        self.buf = None          # [capacity, nw, nd] on the device, grown by doubling: no re-concatenation per check
+        self.n = 0
 
     def append(self, z_block):
         z = torch.as_tensor(z_block)
-        self.blocks.append(z if z.is_cuda else z.cuda())
+        z = z if z.is_cuda else z.cuda()
+        need = self.n + len(z)
+        if self.buf is None or need > len(self.buf):
+            cap = max(need, 2 * (0 if self.buf is None else len(self.buf)), 1024)
+            buf = torch.empty((cap,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+            if self.n:
+                buf[:self.n] = self.buf[:self.n]
+            self.buf = buf
+        self.buf[self.n:need] = z
+        self.n = need
 
     def __len__(self):
-        return sum(len(b) for b in self.blocks)
+        return self.n
 
     def last(self, n):
         """The last ``n`` steps as one device tensor [n, nw, nd]."""
-        out, need = [], int(n)
-        for b in reversed(self.blocks):
-            if need <= 0:
-                break
-            out.append(b[-need:] if len(b) > need else b)
-            need -= len(out[-1])
-        return torch.cat(out[::-1]) if len(out) > 1 else out[0]
+        return self.buf[max(0, self.n - int(n)):self.n]
 
     def integrated_time(self, discard=0, c=5.0, upto=None):
         """emcee's estimator (FFT autocorrelation averaged over walkers, Sokal window, tol=0) per
         parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %); ``upto``: only
         the first ``upto`` steps (the chain as it was at an earlier check)."""
-        nt_all, nd = (len(self) if upto is None else int(upto)), self.blocks[0].shape[2]
+        nt_all, nd = (self.n if upto is None else int(upto)), self.buf.shape[2]
         nt = nt_all - int(discard)
-        nw = self.blocks[0].shape[1]
+        nw = self.buf.shape[1]
         n = _next_pow_two(nt)
-        dev = self.blocks[0].device
-        ar = torch.arange(nt, device=dev, dtype=torch.float64)[:, None]
+        dev = self.buf.device
+        ar = torch.arange(nt, device=dev, dtype=torch.float64)[None, :]
         out = torch.empty(nd, dtype=torch.float64, device=dev)
-        # all walkers and as many parameters per FFT as ~1 GiB of complex128 allows; no host round trip inside
+        # all walkers and as many parameters per FFT as ~1 GiB of complex128 allows; no host round trip inside.
+        # The series are laid out time-last ([nw, per, nt] contiguous): the transform then runs over unit stride.
         per = max(1, min(nd, int((1 << 30) // max(1, 16 * 2 * n * nw))))
         for d0 in range(0, nd, per):
-            x = torch.cat([b[:, :, d0:d0 + per] for b in self.blocks])[int(discard):nt_all].to(torch.float64)   # [nt, nw, per]
-            x = x - x.mean(0, keepdim=True)
-            f = torch.fft.rfft(x, n=2 * n, dim=0)
-            acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=0)[:nt]
-            fbar = (acf / acf[0:1]).mean(1)                     # [nt, per]; 0/0 -> nan, as the host estimator
-            t = 2.0 * torch.cumsum(fbar, 0) - 1.0
+            x = self.buf[int(discard):nt_all, :, d0:d0 + per].permute(1, 2, 0).to(torch.float64).contiguous()   # [nw, per, nt]
+            x = x - x.mean(2, keepdim=True)
+            f = torch.fft.rfft(x, n=2 * n, dim=2)
+            acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=2)[:, :, :nt]
+            fbar = (acf / acf[:, :, 0:1]).mean(0)               # [per, nt]; 0/0 -> nan, as the host estimator
+            t = 2.0 * torch.cumsum(fbar, 1) - 1.0
             m = ar < c * t                                      # Sokal window: first step with step >= c tau
-            first_false = torch.argmin(m.to(torch.int8), dim=0)
-            keep = m.any(0) & ~m.all(0)
+            first_false = torch.argmin(m.to(torch.int8), dim=1)
+            keep = m.any(1) & ~m.all(1)
             win = torch.where(keep, first_false, torch.full_like(first_false, nt - 1))
-            out[d0:d0 + per] = t.gather(0, win[None, :])[0]
+            out[d0:d0 + per] = t.gather(1, win[:, None])[:, 0]
         return out.cpu().numpy()
 
     def checkmeanstd(self, nlast, meanshift, stdshift):
@@ -155,18 +160,53 @@ class ChainStore(object):
     and ``zeus_256.h5`` as ``ZeusTransformCallback`` does (root datasets ``samples``,
     ``chain_transformed``, ``logprob``; sampler.py:556-577), through ``h5lite`` (no h5py in this
     image), plus the ``<name>.txt`` layout the reference's reader accepts as a fallback
-    (main.py:166-167, 293-295: rows of ``theta..., log_prob``).  Files written by the reference load
+    (main.py:166-167, 293-295: rows of ``theta..., log_prob``; ``write_txt=True``).  Files written by the reference load
     the same way, so a run directory started there resumes here."""
 
     GZIP_LIMIT = 64 << 20           # zeus layout: gzip chunks like the reference below this many bytes per dataset
 
-    def __init__(self, filename, transform=None):
+    def __init__(self, filename, transform=None, write_txt=False):
         self.base = filename[:-3] if filename.endswith(".h5") else filename
         self.layout = "zeus" if os.path.basename(self.base).startswith("zeus") else "emcee"
         self.transform = transform
+        self.write_txt = write_txt          # also keep <name>.txt (theta..., log_prob rows) next to the HDF5 file
         self.chain, self.chain_transformed, self.log_prob = [], [], []
         self.accepted = None
         self._flushed = 0
+        self._writer, self._queue, self._error = None, None, None
+
+    # The incremental part files are written by one background thread: zipping + writing 7 MB per convergence
+    # check (128 walkers) took as long as the 100 iterations between two checks.  numpy's file I/O and zlib's
+    # CRC release the GIL; the sampling thread spends its time inside ctypes calls, which release it too.
+    def _enqueue(self, path, arrays):
+        import queue, threading
+        if self._writer is None:
+            self._queue = queue.Queue()
+
+            def work():
+                while True:
+                    item = self._queue.get()
+                    try:
+                        if item is None:
+                            return
+                        with open(item[0] + ".tmp", "wb") as fh:     # a reader never sees a half-written part
+                            np.savez(fh, **item[1])
+                        os.replace(item[0] + ".tmp", item[0])
+                    except Exception as e:          # surfaced by the next drain()
+                        self._error = e
+                    finally:
+                        self._queue.task_done()
+            self._writer = threading.Thread(target=work, name="linna-chain-writer", daemon=True)
+            self._writer.start()
+        self._queue.put((path, arrays))
+
+    def drain(self):
+        """Wait until every part queued so far is on disk."""
+        if self._queue is not None:
+            self._queue.join()
+        if self._error is not None:
+            e, self._error = self._error, None
+            raise e
 
     @property
     def h5(self):
@@ -180,6 +220,7 @@ class ChainStore(object):
         return os.path.isfile(self.h5) or os.path.isfile(self.npz) or bool(self._parts(self.base))
 
     def remove(self):
+        self.drain()
         for f in [self.h5, self.npz, self.base + ".txt"] + self._parts(self.base):
             if os.path.isfile(f):
                 os.remove(f)
@@ -201,14 +242,16 @@ class ChainStore(object):
         walkers).  ``load`` reads either form, so a killed run resumes from the parts."""
         if not final:
             for k in range(self._flushed, len(self.chain)):
-                np.savez(self._part(k), chain=self.chain[k], chain_transformed=self.chain_transformed[k],
-                         log_prob=self.log_prob[k], accepted=self.accepted)
+                self._enqueue(self._part(k), dict(chain=self.chain[k], chain_transformed=self.chain_transformed[k],
+                                                  log_prob=self.log_prob[k], accepted=np.array(self.accepted)))
             self._flushed = len(self.chain)
             return
+        self.drain()
         z, th, lp = self.arrays()
         self.write_h5(self.h5, z, th, lp, self.accepted, self.layout)
-        flat = np.concatenate([th.reshape(-1, th.shape[-1]), lp.reshape(-1, 1)], axis=1)
-        np.savetxt(self.base + ".txt", flat[-100000:])
+        if self.write_txt:
+            flat = np.concatenate([th.reshape(-1, th.shape[-1]), lp.reshape(-1, 1)], axis=1)
+            np.savetxt(self.base + ".txt", flat[-100000:])
         for f in self._parts(self.base) + [self.npz]:       # superseded by the consolidated file
             if os.path.isfile(f):
                 os.remove(f)
@@ -286,6 +329,7 @@ class ChainStore(object):
         return d
 
     def get_last_sample(self):
+        self.drain()
         return self.load(self.base)["chain"][-1]
 
 

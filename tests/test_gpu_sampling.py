@@ -200,7 +200,7 @@ def test_ml_sampler_core_end_to_end(tmp_path):
     assert chain.ndim == 2 and chain.shape[1] == ndim and len(chain) > 0
     assert np.all(np.isfinite(chain)) and np.all(np.abs(chain) <= 2.0)
     for f in ("train_samples_x.txt", "train_samples_y.npy", "best.pth.tar", "X_transform.pkl", "finish.pkl", "lr.npy",
-              "chemcee_256.h5", "chemcee_256.txt", "model_args.pkl"):
+              "chemcee_256.h5", "model_args.pkl"):
         assert os.path.isfile(os.path.join(out, "iter_0", f)), f
     # second call: every stage is skipped because its artefact exists (tests/test_main.py:47-51)
     chain2, _ = ml_sampler_core([20], [5], [1], [2], [0.5], [100], [100], out, theory, priors, means, cov, init, None, 4, "cuda",

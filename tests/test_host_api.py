@@ -165,18 +165,20 @@ def test_chainstore_incremental_parts_roundtrip(tmp_path):
     for i, (z, th, lp) in enumerate(blocks[:2]):
         st.append(z, th, lp, np.full(4, i + 1.0))
         st.flush(final=False)
+    st.drain()                                              # the parts are written by a background thread
     assert st.exists() and not os.path.isfile(st.h5) and len(ChainStore._parts(st.base)) == 2
     d = ChainStore.load(name)
     np.testing.assert_array_equal(d["chain"], np.concatenate([b[0] for b in blocks[:2]]))
     np.testing.assert_array_equal(d["log_prob"], np.concatenate([b[2] for b in blocks[:2]]))
     assert d["iteration"] == 10
     # resume: load, append as one block, consolidate, continue with a new part
-    st2 = ChainStore(name)
+    st2 = ChainStore(name, write_txt=True)
     st2.append(d["chain"], d["chain_transformed"], d["log_prob"], d["accepted"])
     st2.flush()
     assert os.path.isfile(st2.h5) and not ChainStore._parts(st2.base)
     st2.append(*blocks[2], np.full(4, 3.0))
     st2.flush(final=False)
+    st2.drain()
     d2 = ChainStore.load(name)
     np.testing.assert_array_equal(d2["chain"], np.concatenate([b[0] for b in blocks]))
     np.testing.assert_array_equal(d2["chain_transformed"], np.concatenate([b[1] for b in blocks]))
