@@ -237,6 +237,27 @@ def main():
     # sanity: the timed path produced finite numbers
     assert torch.isfinite(out).all(), "non-finite log-probabilities in the timed path"
 
+    # N > 1: also the strong-scaling figure (the SAME 4096 walkers split over the ranks, BASELINE's "nwalkers=4096
+    # ... at 8xMI355X"): each rank evaluates 4096 / N walkers per step on the small-batch engine of the kernel
+    strong = None
+    if world > 1 and NWALKERS % world == 0:
+        zs, outs = z[:NWALKERS // world].contiguous(), out[:NWALKERS // world]
+        for _ in range(200):
+            lp.evaluate(zs, out=outs)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0s = time.perf_counter()
+        for _ in range(args.steps):
+            lp.evaluate(zs, out=outs)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ts = torch.tensor([time.perf_counter() - t0s], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        strong = {"nwalkers_total": NWALKERS, "nwalkers_per_gpu": NWALKERS // world, "evals_per_s": NWALKERS * args.steps / float(ts.item()),
+                  "ms_per_step": 1e3 * float(ts.item()) / args.steps}
+
     if rank == 0:
         ms_kernel, flop_launch = time_dominant_kernel(lp, z, out, max(500, args.steps))
         achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
@@ -259,6 +280,8 @@ def main():
                          "avg_launch_ms": ms_kernel, "flop_per_launch": flop_launch},
             "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
         }
+        if strong is not None:
+            res["strong_scaling"] = strong
         res["mcmc"] = mcmc_rate(lp, NWALKERS)
         res["mcmc"]["steps_per_s_all_gpus"] = res["mcmc"]["steps_per_s"] * world
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
