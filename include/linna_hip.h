@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 2
+#define LINNA_ABI_VERSION 3   /* 3: + linna_net_stream_state */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblinna_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
