@@ -132,14 +132,18 @@ class TrainEngine(object):
         self._graph_sig = (self.model.flat_params().data_ptr(), id(opt))
 
     # ------------------------------------------------------------------ validation (util.py:1124-1127)
-    def validate(self):
+    def validate_enqueue(self):
+        """Launch the validation pass (util.py:1124-1127) without waiting for it: the epoch loop queues it right
+        behind the epoch's optimiser steps and reads everything back with ONE synchronisation (three round trips
+        per epoch left the GPU idle between them, and an idle MI355X drops its clocks)."""
         v, k, st = self.val, self.k, _lib.stream()
         n = v["n"]
         if "xb" not in v:
             z = lambda *s: torch.zeros(s, dtype=torch.float32, device=self.dev)
             v["xb"], v["pred"] = z(n, _lib.ld4(self.nin)), z(n, _lib.ld4(self.nout))
             v["scratch"] = z(_lib.load().linna_loss_scratch_bytes(n, self.nout) // 4 + 4)
-            v["loss_rows"], v["frac_rows"] = z(n), z(n)
+            v["rows"] = z(2, n)                                  # loss_rows | frac_rows: one copy back
+            v["loss_rows"], v["frac_rows"] = v["rows"][0], v["rows"][1]
         _lib.call("linna_gather_xform", self.ctx, _lib.ptr(v["X"]), v["X"].stride(0), None, n, self.nin,
                   _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]),
                   _lib.ptr(v["xb"]), v["xb"].stride(0), st)
@@ -147,9 +151,15 @@ class TrainEngine(object):
         _lib.call("linna_val_rows", self.ctx, C.byref(self.desc), _lib.ptr(v["pred"]), v["pred"].stride(0), _lib.ptr(v["Y"]),
                   v["Y"].stride(0), _lib.ptr(v["den"]), n, _lib.ptr(v["scratch"]), _lib.ptr(v["loss_rows"]),
                   _lib.ptr(v["frac_rows"]), st)
-        loss = v["loss_rows"].cpu().numpy()
-        frac = v["frac_rows"].cpu().numpy()
+
+    def validate_finish(self):
+        rows = self.val["rows"].cpu().numpy()
+        loss, frac = rows[0], rows[1]
         return np.array([_lower_median(loss.tolist()), frac.max(), _lower_median(frac.tolist())], dtype=np.float64)
+
+    def validate(self):
+        self.validate_enqueue()
+        return self.validate_finish()
 
 
 def _read_lr(pred, engine, rank):
@@ -220,13 +230,15 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
         perm = torch.stack(mine).to(torch.int32).to(engine.dev) if nsteps else None
         for s in range(nsteps):
             engine.step(opt, perm[s], loss_hist[s:s + 1])                       # :273-288
+        if val_dataset is not None:
+            val_dataset.epoch_batches()                                         # keeps torch's RNG stream aligned
+            engine.validate_enqueue()                                           # queued behind the steps: one sync per epoch
         epoch_losses = loss_hist[:nsteps].cpu().numpy().astype(np.float64)
         train_losses.extend(epoch_losses.tolist())
         loss = float(epoch_losses[-1]) if nsteps else float("nan")
         is_best = False
         if val_dataset is not None:
-            val_dataset.epoch_batches()                                         # keeps torch's RNG stream aligned
-            vm = engine.validate()
+            vm = engine.validate_finish()
             val_metrics.append(vm)
             if progress and rank == 0:
                 print("epoch %d  train %.5e  val %.5e" % (i, loss, vm[0]), flush=True)
@@ -234,7 +246,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
                 is_best = vm[0] < pred.best_val_loss
                 if is_best:
                     pred.best_val_loss = vm[0]
-            recent = np.array(val_metrics)[-10:, 0]
+            recent = np.array(val_metrics[-10:])[:, 0]
             if np.std(recent) < 0.01 * np.mean(recent) and 10 <= i < 120 and i % 10 == 0:      # :319-335
                 print("bad trainning: {0}".format(i), flush=True)
                 lr_now = opt.lr
