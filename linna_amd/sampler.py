@@ -37,6 +37,7 @@ def _next_pow_two(n):
 
 
 def _autocorr_1d(x):
+    x = np.asarray(x, np.float64)
     n = _next_pow_two(len(x))
     f = np.fft.fft(x - np.mean(x), n=2 * n)
     acf = np.fft.ifft(f * np.conjugate(f))[:len(x)].real
@@ -100,13 +101,17 @@ class DeviceChain(object):
         """The last ``n`` steps as one device tensor [n, nw, nd]."""
         return self.buf[max(0, self.n - int(n)):self.n]
 
+    MAX_WALKERS = 512       # the estimator averages the autocorrelation function over walkers: beyond this many it uses
+                            # an evenly spaced subset of them (135 k FFTs per check at 4096 walkers otherwise)
+
     def integrated_time(self, discard=0, c=5.0, upto=None):
         """emcee's estimator (FFT autocorrelation averaged over walkers, Sokal window, tol=0) per
         parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %); ``upto``: only
         the first ``upto`` steps (the chain as it was at an earlier check)."""
         nt_all, nd = (self.n if upto is None else int(upto)), self.buf.shape[2]
         nt = nt_all - int(discard)
-        nw = self.buf.shape[1]
+        wstride = max(1, self.buf.shape[1] // self.MAX_WALKERS)
+        nw = len(range(0, self.buf.shape[1], wstride))
         n = _next_pow_two(nt)
         dev = self.buf.device
         ar = torch.arange(nt, device=dev, dtype=torch.float64)[None, :]
@@ -115,7 +120,7 @@ class DeviceChain(object):
         # The series are laid out time-last ([nw, per, nt] contiguous): the transform then runs over unit stride.
         per = max(1, min(nd, int((1 << 30) // max(1, 16 * 2 * n * nw))))
         for d0 in range(0, nd, per):
-            x = self.buf[int(discard):nt_all, :, d0:d0 + per].permute(1, 2, 0).to(torch.float64).contiguous()   # [nw, per, nt]
+            x = self.buf[int(discard):nt_all, ::wstride, d0:d0 + per].permute(1, 2, 0).to(torch.float64).contiguous()   # [nw, per, nt]
             x = x - x.mean(2, keepdim=True)
             f = torch.fft.rfft(x, n=2 * n, dim=2)
             acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=2)[:, :, :nt]
@@ -226,9 +231,12 @@ class ChainStore(object):
                 os.remove(f)
 
     def append(self, z_block, theta_block, logp_block, accepted):
-        self.chain.append(np.asarray(z_block, np.float64))
-        self.chain_transformed.append(np.asarray(theta_block, np.float64))
-        self.log_prob.append(np.asarray(logp_block, np.float64))
+        # float32 blocks stay float32 (what the device produced; emcee / h5py read either width): half the
+        # bytes of every part file and of the final HDF5 file -- at 4096 walkers the chain is 2 x 54 MB per 100 steps
+        keep = lambda a: np.asarray(a) if np.asarray(a).dtype == np.float32 else np.asarray(a, np.float64)
+        self.chain.append(keep(z_block))
+        self.chain_transformed.append(keep(theta_block))
+        self.log_prob.append(keep(logp_block))
         self.accepted = np.asarray(accepted, np.float64)
 
     def arrays(self):
@@ -348,8 +356,8 @@ def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee"
     nkeep = int(np.nanmedian(tau) * nk)
     chain = d["chain_transformed"]
     lp = d["log_prob"]
-    chain = chain[-nkeep:].reshape(-1, chain.shape[-1])
-    lp = lp[-nkeep:]
+    chain = np.asarray(chain[-nkeep:].reshape(-1, chain.shape[-1]), np.float64)
+    lp = np.asarray(lp[-nkeep:], np.float64)
     if flat:
         lp = lp.reshape(-1, 1)
     return chain, lp, d
@@ -765,7 +773,7 @@ class HMCSampler(object):
         dchain = DeviceChain()                                               # convergence statistics stay on the GPU
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
-        next_check = 0
+        next_check, last_check = 0, -1
         while done < nsamp:
             c, l = ens.run(ncheck)
             th = ens.theta_of(c)
@@ -778,12 +786,18 @@ class HMCSampler(object):
             # the chain length (a 270 k-iteration run spent 15 of 17 minutes here).  Same criterion, evaluated at
             # every check up to 2000 iterations and then whenever the chain has grown by 2 %: tau now against tau
             # `ncheck` iterations earlier, exactly the pair the reference compares at that iteration.
-            if done > 2000 and done < next_check:
+            # A check is also skipped while the chain is shorter than 0.9 x ntimes x the last tau estimate: the
+            # criterion's first clause cannot hold there unless the estimate drops by more than 10 % (each check is
+            # a batch of FFTs over the whole chain, and every new chain length costs rocFFT a new plan).
+            if done < next_check:
                 continue
-            next_check = int(done * 1.02)
             tau = dchain.integrated_time()                                    # sampler.py:538
-            if done > 2000 + ncheck:
+            if last_check != done - ncheck and done > ncheck:
                 old_tau = dchain.integrated_time(upto=done - ncheck)
+            last_check = done
+            next_check = int(done * 1.02) if done > 2000 else done + ncheck
+            if np.all(np.isfinite(tau)):
+                next_check = max(next_check, min(int(0.9 * ntimes * float(np.max(tau))), nsamp - nsamp % ncheck))
             if np.isnan(np.sum(tau)) and done > 10:
                 break
             converged = np.all(tau * ntimes < done)                           # :545-547
@@ -827,7 +841,7 @@ class ZeusSampler(object):
         dchain = DeviceChain()
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
-        next_check = 0
+        next_check, last_check = 0, -1
         while done < min(nsamp, 100000):
             c, l = ens.run(ncheck)
             store.append(c.cpu().numpy(), ens.theta_of(c).cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
@@ -835,13 +849,16 @@ class ZeusSampler(object):
             done += ncheck
             if incremental:
                 store.flush(final=False)
-            if done > 2000 and done < next_check:           # checks thin out as in HMCSampler.sample (same criterion)
+            if done < next_check:                           # checks thin out as in HMCSampler.sample (same criterion)
                 continue
-            next_check = int(done * 1.02)
-            if done > 2000 + ncheck:
+            if last_check != done - ncheck and done > ncheck:
                 prev = done - ncheck
                 old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev)))
             tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2))))   # discard=0.2, sampler.py:684,729
+            last_check = done
+            next_check = int(done * 1.02) if done > 2000 else done + ncheck
+            if np.isfinite(tau):
+                next_check = max(next_check, int(0.9 * ntimes * tau))
             converged = tau * ntimes < done
             converged &= abs(old_tau - tau) / tau < tautol
             converged &= bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
