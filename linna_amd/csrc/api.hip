@@ -584,7 +584,7 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
             }
         }
         if (ready) {
-            TRY(gemm_launch_group(ctx->group_dev, np, nb, st));
+            if (np) TRY(gemm_launch_group(ctx->group_dev, np, nb, st));      // (none when every tile shape is the small one)
             if (nc) TRY(launch_colsum_group(reinterpret_cast<const ColsumProb*>(static_cast<const char*>(ctx->group_dev) + cs_off), nc, csblocks, B, st));
         } else {
             for (const GemmArgs& a : dwq) TRY(gemm_launch(a, st));
