@@ -924,8 +924,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
     for (int i = 0; i < nfwd; ++i) { p.seg_op.push_back(lins[i].op); p.seg_hidden.push_back(lins[i].same_buf ? 1 : 0); }
     p.bias_total = bias_off;
-    p.LD = ((maxext + 63) & ~63) + 4;
-    if (NS_ROWS * p.LD < 8192 + 64) return p;               // SPLIT partials need [8][16][64] floats in one buffer
+    p.LD = std::max(((maxext + 63) & ~63) + 4, 516);        // >= 516: SPLIT partials need [8][rows][64] floats in one buffer
     if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
     p.lds_bytes = (size_t)(2 * NS_ROWS * p.LD + ((bias_off + 3) & ~3)) * sizeof(float);
 #ifdef NS_STAMPS

@@ -1,15 +1,23 @@
-"""Randomised network shapes through the whole-network kernel (tools/fuzz_net_stream.py): plain MLPs and the
-reference's residual architectures, every engine, diagonal and dense covariance, evaluation, gradient, training
-forward and the one-launch dX chain, against the numpy oracle and the GEMM-chain paths."""
+"""Randomised shapes (tools/fuzz_net_stream.py, tools/fuzz_moves_loss.py): plain MLPs and the reference's residual
+architectures through the whole-network kernel -- every engine, diagonal and dense covariance, evaluation,
+gradient, training forward and one-launch dX chain against the numpy oracle and the GEMM-chain paths; the
+one-launch stretch half step bit for bit against its three-launch form; the one-launch loss against the
+five-launch path."""
 import os
 import sys
 
 import pytest
 
 pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
-def test_random_shapes():
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+def test_random_network_shapes():
     import fuzz_net_stream
     assert fuzz_net_stream.run(48, 9000) == 0
+
+
+def test_random_moves_and_losses():
+    import fuzz_moves_loss
+    assert fuzz_moves_loss.moves(16, 9100) == 0
+    assert fuzz_moves_loss.loss(24, 9200) == 0
