@@ -2,7 +2,7 @@
 architectures through the whole-network kernel -- every engine, diagonal and dense covariance, evaluation,
 gradient, training forward and one-launch dX chain against the numpy oracle and the GEMM-chain paths; the
 one-launch stretch half step bit for bit against its three-launch form; the one-launch loss against the
-five-launch path."""
+five-launch path; random shapes, layouts and epilogues through linna_gemm_f32 against numpy."""
 import os
 import sys
 
@@ -21,3 +21,8 @@ def test_random_moves_and_losses():
     import fuzz_moves_loss
     assert fuzz_moves_loss.moves(16, 9100) == 0
     assert fuzz_moves_loss.loss(24, 9200) == 0
+
+
+def test_random_gemms():
+    import fuzz_gemm
+    assert fuzz_gemm.run(80, 9300) == 0
