@@ -20,6 +20,7 @@ def test_random_network_shapes():
 def test_random_moves_and_losses():
     import fuzz_moves_loss
     assert fuzz_moves_loss.moves(16, 9100) == 0
+    assert fuzz_moves_loss.slices(10, 9150) == 0
     assert fuzz_moves_loss.loss(24, 9200) == 0
 
 

@@ -38,6 +38,36 @@ def moves(n, seed0):
     return bad
 
 
+def slices(n, seed0):
+    """Ensemble slice sampler: trial points built in the evaluation kernel's prologue against points written
+    to memory first (linna_slice_points + gated evaluation): same states, bit for bit."""
+    bad = 0
+    for it in range(n):
+        rs = np.random.RandomState(seed0 + it)
+        nin = int(rs.choice([2, 5, 16, 33, 64])); nout = int(rs.choice([1, 8, 33, 100, 300]))
+        width = int(rs.choice([16, 64, 256, 512])); depth = int(rs.randint(1, 4)); dense = bool(rs.randint(0, 2))
+        nw = int(rs.choice([4, 10, 34, 128, 600, 2100]))
+        tag = "slice cfg %d: nin %d nout %d width %d depth %d dense %d nw %d" % (seed0 + it, nin, nout, width, depth, dense, nw)
+        try:
+            prob = _custom_problem(nin, nout, 12000 + seed0 + it, width, depth, dense=dense)
+            lp = build_logprob(None, 2.0, prob=prob)[0]
+            x0 = (0.3 * rs.standard_normal((nw, nin))).astype(np.float32)
+            a = sampler.SliceEnsembleSampler(nw, nin, lp, seed=5 + it)
+            b = sampler.SliceEnsembleSampler(nw, nin, lp, seed=5 + it)
+            b.fused_points = False
+            a.set_state(x0); b.set_state(x0)
+            for _ in range(2):
+                a.step(); b.step()
+            torch.cuda.synchronize()
+            ok = a.fused_points is True and torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp) and a.mu == b.mu
+            ok = ok and bool(torch.isfinite(a.logp).all())
+            print(("ok   " if ok else "BAD  ") + tag + "  mu %.3f evals/walker %.1f" % (a.mu, a.neval / (2.0 * nw)), flush=True)
+            bad += 0 if ok else 1
+        except Exception as e:
+            print("EXC  " + tag + "  " + repr(e)[:300], flush=True); bad += 1
+    return bad
+
+
 def loss(n, seed0):
     bad = 0
     lib = _lib.load()
@@ -82,6 +112,6 @@ def loss(n, seed0):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     s0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    bad = moves(n, s0) + loss(n, s0)
+    bad = moves(n, s0) + slices(n, s0) + loss(n, s0)
     print("fuzz moves/loss: %d bad" % bad)
     sys.exit(1 if bad else 0)

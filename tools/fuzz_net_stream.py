@@ -38,6 +38,12 @@ def run(ncfg, seed0):
                 import synth
                 prob["kind"], prob["kw"] = kind, {}
                 prob["weights"] = synth.weights(kind, nin, nout, 7000 + seed0 + it)
+            if nin > 2 and rs.randint(0, 3) == 0:                 # log10 of some positive-range inputs (util.py:483-497)
+                cols = sorted(set(int(c) for c in rs.choice(nin, size=min(3, nin), replace=False)))
+                prob["dolog10"] = cols
+                for c in cols:
+                    prob["priors"][c] = {"param": "p%d" % c, "dist": "flat", "arg1": 0.1, "arg2": 2.0}
+                tag += " log10 %s" % cols
             lp = build_logprob(None, 2.0, prob=prob)[0]
             emu = cases.oracle_emulator(prob)
             z = (0.6 * rs.standard_normal((B, nin))).astype(np.float32)
