@@ -2,7 +2,7 @@
 architectures through the whole-network kernel -- every engine, diagonal and dense covariance, evaluation,
 gradient, training forward and one-launch dX chain against the numpy oracle and the GEMM-chain paths; the
 one-launch stretch half step bit for bit against its three-launch form; the one-launch loss against the
-five-launch path; random shapes, layouts and epilogues through linna_gemm_f32 against numpy."""
+five-launch path; random shapes, layouts and epilogues through linna_gemm_f32 against numpy; random training steps against the oracle and against the run with every one-launch path off."""
 import os
 import sys
 
@@ -27,3 +27,8 @@ def test_random_moves_and_losses():
 def test_random_gemms():
     import fuzz_gemm
     assert fuzz_gemm.run(80, 9300) == 0
+
+
+def test_random_training_steps():
+    import fuzz_train
+    assert fuzz_train.run(24, 9400) == 0
