@@ -181,3 +181,35 @@ def test_reader_rejects_what_it_does_not_implement(tmp_path):
     open(p, "wb").write(bytes(raw))
     with pytest.raises(h5lite.H5Error):
         h5lite.File(p)
+
+
+def test_random_files_roundtrip(tmp_path):
+    """Random dataset shapes / dtypes / layouts / attributes through the writer and back through the reader."""
+    rs = np.random.RandomState(7)
+    for it in range(40):
+        w = h5lite.Writer(attrs={"run": np.int64(it)})
+        want = {}
+        groups = [None] + [w.group("g%d" % k, attrs={"k": np.float64(k), "name": "grp%d" % k}) for k in range(rs.randint(0, 3))]
+        for gi, g in enumerate(groups):
+            for d in range(rs.randint(1, 5)):
+                rank = rs.randint(1, 4)
+                shape = tuple(int(rs.choice([0, 1, 2, 3, 7, 64, 130])) if ax == 0 else int(rs.randint(1, 6)) for ax in range(rank))
+                dt = rs.choice([np.float64, np.float32, np.int32, np.int64, np.uint8])
+                a = (rs.standard_normal(shape) * 100).astype(dt)
+                comp = "gzip" if rs.randint(0, 2) else None
+                name = "d%d" % d
+                w.dataset(g, name, a, attrs={"scale": np.float32(d + 0.5)} if rs.randint(0, 2) else None, compression=comp,
+                          shuffle=bool(rs.randint(0, 2)) and comp is not None)
+                want[("g%d/" % (gi - 1) if g is not None else "") + name] = a
+        path = str(tmp_path / ("r%d.h5" % it))
+        w.save(path)
+        with h5lite.File(path) as f:
+            assert f.attrs["run"] == it
+            for key, a in want.items():
+                ds = f[key]
+                assert ds.shape == a.shape and ds.dtype == a.dtype, key
+                np.testing.assert_array_equal(ds.read(), a, err_msg=key)
+                if a.shape[0] > 2:
+                    np.testing.assert_array_equal(ds.read(nrows=2), a[:2], err_msg=key)
+            for k in range(len(groups) - 1):
+                assert f["g%d" % k].attrs["name"] == "grp%d" % k
