@@ -146,7 +146,11 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
         if (S.type == NS_WIDE) { n = 512 * p.run_pass[r] + 64 * w + nl; k0 = 16 * s + kl; }
         else { n = 64 * (w % S.ncg) + nl; k0 = 16 * ((w / S.ncg) * S.steps + s) + kl; }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < S.N) {
+        if (n < S.N && S.Wa && !S.transA && k0 + 3 < S.Ka && (S.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(S.Wa) & 15) == 0) {
+            // the common case: four consecutive k of one weight row, 16 bytes aligned (rows are padded to 4 floats)
+            v = *reinterpret_cast<const f32x4*>(S.Wa + (size_t)n * S.lda + k0);
+            if (S.rscale) { const float r = S.rscale[n]; v = f32x4{v[0] * r, v[1] * r, v[2] * r, v[3] * r}; }
+        } else if (n < S.N) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = k0 + e;
