@@ -123,6 +123,67 @@ def mcmc_rate(lp, nwalkers, nsteps=1000):
             "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
+def training_rate(device, world, rank, backend, nsteps=150):
+    """BASELINE configs[2] shape: ChtoModelv2(26, 457) (3x2pt-like stand-in), dense covariance, batch 500 PER RANK,
+    one all-reduce of the flat gradient per step when N > 1 (RCCL over xGMI), lr * N (predictor_gpu.py:246).
+    Full optimiser steps: gather -> forward -> chi2-ratio loss -> backward -> [all-reduce] -> AdamW."""
+    import torch
+    import torch.distributed as dist
+    from linna_amd import nn, util, predictor_gpu, trainer
+    nin, nout, B, n = 26, 457, 500, 20000
+    rs = np.random.RandomState(5)
+    q, _ = np.linalg.qr(rs.standard_normal((nout, nout)))
+    cov = (q * (np.logspace(0, -2, nout) * 0.1)[None, :]) @ q.T
+    cov = 0.5 * (cov + cov.T)
+    data, sigma = rs.uniform(size=nout), np.sqrt(np.diag(cov))
+    X_mean, X_std = rs.uniform(-0.5, 0.5, nin).astype(np.float32), rs.uniform(0.5, 3.0, nin).astype(np.float32)
+    y_mean, y_std = rs.uniform(-0.5, 0.5, nout).astype(np.float32), rs.uniform(0.5, 2.0, nout).astype(np.float32)
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    torch.manual_seed(1234)
+    model = nn.ChtoModelv2(nin, nout, None)
+    pred = predictor_gpu.Predictor(nin, nout, model=model, device=device,
+                                   X_transform=util.X_transform_class(t(X_mean), t(X_std), "cpu", None),
+                                   y_transform=util.Y_transform_class(t(y_mean), t(y_std), "cpu"))
+    rs = np.random.RandomState(100 + rank)                           # every rank its own rows
+    X = (X_mean[None, :] + X_std[None, :] * rs.standard_normal((n, nin))).astype(np.float32)
+    Y = (data[None, :] + 3 * sigma[None, :] * rs.standard_normal((n, nout))).astype(np.float32)
+    ytd = util.Y_transform_data(sigma, "cpu")
+    yinv = util.Y_invtransform_class(t(y_mean), t(y_std), t(data), "cpu")
+    lf = util.Loss_fn(t(data), torch.tensor(cov, dtype=torch.float64), torch.tensor(np.linalg.inv(cov), dtype=torch.float64), ytd, yinv, "cpu")
+    loader = predictor_gpu.BatchLoader(util.ArrayDataset(X, Y), B, shuffle=True, drop_last=True)
+    eng = trainer.TrainEngine(pred, loader, lf, None, world_size=world, dist_group=None)
+    opt = predictor_gpu._AdamWState(model, 1e-4 * world, weight_decay=1e-4)
+    perm = torch.stack(loader.epoch_batches()).to(torch.int32).to(device)
+    k = [0]
+
+    def step():
+        eng.step(opt, perm[k[0] % len(perm)]); k[0] += 1
+    t_end = time.perf_counter() + 0.4
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tm = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dt = float(tm.item())
+    loss = float(eng.loss_mean.item())
+    return {"workload": "ChtoModelv2(26,457), dense covariance, batch 500 per GPU, AdamW, gradient all-reduce per step for N > 1",
+            "samples_per_s": world * B * nsteps / dt, "ms_per_step": 1e3 * dt / nsteps, "global_batch": world * B, "steps": nsteps,
+            "loss_finite": bool(np.isfinite(loss))}
+
+
 def time_dominant_kernel(lp, z, out, iters):
     """HIP-event timing (events recorded on the launch stream) of the dominant kernel: the
     whole-network serving kernel net_stream_kernel<6, 0, false, false, 16> -- ONE launch per step evaluates prior map,
@@ -151,6 +212,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph instead of direct launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-training", action="store_true", help="skip the secondary training-throughput measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank path on a box with fewer GPUs)")
     args = ap.parse_args()
@@ -258,6 +320,15 @@ def main():
         strong = {"nwalkers_total": NWALKERS, "nwalkers_per_gpu": NWALKERS // world, "evals_per_s": NWALKERS * args.steps / float(ts.item()),
                   "ms_per_step": 1e3 * float(ts.item()) / args.steps}
 
+    # secondary figure, every rank takes part (collective inside): training throughput on the configs[2] shape.
+    # Guarded: a failure here must not cost the headline line.
+    training = None
+    if not args.no_training:
+        try:
+            training = training_rate(device, world, rank, args.backend)
+        except Exception as e:                                      # noqa: BLE001
+            training = {"error": repr(e)[:300]}
+
     if rank == 0:
         ms_kernel, flop_launch = time_dominant_kernel(lp, z, out, max(500, args.steps))
         achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
@@ -282,6 +353,8 @@ def main():
         }
         if strong is not None:
             res["strong_scaling"] = strong
+        if training is not None:
+            res["training"] = training
         res["mcmc"] = mcmc_rate(lp, NWALKERS)
         res["mcmc"]["steps_per_s_all_gpus"] = res["mcmc"]["steps_per_s"] * world
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
