@@ -458,6 +458,17 @@ def _object_header(messages):
     return struct.pack("<BBHII4x", 1, 0, len(messages), 1, len(blob)) + blob
 
 
+class _Blocks(object):
+    """Concatenation along axis 0 of arrays with equal trailing dimensions, never materialised."""
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+        self.dtype = blocks[0].dtype
+        self.shape = (sum(len(b) for b in blocks),) + tuple(blocks[0].shape[1:])
+        self.ndim = len(self.shape)
+        self.nbytes = sum(b.nbytes for b in blocks)
+
+
 class Writer(object):
     """Builds a file of old-style groups and contiguous datasets, written in one pass::
 
@@ -483,7 +494,18 @@ class Writer(object):
 
     def dataset(self, parent, name, array, attrs=None, compression=None, shuffle=False):
         """``compression="gzip"``: chunked along axis 0 with deflate (level 4) chunks and an unlimited first
-        dimension, the layout ``ZeusTransformCallback`` asks h5py for (sampler.py:567-569)."""
+        dimension, the layout ``ZeusTransformCallback`` asks h5py for (sampler.py:567-569).
+        ``array`` may be a list of blocks that share dtype and trailing dimensions: stored as their concatenation
+        along axis 0 without building it in memory (contiguous layout only)."""
+        if isinstance(array, (list, tuple)):
+            blocks = [np.ascontiguousarray(b) for b in array]
+            dt = np.result_type(*[b.dtype for b in blocks])
+            blocks = [b.astype(dt.newbyteorder("<") if dt.byteorder == ">" else dt, copy=False) for b in blocks]
+            if compression is not None or len(set(b.shape[1:] for b in blocks)) != 1:
+                array = np.concatenate(blocks)
+            else:
+                (parent or self.root).children.append((name, (_Blocks(blocks), dict(attrs or {}), None, False)))
+                return
         array = np.ascontiguousarray(array)
         if array.dtype.byteorder == ">":
             array = array.astype(array.dtype.newbyteorder("<"))
@@ -548,7 +570,14 @@ class Writer(object):
             if compression and array.ndim >= 1:
                 return write_chunked(array, attrs, shuffle)
             nbytes = array.nbytes
-            daddr = alloc(memoryview(array.reshape(-1)).cast("B")) if nbytes else UNDEF
+            if isinstance(array, _Blocks):
+                daddr = UNDEF
+                for b in array.blocks:                              # back to back: the first one aligned, the rest unpadded
+                    if b.nbytes:
+                        a = alloc(memoryview(b.reshape(-1)).cast("B"), 8 if daddr == UNDEF else 1)
+                        daddr = a if daddr == UNDEF else daddr
+            else:
+                daddr = alloc(memoryview(array.reshape(-1)).cast("B")) if nbytes else UNDEF
             msgs = [_message(0x0001, _dataspace_message(array.shape)),
                     _message(0x0003, _dtype_message(array.dtype), flags=1),
                     _message(0x0005, struct.pack("<BBBB", 2, 2, 2, 0)),    # fill value: late allocation, if-set, undefined

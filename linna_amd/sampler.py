@@ -112,7 +112,9 @@ class DeviceChain(object):
         nt = nt_all - int(discard)
         wstride = max(1, self.buf.shape[1] // self.MAX_WALKERS)
         nw = len(range(0, self.buf.shape[1], wstride))
-        n = _next_pow_two(nt)
+        # every new transform length costs rocFFT a plan (0.2-0.4 s the first time on a machine): chains shorter than
+        # 4096 steps all use the 8192-point transform (more zero padding leaves the linear autocorrelation unchanged)
+        n = max(_next_pow_two(nt), 4096)
         dev = self.buf.device
         ar = torch.arange(nt, device=dev, dtype=torch.float64)[None, :]
         out = torch.empty(nd, dtype=torch.float64, device=dev)
@@ -179,6 +181,8 @@ class ChainStore(object):
         self.accepted = None
         self._flushed = 0
         self._writer, self._queue, self._error = None, None, None
+        self._events, self._copy_stream = {}, None
+        self._cancel = False
 
     # The incremental part files are written by one background thread: zipping + writing 7 MB per convergence
     # check (128 walkers) took as long as the 100 iterations between two checks.  numpy's file I/O and zlib's
@@ -194,16 +198,47 @@ class ChainStore(object):
                     try:
                         if item is None:
                             return
-                        with open(item[0] + ".tmp", "wb") as fh:     # a reader never sees a half-written part
-                            np.savez(fh, **item[1])
-                        os.replace(item[0] + ".tmp", item[0])
+                        path, k, accepted = item
+                        if self._cancel:                              # the consolidated file is about to supersede the parts
+                            continue
+                        self._to_host(k)                              # device blocks come to the host HERE, off the sampling thread
+                        with open(path + ".tmp", "wb") as fh:         # a reader never sees a half-written part
+                            np.savez(fh, chain=self.chain[k], chain_transformed=self.chain_transformed[k],
+                                     log_prob=self.log_prob[k], accepted=self._acc_host(accepted))
+                        os.replace(path + ".tmp", path)
                     except Exception as e:          # surfaced by the next drain()
                         self._error = e
                     finally:
                         self._queue.task_done()
             self._writer = threading.Thread(target=work, name="linna-chain-writer", daemon=True)
             self._writer.start()
-        self._queue.put((path, arrays))
+        self._queue.put((path, arrays[0], arrays[1]))
+
+    def _acc_host(self, a):
+        if torch.is_tensor(a):
+            if a.is_cuda and self._copy_stream is not None:
+                with torch.cuda.stream(self._copy_stream):
+                    return a.to("cpu", torch.float64).numpy()
+            return a.to("cpu", torch.float64).numpy()
+        return np.asarray(a, np.float64)
+
+    def _to_host(self, k):
+        """Block k as numpy arrays (in place).  Blocks appended as device tensors are copied on a stream of their own,
+        after the event recorded when they were appended: the copy neither waits for nor delays the sampling stream."""
+        if not torch.is_tensor(self.chain[k]):
+            return
+        ev = self._events.pop(k, None)
+        dev = self.chain[k].device
+        if dev.type == "cuda":
+            if self._copy_stream is None:
+                self._copy_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(self._copy_stream):
+                if ev is not None:
+                    self._copy_stream.wait_event(ev)
+                host = [t.to("cpu", non_blocking=False).numpy() for t in (self.chain[k], self.chain_transformed[k], self.log_prob[k])]
+        else:
+            host = [t.numpy() for t in (self.chain[k], self.chain_transformed[k], self.log_prob[k])]
+        self.chain[k], self.chain_transformed[k], self.log_prob[k] = host           # (frees the device copies)
 
     def drain(self):
         """Wait until every part queued so far is on disk."""
@@ -233,6 +268,15 @@ class ChainStore(object):
     def append(self, z_block, theta_block, logp_block, accepted):
         # float32 blocks stay float32 (what the device produced; emcee / h5py read either width): half the
         # bytes of every part file and of the final HDF5 file -- at 4096 walkers the chain is 2 x 54 MB per 100 steps
+        # Device tensors are kept as they are (no copy on the sampling thread: at 4096 walkers a block is 2 x 54 MB);
+        # they come to the host in the writer thread, or at the latest when the arrays are asked for.
+        if torch.is_tensor(z_block) and z_block.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(z_block.device))
+            self._events[len(self.chain)] = ev
+            self.chain.append(z_block); self.chain_transformed.append(theta_block); self.log_prob.append(logp_block)
+            self.accepted = accepted.detach().clone() if torch.is_tensor(accepted) else np.asarray(accepted, np.float64)
+            return
         keep = lambda a: np.asarray(a) if np.asarray(a).dtype == np.float32 else np.asarray(a, np.float64)
         self.chain.append(keep(z_block))
         self.chain_transformed.append(keep(theta_block))
@@ -240,6 +284,9 @@ class ChainStore(object):
         self.accepted = np.asarray(accepted, np.float64)
 
     def arrays(self):
+        self.drain()
+        for k in range(len(self.chain)):
+            self._to_host(k)
         return (np.concatenate(self.chain), np.concatenate(self.chain_transformed), np.concatenate(self.log_prob))
 
     def flush(self, final=True):
@@ -250,14 +297,21 @@ class ChainStore(object):
         walkers).  ``load`` reads either form, so a killed run resumes from the parts."""
         if not final:
             for k in range(self._flushed, len(self.chain)):
-                self._enqueue(self._part(k), dict(chain=self.chain[k], chain_transformed=self.chain_transformed[k],
-                                                  log_prob=self.log_prob[k], accepted=np.array(self.accepted)))
+                self._enqueue(self._part(k), (k, self.accepted.clone() if torch.is_tensor(self.accepted) else np.array(self.accepted)))
             self._flushed = len(self.chain)
             return
-        self.drain()
-        z, th, lp = self.arrays()
-        self.write_h5(self.h5, z, th, lp, self.accepted, self.layout)
+        self._cancel = True                                 # parts still queued are not worth writing any more
+        try:
+            self.drain()
+        finally:
+            self._cancel = False
+        for k in range(len(self.chain)):
+            self._to_host(k)
+        self.accepted = self._acc_host(self.accepted) if self.accepted is not None else None
+        # the blocks go to the file one after the other: no concatenated copy of the chain in memory
+        self.write_h5(self.h5, list(self.chain), list(self.chain_transformed), list(self.log_prob), self.accepted, self.layout)
         if self.write_txt:
+            z, th, lp = self.arrays()
             flat = np.concatenate([th.reshape(-1, th.shape[-1]), lp.reshape(-1, 1)], axis=1)
             np.savetxt(self.base + ".txt", flat[-100000:])
         for f in self._parts(self.base) + [self.npz]:       # superseded by the consolidated file
@@ -268,14 +322,17 @@ class ChainStore(object):
     @staticmethod
     def write_h5(path, z, th, lp, accepted, layout="emcee"):
         w = h5lite.Writer()
+        nbytes = lambda a: sum(b.nbytes for b in a) if isinstance(a, list) else a.nbytes
+        first = z[0] if isinstance(z, list) else z
+        nsteps = sum(len(b) for b in z) if isinstance(z, list) else len(z)
         if layout == "zeus":
             for name, a in (("samples", z), ("chain_transformed", th), ("logprob", lp)):
-                w.dataset(None, name, a, compression="gzip" if a.nbytes <= ChainStore.GZIP_LIMIT else None)
+                w.dataset(None, name, a, compression="gzip" if nbytes(a) <= ChainStore.GZIP_LIMIT else None)
         else:
-            nw, nd = z.shape[1], z.shape[2]
+            nw, nd = first.shape[1], first.shape[2]
             g = w.group("mcmc", attrs=dict(version="3.0.2",                  # the emcee release whose layout this is
                                            nwalkers=np.int64(nw), ndim=np.int64(nd), has_blobs=False,
-                                           iteration=np.int64(len(z))))
+                                           iteration=np.int64(nsteps)))
             w.dataset(g, "accepted", np.zeros(nw) if accepted is None else np.asarray(accepted, np.float64))
             w.dataset(g, "chain", z)
             w.dataset(g, "chain_transformed", th)
@@ -777,7 +834,7 @@ class HMCSampler(object):
         while done < nsamp:
             c, l = ens.run(ncheck)
             th = ens.theta_of(c)
-            store.append(c.cpu().numpy(), th.cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
+            store.append(c, th, l, ens.naccept)                               # device tensors: copied off this thread
             dchain.append(c)
             done += ncheck
             if incremental:
@@ -844,7 +901,7 @@ class ZeusSampler(object):
         next_check, last_check = 0, -1
         while done < min(nsamp, 100000):
             c, l = ens.run(ncheck)
-            store.append(c.cpu().numpy(), ens.theta_of(c).cpu().numpy(), l.cpu().numpy(), ens.naccept.cpu().numpy())
+            store.append(c, ens.theta_of(c), l, ens.naccept)
             dchain.append(c)
             done += ncheck
             if incremental:

@@ -14,7 +14,7 @@ for nw in (4096, 128):
     raw = 1000 / (time.perf_counter() - t0)
     out = tempfile.mkdtemp()
     drv = sampler.HMCSampler(lp, None, None, 33, nw, x0=x0, transform=util.Transform(priors))
-    nsamp = 1500
+    nsamp = 3000 if nw > 1000 else 20000
     t0 = time.perf_counter()
     store = drv.sample(None, nsamp, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True)     # never converges: runs nsamp
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
