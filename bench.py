@@ -201,8 +201,23 @@ def time_dominant_kernel(lp, z, out, iters):
     _lib.call("linna_event_record", e1, st)
     ms = C.c_float()
     _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+    ms_avg = ms.value / iters
     _lib.call("linna_event_destroy", e0); _lib.call("linna_event_destroy", e1)
-    return ms.value / iters, float(z.shape[0]) * (2.0 * MACS_PER_EVAL + 3 * NOUT)
+    # spread of single launches (median and p10 / p90): one event pair per launch, 200 launches
+    evs = []
+    for _ in range(201):
+        e = C.c_void_p(); _lib.call("linna_event_create", C.byref(e)); evs.append(e)
+    _lib.call("linna_event_record", evs[0], st)
+    for i in range(200):
+        lp.evaluate(z, out=out)
+        _lib.call("linna_event_record", evs[i + 1], st)
+    per = []
+    for i in range(200):
+        _lib.call("linna_event_elapsed_ms", evs[i], evs[i + 1], C.byref(ms)); per.append(ms.value)
+    for e in evs:
+        _lib.call("linna_event_destroy", e)
+    q = np.percentile(per, [10, 50, 90])
+    return ms_avg, float(z.shape[0]) * (2.0 * MACS_PER_EVAL + 3 * NOUT), [float(v) for v in q]
 
 
 def main():
@@ -330,7 +345,7 @@ def main():
             training = {"error": repr(e)[:300]}
 
     if rank == 0:
-        ms_kernel, flop_launch = time_dominant_kernel(lp, z, out, max(500, args.steps))
+        ms_kernel, flop_launch, ms_q = time_dominant_kernel(lp, z, out, max(500, args.steps))
         achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
         res = {
             "metric": "emulator log-likelihood evals/sec",
@@ -348,7 +363,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
                          "kernel": "net_stream_kernel<6, 0, false, false, 16> (whole network per launch: 16 walkers/workgroup, activations in LDS, fragment-order weight stream loaded straight into the MFMA operand registers, v_mfma_f32_16x16x4_f32)",
-                         "avg_launch_ms": ms_kernel, "flop_per_launch": flop_launch},
+                         "avg_launch_ms": ms_kernel, "launch_ms_p10_p50_p90": ms_q, "flop_per_launch": flop_launch},
             "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
         }
         if strong is not None:
