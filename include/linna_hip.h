@@ -205,7 +205,10 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
 int linna_logprob_destroy(linna_logprob_t* lp);
 /* Networks of LINEAR / RESBLOCK ops up to 1024 wide (every model of nn.py) are served by ONE
  * whole-network kernel from a fragment-order copy of the weights owned by the linna_logprob_t
- * (net_stream.hip).  The copy is refreshed automatically
+ * (net_stream.hip): 16 walker rows per workgroup for batches that fill the GPU, 8 or 4 rows per
+ * workgroup below 2048 / 1024 walkers; with a dense S the output map is folded into the copy's last
+ * layer and S is the program's last segment, so lnP still comes out of the one launch.
+ * The copy is refreshed automatically
  * after linna_adamw_step and after any linna_graph_launch; a caller that overwrites parameter
  * memory by other means (hipMemcpy of a checkpoint, a torch-side copy_) calls this once
  * afterwards -- the reference has no counterpart because `model.load_state_dict`
