@@ -101,16 +101,17 @@ class DeviceChain(object):
         """The last ``n`` steps as one device tensor [n, nw, nd]."""
         return self.buf[max(0, self.n - int(n)):self.n]
 
-    MAX_WALKERS = 512       # the estimator averages the autocorrelation function over walkers: beyond this many it uses
-                            # an evenly spaced subset of them (135 k FFTs per check at 4096 walkers otherwise)
+    MAX_WALKERS = 512       # the estimator averages the autocorrelation function over walkers: beyond this many the routine
+                            # checks use an evenly spaced subset of them (135 k FFTs per check at 4096 walkers otherwise);
+                            # the drivers confirm a positive check with all walkers (all_walkers=True) before they stop
 
-    def integrated_time(self, discard=0, c=5.0, upto=None):
+    def integrated_time(self, discard=0, c=5.0, upto=None, all_walkers=False):
         """emcee's estimator (FFT autocorrelation averaged over walkers, Sokal window, tol=0) per
         parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %); ``upto``: only
         the first ``upto`` steps (the chain as it was at an earlier check)."""
         nt_all, nd = (self.n if upto is None else int(upto)), self.buf.shape[2]
         nt = nt_all - int(discard)
-        wstride = max(1, self.buf.shape[1] // self.MAX_WALKERS)
+        wstride = 1 if all_walkers else max(1, self.buf.shape[1] // self.MAX_WALKERS)
         nw = len(range(0, self.buf.shape[1], wstride))
         # every new transform length costs rocFFT a plan (0.2-0.4 s the first time on a machine): chains shorter than
         # 4096 steps all use the 8192-point transform (more zero padding leaves the linear autocorrelation unchanged)
@@ -859,7 +860,12 @@ class HMCSampler(object):
                 break
             converged = np.all(tau * ntimes < done)                           # :545-547
             converged &= np.all(np.abs(old_tau - tau) / tau < tautol)
-            converged &= dchain.checkmeanstd(max(2, int(nk * np.mean(tau))), meanshift, stdshift)
+            if converged and self.nwalkers > dchain.MAX_WALKERS:
+                # the estimate above averaged over a subset of the walkers: the decision is taken on all of them
+                tau = dchain.integrated_time(all_walkers=True)
+                old_tau = dchain.integrated_time(upto=done - ncheck, all_walkers=True) if done > ncheck else old_tau
+                converged = np.all(tau * ntimes < done) and np.all(np.abs(old_tau - tau) / tau < tautol)
+            converged = converged and dchain.checkmeanstd(max(2, int(nk * np.mean(tau))), meanshift, stdshift)
             print("max, min tau diff, max tau, ninter: {0}, {1}, {2}, {3}\n".format(
                 np.max(np.abs(old_tau - tau) / tau), np.min(np.abs(old_tau - tau) / tau), np.max(tau), done), flush=True)
             if converged:
@@ -918,7 +924,13 @@ class ZeusSampler(object):
                 next_check = max(next_check, int(0.9 * ntimes * tau))
             converged = tau * ntimes < done
             converged &= abs(old_tau - tau) / tau < tautol
-            converged &= bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
+            if converged and self.nwalkers > dchain.MAX_WALKERS:      # decide on all walkers (the routine checks use a subset)
+                tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2), all_walkers=True)))
+                if done > ncheck:
+                    prev = done - ncheck
+                    old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev, all_walkers=True)))
+                converged = tau * ntimes < done and abs(old_tau - tau) / tau < tautol
+            converged = converged and bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
             old_tau = tau
             if converged:
                 break
