@@ -566,7 +566,20 @@ class Writer(object):
             msgs += [_attribute_message(k, v) for k, v in attrs.items()]
             return alloc(_object_header(msgs))
 
+        def write_extensible(ext, attrs):
+            rank, es = ext.ndim, ext.dtype.itemsize
+            dims = struct.pack("<%dQ" % rank, *ext.shape) + struct.pack("<%dQ" % rank, UNDEF, *ext.tail)
+            msgs = [_message(0x0001, struct.pack("<BBBB4x", 1, rank, 1, 0) + dims),
+                    _message(0x0003, _dtype_message(ext.dtype), flags=1),
+                    _message(0x0005, struct.pack("<BBBB", 2, 3, 2, 0)),    # incremental allocation
+                    _message(0x0008, struct.pack("<BBBQ", 3, 2, rank + 1, UNDEF) +
+                             struct.pack("<%dI" % (rank + 1), *((ext.chunk_rows,) + ext.tail + (es,))))]
+            msgs += [_attribute_message(k, v) for k, v in attrs.items()]
+            return alloc(_object_header(msgs))
+
         def write_dataset(array, attrs, compression=None, shuffle=False):
+            if isinstance(array, _Extensible):
+                return write_extensible(array, attrs)
             if compression and array.ndim >= 1:
                 return write_chunked(array, attrs, shuffle)
             nbytes = array.nbytes
@@ -632,3 +645,247 @@ class Writer(object):
         with open(path, "wb") as fh:
             for piece in pieces:
                 fh.write(piece)
+
+
+# ------------------------------------------------------------------------------------ appending
+class Appender(object):
+    """An HDF5 file whose datasets grow along axis 0, one uncompressed chunk per append -- what emcee's
+    ``HDFBackend`` does through h5py (``grow`` + ``save_step``, reference sampler.py:340-368) -- so that the chain
+    file is current after every flush and nothing has to be consolidated at the end.
+
+    ``Appender.create(path, layout)`` writes the skeleton (groups, empty extensible datasets, attributes);
+    ``append({name: block, ...})`` adds ``len(block)`` rows to each named dataset (a chunk holds ``chunk_rows`` rows;
+    a short append leaves the chunk partly filled for the next one, a long one is split); ``set_attr`` / ``set_data`` overwrite fixed-size
+    attribute / dataset values in place; ``Appender.open(path)`` continues a file written this way.
+    Write order of an append: chunk data, B-tree nodes, dataspace, end-of-file address -- a reader that comes
+    in between sees the state before the append."""
+
+    K2 = 64                                                         # entries per chunk B-tree node (2K, K = 32)
+
+    def __init__(self, path):
+        self.path = path
+        self.fh = open(path, "r+b")
+        self.ds = {}                                                # name -> state
+        self.attr_off = {}                                          # (object name, attribute) -> (file offset, dtype)
+        self.data_off = {}                                          # fixed dataset name -> (offset, dtype, shape)
+        self.fh.seek(0, 2)
+        self.eof = self.fh.tell()
+
+    # -- skeleton ------------------------------------------------------------------------------
+    @staticmethod
+    def create(path, spec, attrs=None, group=None, group_attrs=None, fixed=None, chunk_rows=100):
+        """``spec``: {dataset name: (trailing shape, dtype)} extensible datasets inside ``group`` (or the root);
+        ``fixed``: {name: array} small contiguous datasets next to them; attributes of the root / the group."""
+        w = Writer(attrs=attrs)
+        g = w.group(group, attrs=group_attrs) if group else None
+        for name, a in (fixed or {}).items():
+            w.dataset(g, name, np.asarray(a))
+        for name, (tail, dt) in spec.items():
+            (g or w.root).children.append((name, (_Extensible(tuple(tail), np.dtype(dt), int(chunk_rows)), {}, None, False)))
+        w.save(path)
+        return Appender.open(path)
+
+    @staticmethod
+    def open(path):
+        ap = Appender(path)
+        f = File(path)
+        def visit(grp, prefix):
+            for name in grp.keys():
+                obj = grp[name]
+                full = prefix + name
+                if isinstance(obj, Group):
+                    ap._index_attrs(f, obj, full)
+                    visit(obj, full + "/")
+                else:
+                    ap._index_dataset(f, obj, full)
+        ap._index_attrs(f, f, "")
+        visit(f, "")
+        return ap
+
+    def _messages_with_offsets(self, f, addr):
+        """(type, file offset of the body, size) of every header message of the object at ``addr``."""
+        b = f.buf
+        ver, _, nmsg, _, hsize = struct.unpack_from("<BBHII", b, addr + f.base)
+        blocks, out = [(addr + 16, hsize)], []
+        while blocks and len(out) < nmsg:
+            p, n = blocks.pop(0)
+            p += f.base
+            end = p + n
+            while p + 8 <= end and len(out) < nmsg:
+                t, size, _ = struct.unpack_from("<HHB", b, p)
+                if t == 0x0010:
+                    blocks.append(struct.unpack_from("<QQ", b, p + 8))
+                out.append((t, p + 8, size))
+                p += 8 + size
+        return out
+
+    def _index_attrs(self, f, obj, name):
+        for t, off, size in self._messages_with_offsets(f, obj.addr):
+            if t != 0x000C:
+                continue
+            body = f.buf[off:off + size]
+            if body[0] != 1:
+                continue
+            nsz, dsz, ssz = struct.unpack_from("<HHH", body, 2)
+            pad = lambda n: ((n + 7) // 8) * 8
+            aname = bytes(body[8:8 + nsz]).split(b"\x00")[0].decode("utf-8")
+            dt, _ = _parse_datatype(body, 8 + pad(nsz))
+            if dt.kind == "num":
+                self.attr_off[(name, aname)] = (off + 8 + pad(nsz) + pad(dsz) + pad(ssz), dt.dtype)
+
+    def _index_dataset(self, f, ds, name):
+        msgs = self._messages_with_offsets(f, ds.addr)
+        lay = [(off, size) for t, off, size in msgs if t == 0x0008][0]
+        spc = [(off, size) for t, off, size in msgs if t == 0x0001][0]
+        body = f.buf[lay[0]:lay[0] + lay[1]]
+        if body[1] == 1:                                            # contiguous: a fixed dataset, writable in place
+            addr, = struct.unpack_from("<Q", body, 2)
+            self.data_off[name] = (addr + f.base, ds.dtype, ds.shape)
+            return
+        if body[1] != 2 or ds._filters():
+            return
+        rank = body[2] - 1
+        btree, = struct.unpack_from("<Q", body, 3)
+        cdims = struct.unpack_from("<%dI" % (rank + 1), body, 11)
+        st = dict(rank=rank, dtype=ds.dtype, tail=tuple(ds.shape[1:]), chunk_rows=cdims[0], nrows=ds.shape[0],
+                  dims_off=spc[0] + 8, btree_off=lay[0] + 3, path=[])
+        st["chunk_bytes"] = int(np.prod(cdims[:-1], dtype=np.int64)) * cdims[-1]
+        # rightmost path of the chunk B-tree (root first)
+        addr = btree
+        while addr != UNDEF:
+            node = self._read_node(f, addr, rank)
+            st["path"].append(node)
+            addr = node["children"][-1] if node["level"] > 0 and node["children"] else UNDEF
+        st["path"].reverse()                                        # path[level]
+        self.ds[name] = st
+
+    def _read_node(self, f, addr, rank):
+        nb = f._at(addr, 24)
+        level, used = nb[5], struct.unpack_from("<H", nb, 6)[0]
+        left, right = struct.unpack_from("<QQ", nb, 8)
+        ksz = 8 + 8 * (rank + 1)
+        body = f._at(addr + 24, used * (ksz + 8) + ksz)
+        keys, children = [], []
+        for k in range(used + 1):
+            p = k * (ksz + 8)
+            size, mask = struct.unpack_from("<II", body, p)
+            offs = struct.unpack_from("<%dQ" % (rank + 1), body, p + 8)
+            keys.append((size, offs[0]))
+            if k < used:
+                children.append(struct.unpack_from("<Q", body, p + ksz)[0])
+        return dict(addr=addr, level=level, keys=keys[:-1], final=keys[-1][1], children=children, left=left, right=right)
+
+    # -- writing -------------------------------------------------------------------------------
+    def _alloc(self, nbytes):
+        self.eof += -self.eof % 8
+        addr = self.eof
+        self.eof += nbytes
+        return addr
+
+    def _node_bytes(self, st):
+        return 24 + self.K2 * (8 + 8 * (st["rank"] + 1) + 8) + 8 + 8 * (st["rank"] + 1)
+
+    def _write_node(self, st, node):
+        rank = st["rank"]
+        out = bytearray(struct.pack("<4sBBHQQ", b"TREE", 1, node["level"], len(node["children"]), node["left"], node["right"]))
+        for (size, row), child in zip(node["keys"], node["children"]):
+            out += struct.pack("<II", size, 0) + struct.pack("<%dQ" % (rank + 1), row, *([0] * rank)) + struct.pack("<Q", child)
+        out += struct.pack("<II", 0, 0) + struct.pack("<%dQ" % (rank + 1), node["final"], *([0] * rank))
+        out += b"\x00" * (self._node_bytes(st) - len(out))
+        self.fh.seek(node["addr"]); self.fh.write(out)
+
+    def _insert(self, st, level, key, child, final):
+        """Append (key, child) at ``level`` of the rightmost path; ``final``: row just past everything stored."""
+        path = st["path"]
+        node = path[level]
+        if len(node["children"]) < self.K2:
+            node["keys"].append(key); node["children"].append(child); node["final"] = final
+            self._write_node(st, node)
+            for up in path[level + 1:]:                             # the boundary key moves up the rightmost path
+                up["final"] = final
+                self._write_node(st, up)
+            return
+        # full: a new rightmost node at this level, linked as sibling, announced one level up
+        new = dict(addr=self._alloc(self._node_bytes(st)), level=level, keys=[key], children=[child], final=final, left=node["addr"], right=UNDEF)
+        node["right"] = new["addr"]
+        self._write_node(st, node)
+        self._write_node(st, new)
+        if level + 1 == len(path):                                  # the full node was the root: new root over both
+            root = dict(addr=self._alloc(self._node_bytes(st)), level=level + 1, keys=[node["keys"][0]], children=[node["addr"]],
+                        final=final, left=UNDEF, right=UNDEF)
+            path.append(root)
+            self.fh.seek(st["btree_off"]); self.fh.write(struct.pack("<Q", root["addr"]))
+        path[level] = new
+        self._insert(st, level + 1, key, new["addr"], final)
+
+    def append(self, blocks):
+        n = None
+        for name, a in blocks.items():
+            st = self.ds[name]
+            a = np.ascontiguousarray(a, dtype=st["dtype"])
+            if tuple(a.shape[1:]) != st["tail"]:
+                raise H5Error("append: %s has trailing shape %s, the dataset %s" % (name, a.shape[1:], st["tail"]))
+            n = len(a) if n is None else n
+            if len(a) != n:
+                raise H5Error("append: blocks of different length")
+            fill = st["nrows"] % st["chunk_rows"]
+            if fill:                                                # the last chunk is partial: continue inside it
+                take = min(len(a), st["chunk_rows"] - fill)
+                row_bytes = st["chunk_bytes"] // st["chunk_rows"]
+                self.fh.seek(st["path"][0]["children"][-1] + fill * row_bytes)
+                self.fh.write(memoryview(np.ascontiguousarray(a[:take]).reshape(-1)).cast("B"))
+                st["nrows"] += take
+                a = a[take:]
+            for r0 in range(0, len(a), st["chunk_rows"]):
+                part = a[r0:r0 + st["chunk_rows"]]
+                addr = self._alloc(st["chunk_bytes"])
+                self.fh.seek(addr); self.fh.write(memoryview(part.reshape(-1)).cast("B"))
+                if part.nbytes < st["chunk_bytes"]:
+                    self.fh.write(b"\x00" * (st["chunk_bytes"] - part.nbytes))
+                row = st["nrows"]
+                st["nrows"] += len(part)
+                final = (row // st["chunk_rows"] + 1) * st["chunk_rows"]
+                if not st["path"]:                                  # first chunk: the root leaf
+                    node = dict(addr=self._alloc(self._node_bytes(st)), level=0, keys=[], children=[], final=final, left=UNDEF, right=UNDEF)
+                    st["path"].append(node)
+                    self.fh.seek(st["btree_off"]); self.fh.write(struct.pack("<Q", node["addr"]))
+                self._insert(st, 0, (st["chunk_bytes"], row), addr, final)
+        for name in blocks:                                         # the new length becomes visible last
+            st = self.ds[name]
+            self.fh.seek(st["dims_off"]); self.fh.write(struct.pack("<Q", st["nrows"]))
+        self._finish()
+
+    def _finish(self):
+        self.fh.seek(40); self.fh.write(struct.pack("<Q", self.eof))
+        self.fh.seek(0, 2)
+        if self.fh.tell() < self.eof:
+            self.fh.write(b"\x00" * (self.eof - self.fh.tell()))
+        self.fh.flush()
+
+    def set_attr(self, obj, name, value):
+        off, dt = self.attr_off[(obj, name)]
+        self.fh.seek(off); self.fh.write(np.asarray(value, dt).tobytes()); self.fh.flush()
+
+    def set_data(self, name, array):
+        off, dt, shape = self.data_off[name]
+        a = np.ascontiguousarray(array, dt)
+        if a.shape != tuple(shape):
+            raise H5Error("set_data: %s is %s, got %s" % (name, shape, a.shape))
+        self.fh.seek(off); self.fh.write(a.tobytes()); self.fh.flush()
+
+    def nrows(self, name):
+        return self.ds[name]["nrows"]
+
+    def close(self):
+        if self.fh is not None:
+            self.fh.close(); self.fh = None
+
+
+class _Extensible(object):
+    """Placeholder for Writer: an empty chunked dataset that an Appender will grow along axis 0."""
+
+    def __init__(self, tail, dtype, chunk_rows):
+        self.tail, self.dtype, self.chunk_rows = tail, dtype, chunk_rows
+        self.shape = (0,) + tail
+        self.ndim = len(self.shape)
+        self.nbytes = 0

@@ -183,7 +183,7 @@ class ChainStore(object):
         self._flushed = 0
         self._writer, self._queue, self._error = None, None, None
         self._events, self._copy_stream = {}, None
-        self._cancel = False
+        self._appender, self._appended = None, 0
 
     # The incremental part files are written by one background thread: zipping + writing 7 MB per convergence
     # check (128 walkers) took as long as the 100 iterations between two checks.  numpy's file I/O and zlib's
@@ -199,14 +199,8 @@ class ChainStore(object):
                     try:
                         if item is None:
                             return
-                        path, k, accepted = item
-                        if self._cancel:                              # the consolidated file is about to supersede the parts
-                            continue
-                        self._to_host(k)                              # device blocks come to the host HERE, off the sampling thread
-                        with open(path + ".tmp", "wb") as fh:         # a reader never sees a half-written part
-                            np.savez(fh, chain=self.chain[k], chain_transformed=self.chain_transformed[k],
-                                     log_prob=self.log_prob[k], accepted=self._acc_host(accepted))
-                        os.replace(path + ".tmp", path)
+                        _, k, accepted = item
+                        self._append_block(k, accepted)               # device blocks come to the host HERE, off the sampling thread
                     except Exception as e:          # surfaced by the next drain()
                         self._error = e
                     finally:
@@ -284,6 +278,47 @@ class ChainStore(object):
         self.log_prob.append(keep(logp_block))
         self.accepted = np.asarray(accepted, np.float64)
 
+    # -- the chain file grows in place (h5lite.Appender): one chunk of every dataset per flushed block ------------
+    def _names(self):
+        return (("samples", "chain_transformed", "logprob") if self.layout == "zeus"
+                else ("mcmc/chain", "mcmc/chain_transformed", "mcmc/log_prob"))
+
+    def _start_appender(self, k):
+        """Create the extensible file from block k's shapes; blocks before k (a resumed run) are appended first."""
+        self._to_host(k)
+        nw, nd = self.chain[k].shape[1], self.chain[k].shape[2]
+        dt = lambda blocks: np.result_type(*[np.asarray(b).dtype for b in blocks if not torch.is_tensor(b)] or [np.float32])
+        rows = max(1, len(self.chain[k]))
+        tmp = self.h5 + ".tmp"
+        if self.layout == "zeus":
+            ap = h5lite.Appender.create(tmp, {"samples": ((nw, nd), dt(self.chain[:k + 1])), "chain_transformed": ((nw, nd), dt(self.chain_transformed[:k + 1])),
+                                              "logprob": ((nw,), dt(self.log_prob[:k + 1]))}, chunk_rows=rows)
+        else:
+            ap = h5lite.Appender.create(tmp, {"chain": ((nw, nd), dt(self.chain[:k + 1])), "chain_transformed": ((nw, nd), dt(self.chain_transformed[:k + 1])),
+                                              "log_prob": ((nw,), dt(self.log_prob[:k + 1]))}, group="mcmc",
+                                        group_attrs=dict(version="3.0.2", nwalkers=np.int64(nw), ndim=np.int64(nd), has_blobs=False,
+                                                         iteration=np.int64(0)),
+                                        fixed={"accepted": np.zeros(nw)}, chunk_rows=rows)
+        ap.close()
+        os.replace(tmp, self.h5)
+        self._appender = h5lite.Appender.open(self.h5)
+        self._appended = 0
+
+    def _append_block(self, k, accepted):
+        if self._appender is None:
+            self._start_appender(k)
+        names = self._names()
+        while self._appended <= k:                                  # (blocks of a resumed run first, then block k)
+            j = self._appended
+            self._to_host(j)
+            z, th, lp = self.chain[j], self.chain_transformed[j], self.log_prob[j]
+            self._appender.append({names[0]: z, names[1]: th, names[2]: lp})
+            self._appended += 1
+        if self.layout != "zeus":
+            self._appender.set_attr("mcmc", "iteration", self._appender.nrows(names[0]))
+            if accepted is not None:
+                self._appender.set_data("mcmc/accepted", self._acc_host(accepted))
+
     def arrays(self):
         self.drain()
         for k in range(len(self.chain)):
@@ -291,26 +326,29 @@ class ChainStore(object):
         return (np.concatenate(self.chain), np.concatenate(self.chain_transformed), np.concatenate(self.log_prob))
 
     def flush(self, final=True):
-        """``final=True``: the consolidated ``<name>.h5`` + ``<name>.txt``.  ``final=False`` (the
-        incremental flush after every convergence check, sampler.py:359/720): only the blocks that are
-        not on disk yet, as ``<name>.partNNNNN.npz`` -- the reference's HDF5 backend appends, and
-        rewriting the whole chain at every check is quadratic (216 MB per 100 iterations at 4096
-        walkers).  ``load`` reads either form, so a killed run resumes from the parts."""
+        """``final=False`` (the incremental flush after every convergence check, sampler.py:359/720): the blocks that
+        are not on disk yet are appended to ``<name>.h5`` by the writer thread, one chunk per dataset and block, as the
+        reference's HDF5 backend does -- the file is current after every flush and a killed run resumes from it.
+        ``final=True``: whatever is left, then the file is closed (a store that was never flushed incrementally writes
+        contiguous datasets in one pass); ``<name>.txt`` on request."""
         if not final:
             for k in range(self._flushed, len(self.chain)):
-                self._enqueue(self._part(k), (k, self.accepted.clone() if torch.is_tensor(self.accepted) else np.array(self.accepted)))
+                self._enqueue(None, (k, self.accepted.clone() if torch.is_tensor(self.accepted) else np.array(self.accepted)))
             self._flushed = len(self.chain)
             return
-        self._cancel = True                                 # parts still queued are not worth writing any more
-        try:
-            self.drain()
-        finally:
-            self._cancel = False
+        self.drain()
         for k in range(len(self.chain)):
             self._to_host(k)
         self.accepted = self._acc_host(self.accepted) if self.accepted is not None else None
-        # the blocks go to the file one after the other: no concatenated copy of the chain in memory
-        self.write_h5(self.h5, list(self.chain), list(self.chain_transformed), list(self.log_prob), self.accepted, self.layout)
+        if self._appender is not None:                      # the file has grown with the run: add what is left, done
+            if len(self.chain) > self._appended:
+                self._append_block(len(self.chain) - 1, self.accepted)
+            self._appender.close()
+            self._appender = None
+        else:
+            # never flushed incrementally: the blocks go to the file one after the other (contiguous datasets), without a
+            # concatenated copy of the chain in memory
+            self.write_h5(self.h5, list(self.chain), list(self.chain_transformed), list(self.log_prob), self.accepted, self.layout)
         if self.write_txt:
             z, th, lp = self.arrays()
             flat = np.concatenate([th.reshape(-1, th.shape[-1]), lp.reshape(-1, 1)], axis=1)
@@ -811,8 +849,7 @@ class HMCSampler(object):
                 print("init from previous")
                 prev = ChainStore.load(filename)
                 x0, resume = prev["chain"][-1], True
-                store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])
-                store.flush()                                                # consolidate: parts written from here on are new
+                store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])   # re-chunked into the new file at the first flush
         ens = EnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
         self.sampler = ens
         print("start", flush=True)
@@ -895,8 +932,7 @@ class ZeusSampler(object):
             print("init from previous")
             prev = ChainStore.load(store.base)
             x0 = prev["chain"][-1]
-            store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])
-            store.flush()                                                    # consolidate: parts written from here on are new
+            store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])   # re-chunked into the new file at the first flush
         ens = SliceEnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
         self.sampler = ens
         ens.set_state(x0)

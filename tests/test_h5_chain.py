@@ -213,3 +213,43 @@ def test_random_files_roundtrip(tmp_path):
                     np.testing.assert_array_equal(ds.read(nrows=2), a[:2], err_msg=key)
             for k in range(len(groups) - 1):
                 assert f["g%d" % k].attrs["name"] == "grp%d" % k
+
+
+def test_appender_grows_chunked_datasets(tmp_path):
+    """h5lite.Appender: datasets that grow along axis 0 one chunk at a time (what emcee's backend does through
+    h5py): every state readable, partial chunks continued, the chunk B-tree growing to three levels, reopening."""
+    rs = np.random.RandomState(3)
+    p = str(tmp_path / "a.h5")
+    ap = h5lite.Appender.create(p, {"chain": ((4, 3), np.float32), "log_prob": ((4,), np.float64)}, group="mcmc",
+                                group_attrs=dict(nwalkers=np.int64(4), iteration=np.int64(0), version="3.0.2"),
+                                fixed={"accepted": np.zeros(4)}, chunk_rows=5)
+    c, l = [], []
+    for it, n in enumerate([5, 5, 3, 4, 5, 12, 1] + [5] * 70):
+        a, b = rs.standard_normal((n, 4, 3)).astype(np.float32), rs.standard_normal((n, 4))
+        ap.append({"mcmc/chain": a, "mcmc/log_prob": b}); c.append(a); l.append(b)
+        ap.set_attr("mcmc", "iteration", ap.nrows("mcmc/chain")); ap.set_data("mcmc/accepted", np.full(4, it + 1.0))
+        if it in (0, 2, 3, 5, 6, 20, 76):
+            with h5lite.File(p) as f:
+                g = f["mcmc"]
+                np.testing.assert_array_equal(g["chain"].read(), np.concatenate(c))
+                np.testing.assert_array_equal(g["log_prob"].read(), np.concatenate(l))
+                assert g.attrs["iteration"] == sum(len(x) for x in c) and g["chain"].maxshape[0] == h5lite.UNDEF
+                np.testing.assert_array_equal(g["accepted"].read(), np.full(4, it + 1.0))
+    assert len(ap.ds["mcmc/chain"]["path"]) == 2            # more than 64 chunks: a second B-tree level
+    ap.close()
+    ap = h5lite.Appender.open(p)                            # continue a file written earlier
+    a, b = rs.standard_normal((7, 4, 3)).astype(np.float32), rs.standard_normal((7, 4))
+    ap.append({"mcmc/chain": a, "mcmc/log_prob": b}); c.append(a); l.append(b); ap.close()
+    with h5lite.File(p) as f:
+        np.testing.assert_array_equal(f["mcmc/chain"].read(), np.concatenate(c))
+        np.testing.assert_array_equal(f["mcmc/log_prob"].read(nrows=9), np.concatenate(l)[:9])
+    # one-row chunks, 4200 of them: three levels
+    p2 = str(tmp_path / "b.h5")
+    ap = h5lite.Appender.create(p2, {"samples": ((2,), np.float64)}, chunk_rows=1)
+    x = rs.standard_normal((4200, 2))
+    for i in range(4200):
+        ap.append({"samples": x[i:i + 1]})
+    assert len(ap.ds["samples"]["path"]) == 3
+    ap.close()
+    with h5lite.File(p2) as f:
+        np.testing.assert_array_equal(f["samples"].read(), x)

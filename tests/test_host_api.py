@@ -153,36 +153,50 @@ def test_cpu_model_refuses_to_compute():
         m.forward(torch.zeros(2, 7))
 
 
-def test_chainstore_incremental_parts_roundtrip(tmp_path):
-    """Incremental flushes write only the new blocks; load() sees consolidated file + parts; the final
-    flush consolidates and removes the parts; a resumed store does not duplicate what it loaded."""
+def test_chainstore_grows_the_hdf5_file_in_place(tmp_path):
+    """Incremental flushes append to ``<name>.h5`` (one chunk per dataset and block, written by the background
+    thread): the file is current after every flush; a resumed store continues it without duplicating what it
+    loaded; blocks of different lengths and a legacy part file of an earlier version are taken in."""
     from linna_amd.sampler import ChainStore
+    from linna_amd import h5lite
     rs = np.random.RandomState(0)
     name = str(tmp_path / "chemcee_256.h5")
-    blocks = [(rs.standard_normal((5, 4, 3)), rs.standard_normal((5, 4, 3)), rs.standard_normal((5, 4))) for _ in range(3)]
+    blocks = [(rs.standard_normal((n, 4, 3)), rs.standard_normal((n, 4, 3)), rs.standard_normal((n, 4))) for n in (5, 5, 3, 5)]
+    cat = lambda j, upto: np.concatenate([b[j] for b in blocks[:upto]])
     st = ChainStore(name)
     assert not st.exists()
     for i, (z, th, lp) in enumerate(blocks[:2]):
         st.append(z, th, lp, np.full(4, i + 1.0))
         st.flush(final=False)
-    st.drain()                                              # the parts are written by a background thread
-    assert st.exists() and not os.path.isfile(st.h5) and len(ChainStore._parts(st.base)) == 2
+        st.drain()                                          # written by a background thread
+        d = ChainStore.load(name)
+        np.testing.assert_array_equal(d["chain"], cat(0, i + 1))
+        np.testing.assert_array_equal(d["accepted"], np.full(4, i + 1.0))
+    assert st.exists() and os.path.isfile(st.h5) and not ChainStore._parts(st.base)
+    with h5lite.File(st.h5) as f:                           # emcee's layout, extensible along the step axis
+        assert f["mcmc/chain"].maxshape == (h5lite.UNDEF, 4, 3) and f["mcmc"].attrs["iteration"] == 10
+    # resume in a new store: load, append as one block, continue; a short block, then a full one
     d = ChainStore.load(name)
-    np.testing.assert_array_equal(d["chain"], np.concatenate([b[0] for b in blocks[:2]]))
-    np.testing.assert_array_equal(d["log_prob"], np.concatenate([b[2] for b in blocks[:2]]))
-    assert d["iteration"] == 10
-    # resume: load, append as one block, consolidate, continue with a new part
     st2 = ChainStore(name, write_txt=True)
     st2.append(d["chain"], d["chain_transformed"], d["log_prob"], d["accepted"])
-    st2.flush()
-    assert os.path.isfile(st2.h5) and not ChainStore._parts(st2.base)
-    st2.append(*blocks[2], np.full(4, 3.0))
-    st2.flush(final=False)
+    for i in (2, 3):
+        st2.append(*blocks[i], np.full(4, i + 1.0))
+        st2.flush(final=False)
     st2.drain()
     d2 = ChainStore.load(name)
-    np.testing.assert_array_equal(d2["chain"], np.concatenate([b[0] for b in blocks]))
-    np.testing.assert_array_equal(d2["chain_transformed"], np.concatenate([b[1] for b in blocks]))
+    np.testing.assert_array_equal(d2["chain"], cat(0, 4))
+    np.testing.assert_array_equal(d2["chain_transformed"], cat(1, 4))
+    np.testing.assert_array_equal(d2["log_prob"], cat(2, 4))
+    assert d2["iteration"] == 18
     st2.flush()
     d3 = ChainStore.load(name)
     np.testing.assert_array_equal(d3["chain"], d2["chain"])
-    assert not ChainStore._parts(st2.base) and os.path.isfile(st2.base + ".txt")
+    assert os.path.isfile(st2.base + ".txt")
+    # a store that is only flushed at the end writes contiguous datasets in one pass
+    st3 = ChainStore(str(tmp_path / "zeus_256.h5"))
+    for z, th, lp in blocks:
+        st3.append(z.astype(np.float32), th.astype(np.float32), lp.astype(np.float32), np.zeros(4))
+    st3.flush()
+    d4 = ChainStore.load(st3.h5)
+    np.testing.assert_array_equal(d4["chain"], cat(0, 4).astype(np.float32))
+    assert d4["chain"].dtype == np.float32
