@@ -186,7 +186,7 @@ def training_rate(device, world, rank, backend, nsteps=150):
 
 def time_dominant_kernel(lp, z, out, iters):
     """HIP-event timing (events recorded on the launch stream) of the dominant kernel: the
-    whole-network serving kernel net_stream_kernel<6, 0, false, false, 16> -- ONE launch per step evaluates prior map,
+    whole-network serving kernel net_stream_kernel<6, 0, false, 0, 16> -- ONE launch per step evaluates prior map,
     5 layers and the log-likelihood for all walkers.  Returns (avg ms per launch, algorithmic
     FLOP per launch = nwalkers x (2 x 820 224 MACs + 99 log-likelihood FLOP))."""
     from linna_amd import _lib
@@ -362,7 +362,7 @@ def main():
                        "parallelism": "walkers sharded, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "kernel": "net_stream_kernel<6, 0, false, false, 16> (whole network per launch: 16 walkers/workgroup, activations in LDS, fragment-order weight stream loaded straight into the MFMA operand registers, v_mfma_f32_16x16x4_f32)",
+                         "kernel": "net_stream_kernel<6, 0, false, 0, 16> (whole network per launch: 16 walkers/workgroup, activations in LDS, fragment-order weight stream loaded straight into the MFMA operand registers, v_mfma_f32_16x16x4_f32)",
                          "avg_launch_ms": ms_kernel, "launch_ms_p10_p50_p90": ms_q, "flop_per_launch": flop_launch},
             "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
         }
