@@ -11,6 +11,11 @@ of the reference).  Inputs are resident in HBM before the timed region.
 
 For N > 1 launch with torch.distributed.run (one rank per GPU); walkers shard across ranks
 with no data-path collective (weak scaling: 4096 walkers per GPU).  Rank 0 prints ONE JSON line.
+
+Besides the contract's fields the line carries: ``roofline`` (dominant kernel, HIP-event timing, p10/p50/p90 of
+single launches, PMC traffic from profiles/), ``cpu_baseline`` (N = 1), ``mcmc`` (ensemble iterations/s of the
+bare sampler loop), ``strong_scaling`` (N > 1: the same 4096 walkers split over the ranks) and ``training``
+(optimiser steps of ChtoModelv2(26,457), batch 500 per GPU, gradient all-reduce for N > 1).
 """
 import argparse
 import ctypes as C
