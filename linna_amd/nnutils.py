@@ -28,11 +28,31 @@ def save_state(state, filepath):
     torch.save(state, filepath)
 
 
+def _numpy_scalar_globals():
+    """The reconstructors a ``torch.optim`` state dict needs when ``lr`` came from ``np.load(lr.npy)``
+    (SURVEY §8 a19): numpy scalars / arrays of the plain float / int dtypes (data-only constructors), nothing else."""
+    import numpy as np
+    core = getattr(np, "_core", None) or np.core
+    out = [core.multiarray.scalar, core.multiarray._reconstruct, np.ndarray, np.dtype]
+    for name in ("Float64DType", "Float32DType", "Int64DType", "Int32DType", "BoolDType"):
+        t = getattr(getattr(np, "dtypes", None), name, None)
+        if t is not None:
+            out.append(t)
+    return out
+
+
 def read_checkpoint(path, device=None):
+    """A checkpoint file is only ever read with ``weights_only=True`` (tensors, containers, plain numbers --
+    nothing in the file is executed); files whose ``optim_dict`` holds numpy scalars get exactly those
+    reconstructors allowed, and a file that still does not load is refused."""
     if not os.path.exists(path):
         raise FileNotFoundError("File doesn't exist {}".format(path))
-    # optim_dict of reference-written files can hold numpy scalars: full unpickle
-    return torch.load(path, map_location=device if device is not None else "cpu", weights_only=False)
+    where = device if device is not None else "cpu"
+    try:
+        return torch.load(path, map_location=where, weights_only=True)
+    except Exception:
+        with torch.serialization.safe_globals(_numpy_scalar_globals()):
+            return torch.load(path, map_location=where, weights_only=True)
 
 
 def load_checkpoint(checkpoint, model, optimizer=None, device=None, ismpi=False):

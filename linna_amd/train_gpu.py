@@ -13,7 +13,7 @@ if __name__ == "__main__":
     from linna_amd import util, nn
     outdir = sys.argv[1]
     with open(outdir + "/model_args.pkl", "rb") as f:
-        args = pickle.load(f)
+        args = util.ArgsUnpickler(f).load()
     if args[15] is None:
         args[15] = nn.ChtoModelv2
     util.train_NN(*args)

@@ -15,6 +15,7 @@ import ctypes as C
 import io
 import os
 import pickle
+from collections import OrderedDict
 from copy import deepcopy
 
 import numpy as np
@@ -182,15 +183,44 @@ _REFERENCE_CLASSES = ("Transform", "invTransform", "Y_transform_data", "Y_invtra
 
 
 class CPU_Unpickler(pickle.Unpickler):
-    """util.py:51-55 plus a module remap: pickles written by the reference name their classes
-    ``linna.util.*``; they load as the classes of this module (same attribute names)."""
+    """util.py:51-55 as a CLOSED allow-list: the transform pickles of a run directory name the seven
+    transform classes (``linna.util.*`` when the reference wrote them: loaded as the classes of this
+    module, same attribute names), ``collections.OrderedDict``, ``torch._utils._rebuild_tensor_v2`` and
+    ``torch.storage._load_from_bytes``; the storage bytes go through ``torch.load(weights_only=True)``.
+    Any other global is refused -- nothing a file names is ever imported or called."""
 
     def find_class(self, module, name):
         if module == "torch.storage" and name == "_load_from_bytes":
-            return lambda b: torch.load(io.BytesIO(b), map_location="cpu", weights_only=False)
+            return _storage_from_bytes
+        if module == "torch._utils" and name == "_rebuild_tensor_v2":
+            return torch._utils._rebuild_tensor_v2
+        if module == "collections" and name == "OrderedDict":
+            return OrderedDict
         if module in ("linna.util", "linna_amd.util") and name in _REFERENCE_CLASSES:
             return globals()[name]
-        return super().find_class(module, name)
+        raise pickle.UnpicklingError("refusing to load global %s.%s from a transform pickle" % (module, name))
+
+
+def _storage_from_bytes(b):
+    return torch.load(io.BytesIO(b), map_location="cpu", weights_only=True)
+
+
+class ArgsUnpickler(pickle.Unpickler):
+    """``model_args.pkl`` (main.py:189-198: the positional arguments of ``train_NN``) read with a closed allow-list:
+    numpy array / scalar reconstructors, the point-design helper and the network classes of ``linna.nn`` /
+    ``linna.util`` (loaded as this package's), and ``train_NN`` itself (``model_pickle.pkl``)."""
+
+    def find_class(self, module, name):
+        core = getattr(np, "_core", None) or np.core
+        if module in ("numpy.core.multiarray", "numpy._core.multiarray") and name in ("_reconstruct", "scalar"):
+            return getattr(core.multiarray, name)
+        if module == "numpy" and name in ("ndarray", "dtype"):
+            return getattr(np, name)
+        if module in ("linna.util", "linna_amd.util") and name in ("NN_samplerv1", "train_NN"):
+            return globals()[name]
+        if module in ("linna.nn", "linna_amd.nn", "linna.util", "linna_amd.util") and name in lnn.__all__:
+            return getattr(lnn, name)
+        raise pickle.UnpicklingError("refusing to load global %s.%s from model_args.pkl" % (module, name))
 
 
 def retrieve_model(outdir, inshape, outshape, nnmodel_in=lnn.ChtoModelv2, device=None):

@@ -130,7 +130,7 @@ def test_train_NN_trajectory_matches_reference(tmp_path):
     for f in ("best.pth.tar", "last.pth.tar", "X_transform.pkl", "y_transform.pkl", "y_invtransform.pkl",
               "y_transform_data.pkl", "y_invtransform_data.pkl"):
         assert os.path.isfile(out + f), f
-    ck = torch.load(out + "best.pth.tar", weights_only=False)
+    ck = torch.load(out + "best.pth.tar", weights_only=True)
     assert int(ck["epoch"]) == int(g["best_epoch"])
     for k, v in ck["state_dict"].items():
         ref = g["best/" + k]

@@ -89,6 +89,48 @@ def test_reference_fixture_artefacts_load_on_cpu():
         np.testing.assert_array_equal(model.model.state_dict()[k].numpy(), v.numpy())
 
 
+def test_artefact_readers_execute_nothing(tmp_path):
+    """Transform pickles and checkpoints of a run directory go through closed allow-lists: a file naming any
+    other global (here os.system / builtins.eval) is refused before anything is imported or called."""
+    import pickle
+    from linna_amd import util, nnutils
+
+    class Evil(object):
+        def __reduce__(self):
+            return (os.system, ("echo pwned > %s" % os.path.join(str(tmp_path), "pwned"),))
+    bad = os.path.join(str(tmp_path), "X_transform.pkl")
+    with open(bad, "wb") as f:
+        pickle.dump(Evil(), f)
+    with open(bad, "rb") as f, pytest.raises(pickle.UnpicklingError):
+        util.CPU_Unpickler(f).load()
+    with open(bad, "wb") as f:
+        f.write(b"cbuiltins\neval\n(V1+1\ntR.")
+    with open(bad, "rb") as f, pytest.raises(pickle.UnpicklingError):
+        util.CPU_Unpickler(f).load()
+    ck = os.path.join(str(tmp_path), "best.pth.tar")
+    torch.save({"epoch": 1, "state_dict": {}, "optim_dict": Evil()}, ck)
+    with pytest.raises(Exception):
+        nnutils.read_checkpoint(ck)
+    assert not os.path.exists(os.path.join(str(tmp_path), "pwned"))
+    # a checkpoint whose optimiser state holds numpy scalars (lr from np.load(lr.npy), SURVEY a19) still loads
+    torch.save({"epoch": 2, "state_dict": {"w": torch.ones(2)},
+                "optim_dict": {"param_groups": [{"lr": np.float64(1e-3), "weight_decay": np.load(_npy(tmp_path, 1e-4))}]}}, ck)
+    got = nnutils.read_checkpoint(ck)
+    assert float(got["optim_dict"]["param_groups"][0]["lr"]) == 1e-3
+    # our own transform pickles round-trip through the same reader
+    xt = util.X_transform_class(torch.zeros(3), torch.ones(3), "cpu", [0, 2])
+    xt.pickle(bad)
+    with open(bad, "rb") as f:
+        back = util.CPU_Unpickler(f).load()
+    assert back.dolog10index == [0, 2] and torch.equal(back.X_std, torch.ones(3))
+
+
+def _npy(tmp_path, v):
+    p = os.path.join(str(tmp_path), "v.npy")
+    np.save(p, v)
+    return p
+
+
 def test_checkpoint_written_in_reference_layout(tmp_path):
     from linna_amd import nn, nnutils
     from linna_amd.predictor_gpu import _AdamWState
@@ -99,7 +141,7 @@ def test_checkpoint_written_in_reference_layout(tmp_path):
     opt.step_dev, opt.hyper = torch.tensor([7], dtype=torch.int32), torch.zeros(4)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     nnutils.save_checkpoint({"epoch": 3, "state_dict": sd, "optim_dict": opt.state_dict()}, True, str(tmp_path))
-    ck = torch.load(os.path.join(str(tmp_path), "best.pth.tar"), weights_only=False)
+    ck = torch.load(os.path.join(str(tmp_path), "best.pth.tar"), weights_only=True)
     assert ck["epoch"] == 3 and list(ck["state_dict"]) == list(m.state_dict())
     pg = ck["optim_dict"]["param_groups"][0]
     assert pg["lr"] == 1e-3 and pg["weight_decay"] == 1e-4 and len(pg["params"]) == len(sd)
