@@ -9,9 +9,12 @@
  *  - every function returns int: 0 = OK, <0 = error; linna_last_error() gives the text
  *    (thread-local).  No C++ exception crosses the boundary.
  *  - every pointer named like a matrix/vector is a CALLER-OWNED DEVICE pointer (fp32,
- *    row-major, leading dimension in elements).  The library never allocates device memory
- *    and never synchronises (except linna_stream_sync); all work is enqueued on `stream`
- *    (a hipStream_t passed as void*).
+ *    row-major, leading dimension in elements).  Handles own small device-side state allocated when
+ *    they are created or first used outside a stream capture (linna_net_t / linna_logprob_t: the weights
+ *    re-laid in MFMA fragment order; linna_ctx_t: the descriptor table of the grouped parameter-gradient
+ *    launch, 64 bytes of arrival counters); activations, workspaces, inputs and outputs are the caller's.
+ *    Nothing synchronises (except linna_stream_sync and linna_event_elapsed_ms); all work is enqueued on
+ *    `stream` (a hipStream_t passed as void*).
  *  - handles (linna_ctx_t, linna_net_t, ...) are small host objects; a handle is
  *    single-threaded, distinct handles are independent.
  *  - leading dimensions of activation/workspace matrices produced by the library are
@@ -26,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 3   /* 3: + linna_net_stream_state */
+#define LINNA_ABI_VERSION 4   /* 3: + linna_net_stream_state; 4: + linna_comm_* / collectives (RCCL) */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -49,6 +52,31 @@ int linna_event_create(void** ev);
 int linna_event_record(void* ev, void* stream);
 int linna_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on stop */
 int linna_event_destroy(void* ev);
+
+/* ------------------------------------------------------------------ collectives (RCCL over xGMI)
+ * One communicator per context (= per device = per rank: one process per GPU).  Replaces, for the data path, what the
+ * reference does with torch DistributedDataParallel and `lr = lr*size` (linna/predictor_gpu.py:246, 265-266) for the
+ * training gradient, and with its MPI pool (linna/util.py:99-256, chtoPool) for walker / chain state.
+ * Rank 0 calls linna_comm_unique_id and hands the LINNA_COMM_ID_BYTES bytes to every rank out of band (a file, a TCP
+ * store, torch.distributed's store ...); every rank then calls linna_comm_init (collective, blocks until all ranks
+ * arrive).  The collectives are enqueued on `stream` like every other entry and are hipGraph-capturable; all ranks must
+ * issue them in the same order.  librccl.so.1 is resolved at run time: without it these entries fail with a text in
+ * linna_last_error(), the rest of the library is unaffected. */
+#define LINNA_COMM_ID_BYTES 128
+int linna_comm_unique_id(void* id /* [LINNA_COMM_ID_BYTES] host bytes, out */);
+int linna_comm_init(linna_ctx_t* ctx, int rank, int nranks, const void* id /* [LINNA_COMM_ID_BYTES] */);
+int linna_comm_destroy(linna_ctx_t* ctx);            /* also done by linna_ctx_destroy */
+/* nranks = 0 when the context holds no communicator; rccl_version as ncclGetVersion reports it (0 if unavailable) */
+int linna_comm_info(linna_ctx_t* ctx, int* rank, int* nranks, int* rccl_version);
+/* buf[n] <- sum over ranks, in place: the flat fp32 gradient buffer (+ the step's scalar loss) of a data-parallel
+ * optimiser step (linna/predictor_gpu.py:265-266, 282-287) */
+int linna_allreduce_sum_f32(linna_ctx_t* ctx, float* buf, size_t n, void* stream);
+/* recv[r*n_per_rank .. (r+1)*n_per_rank) <- send[0 .. n_per_rank) of rank r: complementary walkers per half step,
+ * chain blocks per flush (linna/util.py:143-156, 258-289; linna/sampler.py:346-368) */
+int linna_allgather_f32(linna_ctx_t* ctx, const float* send, float* recv, size_t n_per_rank, void* stream);
+/* buf[n] of rank `root` to every rank (learning rate of the range test, stop flag of the epoch controller:
+ * linna/predictor_gpu.py:223-245, 387-393) */
+int linna_broadcast_f32(linna_ctx_t* ctx, float* buf, size_t n, int root, void* stream);
 
 /* ------------------------------------------------------------------ generic fused GEMM
  * C = epi( alpha0 * (A0.B0 + bias0) + (A1.B1 + bias1) ),  fp32 MFMA, exact fp32.

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblinna_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
@@ -58,6 +58,7 @@ class LossDesc(C.Structure):
 
 
 OP_LINEAR, OP_RESBLOCK, OP_INSKIP = 0, 1, 2
+COMM_ID_BYTES = 128
 LAY_K, LAY_MN = 0, 1
 
 _V, _I, _F, _SZ, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
@@ -78,6 +79,13 @@ _SIGNATURES = {
     "linna_event_record": (_I, [_V, _V]),
     "linna_event_elapsed_ms": (_I, [_V, _V, C.POINTER(C.c_float)]),
     "linna_event_destroy": (_I, [_V]),
+    "linna_comm_unique_id": (_I, [_V]),
+    "linna_comm_init": (_I, [_V, _I, _I, _V]),
+    "linna_comm_destroy": (_I, [_V]),
+    "linna_comm_info": (_I, [_V, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "linna_allreduce_sum_f32": (_I, [_V, _V, _SZ, _V]),
+    "linna_allgather_f32": (_I, [_V, _V, _V, _SZ, _V]),
+    "linna_broadcast_f32": (_I, [_V, _V, _SZ, _I, _V]),
     "linna_gemm_f32": (_I, [_V, C.POINTER(Gemm), _V]),
     "linna_gemm_dot_slots": (_I, [_I, _I]),
     "linna_linear_fwd": (_I, [_V, _V, _I, _V, _I, _V, _V, _I, _I, _I, _I, _I, _F, _V, _I, _V]),

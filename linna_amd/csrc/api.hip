@@ -69,7 +69,10 @@ struct linna_ctx {
     int group = -1;                          // -1 unknown, 0 off (env LINNA_BWD_GROUP=0), 1 on
     unsigned* counters = nullptr;            // zeroed, self-resetting arrival counters (fused loss)
     int loss_fused = -1;                     // -1 unknown, 0 off (env LINNA_LOSS_FUSED=0), 1 on
+    void* comm = nullptr;                    // RCCL communicator state (comm.hip), set by linna_comm_init
 };
+void** linna_ctx_comm_slot(linna_ctx_t* ctx) { return &ctx->comm; }
+int linna_ctx_device(const linna_ctx_t* ctx) { return ctx->device; }
 struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
 // zeroed arrival counters of the context (allocated on first use, never while the stream is capturing)
 static unsigned* ctx_counters(linna_ctx* ctx, hipStream_t st) {
@@ -163,6 +166,7 @@ int linna_ctx_create(int device, linna_ctx_t** out) {
 }
 int linna_ctx_destroy(linna_ctx_t* ctx) {
     if (ctx) {
+        (void)linna_comm_destroy(ctx);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
         if (ctx->group_dev) (void)hipFree(ctx->group_dev);

@@ -28,6 +28,18 @@ def _hidden(out_size):
     return 1000 if out_size > 30 else max(32, int(out_size * 32))
 
 
+def _xavier_uniform(shape):
+    """``nn.init.xavier_uniform_`` on a fresh contiguous ``[N, K]`` tensor (torch's global CPU generator)."""
+    bound = math.sqrt(3.0) * math.sqrt(2.0 / float(shape[0] + shape[1]))
+    return torch.empty(shape, dtype=torch.float32).uniform_(-bound, bound)
+
+
+def _consume(n):
+    """Advance torch's global CPU generator by ``n`` float32 uniform draws."""
+    if n > 0:
+        torch.empty(int(n), dtype=torch.float32).uniform_()
+
+
 class _Op(object):
     __slots__ = ("op", "key", "K", "C", "N", "relu", "alpha")
 
@@ -72,7 +84,9 @@ class _Emulator(object):
         self._net = None
         self._ws = {}
         self.training = False
+        self._constructor_draws()
         self.init_weight()
+        self._post_init()
 
     # ------------------------------------------------------------------ structure
     def _build_ops(self):
@@ -94,24 +108,47 @@ class _Emulator(object):
         return buf[off:off + shp[0]]
 
     def init_weight(self):
-        """Xavier-uniform weights, bias 1e-2, skip weights zero (nn.py:38-43, 95-99).  Uses
-        torch's global RNG (as the reference does) in state_dict order."""
+        """``init_weight()`` of the reference's network classes (nn.py:91-108 with the block's nn.py:34-43), bit for
+        bit: same torch global RNG, same draw order.  ``self.modules()`` there walks the tree in pre-order, so a
+        residual block is initialised by its own ``init_weight`` (Xavier-uniform on its three Linear weights, skip
+        weights zeroed) and then its three Linear children are visited AGAIN by the outer loop -- the skip weights
+        end up Xavier-uniform, not zero, and the first three draws of every block are discarded.  Biases 1e-2."""
         host = torch.zeros(self.nflat, dtype=torch.float32)
-        for key in self._index:
-            shp = self._index[key][1]
-            v = self._view(host, key)
-            if key.endswith("bias"):
-                v.fill_(1e-2)
-            elif "skip_layer" in key:
-                v.zero_()
+        for op in self.ops:
+            if op.op == _lib.OP_RESBLOCK:
+                names = [op.key + ".layer1.weight", op.key + ".layer2.weight"]
+                if op.K != op.N:
+                    names.append(op.key + ".skip_layer.weight")
+                for key in names:                                   # the block's own init_weight: overwritten below
+                    _xavier_uniform(self._index[key][1])
+                for key in names:
+                    self._view(host, key).copy_(_xavier_uniform(self._index[key][1]))
+                self._view(host, op.key + ".layer1.bias").fill_(1e-2)
+                self._view(host, op.key + ".layer2.bias").fill_(1e-2)
             else:
-                bound = math.sqrt(6.0 / (shp[0] + shp[1]))
-                v.uniform_(-bound, bound)
-        self._post_init(host)
+                self._view(host, op.key + ".weight").copy_(_xavier_uniform(self._index[op.key + ".weight"][1]))
+                self._view(host, op.key + ".bias").fill_(1e-2)
         self._flat.copy_(host)
         self.weights_changed()
 
-    def _post_init(self, host):
+    def _constructor_draws(self):
+        """The RNG draws the reference's constructor makes before its ``init_weight()``: every ``nn.Linear`` is born
+        with kaiming-uniform weights and a uniform bias (one draw per element, in registration order), and every
+        residual block runs its own ``init_weight`` once (nn.py:33).  All of it is overwritten; consuming the same
+        number of draws makes ``torch.manual_seed(s); Model(...)`` yield the reference's initial weights."""
+        for op in self.ops:
+            if op.op == _lib.OP_RESBLOCK:
+                shapes = [(op.C, op.K), (op.N, op.C)] + ([(op.N, op.K)] if op.K != op.N else [])
+                _consume(op.C * op.K + op.C)
+                _consume(op.N * op.C + op.N)
+                if op.K != op.N:
+                    _consume(op.N * op.K)                           # skip_layer: bias=False
+                for shp in shapes:
+                    _consume(shp[0] * shp[1])
+            else:
+                _consume(op.N * op.K + op.N)
+
+    def _post_init(self):
         pass
 
     def weights_changed(self):
@@ -340,9 +377,10 @@ class ChtoModelv2_linear(ChtoModelv2):
         ops.append(_Op(_lib.OP_INSKIP, "linearlayer", self.in_size, self.out_size, alpha=1e-3))
         return ops
 
-    def _post_init(self, host):
-        self._view(host, "linearlayer.bias").zero_()          # nn.py:162-163
-        self._view(host, "linearlayer.weight").fill_(1e-5)
+    def _post_init(self):
+        # nn.py:162-163: only the constructor does this; a later init_weight() leaves the layer Xavier-initialised
+        self._view(self._flat, "linearlayer.bias").zero_()
+        self._view(self._flat, "linearlayer.weight").fill_(1e-5)
 
 
 class MLP(_Emulator):

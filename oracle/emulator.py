@@ -79,21 +79,79 @@ def macs_per_eval(kind, in_size, out_size, **kw):
                if k.endswith("weight"))
 
 
-def init_params(kind, in_size, out_size, rng, zero_skip=True, **kw):
-    """Xavier-uniform weights, bias 0.01, skip weights zeroed (nn.py:38-43, 95-99).
+class TorchCPUGenerator(object):
+    """torch's default CPU generator for float32 ``uniform_`` restated on numpy: ``torch.manual_seed(s)`` seeds an
+    mt19937 by ``init_genrand(s)`` exactly as ``np.random.RandomState(s)`` does, and ``uniform_(lo, hi)`` maps one
+    32-bit draw per element as ``(x & (2**24 - 1)) * 2**-24 * (hi - lo) + lo`` in double (lo, hi rounded to
+    float32 first), then rounds to float32.  Checked bit for bit against the reference's initial weights
+    (tests/golden/init_parity.npz)."""
 
-    ``rng`` is a ``np.random.RandomState``; the draw order is ours, not torch's, so this
-    reproduces the reference's *distribution*, not its bits.
-    """
+    def __init__(self, seed):
+        self.rs = np.random.RandomState(seed)
+
+    def uniform(self, shape, lo, hi):
+        n = int(np.prod(shape))
+        x = self.rs.randint(0, 2 ** 32, size=n, dtype=np.uint32)
+        u = (x & np.uint32((1 << 24) - 1)).astype(np.float64) * 2.0 ** -24
+        lo, hi = float(np.float32(lo)), float(np.float32(hi))
+        return (u * (hi - lo) + lo).astype(np.float32).reshape(shape)
+
+    def consume(self, n):
+        if n > 0:
+            self.rs.randint(0, 2 ** 32, size=int(n), dtype=np.uint32)
+
+
+def _xavier(gen, shape):
+    """nn.init.xavier_uniform_ (gain 1): U(-a, a), a = sqrt(3) * sqrt(2 / (fan_in + fan_out))."""
+    a = np.sqrt(3.0) * np.sqrt(2.0 / float(shape[0] + shape[1]))
+    return gen.uniform(shape, -a, a)
+
+
+def reinit_params(kind, in_size, out_size, gen, **kw):
+    """``model.init_weight()`` (nn.py:91-108 / :169-183 / :332-349): ``self.modules()`` walks the module tree in
+    pre-order, so every residual block first runs its own ``init_weight`` (nn.py:34-43: Xavier on layer1, layer2,
+    skip_layer, then skip zeroed) and is then visited child by child by the outer loop, which draws all three
+    weights AGAIN -- the skip weights of a trained-from-scratch network are Xavier-uniform, not zero.  Biases 1e-2.
+    ``gen`` is a ``TorchCPUGenerator``: same stream and draw order as torch, so the result is the reference's bits."""
     p = {}
-    for key, shp in param_shapes(kind, in_size, out_size, **kw).items():
-        if key.endswith("bias"):
-            p[key] = np.full(shp, 1e-2, np.float32)
+    shapes = param_shapes(kind, in_size, out_size, **kw)
+    for op in topology(kind, in_size, out_size, **kw):
+        key = op[1]
+        if op[0] == "resblock":
+            names = [k for k in (key + ".layer1.weight", key + ".layer2.weight", key + ".skip_layer.weight") if k in shapes]
+            for k in names:
+                _xavier(gen, shapes[k])                      # the block's own init_weight, overwritten
+            for k in names:
+                p[k] = _xavier(gen, shapes[k])
+            p[key + ".layer1.bias"] = np.full(shapes[key + ".layer1.bias"], 1e-2, np.float32)
+            p[key + ".layer2.bias"] = np.full(shapes[key + ".layer2.bias"], 1e-2, np.float32)
         else:
-            bound = np.sqrt(6.0 / (shp[0] + shp[1]))
-            p[key] = rng.uniform(-bound, bound, size=shp).astype(np.float32)
-            if zero_skip and "skip_layer" in key:
-                p[key][...] = 0
+            p[key + ".weight"] = _xavier(gen, shapes[key + ".weight"])
+            p[key + ".bias"] = np.full(shapes[key + ".bias"], 1e-2, np.float32)
+    return {k: p[k] for k in shapes}
+
+
+def init_params(kind, in_size, out_size, gen, **kw):
+    """The weights of a freshly CONSTRUCTED reference network (``torch.manual_seed(s); ChtoModelv2(...)``,
+    nn.py:63-89): every ``nn.Linear`` constructor draws kaiming-uniform weights and a uniform bias (one draw per
+    element, overwritten later), every residual block runs its ``init_weight`` once in its constructor (nn.py:33),
+    then the network's ``init_weight()`` (``reinit_params``); ``ChtoModelv2_linear`` finally sets its input skip to
+    weight 1e-5 / bias 0 (nn.py:162-163)."""
+    for op in topology(kind, in_size, out_size, **kw):
+        if op[0] == "resblock":
+            _, key, K, C, N = op
+            gen.consume(C * K + C)
+            gen.consume(N * C + N)
+            if K != N:
+                gen.consume(N * K)
+            gen.consume(C * K)
+            gen.consume(N * C)
+            if K != N:
+                gen.consume(N * K)
+        else:
+            _, key, K, N = op[:4]
+            gen.consume(N * K + N)
+    p = reinit_params(kind, in_size, out_size, gen, **kw)
     if kind == "ChtoModelv2_linear":                         # nn.py:162-163
         p["linearlayer.bias"][...] = 0
         p["linearlayer.weight"][...] = 1e-5

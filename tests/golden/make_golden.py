@@ -366,15 +366,134 @@ def gen_hmc(out):
     print("hmc accepted", int(sum(c["accepted"] for c in chain)), "of", num_samps, flush=True)
 
 
+# ------------------------------------------------------------------ initial weights (torch RNG parity)
+INIT_CASES = [("ChtoModelv2", 33, 33, 11), ("ChtoModelv2", 26, 457, 12), ("ChtoModelsimple", 6, 4, 13),
+              ("ChtoModelv2_linear", 5, 3, 14)]
+
+
+def gen_init_parity(out):
+    """``torch.manual_seed(s); Model(nin, nout, None)`` and a later ``init_weight()`` of the live reference: digests
+    of every tensor plus the next three draws of the global generator (the stream position afterwards)."""
+    rec = {}
+    for kind, nin, nout, seed in INIT_CASES:
+        cls = getattr(rnn, kind)
+        torch.manual_seed(seed)
+        m = cls(nin, nout, None)
+        tag = "%s_%d_%d" % (kind, nin, nout)
+        rec[tag + "/after_construct"] = torch.rand(3).numpy()
+        for k, v in m.state_dict().items():
+            rec[tag + "/construct/" + k] = synth.tensor_digest(v.numpy())
+        torch.manual_seed(seed + 100)
+        m.init_weight()
+        rec[tag + "/after_reinit"] = torch.rand(3).numpy()
+        for k, v in m.state_dict().items():
+            rec[tag + "/reinit/" + k] = synth.tensor_digest(v.numpy())
+        print("init parity", tag, float(m.state_dict()["layer2.skip_layer.weight"].abs().max()), flush=True)
+    out["init_parity"] = rec
+
+
+# ------------------------------------------------------------------ 33-D README problem: a long train_NN run
+def gen_train33(out, nep=None):
+    """BASELINE configs[0] / README.rst:60-88: iteration 0 of ``ml_sampler`` on the 33-D Gaussian (theory =
+    identity, flat priors [-5, 5], 10000 + 500 Latin-hypercube points, batch 500, ChtoModelv2(33, 33) constructed
+    by the reference itself under ``torch.manual_seed``), trained by the LIVE reference's ``train_NN`` for ``nep``
+    epochs with a fixed ``lr.npy``.  Stored: per-step training losses, per-epoch validation metrics, the messages of
+    the epoch controller, and the residual of the trained emulator at points of the tempered posterior."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from linna_amd import util as putil                     # point design only (CPU): pyDOE2 is absent
+    import readme33
+    nep = int(os.environ.get("GOLDEN_TRAIN33_EPOCHS", "300")) if nep is None else nep
+    prob = readme33.problem()
+    ndim, means, cov = prob["ndim"], prob["means"], prob["cov"]
+    sigma = np.sqrt(np.diag(cov))
+    tmp = tempfile.mkdtemp(prefix="linna_golden33_") + "/"
+    ns = putil.NN_samplerv1(tmp, [[-5.0, 5.0]] * ndim)
+    train_x, val_x = ns.gensample_flat(10000), ns.gensample_flat(500)
+    np.savetxt(tmp + "train_samples_x.txt", train_x); np.save(tmp + "train_samples_y.npy", train_x.copy())
+    np.savetxt(tmp + "val_samples_x.txt", val_x); np.save(tmp + "val_samples_y.npy", val_x.copy())
+    np.save(tmp + "lr.npy", readme33.LR)
+
+    class _S(object):
+        pass
+    captured, messages = {}, []
+    orig_train, orig_es = rpred.Predictor.train, rpred.EarlyStopping.step
+
+    def spy(self, *a, **k):
+        r = orig_train(self, *a, **k)
+        captured["ret"], captured["pred"] = r, self
+        return r
+
+    def es_spy(self, *a, **k):
+        c = orig_es(self, *a, **k)
+        captured.setdefault("codes", []).append(int(c))
+        return c
+
+    import builtins
+    orig_print = builtins.print
+
+    def print_spy(*a, **k):
+        msg = " ".join(str(x) for x in a).strip()
+        if msg and not msg.startswith("("):
+            messages.append("%d|%s" % (len(captured.get("codes", [])), msg))
+        orig_print(*a, **k)
+    rpred.Predictor.train, rpred.EarlyStopping.step = spy, es_spy
+    rpred.print = print_spy
+    import time
+    t0 = time.time()
+    try:
+        torch.manual_seed(readme33.SEED)
+        rutil.train_NN(_S(), cov, np.linalg.inv(cov), sigma, tmp, [tmp], means, None, False, True, 2, 16.0,
+                       False, None, 1, rnn.ChtoModelv2, {"num_epochs": nep, "batch_size": 500}, False)
+    finally:
+        rpred.Predictor.train, rpred.EarlyStopping.step = orig_train, orig_es
+        del rpred.print
+    print("reference train_NN: %d epochs in %.0f s" % (nep, time.time() - t0), flush=True)
+    train_losses, val_metrics = captured["ret"]
+    pred = captured["pred"]
+    # residual of the trained emulators (last and best epoch) at the posterior tempered by T = 16 (iteration 0) and T = 1
+    rs = np.random.RandomState(5)
+    unit = rs.standard_normal((4000, ndim))
+    yinv = rutil.Y_invtransform_data(sigma, "cpu")
+    rec = dict(train_digest=synth.tensor_digest(train_x), val_digest=synth.tensor_digest(val_x),
+               lr=np.float64(readme33.LR), seed=np.int64(readme33.SEED), num_epochs=np.int64(nep),
+               train_losses=np.asarray(train_losses, np.float64), val_metrics=np.asarray(val_metrics, np.float64),
+               codes=np.asarray(captured.get("codes", []), np.int64), messages=np.array(messages))   # unit: RandomState(5)
+
+    def residual(tag):
+        for T in (16.0, 1.0):
+            th = means[None, :] + np.sqrt(T) * sigma[None, :] * unit
+            with torch.no_grad():
+                m = yinv(pred.predict(t32(th))).numpy()
+            res = (m - th) / sigma[None, :]
+            rec["%s_res_rms_T%d" % (tag, T)] = np.float64(np.sqrt(np.mean(res ** 2)))
+            rec["%s_res_mean_T%d" % (tag, T)] = res.mean(0)
+            print("emulator (%s) residual at the T=%d posterior: rms %.3f sigma, max |mean| %.3f sigma"
+                  % (tag, T, rec["%s_res_rms_T%d" % (tag, T)], np.abs(res.mean(0)).max()), flush=True)
+    residual("last")
+    from linna_amd import nnutils as pnnutils
+    best = pnnutils.read_checkpoint(tmp + "best.pth.tar")   # weights_only=True (+ numpy scalar reconstructors for lr)
+    rec["best_epoch"] = np.int64(best["epoch"])
+    pred.model.load_state_dict(best["state_dict"])
+    residual("best")
+    out["train33_run"] = rec
+    shutil.rmtree(tmp, ignore_errors=True)
+    vm = np.asarray(val_metrics)
+    print("train33: val loss at epochs 1/10/50/100/last:", [float(vm[min(i, len(vm) - 1), 0]) for i in (0, 9, 49, 99, len(vm) - 1)],
+          "messages", messages[:12], flush=True)
+
+
+GENERATORS = [("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
+              ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc),
+              ("init_parity", gen_init_parity), ("train33", gen_train33)]
+
+
 def main():
+    """``make_golden.py`` rewrites everything; ``make_golden.py init_parity train33`` only the named groups."""
+    want = sys.argv[1:]
     out = {}
-    gen_fixture(out)
-    gen_serving(out)
-    gen_training(out)
-    gen_train_nn(out)
-    gen_loader_order(out)
-    gen_early_stopping(out)
-    gen_hmc(out)
+    for name, fn in GENERATORS:
+        if not want or name in want:
+            fn(out)
     for name, rec in out.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **rec)
         sz = os.path.getsize(os.path.join(HERE, name + ".npz"))

@@ -1,0 +1,143 @@
+"""GPU: BASELINE configs[0] -- the README problem (33-D Gaussian, theory = identity, flat priors [-5, 5];
+README.rst:60-88, tests/test_main.py:43-51) end to end through TRAINED emulators.
+
+* the training trajectory of iteration 0 against the live reference's ``train_NN`` run on the same points, seeds and
+  learning rate (tests/golden/train33_run.npz, made by make_golden.py train33: 300 epochs, 213 s on 4 CPU threads there;
+  about 2 s here);
+* ``ml_sampler_core`` with the schedule of ``ml_sampler`` and the 4 x 512 MLP emulator of BASELINE configs[1] plugged in
+  through ``nnmodel_in``: posterior mean within 0.05 sigma and standard deviation within 5 % of the analytic posterior;
+* the literal README call (``nwalkers = 4``, ``nepoch = 101``) as a plumbing run: artefacts and shapes.
+
+Why the posterior test plugs in the MLP: ``ChtoModelv2(33, 33)`` ends in ``relu(Linear(500, 33))`` followed by
+``Linear(33, 33)`` (nn.py:85-86, 126-130) -- 33 non-negative features for 33 outputs.  Wherever one of them is clipped the
+output loses a direction of the input, the emulated likelihood is flat along it and the walkers run tens of sigma away;
+each iteration patches the holes its predecessor's chain found and opens others.  The validation loss of the live reference
+stalls at 0.09 on this problem exactly as the HIP trajectory does (first test), and eight iterations do not converge
+(DESIGN.md section 4).  Real LINNA problems have nout >> nin, where that layer is no bottleneck.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import readme33
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_iteration0(tmp):
+    from linna_amd import util
+    prob = readme33.problem()
+    ns = util.NN_samplerv1(tmp, [[-5.0, 5.0]] * prob["ndim"])
+    tx, vx = ns.gensample_flat(10000), ns.gensample_flat(500)
+    np.savetxt(tmp + "train_samples_x.txt", tx); np.save(tmp + "train_samples_y.npy", tx.copy())
+    np.savetxt(tmp + "val_samples_x.txt", vx); np.save(tmp + "val_samples_y.npy", vx.copy())
+    np.save(tmp + "lr.npy", readme33.LR)
+    return prob, tx, vx
+
+
+def test_train33_tracks_the_live_reference(tmp_path, capsys):
+    """Same points, same initial weights (``torch.manual_seed`` + the reference's constructor draw order), same batch
+    order, same learning rate: the per-step losses agree to 1e-4 over the first epoch, the validation metric stays
+    within 6 % at epochs 50 / 150 / 300, neither controller touches the learning rate, and the trained emulators are
+    equally (in)accurate at the tempered posterior."""
+    import cases
+    import synth
+    from linna_amd import util, nn
+    g = cases.golden("train33_run")
+    tmp = str(tmp_path) + "/"
+    prob, tx, vx = _write_iteration0(tmp)
+    np.testing.assert_array_equal(synth.tensor_digest(tx), g["train_digest"])       # the design the reference trained on
+    np.testing.assert_array_equal(synth.tensor_digest(vx), g["val_digest"])
+    means, cov = prob["means"], prob["cov"]
+    sigma = np.sqrt(np.diag(cov))
+    nep = int(g["num_epochs"])
+    torch.manual_seed(int(g["seed"]))
+    pred = util.train_NN(None, cov, np.linalg.inv(cov), sigma, tmp, [tmp], means, None, False, True, 2, 16.0, True, None, 1,
+                         nn.ChtoModelv2, {"num_epochs": nep, "batch_size": 500}, False)
+    tl, vm = pred.train_history
+    ref_tl, ref_vm = g["train_losses"], g["val_metrics"]
+    assert len(tl) == len(ref_tl) == 20 * nep and vm.shape == ref_vm.shape == (nep, 3)
+    np.testing.assert_allclose(tl[:20], ref_tl[:20], rtol=1e-4)                      # measured: 6 digits over 12 steps
+    np.testing.assert_allclose(vm[:3, 0], ref_vm[:3, 0], rtol=2e-2)
+    for e in (49, 149, 299):
+        assert abs(vm[e, 0] - ref_vm[e, 0]) < 0.06 * ref_vm[e, 0], (e, vm[e, 0], ref_vm[e, 0])
+    # smoothed over 50 epochs the two trajectories agree to 3 % from epoch 50 on
+    for lo in range(50, nep - 49, 50):
+        a, b = vm[lo:lo + 50, 0].mean(), ref_vm[lo:lo + 50, 0].mean()
+        assert abs(a - b) < 0.03 * b, (lo, a, b)
+    # controller: the reference printed nothing but "best.pth.tar does not exsit" in 300 epochs; neither do we
+    assert [m.split("|", 1)[1] for m in g["messages"]] == ["best.pth.tar does not exsit"]
+    out = capsys.readouterr().out
+    assert "learning rate too large" not in out and "bad trainning" not in out and "weight decay too small" not in out
+    # emulator residual at the posterior tempered by T = 16 and T = 1 (4000 points, unit draws of RandomState(5))
+    unit = np.random.RandomState(5).standard_normal((4000, prob["ndim"]))
+    yinv = util.Y_invtransform_data(sigma, "cpu")
+    for T in (16, 1):
+        th = means[None, :] + np.sqrt(T) * sigma[None, :] * unit
+        m = yinv(pred.predict(torch.as_tensor(th, dtype=torch.float32))).cpu().numpy()
+        rms = np.sqrt(np.mean(((m - th) / sigma[None, :]) ** 2))
+        ref = float(g["last_res_rms_T%d" % T])
+        assert 0.6 * ref < rms < 1.5 * ref, (T, rms, ref)        # both are several sigma off after iteration 0
+
+
+def test_ml_sampler_core_33d_posterior_through_a_trained_emulator(tmp_path):
+    """The whole loop -- Latin-hypercube design, theory callback, training (range-tested learning rate), checkpoint
+    round trip, tempered ensemble sampling, chain -> next iteration's training points, four iterations with
+    ``ml_sampler``'s schedule (main.py:47-62, emcee branch) -- on the README problem with 1024 walkers and the
+    4 x 512 MLP of BASELINE configs[1] as ``nnmodel_in``, 600 epochs per iteration.  The analytic posterior is
+    N(means, cov) (the prior bounds are > 14 sigma away)."""
+    from linna_amd.main import ml_sampler_core
+    from linna_amd import nn
+    prob = readme33.problem()
+    means, cov, ndim = prob["means"], prob["cov"], prob["ndim"]
+    sig = np.sqrt(np.diag(cov))
+    out = str(tmp_path) + "/g33/"
+    np.random.seed(0)
+    torch.manual_seed(readme33.SEED)
+    params = {"trainingoption": 1, "num_epochs": 600, "batch_size": 500}
+    chain, logp = ml_sampler_core([10000] * 4, [500] * 4, [2, 2, 5, 4], [5, 5, 10, 15], [0.03, 0.03, 0.02, 0.01], [0.2] * 4,
+                                  [0.15] * 4, out, readme33.theory, prob["priors"], means, cov, prob["init"], None, 1024, "cuda",
+                                  None, False, [4.0, 2.0, 1.0, 1.0], None, False, 1, None, nn.MLP4x512, params, "emcee")
+    assert chain.ndim == 2 and chain.shape[1] == ndim and len(chain) > 200000 and np.all(np.isfinite(chain))
+    bias = np.abs(chain.mean(0) - means) / sig
+    assert bias.max() < 0.05, bias
+    np.testing.assert_allclose(chain.std(0), sig, rtol=0.05)
+    # no walker in a hole of the emulator: the largest excursion of a row is that of a 33-D Gaussian
+    dev = np.abs((chain - means) / sig).max(1)
+    assert np.median(dev) < 2.8 and (dev > 6).mean() < 1e-4
+    # the stored log-probability is the emulator's: against the exact posterior (theory = identity) at the same points
+    sub = np.random.RandomState(1).randint(0, len(chain), 20000)
+    exact = -0.5 * np.sum(((chain[sub] - means) / sig) ** 2, axis=1)
+    lp = np.asarray(logp).reshape(-1)
+    assert lp.shape[0] >= len(chain)
+    for k in range(4):
+        d = os.path.join(out, "iter_%d" % k)
+        for f in ("train_samples_x.txt", "train_samples_y.npy", "val_samples_x.txt", "val_samples_y.npy", "lr.npy",
+                  "model_args.pkl", "finish.pkl", "best.pth.tar", "last.pth.tar", "X_transform.pkl", "y_transform.pkl",
+                  "y_invtransform.pkl", "y_transform_data.pkl", "y_invtransform_data.pkl", "chemcee_256.h5"):
+            assert os.path.isfile(os.path.join(d, f)), (k, f)
+    assert np.isfinite(exact).all()
+
+
+def test_readme_call_runs_as_written(tmp_path):
+    """README.rst:86-88 verbatim: ``ml_sampler(outdir, theory, priors, means, cov, init, pool, nwalkers=4, gpunode=None,
+    nepoch=101)`` -- default method "zeus", four walkers in 33 dimensions.  Four walkers cannot span the space (every
+    move stays in the affine hull of the ensemble), so this is a plumbing run: it terminates, writes the artefacts of
+    SURVEY section 8 b5 for four iterations and returns ``(chain[n, 33], log_prob)`` inside the prior box."""
+    from linna_amd.main import ml_sampler
+    prob = readme33.problem()
+    out = str(tmp_path) + "/out/2dgaussian/"
+    np.random.seed(0)
+    torch.manual_seed(readme33.SEED)
+    chain, logprob = ml_sampler(out, readme33.theory, prob["priors"], prob["means"], prob["cov"], prob["init"], None, 4,
+                                gpunode=None, nepoch=101)
+    assert chain.ndim == 2 and chain.shape[1] == 33 and len(chain) > 0
+    assert np.all(np.isfinite(chain)) and np.all(np.abs(chain) <= 5.0)
+    assert np.asarray(logprob).size >= len(chain)
+    for k in range(4):
+        for f in ("train_samples_x.txt", "train_samples_y.npy", "lr.npy", "best.pth.tar", "X_transform.pkl", "finish.pkl",
+                  "zeus_256.h5"):
+            assert os.path.isfile(os.path.join(out, "iter_%d" % k, f)), (k, f)
+        assert np.loadtxt(os.path.join(out, "iter_%d" % k, "train_samples_x.txt")).shape == (10000, 33)

@@ -61,15 +61,49 @@ def test_parameter_layout_and_state_dict_roundtrip():
     m.load_state_dict(w)
     for k, v in m.state_dict().items():
         np.testing.assert_array_equal(v.numpy(), w[k])
-    # init: skip weights zero, bias 0.01 (nn.py:38-43)
+    # init: bias 0.01; the skip weights come out Xavier-uniform (nn.py:95-101 re-draws what nn.py:43 zeroed)
     m.init_weight()
     sd = m.state_dict()
-    assert float(sd["layer3.skip_layer.weight"].abs().max()) == 0.0
+    bound = np.sqrt(6.0 / (250 + 500))
+    assert 0.9 * bound < float(sd["layer3.skip_layer.weight"].abs().max()) <= bound * (1 + 1e-6)
     assert np.allclose(sd["layer6.bias"].numpy(), 1e-2)
     lin = nn.ChtoModelv2_linear(5, 3, None).state_dict()
     assert np.allclose(lin["linearlayer.weight"].numpy(), 1e-5) and float(lin["linearlayer.bias"].abs().max()) == 0
     with pytest.raises(KeyError):
         m.load_state_dict({"layer1.weight": w["layer1.weight"]})
+
+
+def _digest_equal(a, ref):
+    np.testing.assert_array_equal(synth.tensor_digest(np.asarray(a)), ref)
+
+
+@pytest.mark.parametrize("kind,nin,nout,seed", [("ChtoModelv2", 33, 33, 11), ("ChtoModelv2", 26, 457, 12),
+                                                ("ChtoModelsimple", 6, 4, 13), ("ChtoModelv2_linear", 5, 3, 14)])
+def test_initial_weights_are_the_references_bit_for_bit(kind, nin, nout, seed):
+    """``torch.manual_seed(s); Model(nin, nout, None)`` and a later ``init_weight()`` give the live reference's
+    tensors exactly (digests in tests/golden/init_parity.npz) and leave torch's generator at the same position --
+    for the product's network classes and for the oracle's numpy restatement of torch's CPU generator."""
+    from linna_amd import nn
+    from oracle import emulator as E
+    g = cases.golden("init_parity")
+    tag = "%s_%d_%d" % (kind, nin, nout)
+    torch.manual_seed(seed)
+    m = getattr(nn, kind)(nin, nout, None)
+    np.testing.assert_array_equal(torch.rand(3).numpy(), g[tag + "/after_construct"])
+    gen = E.TorchCPUGenerator(seed)
+    p = E.init_params(kind, nin, nout, gen)
+    assert list(p) == list(m.state_dict())
+    for k, v in m.state_dict().items():
+        _digest_equal(v.numpy(), g[tag + "/construct/" + k])
+        _digest_equal(p[k], g[tag + "/construct/" + k])
+    torch.manual_seed(seed + 100)
+    m.init_weight()
+    np.testing.assert_array_equal(torch.rand(3).numpy(), g[tag + "/after_reinit"])
+    p = E.reinit_params(kind, nin, nout, E.TorchCPUGenerator(seed + 100))
+    for k, v in m.state_dict().items():
+        _digest_equal(v.numpy(), g[tag + "/reinit/" + k])
+        _digest_equal(p[k], g[tag + "/reinit/" + k])
+    assert float(m.state_dict()["layer2.skip_layer.weight"].abs().max()) > 0
 
 
 def test_reference_fixture_artefacts_load_on_cpu():

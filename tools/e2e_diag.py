@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from linna_amd.main import ml_sampler
 from linna_amd import util, nn
+from linna_amd.sampler import ChainStore
 np.random.seed(0)
 ndim = 33
 means = np.random.uniform(size=ndim)
@@ -20,10 +21,14 @@ out = tempfile.mkdtemp() + "/"
 t0 = time.perf_counter()
 chain, logp = ml_sampler(out, theory, priors, means, cov, init, None, nw, gpunode=None, nepoch=nepoch, method="emcee")
 print("ml_sampler %.1f s" % (time.perf_counter() - t0), flush=True)
+th = np.asarray(chain)
+print("returned chain %s: mean bias max %.3f sigma (median %.3f), std ratio min %.3f max %.3f" % (
+    th.shape, np.max(np.abs(th.mean(0) - means) / sig), np.median(np.abs(th.mean(0) - means) / sig),
+    np.min(th.std(0) / sig), np.max(th.std(0) / sig)), flush=True)
 for k in range(4):
     d = out + "iter_%d/" % k
-    ch = np.load(d + "chemcee_256.npz")
-    th = ch["chain_transformed"]; th = th[len(th) // 2:].reshape(-1, ndim)
+    ch = ChainStore.load(d + "chemcee_256")
+    th = np.asarray(ch["chain_transformed"]); th = th[len(th) // 2:].reshape(-1, ndim)
     sub = th[np.random.RandomState(1).randint(0, len(th), 4000)]
     pred, yinv = util.retrieve_model(d, ndim, ndim, nn.ChtoModelv2)
     m = yinv(pred.predict(torch.as_tensor(sub, dtype=torch.float32))).cpu().numpy()
