@@ -38,6 +38,12 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 MACS_PER_EVAL = NIN * WIDTH + (DEPTH - 1) * WIDTH * WIDTH + WIDTH * NOUT     # 820 224
 
 
+def _stage(msg):
+    """Progress marker on stderr (LINNA_BENCH_TRACE=1): where a multi-rank run is, per rank."""
+    if os.environ.get("LINNA_BENCH_TRACE", "0") == "1":
+        print("[bench rank %s] %.1f %s" % (os.environ.get("RANK", "0"), time.perf_counter(), msg), file=sys.stderr, flush=True)
+
+
 def build_problem(device):
     """README.rst:69-83 shaped problem with a random-init emulator (seed 1234, Xavier-uniform
     weights, bias 0.01 -- nn.py:97-99); synthetic: there is no trained checkpoint offline."""
@@ -111,27 +117,36 @@ def pmc_traffic():
         return None
 
 
-def mcmc_rate(lp, nwalkers, nsteps=1000):
-    """Ensemble (stretch-move) iterations per second with every walker advanced once per
-    iteration: 2 half steps, each ONE launch (proposal -> whole-network lnP of nwalkers/2 -> accept)."""
+def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
+    """Ensemble (stretch-move) iterations per second with every walker advanced once per iteration: 2 half steps, each
+    ONE launch (proposal -> whole-network lnP of nwalkers/2 -> accept).  N > 1: EVERY rank runs this with its own
+    ``nwalkers`` walkers and draws the stretch partners of a half step from the complementary walkers of ALL ranks
+    (one RCCL all-gather of [nwalkers/2, ndim] per half step through linna_allgather_f32): one ensemble of
+    N x nwalkers walkers; the rate is that of the slowest rank between two barriers."""
     import torch
     from linna_amd import sampler
-    ens = sampler.EnsembleSampler(nwalkers, NIN, lp, seed=1)
-    ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nwalkers, NIN)))
-    ens.run(500, store=False)              # untimed: > 50 ms of work, past the clock ramp
+    ens = sampler.EnsembleSampler(nwalkers, NIN, lp, seed=1, exchange="allgather" if world > 1 else "none")
+    ens.set_state(0.05 * np.random.RandomState(7 + ens.rank).standard_normal((nwalkers, NIN)))
+    ens.run(warm, store=False)             # untimed: > 50 ms of work, past the clock ramp
     torch.cuda.synchronize()
+    if sync is not None:
+        sync()
     t0 = time.perf_counter()
     ens.run(nsteps, store=False)
     torch.cuda.synchronize()
+    if sync is not None:
+        sync()
     dt = time.perf_counter() - t0
-    return {"steps_per_s": nsteps / dt, "walker_updates_per_s": nsteps * nwalkers / dt,
-            "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
+    return dt, {"steps_per_s": nsteps / dt, "walker_updates_per_s": nsteps * nwalkers * world / dt,
+                "walkers_total": nwalkers * world, "exchange": "allgather of the complementary half per half step" if world > 1 else "none",
+                "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
 def training_rate(device, world, rank, backend, nsteps=150):
     """BASELINE configs[2] shape: ChtoModelv2(26, 457) (3x2pt-like stand-in), dense covariance, batch 500 PER RANK,
     one all-reduce of the flat gradient per step when N > 1 (RCCL over xGMI), lr * N (predictor_gpu.py:246).
     Full optimiser steps: gather -> forward -> chi2-ratio loss -> backward -> [all-reduce] -> AdamW."""
+    nsteps = nsteps if (world == 1 or backend == "nccl") else 30          # (a gloo rehearsal stages through the host)
     import torch
     import torch.distributed as dist
     from linna_amd import nn, util, predictor_gpu, trainer
@@ -163,9 +178,14 @@ def training_rate(device, world, rank, backend, nsteps=150):
 
     def step():
         eng.step(opt, perm[k[0] % len(perm)]); k[0] += 1
-    t_end = time.perf_counter() + 0.4
-    while time.perf_counter() < t_end:
-        for _ in range(8):
+    if world == 1:
+        t_end = time.perf_counter() + 0.4
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                step()
+            torch.cuda.synchronize()
+    else:                                   # a step holds a collective: every rank must run the SAME number of them
+        for _ in range(400 if backend == "nccl" else 20):
             step()
         torch.cuda.synchronize()
     if world > 1:
@@ -184,9 +204,31 @@ def training_rate(device, world, rank, backend, nsteps=150):
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
     loss = float(eng.loss_mean.item())
-    return {"workload": "ChtoModelv2(26,457), dense covariance, batch 500 per GPU, AdamW, gradient all-reduce per step for N > 1",
-            "samples_per_s": world * B * nsteps / dt, "ms_per_step": 1e3 * dt / nsteps, "global_batch": world * B, "steps": nsteps,
-            "loss_finite": bool(np.isfinite(loss))}
+    res = {"workload": "ChtoModelv2(26,457), dense covariance, batch 500 per GPU, AdamW, gradient all-reduce per step for N > 1",
+           "samples_per_s": world * B * nsteps / dt, "ms_per_step": 1e3 * dt / nsteps, "global_batch": world * B, "steps": nsteps,
+           "loss_finite": bool(np.isfinite(loss))}
+    # algorithmic work of one step on one rank: 3 x forward MLP FLOP per sample + the loss's 3 x 2 nout^2
+    flop = B * (3 * 2.0 * model.macs_per_eval() + 6.0 * nout * nout)
+    res["roofline"] = {"bound": "mfma", "flop_per_step": flop, "achieved": flop / (dt / nsteps) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                       "unit": "TFLOP/s per GPU", "frac": flop / (dt / nsteps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    if world > 1:
+        # the gradient all-reduce alone (flat fp32 buffer + the loss scalar), HIP events on the launch stream
+        from linna_amd import dist as ldist, _lib
+        g = model.flat_grads()
+        e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+        _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
+        for _ in range(20):
+            ldist.allreduce_grads(g, eng.loss_mean)
+        _lib.call("linna_event_record", e0, _lib.stream())
+        for _ in range(100):
+            ldist.allreduce_grads(g, eng.loss_mean)
+        _lib.call("linna_event_record", e1, _lib.stream())
+        _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+        _lib.call("linna_event_destroy", e0); _lib.call("linna_event_destroy", e1)
+        res["allreduce_us"] = 1e3 * ms.value / 100
+        res["allreduce_bytes"] = 4 * (g.numel() + 1)
+        res["allreduce_transport"] = "RCCL through linna_allreduce_sum_f32" if ldist.comm_active(g) else "torch.distributed (%s)" % backend
+    return res
 
 
 def time_dominant_kernel(lp, z, out, iters):
@@ -253,12 +295,26 @@ def main():
     dev_index = local_rank % max(ndev, 1)           # (gloo rehearsal may share a GPU between ranks)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    collectives = None
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(args.backend)
+        # data-path collectives: the library's own RCCL communicator (C ABI); torch.distributed stays the control plane
+        # (rendezvous, unique-id hand-off, barriers).  One rank per device is what RCCL needs; a gloo rehearsal that
+        # shares a GPU between ranks keeps torch.distributed as the transport.
+        from linna_amd import dist as ldist
+        if args.backend == "nccl":
+            try:
+                ldist.comm_init(dev_index)
+                collectives = "RCCL %s through the C ABI (linna_comm_init / linna_allreduce_sum_f32 / linna_allgather_f32)" % (ldist.comm_info(dev_index)[2],)
+            except Exception as e:                                  # noqa: BLE001
+                collectives = "torch.distributed nccl (linna_comm_init failed: %s)" % repr(e)[:200]
+        else:
+            collectives = "torch.distributed %s (rehearsal)" % args.backend
 
+    _stage("process group up: %s" % collectives)
     lp, model, consts = build_problem(device)
     z_host = np.random.RandomState(100 + rank).standard_normal((NWALKERS, NIN)).astype(np.float32)
     z = torch.as_tensor(z_host, device=device)
@@ -316,6 +372,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    _stage("headline timed")
     # sanity: the timed path produced finite numbers
     assert torch.isfinite(out).all(), "non-finite log-probabilities in the timed path"
 
@@ -342,6 +399,7 @@ def main():
 
     # secondary figure, every rank takes part (collective inside): training throughput on the configs[2] shape.
     # Guarded: a failure here must not cost the headline line.
+    _stage("strong scaling done")
     training = None
     if not args.no_training:
         try:
@@ -349,6 +407,23 @@ def main():
         except Exception as e:                                      # noqa: BLE001
             training = {"error": repr(e)[:300]}
 
+    _stage("training done: %s" % (training,))
+    # ensemble iterations: every rank takes part (cross-rank partner exchange for N > 1)
+    mcmc = None
+    try:
+        sync = (lambda: (dist.barrier(), torch.cuda.synchronize())) if world > 1 else None
+        quick = world > 1 and args.backend != "nccl"                 # (a gloo rehearsal stages every all-gather through the host)
+        dt_m, mcmc = mcmc_rate(lp, NWALKERS, world, sync, 100 if quick else 1000, 20 if quick else 500)
+        if world > 1:
+            tm = torch.tensor([dt_m], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            k = dt_m / float(tm.item())
+            mcmc["steps_per_s"] *= k
+            mcmc["walker_updates_per_s"] *= k
+    except Exception as e:                                          # noqa: BLE001
+        mcmc = {"error": repr(e)[:300]}
+
+    _stage("mcmc done: %s" % (mcmc,))
     if rank == 0:
         ms_kernel, flop_launch, ms_q = time_dominant_kernel(lp, z, out, max(500, args.steps))
         achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
@@ -375,13 +450,16 @@ def main():
             res["strong_scaling"] = strong
         if training is not None:
             res["training"] = training
-        res["mcmc"] = mcmc_rate(lp, NWALKERS)
-        res["mcmc"]["steps_per_s_all_gpus"] = res["mcmc"]["steps_per_s"] * world
+        res["mcmc"] = mcmc
+        if collectives is not None:
+            res["collectives"] = collectives
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
             res["cpu_baseline"] = cpu_baseline(consts, z_host)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
+        from linna_amd import dist as ldist
+        ldist.comm_destroy()
         dist.destroy_process_group()
 
 

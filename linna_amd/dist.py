@@ -1,5 +1,9 @@
-"""Multi-GPU plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
-xGMI on ROCm; "gloo" on CPU for tests).  The hot path shards without data-path collectives:
+"""Multi-GPU plumbing: one process per GPU.  The DATA PATH collectives -- gradient all-reduce, walker / chain
+all-gather -- go through the library's own RCCL communicator (``linna_comm_init`` / ``linna_allreduce_sum_f32`` /
+``linna_allgather_f32`` of include/linna_hip.h, enqueued on the caller's stream) once ``comm_init()`` has been called;
+``torch.distributed`` is the control plane (rendezvous, hand-off of the RCCL unique id, host-side barriers) and the
+fallback transport where RCCL cannot run: CPU tensors and the gloo tests, including two ranks sharing the single GPU of
+a test box (RCCL refuses two ranks on one device).  The hot path shards without data-path collectives:
 
 * walkers: every rank owns ``nwalkers`` walkers and advances them independently; chain state
   is gathered to all ranks once per flush (``gather_chain``); optionally the complementary
@@ -9,10 +13,68 @@ xGMI on ROCm; "gloo" on CPU for tests).  The hot path shards without data-path c
   per-rank loss gradient is already scaled by 1/(B * world) so the sum is the global mean, and
   the learning rate follows the reference's ``lr * size`` rule (predictor_gpu.py:246).
 """
+import ctypes as C
 import os
 
 import torch
 import torch.distributed as dist
+
+from . import _lib
+
+_comm = {}          # device index -> (rank, world) of the RCCL communicator held by that device's context
+
+
+def comm_init(device_index=None, group=None, rank=None, world=None, unique_id=None):
+    """Create this rank's RCCL communicator (collective over the ranks of ``group``).  Rank 0 draws the unique id and
+    every rank receives it through torch.distributed's object broadcast (any backend), unless ``unique_id`` bytes are
+    handed in (a file, a store).  One rank per device: RCCL refuses two ranks on one GPU."""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index in _comm:
+        return _comm[device_index]
+    if world is None:
+        world, rank = world_size(group), globals()["rank"](group)
+    if unique_id is None:
+        buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        if rank == 0:
+            _lib.call("linna_comm_unique_id", buf)
+        box = [buf.raw]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+        unique_id = box[0]
+    if len(unique_id) != _lib.COMM_ID_BYTES:
+        raise ValueError("an RCCL unique id is %d bytes" % _lib.COMM_ID_BYTES)
+    with torch.cuda.device(device_index):
+        _lib.call("linna_comm_init", _lib.ctx(device_index), int(rank), int(world), C.create_string_buffer(unique_id, _lib.COMM_ID_BYTES))
+    _comm[device_index] = (int(rank), int(world))
+    return _comm[device_index]
+
+
+def comm_active(t):
+    """True when ``t`` is a device tensor whose device holds an RCCL communicator."""
+    return torch.is_tensor(t) and t.is_cuda and t.device.index in _comm
+
+
+def comm_info(device_index=None):
+    """(rank, nranks, rccl version) as the library reports them; nranks 0 = no communicator."""
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    r, n, v = C.c_int(), C.c_int(), C.c_int()
+    _lib.call("linna_comm_info", _lib.ctx(device_index), C.byref(r), C.byref(n), C.byref(v))
+    return r.value, n.value, v.value
+
+
+def comm_destroy(device_index=None):
+    for d in ([device_index] if device_index is not None else list(_comm)):
+        if d in _comm:
+            _lib.call("linna_comm_destroy", _lib.ctx(d))
+            del _comm[d]
+
+
+def _f32(t):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _lib.LinnaHipError("RCCL entries take contiguous float32 device tensors")
+    return C.c_void_p(t.data_ptr())
 
 
 def init(backend=None, device=None):
@@ -27,11 +89,15 @@ def init(backend=None, device=None):
 
 
 def world_size(group=None):
-    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group)
+    return max([w for _, w in _comm.values()] + [1])
 
 
 def rank(group=None):
-    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group)
+    return max([r for r, _ in _comm.values()] + [0])
 
 
 def rank_batches(batches, rank, size):
@@ -41,7 +107,17 @@ def rank_batches(batches, rank, size):
 
 
 def allreduce_grads(flat_grad, loss_scalar=None, group=None):
-    """Sum the flat gradient buffer (and the scalar loss) over ranks, in place."""
+    """Sum the flat gradient buffer (and the scalar loss) over ranks, in place.  When the scalar sits right behind the
+    gradient buffer in memory (``nn._Emulator.grad_tail``) the two travel in ONE all-reduce."""
+    if comm_active(flat_grad):
+        ctx, st, n = _lib.ctx(flat_grad.device.index), _lib.stream(), flat_grad.numel()
+        if loss_scalar is not None and loss_scalar.data_ptr() == flat_grad.data_ptr() + 4 * n:
+            _lib.call("linna_allreduce_sum_f32", ctx, _f32(flat_grad), n + 1, st)
+            return
+        _lib.call("linna_allreduce_sum_f32", ctx, _f32(flat_grad), n, st)
+        if loss_scalar is not None:
+            _lib.call("linna_allreduce_sum_f32", ctx, _f32(loss_scalar), loss_scalar.numel(), st)
+        return
     if world_size(group) == 1:
         return
     dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
@@ -49,26 +125,47 @@ def allreduce_grads(flat_grad, loss_scalar=None, group=None):
         dist.all_reduce(loss_scalar, op=dist.ReduceOp.SUM, group=group)
 
 
+def _allgather(x, group):
+    """``x`` of every rank concatenated along dim 0 (rank order)."""
+    x = x.contiguous()
+    if comm_active(x) and x.dtype == torch.float32:
+        w = _comm[x.device.index][1]
+        out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        _lib.call("linna_allgather_f32", _lib.ctx(x.device.index), _f32(x), _f32(out), x.numel(), _lib.stream())
+        return out, w
+    w = world_size(group)
+    out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x, group=group)
+    return out, w
+
+
 def gather_chain(chain, lps, group=None):
     """``chain[n, nw, ndim]``, ``lps[n, nw]`` of every rank -> ``[n, world*nw, ndim]``, ``[n, world*nw]``
     on every rank (walker blocks ordered by rank)."""
-    w = world_size(group)
-    if w == 1:
+    if world_size(group) == 1:
         return chain, lps
     n, nw, nd = chain.shape
-    allc = torch.empty((w * n, nw, nd), dtype=chain.dtype, device=chain.device)     # concatenation along dim 0
-    alll = torch.empty((w * n, nw), dtype=lps.dtype, device=lps.device)
-    dist.all_gather_into_tensor(allc, chain.contiguous(), group=group)
-    dist.all_gather_into_tensor(alll, lps.contiguous(), group=group)
+    allc, w = _allgather(chain, group)
+    alll, _ = _allgather(lps, group)
     return (allc.view(w, n, nw, nd).permute(1, 0, 2, 3).reshape(n, w * nw, nd),
             alll.view(w, n, nw).permute(1, 0, 2).reshape(n, w * nw))
 
 
 def gather_rows(x, group=None):
     """All-gather of ``x[m, ...]`` along dim 0 (complementary walkers of every rank)."""
-    w = world_size(group)
-    if w == 1:
+    if world_size(group) == 1:
         return x
-    out = torch.empty((w * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
-    return out
+    return _allgather(x, group)[0]
+
+
+def broadcast_value(v, group=None, device=None):
+    """A host float of rank 0 to every rank (the range-tested learning rate, predictor_gpu.py:223-245)."""
+    if world_size(group) == 1:
+        return float(v)
+    if device is not None and torch.device(device).index in _comm:
+        t = torch.tensor([float(v)], dtype=torch.float32, device=device)
+        _lib.call("linna_broadcast_f32", _lib.ctx(t.device.index), _f32(t), 1, 0, _lib.stream())
+        return float(t.item())
+    box = [float(v)]
+    dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+    return float(box[0])

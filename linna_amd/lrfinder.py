@@ -28,7 +28,7 @@ def range_test(pred, engine, start_lr=1e-4, end_lr=5e-3, num_iter=100, smooth_f=
         opt.lr = start_lr * (end_lr / start_lr) ** (it / max(num_iter - 1, 1))
         opt.push_hyper()
         engine.rows.copy_(rows)
-        engine._step_body(opt)
+        engine._step_body(opt, local=True)
         if engine.val is not None:
             engine.validate()
             loss = float(engine.val["loss_rows"].mean().item())

@@ -194,9 +194,16 @@ class _Emulator(object):
 
     def flat_grads(self):
         if self._grad is None or self._grad.device != self._flat.device:
-            self._grad = torch.zeros_like(self._flat)
+            # four spare floats behind the gradients: the step's scalar loss rides in the same all-reduce (grad_tail)
+            self._grad_buf = torch.zeros(self.nflat + 4, dtype=torch.float32, device=self._flat.device)
+            self._grad = self._grad_buf[:self.nflat]
             self._net = None           # layer table carries gradient pointers
         return self._grad
+
+    def grad_tail(self):
+        """One float right behind the flat gradient buffer (data-parallel training sums gradient and loss in one call)."""
+        self.flat_grads()
+        return self._grad_buf[self.nflat:self.nflat + 1]
 
     def grad_dict(self):
         g = self.flat_grads()
@@ -228,7 +235,7 @@ class _Emulator(object):
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
-        new.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_flat", "_grad", "_net", "_ws")})
+        new.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ("_flat", "_grad", "_grad_buf", "_net", "_ws")})
         new._flat = self._flat.clone()
         new._grad = None
         new._net = None

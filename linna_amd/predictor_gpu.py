@@ -5,9 +5,10 @@ Mirrors ``linna/predictor_gpu.py``: ``EarlyStopping`` (:19-150, same return code
 outdir)`` with ``train`` (:201-449), ``predict`` (:461-504), ``load_checkpoint`` (:451-459).
 
 The minibatch step -- gather + input transform, forward, chi^2-ratio loss, backward, AdamW
--- is a chain of HIP kernels over device-resident data, captured once into a hipGraph and
-replayed per step; only the epoch-level controller (learning-rate / weight-decay schedule,
-divergence recovery, checkpoints) runs on the host, with the reference's semantics.
+-- is a chain of HIP kernels over device-resident data, launched directly (a hipGraph replay of
+the same step is available, ``TrainEngine(use_graph=True)``: measured equal or slower on ROCm 7.2);
+only the epoch-level controller (learning-rate / weight-decay schedule, divergence recovery,
+checkpoints) runs on the host, with the reference's semantics.
 """
 import copy
 import ctypes as C
@@ -277,10 +278,12 @@ class Predictor(object):
 
     # ------------------------------------------------------------------ training
     def train(self, dataset, num_epochs, loss_fn, val_dataset=None, val_metric_fn=None, initfrombest=False, pool=None,
-              nocpu=False, rank=0, size=1, dist_group=None, checkpoint_every=1, progress=False):
+              nocpu=False, rank=0, size=1, dist_group=None, checkpoint_every=1, progress=False, patience=500):
+        """predictor_gpu.py:201-449.  ``dist_group``, ``checkpoint_every``, ``progress`` and ``patience`` (the
+        reference hard-wires 500, :256) are additions with the reference's behaviour as default."""
         from . import trainer          # the HIP training engine (kept separate from the API shell)
         return trainer.run(self, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrombest, rank, size,
-                           dist_group, checkpoint_every, progress)
+                           dist_group, checkpoint_every, progress, patience)
 
 
 def _t2n(t):

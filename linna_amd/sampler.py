@@ -493,11 +493,8 @@ class EnsembleSampler(object):
         self._rs = np.random.RandomState(self.seed ^ 0x5EED)
         self._split_pos, self._split_host, self._split_dev, self._split_evt = 0, None, None, None
         self._split = None
-        self.rank = 0
-        self.world = 1
-        if dist_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            import torch.distributed as dist
-            self.rank, self.world = dist.get_rank(dist_group), dist.get_world_size(dist_group)
+        from . import dist as ldist
+        self.rank, self.world = ldist.rank(dist_group), ldist.world_size(dist_group)
         self._gathered = None
 
     # -- state

@@ -6,9 +6,10 @@ Data layout: the whole training / validation set lives in HBM once (``X[n, nin]`
     gather + input transform -> network forward (activations kept) -> chi^2-ratio loss and its
     gradient -> network backward (flat gradient buffer) -> [RCCL all-reduce over ranks] -> AdamW
 
-all enqueued on one HIP stream; on a single rank the step is captured once into a hipGraph and
-replayed (learning rate / weight decay are read from a device array, the AdamW step counter
-lives on the device).  The per-epoch controller is the reference's, on the host.
+all enqueued on one HIP stream as direct launches (``TrainEngine(use_graph=True)`` captures the same
+step once into a hipGraph and replays it -- learning rate / weight decay are read from a device
+array, the AdamW step counter lives on the device -- measured equal or slower on ROCm 7.2, so
+``run`` does not use it).  The per-epoch controller is the reference's, on the host.
 """
 import ctypes as C
 import os
@@ -56,6 +57,8 @@ class TrainEngine(object):
         self.xb, self.predb, self.dpred = z(B, ldx), z(B, ldo), z(B, ldo)
         self.scratch = z(_lib.load().linna_loss_scratch_bytes(B, self.nout) // 4 + 4)
         self.loss_rows, self.loss_mean = z(B), z(1)
+        if self.world > 1:
+            self.loss_mean = self.model.grad_tail()      # right behind the gradients: ONE all-reduce carries both
         self.rows = torch.zeros(B, dtype=torch.int32, device=dev)
         self.graph = None
         self.inv_batch = 1.0 / (B * self.world)          # the global batch is B per rank x ranks
@@ -87,11 +90,23 @@ class TrainEngine(object):
                   self.dpred.stride(0), self.inv_batch, st)
         self.model.backward(self.dpred[:, :self.nout], param_grads=True)
 
-    def _step_body(self, opt, rows=None, loss_out=None):
-        self._forward_loss_backward(rows, loss_out)
-        if self.world > 1:
+    def _step_body(self, opt, rows=None, loss_out=None, local=False):
+        """``local``: this rank alone (no collective, gradient of its own batch) -- the learning-rate range test, which
+        the reference runs on rank 0 only, on a private copy of the model (predictor_gpu.py:223-227)."""
+        if self.world > 1 and not local:
             from . import dist as ldist
-            ldist.allreduce_grads(self.model.flat_grads(), self.loss_mean if loss_out is None else loss_out, self.group)   # RCCL over xGMI
+            self._forward_loss_backward(rows, self.loss_mean)
+            ldist.allreduce_grads(self.model.flat_grads(), self.loss_mean, self.group)        # RCCL over xGMI
+            if loss_out is not None:
+                loss_out.copy_(self.loss_mean, non_blocking=True)
+        elif local and self.world > 1:
+            keep, self.inv_batch = self.inv_batch, 1.0 / self.B
+            try:
+                self._forward_loss_backward(rows, loss_out)
+            finally:
+                self.inv_batch = keep
+        else:
+            self._forward_loss_backward(rows, loss_out)
         opt.apply()
 
     def step(self, opt, rows_dev, loss_out=None):
@@ -162,26 +177,29 @@ class TrainEngine(object):
         return self.validate_finish()
 
 
-def _read_lr(pred, engine, rank):
-    """predictor_gpu.py:222-245: learning rate from lr.npy (rank 0 runs the range test if absent)."""
+def _read_lr(pred, engine, rank, size=1, group=None):
+    """predictor_gpu.py:222-245: learning rate from lr.npy; rank 0 runs the range test if the file is absent -- on its
+    own batches, without collectives (the other ranks are not in it) -- and every rank receives the value by broadcast
+    (the reference's other ranks spin on the file)."""
     path = os.path.join(pred.outdir, "lr.npy") if pred.outdir is not None else None
-    if path is not None and os.path.isfile(path):
-        return float(np.load(path))
+    lr = 0.0
     if rank == 0:
-        from . import lrfinder
-        lr = lrfinder.range_test(pred, engine)
-        if path is not None:
-            np.save(path, lr)
-        return float(lr)
-    while True:                                    # other ranks wait for rank 0's file
-        try:
-            return float(np.load(path))
-        except Exception:
-            time.sleep(0.05)
+        if path is not None and os.path.isfile(path):
+            lr = float(np.load(path))
+        else:
+            from . import lrfinder
+            lr = float(lrfinder.range_test(pred, engine))
+            if path is not None:
+                np.save(path + ".tmp.npy", lr)
+                os.replace(path + ".tmp.npy", path)
+    if size > 1:
+        from . import dist as ldist
+        lr = ldist.broadcast_value(lr, group, engine.dev)
+    return lr
 
 
 def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrombest, rank, size, dist_group,
-        checkpoint_every, progress):
+        checkpoint_every, progress, patience=500):
     """The body of ``Predictor.train``; returns (train_losses[steps], val_metrics[epochs, 3])."""
     progress = progress or os.environ.get("LINNA_TRAIN_PROGRESS", "0") == "1"   # per-epoch train / validation loss
     torch.manual_seed(1234)                                                     # predictor_gpu.py:221
@@ -189,7 +207,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     model = pred.model
     engine = TrainEngine(pred, dataset, loss_fn, val_dataset, world_size=size, dist_group=dist_group)
     if pred.optim == "automatic" or pred.optim is None:
-        lr = _read_lr(pred, engine, rank)
+        lr = _read_lr(pred, engine, rank, size, dist_group)
     else:
         lr = float(getattr(pred.optim, "lr", 1e-3))
     lr = lr * size                                                              # :246
@@ -200,7 +218,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     opt = _AdamWState(model, lr, weight_decay=1e-4)                             # :267
     pred.optim = opt
     engine.prepare_graph(opt)
-    es = EarlyStopping(patience=500)                                            # :256
+    es = EarlyStopping(patience=patience)                                       # :256 (500)
     ckpt = _Checkpoints(pred, model, rank)
     last_epoch = -1
     train_losses, val_metrics = [], []
@@ -284,10 +302,12 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
                 if criteria == 2:
                     print("early stop", flush=True)
                     print("learning rate", opt.lr, flush=True)
-                    if rank == 0:
-                        ckpt.record(opt, i, is_best, checkpoint_every, num_epochs, force=True)
-                        last_epoch = i
-                        break
+                    # the reference breaks on rank 0 only (predictor_gpu.py:392-393), harmless there because nothing
+                    # collective follows; here every rank holds the same metrics (all-reduced loss, replicated
+                    # validation set) and the next epoch starts with an all-reduce, so every rank stops
+                    ckpt.record(opt, i, is_best, checkpoint_every, num_epochs, force=True)
+                    last_epoch = i
+                    break
                 if criteria == 3:
                     print("\n weight decay too small: {0}\n".format(opt.weight_decay), flush=True)
                     if opt.weight_decay < 1e0:

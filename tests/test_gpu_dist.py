@@ -1,6 +1,10 @@
-"""Two ranks on the ONE GPU of the test box (gloo; RCCL refuses two ranks on one device): the multi-rank
-paths of the sampler and of the trainer on device tensors -- gradient all-reduce, complementary-ensemble
-all-gather, chain gather -- against the single-rank results they must reproduce."""
+"""The multi-rank paths of the sampler and of the trainer on device tensors -- gradient all-reduce,
+complementary-ensemble all-gather, chain gather -- against the single-rank results they must reproduce.
+
+Transport: with two devices visible every rank takes its own GPU and the collectives are the library's RCCL entries
+(``linna_comm_init`` / ``linna_allreduce_sum_f32`` / ``linna_allgather_f32``); on the ONE-GPU test box the two ranks
+share device 0 and torch.distributed's gloo carries them (RCCL refuses two ranks on one device) -- there RCCL is
+exercised by the single-rank self-test through the C ABI below."""
 import os
 import socket
 
@@ -25,11 +29,17 @@ def _free_port():
 
 def _worker(rank, world, port, fn, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    torch.cuda.set_device(0)
+    two = torch.cuda.device_count() >= world
+    torch.cuda.set_device(rank if two else 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if two:
+            from linna_amd import dist as ldist
+            ldist.comm_init()                               # RCCL communicator through the C ABI (id via gloo)
         ret[rank] = fn(rank, world)
     finally:
+        if two:
+            ldist.comm_destroy()
         dist.destroy_process_group()
 
 
@@ -87,6 +97,84 @@ def test_data_parallel_training_matches_the_global_batch():
     ref = model.flat_params().cpu().numpy()
     np.testing.assert_allclose(res[0][0], ref, rtol=2e-4, atol=2e-6)
     np.testing.assert_allclose(res[0][1], float(eng.loss_mean.item()), rtol=1e-4)
+
+
+def test_rccl_single_rank_through_the_c_abi():
+    """linna_comm_unique_id -> linna_comm_init (one rank) -> all-reduce / all-gather / broadcast on the caller's stream
+    -> linna_comm_destroy, and the same through linna_amd.dist's helpers that the trainer and the sampler call."""
+    import ctypes as C
+    from linna_amd import _lib, dist as ldist
+    dev = torch.cuda.current_device()
+    assert ldist.comm_info(dev)[1] == 0                              # no communicator yet
+    with pytest.raises(_lib.LinnaHipError):
+        _lib.call("linna_allreduce_sum_f32", _lib.ctx(dev), _lib.ptr(torch.ones(4, device="cuda")), 4, _lib.stream())
+    r, n = ldist.comm_init(dev, rank=0, world=1)
+    try:
+        assert (r, n) == (0, 1)
+        rank, nranks, ver = ldist.comm_info(dev)
+        assert (rank, nranks) == (0, 1) and ver > 20000              # RCCL 2.x reports 2xxyy
+        g = torch.arange(1000003, dtype=torch.float32, device="cuda")
+        ref = g.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                                # on the caller's stream, whichever it is
+            _lib.call("linna_allreduce_sum_f32", _lib.ctx(dev), _lib.ptr(g), g.numel(), _lib.stream())
+            out = torch.empty(2 * 77, dtype=torch.float32, device="cuda")
+            _lib.call("linna_allgather_f32", _lib.ctx(dev), _lib.ptr(g[:154].contiguous()), _lib.ptr(out), 154, _lib.stream())
+            _lib.call("linna_broadcast_f32", _lib.ctx(dev), _lib.ptr(out), 154, 0, _lib.stream())
+        side.synchronize()
+        assert torch.equal(g, ref) and torch.equal(out, ref[:154])
+        with pytest.raises(_lib.LinnaHipError):
+            ldist._lib.call("linna_comm_init", _lib.ctx(dev), 0, 1, C.create_string_buffer(128))   # one per context
+        # the helpers: gradient + loss scalar in one call when the scalar sits behind the buffer
+        from linna_amd import nn
+        m = nn.MLP(5, 3, None, width=16, depth=2).to("cuda")
+        fg, tail = m.flat_grads(), m.grad_tail()
+        fg.fill_(2.0); tail.fill_(7.0)
+        assert tail.data_ptr() == fg.data_ptr() + 4 * fg.numel() and ldist.comm_active(fg)
+        ldist.allreduce_grads(fg, tail)
+        torch.cuda.synchronize()
+        assert float(fg.sum()) == 2.0 * fg.numel() and float(tail) == 7.0
+        assert ldist.broadcast_value(0.125, device="cuda:%d" % dev) == 0.125
+    finally:
+        ldist.comm_destroy(dev)
+    assert ldist.comm_info(dev)[1] == 0
+
+
+def _trainer_run_job(rank, world):
+    """``Predictor.train`` on two ranks with lr.npy absent (rank 0 runs the range test alone, the value is broadcast)
+    and a short patience (every rank must leave the epoch loop at the same epoch)."""
+    import tempfile
+    from linna_amd import util, nn, predictor_gpu
+    g = cases.golden("train_nn_run")
+    tmp = os.environ["LINNA_TEST_SHARED_DIR"] + "/"
+    cov = g["cov"]
+    sigma = np.sqrt(np.diag(cov))
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    Xt = util.X_transform_class(t(g["X_mean"]), t(g["X_std"]), "cpu", None)
+    Yt = util.Y_transform_class(t(g["y_mean"]), t(g["y_std"]), "cpu")
+    ytd = util.Y_transform_data(sigma, "cpu")
+    yinv = util.Y_invtransform_class(t(g["y_mean"]), t(g["y_std"]), t(g["data"]), "cpu")
+    lf = util.Loss_fn(t(g["data"]), torch.tensor(cov, dtype=torch.float64), torch.tensor(np.linalg.inv(cov), dtype=torch.float64),
+                      ytd, yinv, "cpu")
+    torch.manual_seed(3)
+    model = nn.ChtoModelv2(g["train_x"].shape[1], g["train_y"].shape[1], None)
+    pred = predictor_gpu.Predictor(model.in_size, model.out_size, model=model, device="cuda", optim="automatic",
+                                   X_transform=Xt, y_transform=Yt, outdir=tmp)
+    loader = predictor_gpu.BatchLoader(util.ArrayDataset(g["train_x"], g["train_y"]), 25, shuffle=True, drop_last=True)
+    vloader = predictor_gpu.BatchLoader(util.ArrayDataset(g["val_x"], g["val_y"]), len(g["val_y"]), shuffle=False)
+    tl, vm = pred.train(loader, 400, lf, vloader, lf, initfrombest=False, rank=rank, size=world, patience=8)
+    torch.cuda.synchronize()
+    return len(vm), float(np.load(tmp + "lr.npy")), model.flat_params().cpu().numpy(), float(pred.optim.lr)
+
+
+def test_trainer_run_on_two_ranks_range_test_and_early_stop(tmp_path, monkeypatch):
+    monkeypatch.setenv("LINNA_TEST_SHARED_DIR", str(tmp_path))
+    res = _run(_trainer_run_job)
+    assert res[0][0] == res[1][0] and 8 < res[0][0] < 400            # both ranks stopped, at the same epoch, early
+    assert 1e-4 <= res[0][1] <= 5e-3 and res[0][1] == res[1][1]      # one range test, one value
+    np.testing.assert_array_equal(res[0][2], res[1][2])              # identical replicas throughout
+    assert res[0][3] == res[1][3]
 
 
 def _sampler_job(rank, world):
