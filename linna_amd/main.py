@@ -107,22 +107,41 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
         log_prob = Log_prob(data.astype(np.float32), inv_cov.astype(np.float32), model, y_invtransform_data, transform,
                             temperature, nograd=True, loglikelihoodfunc=loglikelihoodfunc or gaussianlogliklihood,
                             externalloglike=externalloglike)
+        if pool is not None:
+            pool.noduplicate = True                                              # main.py:282-283
         store = run_mcmc(nnsampler, outdir_in, method, ndim, nwalkers, init, log_prob, pool=pool, transform=transform,
                          ntimes=ntimes, tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
+        if pool is not None:
+            pool.noduplicate_close()                                             # main.py:285-286
     last = os.path.join(outdir, "iter_{0}/".format(len(ntrainArr) - 1), filename[:-3])
     chain, _, d = read_chain_and_cut(last, nk, ntimes, method=method)
     log_prob_samples_x = d["log_prob"].reshape(-1)                               # main.py:291
     if "nimp" in params:                                                         # main.py:297-334
-        select = np.random.randint(0, len(chain), params["nimp"])
-        flat_lp = d["log_prob"][-(len(chain) // d["log_prob"].shape[1]):].reshape(-1)
-        chain_s, lp_s = chain[select], flat_lp[select]
-        nns = NN_samplerv1(os.path.join(outdir, "imp/"), prior_range)
-        os.makedirs(nns.outdir, exist_ok=True)
-        th = nns.generate_training_data(zip(range(len(chain_s)), chain_s), theory, pool=pool, args=[nns.outdir])
-        logp = np.array(logp_theory_data(chain_s, th, data, inv_cov, LogPrior(priors)))
-        w = np.exp(logp - lp_s)
-        lw = np.log(w)
-        w[np.abs(lw - np.mean(lw)) > 2 * np.std(lw)] = 0
-        np.save(os.path.join(outdir, "weight_im.npy"), [lp_s, logp, w / np.sum(w)])
-        np.save(os.path.join(outdir, "samples_im.npy"), chain_s)
+        f_samples, f_lp = os.path.join(outdir, "samples_im.npy"), os.path.join(outdir, "log_prob_samples_x.npy")
+        if not os.path.isfile(f_samples):
+            chain, lp_flat, _ = read_chain_and_cut(last, nk, ntimes, method=method, flat=True)
+            print(chain.shape, lp_flat.shape)
+            select = np.random.randint(0, len(chain), params["nimp"])
+            chain, log_prob_samples_x = chain[select], lp_flat[select]
+            np.save(f_samples, chain)
+            np.save(f_lp, log_prob_samples_x)
+        else:
+            chain, log_prob_samples_x = np.load(f_samples), np.load(f_lp)
+        outimp = os.path.join(outdir, "imp/")
+        nns = NN_samplerv1(outimp, prior_range)
+        os.makedirs(outimp, exist_ok=True)
+        f_theory = os.path.join(outdir, "theory.npy")
+        if not os.path.isfile(f_theory):
+            th = nns.generate_training_data(zip(range(len(chain)), chain), theory, pool=pool, args=[outimp])
+            np.save(f_theory, th)
+        else:
+            th = np.load(f_theory)
+        log_prob_samples_x = np.asarray(log_prob_samples_x).flatten()
+        logp = np.array(logp_theory_data(chain, th, data, inv_cov, LogPrior(priors)))   # chi^2 of all rows: one GPU pass
+        w = np.exp(logp - log_prob_samples_x)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            lw = np.log(w)
+            w[np.abs(lw - np.mean(lw)) > 2 * np.std(lw)] = 0
+        w = w / np.sum(w)
+        np.save(os.path.join(outdir, "weight_im.npy"), [log_prob_samples_x.flatten(), logp, w])
     return chain, log_prob_samples_x

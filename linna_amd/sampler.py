@@ -64,7 +64,7 @@ def integrated_time(x, c=5.0):
         f /= nw
         taus = 2.0 * np.cumsum(f) - 1.0
         m = np.arange(len(taus)) < c * taus
-        win = int(np.argmin(m)) if np.any(m) and not np.all(m) else len(taus) - 1
+        win = int(np.argmin(m)) if np.any(m) else len(taus) - 1      # emcee's auto_window, edge cases included
         tau[d] = taus[win]
     return tau
 
@@ -131,8 +131,7 @@ class DeviceChain(object):
             t = 2.0 * torch.cumsum(fbar, 1) - 1.0
             m = ar < c * t                                      # Sokal window: first step with step >= c tau
             first_false = torch.argmin(m.to(torch.int8), dim=1)
-            keep = m.any(1) & ~m.all(1)
-            win = torch.where(keep, first_false, torch.full_like(first_false, nt - 1))
+            win = torch.where(m.any(1), first_false, torch.full_like(first_false, nt - 1))    # emcee's auto_window
             out[d0:d0 + per] = t.gather(1, win[:, None])[:, 0]
         return out.cpu().numpy()
 
@@ -478,6 +477,11 @@ class EnsembleSampler(object):
         self.randomize_split = randomize_split
         self.group, self.exchange = dist_group, exchange
         self.fused = None if fused else False        # None: try linna_stretch_half_step on the first half step
+        # a user loglikelihoodfunc / externalloglike is host code: proposals and the Metropolis test stay kernels,
+        # the log-probability of a half ensemble goes through Log_prob.evaluate_any (emulator on the GPU + callbacks)
+        self.host_lp = not getattr(log_prob, "device_only", True)
+        if self.host_lp:
+            self.fused = False
         p = log_prob._ensure()
         self.dev = p["dev"]
         self.ctx = _lib.ctx(self.dev.index)
@@ -504,9 +508,16 @@ class EnsembleSampler(object):
             raise ValueError("x0 must be [nwalkers, ndim]")
         self.coords.zero_()
         self.coords[:, :self.ndim].copy_(x0)
-        self.lp.evaluate(self.coords, out=self.logp)
+        self._lnp(self.coords, self.logp)
         if not bool(torch.isfinite(self.logp).all()):
             raise ValueError("initial state has non-finite log-probability")   # emcee raises the same way
+
+    def _lnp(self, X, out):
+        """lnP of the rows of ``X[B, ld]`` into ``out[B]``."""
+        if self.host_lp:
+            out.copy_(self.lp.evaluate_any(X))
+        else:
+            self.lp.evaluate(X, out=out)
 
     _SPLIT_CHUNK = 64
 
@@ -566,7 +577,7 @@ class EnsembleSampler(object):
             _lib.call("linna_stretch_propose", self.ctx, _lib.ptr(self.coords), self.ld, self.ndim, _lib.iptr(S), self.half,
                       _lib.ptr(comp), ldc, _lib.iptr(cidx), nc, lib_seed, _lib.iptr(self.step_dev), h, self.a,
                       _lib.ptr(self.Q), self.ld, _lib.ptr(self.factors), st)
-            self.lp.evaluate(self.Q, out=self.lp_new)
+            self._lnp(self.Q, self.lp_new)
             _lib.call("linna_stretch_accept", self.ctx, _lib.ptr(self.coords), self.ld, self.ndim, _lib.ptr(self.logp),
                       _lib.iptr(S), self.half, _lib.ptr(self.Q), self.ld, _lib.ptr(self.lp_new), _lib.ptr(self.factors),
                       lib_seed, _lib.iptr(self.step_dev), h, _lib.iptr(self.naccept), st)
@@ -683,6 +694,9 @@ class SliceEnsembleSampler(EnsembleSampler):
         pending[0].synchronize()
 
     def _eval_if(self, Q, Z, gate):
+        if self.host_lp:                                # host callbacks: evaluated whatever the gate says (results of a
+            Z.copy_(self.lp.evaluate_any(Q))            # gated-off round are never used)
+            return
         p = self.lp._ensure()
         B = Q.shape[0]
         _lib.call("linna_logprob_eval_if", p["handle"], _lib.ptr(Q), Q.stride(0), B, _lib.ptr(self.lp._workspace(B, False)),
@@ -692,6 +706,8 @@ class SliceEnsembleSampler(EnsembleSampler):
         """lnP at coords[S[k]] + w[j*ns + k] DIR[k] into Z2[:nrep*ns]: one launch that never writes the points when
         the whole-network kernel serves this log-probability, else linna_slice_points + the gated evaluation."""
         ns, st, P = self.half, _lib.stream(), _lib.ptr
+        if self.host_lp:
+            self.fused_points = False
         if self.fused_points is not False:
             rc = _lib.load().linna_logprob_eval_slice_points(
                 self.lp._ensure()["handle"], P(self.coords), self.ld, self.ndim, _lib.iptr(S), ns, P(self.DIR), self.ld,
@@ -762,6 +778,9 @@ class BatchedHMC(object):
     x (drift, gradient, kick); final half kick; Metropolis test on H = p^2/2m - lnP."""
 
     def __init__(self, log_prob, x0, mass=None, seed=0):
+        if not getattr(log_prob, "device_only", True):
+            raise NotImplementedError("HMC needs the gradient of the log-probability: a user loglikelihoodfunc / "
+                                      "externalloglike is host code without one")
         self.lp = log_prob
         p = log_prob._ensure()
         self.dev, self.ctx = p["dev"], _lib.ctx(p["dev"].index)

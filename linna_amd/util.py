@@ -396,24 +396,35 @@ class Log_prob(object):
                   _lib.stream())
         return out, grad
 
+    @property
+    def device_only(self):
+        """True when every term of the log-probability is computed by the HIP pipeline: the Gaussian likelihood and no
+        ``externalloglike``.  A user ``loglikelihoodfunc`` / ``externalloglike`` is host code (main.py:277-279,
+        util.py:1003-1008): the emulator still runs on the GPU, the callbacks are applied per walker on the host."""
+        return self.loglikelihoodfunc is gaussianlogliklihood and self.externalloglike is None
+
+    def evaluate_any(self, z):
+        """``lnP[B]`` (device float32) of ``z[B, >= nin]`` on the device, user callbacks included -- what the walker
+        loops call; ``evaluate`` / ``linna_stretch_half_step`` are the launches behind it when ``device_only``."""
+        p = self._ensure()
+        if self.device_only:
+            return self.evaluate(z)
+        zc = z[:, :p["nin"]].contiguous()
+        if self.loglikelihoodfunc is not gaussianlogliklihood:
+            return self._generic(zc).to(z.device)
+        theta = torch.empty_like(zc)
+        like = self.evaluate(zc, theta=theta)
+        th = theta.cpu().numpy()
+        ext = np.array([np.float32(self.externalloglike(t)) for t in th], np.float32)
+        like = like + torch.from_numpy(ext).to(like.device)
+        return torch.where(torch.isnan(like), torch.full_like(like, -float("inf")), like)
+
     def __call__(self, x, returntorch=True, inputnumpy=True):
         z, one = self._to_device(x)
         if z.shape[0] == 0:                              # empty batch: nothing to launch
             like = torch.empty(0, dtype=torch.float32)
             return like if returntorch else like.numpy()
-        if self.loglikelihoodfunc is not gaussianlogliklihood:
-            like = self._generic(z)
-        else:
-            theta = None
-            if self.externalloglike is not None:
-                theta = torch.empty_like(z)
-            like = self.evaluate(z, theta=theta)
-            if self.externalloglike is not None:
-                th = theta.cpu().numpy()
-                ext = np.array([np.float32(self.externalloglike(t)) for t in th], np.float32)
-                like = like + torch.from_numpy(ext).to(like.device)
-                like = torch.where(torch.isnan(like), torch.full_like(like, -float("inf")), like)
-        like = like.cpu()
+        like = self.evaluate_any(z).cpu()
         if one:
             like = like[0]
         return like if returntorch else like.numpy()
@@ -693,10 +704,41 @@ class NN_samplerv1(object):
                            tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
 
 
+def chi2_rows(d, invcov, device=None, chunk=32768):
+    """``d_i^T invcov d_i`` for every row of ``d[n, nout]`` on the GPU: the dense log-likelihood entry
+    (``linna_gauss_loglike_dense``: MFMA GEMM d.S fused with the row-dot) with T = 1 and no prior term returns
+    -chi2/2.  fp32 arithmetic on rows handed over in float32; returns float64 [n]."""
+    d = np.ascontiguousarray(np.atleast_2d(np.asarray(d, np.float64)))
+    n, nout = d.shape
+    if n == 0:
+        return np.zeros(0)
+    dev = torch.device(device if device is not None else "cuda")
+    if dev.type != "cuda" or not torch.cuda.is_available():
+        raise _lib.LinnaHipError("chi2_rows runs on the GPU (no CPU fallback)")
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    ld = _lib.ld4(nout)
+    S = torch.as_tensor(np.pad(np.asarray(invcov, np.float32), ((0, 0), (0, ld - nout))), device=dev)
+    out = np.empty(n)
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    for lo in range(0, n, chunk):
+        blk = d[lo:lo + chunk]
+        B = len(blk)
+        D = torch.zeros((B, ld), dtype=torch.float32, device=dev)
+        D[:, :nout].copy_(torch.as_tensor(blk.astype(np.float32)))
+        scratch = torch.empty(B * lib.linna_gemm_dot_slots(B, nout) + 4, dtype=torch.float32, device=dev)
+        res = torch.empty(B, dtype=torch.float32, device=dev)
+        _lib.call("linna_gauss_loglike_dense", ctx, _lib.ptr(D), ld, B, nout, _lib.ptr(S), ld, _lib.ptr(D), ld, 0, 1.0,
+                  _lib.ptr(scratch), _lib.ptr(res), _lib.stream())
+        out[lo:lo + B] = -2.0 * res.double().cpu().numpy()
+    return out
+
+
 def chisqcut_all(data, invcov, chisqcut, fnamey, fnamex):
-    """util.py:1260-1270."""
+    """util.py:1260-1270: drop the training rows whose ``y^T invcov y`` reaches ``chisqcut`` (the reference measures
+    the theory vector itself here, not its distance to ``data``; kept as is).  The quadratic forms run on the GPU."""
     y, x = np.load(fnamey), np.loadtxt(fnamex)
-    chisq = np.array([y_.dot(invcov).dot(y_) for y_ in y])
+    chisq = chi2_rows(y, invcov)
     np.save(fnamey, y[chisq < chisqcut])
     np.savetxt(fnamex, x[chisq < chisqcut])
 
@@ -749,12 +791,13 @@ class LogPrior(object):
 
 
 def logp_theory_data(samples, theory, data, invcov, logprior):
-    """util.py:1506-1517."""
-    out = []
-    for t, s in zip(theory, samples):
-        d = t[:len(data)] - data
-        out.append(-0.5 * d.dot(invcov.dot(d)) + logprior(s))
-    return out
+    """util.py:1506-1517: ``-chi2/2 + logprior`` of the importance-sampling post step (main.py:297-334), the
+    ``(t - data)^T invcov (t - data)`` of all rows in one pass of the dense log-likelihood kernel."""
+    theory = np.asarray(theory, np.float64)
+    data = np.asarray(data, np.float64)
+    d = theory[:, :len(data)] - data[None, :]
+    chisq = chi2_rows(d, invcov)
+    return [-0.5 * c + logprior(s) for c, s in zip(chisq, samples)]
 
 
 def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee", flat=False):

@@ -115,6 +115,54 @@ def _gaussian_33():
     return ndim, means, cov, priors
 
 
+def test_hip_proposals_satisfy_the_fixture_relation():
+    """The relation every transition of the reference-held emcee chain satisfies (tests/test_stretch_fixture.py,
+    tests/stretch_relation.py) holds for what the HIP kernels do to the same 4-walker, 2-parameter ensembles: the
+    proposals of ``linna_stretch_propose`` lie on the line through the walker and one walker of the complementary half
+    with zz in [1/2, 2] and factor (ndim - 1) log zz, and whole iterations of the one-launch half steps are red/blue
+    stretch steps of the stored ensemble."""
+    import ctypes as C
+    from linna_amd import sampler, _lib
+    from linna_amd.sampler import ChainStore
+    from stretch_relation import explain_step, partners
+    d = ChainStore.read_h5(os.path.join(cases.GOLDEN, "2dgaussian_Fulltconn/iter_0/chemcee_256.h5"))
+    chain = np.asarray(d["chain"], np.float32)
+    nw, nd = chain.shape[1], chain.shape[2]
+    means, cov = np.array([0.1, 1.0]), np.diag([0.5, 0.2])
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -2.0, "arg2": 2.0} for i in range(nd)]
+    lp = identity_emulator_logprob(nd, means, cov, priors)
+    ens = sampler.EnsembleSampler(nw, nd, lp, seed=21)
+    ctx, st = _lib.ctx(ens.dev.index), _lib.stream()
+    S = torch.tensor([0, 2], dtype=torch.int32, device="cuda")
+    Cc = torch.tensor([1, 3], dtype=torch.int32, device="cuda")
+    zzs = []
+    for t in range(0, 200, 5):                                           # 40 stored ensembles x 2 proposals
+        ens.set_state(chain[t])
+        ens.step_dev.fill_(t)
+        _lib.call("linna_stretch_propose", ctx, _lib.ptr(ens.coords), ens.ld, nd, _lib.iptr(S), 2, _lib.ptr(ens.coords), ens.ld,
+                  _lib.iptr(Cc), 2, C.c_uint64(77), _lib.iptr(ens.step_dev), 0, 2.0, _lib.ptr(ens.Q), ens.ld, _lib.ptr(ens.factors), st)
+        q, fac = ens.Q[:, :nd].cpu().numpy().astype(np.float64), ens.factors.cpu().numpy().astype(np.float64)
+        for i, k in enumerate((0, 2)):
+            p = partners(chain[t, k].astype(np.float64), q[i], [(j, chain[t, j].astype(np.float64)) for j in (1, 3)], tol=2e-6)
+            assert p, (t, k)
+            np.testing.assert_allclose(fac[i], (nd - 1) * np.log(p[0][1]), atol=2e-5)
+            zzs.append(p[0][1])
+    zzs = np.array(zzs)
+    assert zzs.min() >= 0.5 - 1e-6 and zzs.max() <= 2.0 + 1e-6 and 0.25 < np.mean(zzs < 1.0) < 0.75
+    # whole iterations (two fused half steps each, random equal splits) from a stored ensemble
+    ens = sampler.EnsembleSampler(nw, nd, lp, seed=22)
+    ens.set_state(chain[100])
+    prev, nmoved = chain[100].astype(np.float64), 0
+    for it in range(60):
+        ens.step()
+        cur = ens.coords[:, :nd].cpu().numpy().astype(np.float64)
+        ex = explain_step(prev, cur, tol=3e-6)
+        assert ex is not None, it
+        nmoved += len(ex[1])
+        prev = cur
+    assert ens.fused and 60 < nmoved < 240
+
+
 @pytest.mark.parametrize("name,nw", [("mlp_33_33", 200), ("v2_33_33", 64), ("custom_7_5", 34)])
 def test_fused_half_step_is_bit_identical_to_three_launches(name, nw):
     """linna_stretch_half_step (propose + whole-network log-probability + accept in one launch) against
