@@ -165,6 +165,11 @@ typedef struct {
 int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers, int in_size,
                      linna_net_t** out);
 int linna_net_destroy(linna_net_t* net);
+/* Allocates every device-side copy the one-launch paths of this network use (fragment-order weight streams of the
+ * forward; with `backward` those of the dX chain, `input_grad`: down to the network input) and the context's auxiliary
+ * stream -- so that nothing is allocated on the launch path and the FIRST step can be captured into a hipGraph.
+ * Without this call the copies are allocated on first use outside a capture. */
+int linna_net_prepare(linna_net_t* net, int backward, int input_grad);
 /* bytes of activation workspace needed for a batch of B rows (forward, all activations
  * kept) and for the backward scratch. */
 size_t linna_net_fwd_ws_bytes(const linna_net_t* net, int B);

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "linna_linear_bwd": (_I, [_V, _V, _I, _V, _I, _V, _I, _V, _I, _V, _I, _V, _I, _V, _I, _I, _I, _F, _V]),
     "linna_net_create": (_I, [_V, C.POINTER(Layer), _I, _I, _PV]),
     "linna_net_destroy": (_I, [_V]),
+    "linna_net_prepare": (_I, [_V, _I, _I]),
     "linna_net_fwd_ws_bytes": (_SZ, [_V, _I]),
     "linna_net_bwd_ws_bytes": (_SZ, [_V, _I]),
     "linna_net_forward": (_I, [_V, _V, _I, _I, _V, _V, _I, C.POINTER(ColMap), _V]),

@@ -63,9 +63,6 @@ struct linna_ctx {
     hipStream_t aux = nullptr;               // second stream: parameter-gradient GEMMs run beside the dX chain
     std::vector<hipEvent_t> events;          // fork/join markers (no timing)
     int overlap = -1;                        // -1 unknown, 0 off (env LINNA_BWD_STREAMS=0), 1 on
-    void* group_dev = nullptr;               // device table of the grouped parameter-gradient GEMMs (gemm_launch_group)
-    size_t group_cap = 0;
-    std::vector<char> group_host;            // what the device table holds
     int group = -1;                          // -1 unknown, 0 off (env LINNA_BWD_GROUP=0), 1 on
     unsigned* counters = nullptr;            // zeroed, self-resetting arrival counters (fused loss)
     int loss_fused = -1;                     // -1 unknown, 0 off (env LINNA_LOSS_FUSED=0), 1 on
@@ -74,18 +71,9 @@ struct linna_ctx {
 void** linna_ctx_comm_slot(linna_ctx_t* ctx) { return &ctx->comm; }
 int linna_ctx_device(const linna_ctx_t* ctx) { return ctx->device; }
 struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
-// zeroed arrival counters of the context (allocated on first use, never while the stream is capturing)
-static unsigned* ctx_counters(linna_ctx* ctx, hipStream_t st) {
-    if (!ctx) return nullptr;
-    if (!ctx->counters) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &cap);
-        if (cap != hipStreamCaptureStatusNone) return nullptr;
-        if (hipMalloc(reinterpret_cast<void**>(&ctx->counters), 64) != hipSuccess) { ctx->counters = nullptr; return nullptr; }
-        if (hipMemsetAsync(ctx->counters, 0, 64, st) != hipSuccess) { (void)hipFree(ctx->counters); ctx->counters = nullptr; return nullptr; }
-    }
-    return ctx->counters;
-}
+// zeroed, self-resetting arrival counters of the context (allocated by linna_ctx_create)
+static unsigned* ctx_counters(linna_ctx* ctx, hipStream_t) { return ctx ? ctx->counters : nullptr; }
+constexpr size_t kGroupTableBytes = 32 * 1024;    // descriptor table of the grouped parameter-gradient launch (~5 KB used)
 
 // The whole-network kernel (net_stream.hip) reads the weights from a copy in MFMA fragment order.  Its 16-row
 // engine and its small-batch engines (8 / 4 rows per workgroup) read different orders, so there are two copies,
@@ -108,6 +96,11 @@ struct StreamCopy {
 
 struct linna_net {
     linna_ctx* ctx;
+    // descriptor table of the grouped parameter-gradient launch (gemm_launch_group), allocated by linna_net_create:
+    // [0] read by direct launches, `group_host` = what it holds; [1] read by captured launches, which carry their own
+    // upload (kernel arguments) so that a replay never depends on -- or disturbs -- what direct launches left there
+    void* group_dev[2] = {nullptr, nullptr};
+    std::vector<char> group_host;
     StreamCopy packed;                       // fragment-order weight streams for the one-launch training forward
     int stream_fwd = -1;
     StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
@@ -159,9 +152,19 @@ int linna_ctx_create(int device, linna_ctx_t** out) {
         set_error("ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
         return LINNA_ERR_UNSUPPORTED;
     }
-    *out = new (std::nothrow) linna_ctx();
-    if (!*out) return LINNA_ERR_INVALID;
-    (*out)->device = device;
+    linna_ctx* c = new (std::nothrow) linna_ctx();
+    if (!c) return LINNA_ERR_INVALID;
+    c->device = device;
+    // the context's device-side state is allocated HERE, so that no launch ever allocates: the arrival counters of the
+    // one-launch loss (networks hold the descriptor tables of their grouped parameter-gradient launch)
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = check_hip(hipSetDevice(device), "hipSetDevice");
+    if (rc == LINNA_OK) rc = check_hip(hipMalloc(reinterpret_cast<void**>(&c->counters), 64), "hipMalloc(counters)");
+    if (rc == LINNA_OK) rc = check_hip(hipMemset(c->counters, 0, 64), "hipMemset(counters)");
+    (void)hipSetDevice(prev);
+    if (rc != LINNA_OK) { (void)linna_ctx_destroy(c); return rc; }
+    *out = c;
     return LINNA_OK;
 }
 int linna_ctx_destroy(linna_ctx_t* ctx) {
@@ -169,7 +172,6 @@ int linna_ctx_destroy(linna_ctx_t* ctx) {
         (void)linna_comm_destroy(ctx);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
         if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
-        if (ctx->group_dev) (void)hipFree(ctx->group_dev);
         if (ctx->counters) (void)hipFree(ctx->counters);
     }
     delete ctx;
@@ -295,12 +297,62 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
         set_error("net_create: INSKIP needs a LINEAR first op"); delete n; return LINNA_ERR_INVALID;
     }
     n->out_size = width;
+    bool grads = false;
+    for (const linna_layer_t& l : n->L) grads = grads || l.gW || l.gW1;
+    for (int k = 0; k < 2 && grads; ++k)
+        if (hipMalloc(&n->group_dev[k], kGroupTableBytes) != hipSuccess) {
+            set_error("net_create: hipMalloc(gemm group table) failed");
+            (void)linna_net_destroy(n); return LINNA_ERR_HIP;
+        }
     *out = n;
     return LINNA_OK;
 }
 int linna_net_destroy(linna_net_t* net) {
-    if (net) { net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release(); }
+    if (net) {
+        net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release();
+        for (int k = 0; k < 2; ++k) if (net->group_dev[k]) (void)hipFree(net->group_dev[k]);
+    }
     delete net;
+    return LINNA_OK;
+}
+
+// Device-side weight copies of the one-launch paths (net_stream.hip): decided once per network, allocated by
+// linna_net_prepare -- or on first use, when the caller did not prepare and the stream is not capturing.
+static void net_ensure_fwd(linna_net* n, bool may_alloc) {
+    const int nl = (int)n->L.size();
+    if (n->stream_fwd < 0) {
+        const char* e = getenv("LINNA_FWD_STREAM");
+        n->stream_fwd = !n->has_inskip && !(e && e[0] == '0') && net_stream_eligible(n->L.data(), nl, n->in_size) ? 1 : 0;
+    }
+    if (n->stream_fwd == 1 && !n->packed.ready() && may_alloc) {
+        if (n->packed.alloc(net_stream_packed_floats(n->L.data(), nl, n->in_size)) != LINNA_OK) n->stream_fwd = 0;
+    }
+}
+static void net_ensure_dx(linna_net* n, int wi, bool may_alloc) {
+    const int nl = (int)n->L.size();
+    if (n->stream_bwd[wi] < 0) {
+        const char* e = getenv("LINNA_BWD_STREAM");
+        n->stream_bwd[wi] = !n->has_inskip && (nl >= 2 || wi) && !(e && e[0] == '0') &&
+                            net_stream_dx_eligible(n->L.data(), nl, n->in_size, wi) ? 1 : 0;
+    }
+    StreamCopy& sc = n->packed_dx[wi];
+    if (n->stream_bwd[wi] == 1 && !sc.ready() && may_alloc) {
+        if (sc.alloc(net_stream_dx_packed_floats(n->L.data(), nl, n->in_size, wi)) != LINNA_OK) n->stream_bwd[wi] = 0;
+    }
+}
+int linna_net_prepare(linna_net_t* n, int backward, int input_grad) {
+    if (!n) { set_error("net_prepare: null network"); return LINNA_ERR_INVALID; }
+    net_ensure_fwd(n, true);
+    if (backward) net_ensure_dx(n, input_grad ? 1 : 0, true);
+    if (n->ctx && backward) {                                // the auxiliary stream and its events, for the same reason
+        linna_ctx* ctx = n->ctx;
+        if (!ctx->aux) TRY(check_hip(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking), "hipStreamCreate"));
+        while ((int)ctx->events.size() < 2 * (int)n->L.size() + 4) {
+            hipEvent_t e;
+            TRY(check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate"));
+            ctx->events.push_back(e);
+        }
+    }
     return LINNA_OK;
 }
 
@@ -328,15 +380,9 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
     if ((!om || !om->cexp) && !n->has_inskip) {
         // ONE launch (net_stream.hip, STORE): at batch 500 the ten layer GEMMs are 10-30 us of latency each.  The
         // fragment-order weight copy is re-laid whenever the weights moved (every optimiser step: ~10 us).
-        if (n->stream_fwd < 0) {
-            const char* e = getenv("LINNA_FWD_STREAM");
-            n->stream_fwd = !(e && e[0] == '0') && net_stream_eligible(n->L.data(), nl, n->in_size) ? 1 : 0;
-        }
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(S(stream), &cap);
-        if (n->stream_fwd == 1 && !n->packed.ready() && cap == hipStreamCaptureStatusNone) {
-            if (n->packed.alloc(net_stream_packed_floats(n->L.data(), nl, n->in_size)) != LINNA_OK) n->stream_fwd = 0;
-        }
+        net_ensure_fwd(n, cap == hipStreamCaptureStatusNone);
         if (n->stream_fwd == 1 && n->packed.ready()) {
             const int rows = net_stream_rows(B);
             const float* packed = nullptr;
@@ -466,16 +512,10 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
     bool fused_dx = false;
     const int wi = dX ? 1 : 0;
     if (!n->has_inskip && (nl >= 2 || dX)) {
-        if (n->stream_bwd[wi] < 0) {
-            const char* e = getenv("LINNA_BWD_STREAM");
-            n->stream_bwd[wi] = !(e && e[0] == '0') && net_stream_dx_eligible(n->L.data(), nl, n->in_size, wi) ? 1 : 0;
-        }
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
+        net_ensure_dx(n, wi, cap == hipStreamCaptureStatusNone);
         StreamCopy& sc = n->packed_dx[wi];
-        if (n->stream_bwd[wi] == 1 && !sc.ready() && cap == hipStreamCaptureStatusNone) {
-            if (sc.alloc(net_stream_dx_packed_floats(n->L.data(), nl, n->in_size, wi)) != LINNA_OK) n->stream_bwd[wi] = 0;
-        }
         if (n->stream_bwd[wi] == 1 && sc.ready()) {
             const int rows = net_stream_rows(B);
             const float* packed = nullptr;
@@ -570,26 +610,21 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         for (int i = 0; i < np; ++i) { first[i] = nb; nb += gemm_group_blocks(dwq[i]); }
         first[np] = nb;
         if (nc) std::memcpy(tab.data() + cs_off, csq.data(), (size_t)nc * sizeof(ColsumProb));
-        bool ready = ctx->group_dev && ctx->group_host == tab;
-        if (!ready) {
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            (void)hipStreamIsCapturing(st, &cap);
-            if (cap == hipStreamCaptureStatusNone) {
-                if (ctx->group_cap < tab.size()) {
-                    if (ctx->group_dev) (void)hipFree(ctx->group_dev);
-                    ctx->group_dev = nullptr; ctx->group_cap = 0;
-                    TRY(check_hip(hipMalloc(&ctx->group_dev, tab.size()), "hipMalloc(gemm group table)"));
-                    ctx->group_cap = tab.size();
-                }
-                ctx->group_host = tab;
-                TRY(check_hip(hipMemcpyAsync(ctx->group_dev, ctx->group_host.data(), tab.size(), hipMemcpyHostToDevice, st),
-                              "hipMemcpyAsync(gemm group table)"));
-                ready = true;
-            }
+        // uploaded only when it changed (first step, new batch size, new buffers) -- as kernel arguments, so the upload
+        // is asynchronous and part of a capture like everything else; a table beyond the context's capacity (never for
+        // the reference's networks) sends the GEMMs out one by one
+        hipStreamCaptureStatus capg = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &capg);
+        const int tk = capg != hipStreamCaptureStatusNone ? 1 : 0;
+        const bool ready = tab.size() <= kGroupTableBytes && n->group_dev[tk];
+        void* const table = n->group_dev[tk];
+        if (ready && (tk == 1 || n->group_host != tab)) {
+            TRY(launch_table_write(tab.data(), tab.size(), table, st));
+            if (tk == 0) n->group_host = tab;
         }
         if (ready) {
-            if (np) TRY(gemm_launch_group(ctx->group_dev, np, nb, st));      // (none when every tile shape is the small one)
-            if (nc) TRY(launch_colsum_group(reinterpret_cast<const ColsumProb*>(static_cast<const char*>(ctx->group_dev) + cs_off), nc, csblocks, B, st));
+            if (np) TRY(gemm_launch_group(table, np, nb, st));      // (none when every tile shape is the small one)
+            if (nc) TRY(launch_colsum_group(reinterpret_cast<const ColsumProb*>(static_cast<const char*>(table) + cs_off), nc, csblocks, B, st));
         } else {
             for (const GemmArgs& a : dwq) TRY(gemm_launch(a, st));
             for (const ColsumProb& q : csq) TRY(launch_colsum(q.dZ, q.ld, B, q.N, q.scale, q.db, st));

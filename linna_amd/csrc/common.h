@@ -108,6 +108,7 @@ int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, co
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
                         const float* Wacc, const float* Zacc, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
+int launch_table_write(const void* host_src, size_t nbytes, void* dst, hipStream_t s);   // capturable small upload
 
 // Dense inverse covariance for the whole-network kernel: the output map d = raw * cscale + cshift is folded into the last
 // layer of the weight stream and S (symmetric, [nout][lds]) is appended as one more segment, chi2 = d . (d S).

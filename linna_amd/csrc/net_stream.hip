@@ -53,6 +53,10 @@
 #include <vector>
 #include <cstring>
 #include <algorithm>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <unordered_map>
 
 namespace linna {
 
@@ -945,9 +949,10 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     return p;
 }
 
-bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size) { return ns_build(layers, nl, in_size).ok; }
+static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn);
+bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 0, nullptr).ok; }
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size) {
-    return ns_build(layers, nl, in_size).packed_floats;
+    return ns_build_prog(layers, nl, in_size, 0, nullptr).packed_floats;
 }
 
 // Engine for a batch of B rows: the fewest rows per workgroup that still fit the batch into one workgroup per CU.
@@ -964,9 +969,33 @@ int net_stream_rows(int B) {
     return B <= 4 * ncu ? 4 : B <= 8 * ncu ? 8 : 16;
 }
 
-static NsProgram ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn = nullptr) {
+static NsProgram ns_build_prog_uncached(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn) {
     if (prog == 0 && dn) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DENSE, dn);
     return prog == 0 ? ns_build(layers, nl, in_size) : ns_build_one(layers, nl, in_size, prog == 2 ? NS_PROG_DX_INPUT : NS_PROG_DX);
+}
+// Kernel-configuration cache: a program is a pure function of the op list (shapes AND parameter pointers:
+// the pack descriptors carry them), the program kind and the dense descriptor, so it is built once and looked up by
+// those bytes on every later launch -- no segment planning, no vector allocation on the launch path.  Entries live for
+// the life of the library (a handful per network; the table is cleared if it ever reaches 256 entries).
+static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn = nullptr) {
+    static std::mutex mu;
+    static std::unordered_map<std::string, std::unique_ptr<NsProgram>> cache;
+    std::string key;
+    key.reserve((size_t)nl * sizeof(linna_layer_t) + 64);
+    key.append(reinterpret_cast<const char*>(layers), (size_t)nl * sizeof(linna_layer_t));
+    const int hdr[3] = {nl, in_size, prog};
+    key.append(reinterpret_cast<const char*>(hdr), sizeof(hdr));
+    if (dn) {                                               // field by field: the struct has padding bytes
+        const void* const ptrs[3] = {dn->S, dn->cscale, dn->cshift};
+        key.append(reinterpret_cast<const char*>(ptrs), sizeof(ptrs));
+        key.append(reinterpret_cast<const char*>(&dn->lds), sizeof(int));
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return *it->second;
+    if (cache.size() >= 256) cache.clear();
+    auto ins = cache.emplace(std::move(key), std::unique_ptr<NsProgram>(new NsProgram(ns_build_prog_uncached(layers, nl, in_size, prog, dn))));
+    return *ins.first->second;
 }
 bool net_stream_dense_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn) {
     return ns_build_prog(layers, nl, in_size, 0, &dn).ok;
@@ -984,7 +1013,7 @@ size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_s
 // prog: 0 the forward program (+ the fused gradient's backward half), 1 / 2 the dX chain without / with op 0
 int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog,
                            const NsDense* dn, hipStream_t s) {
-    const NsProgram p = ns_build_prog(layers, nl, in_size, prog, dn);
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsPackArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -1026,14 +1055,14 @@ static int ns_launch_kernel(const NsArgs& a, int B, const NsProgram& p, int rows
     return LINNA_ERR_INVALID;
 }
 
-bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { return ns_build(layers, nl, in_size).grad_ok; }
+bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 0).grad_ok; }
 
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
                       const NsDense* dn, hipStream_t s) {
-    const NsProgram p = ns_build_prog(layers, nl, in_size, 0, dn);
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 0, dn);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     if (dn && (w || gr || cscale || cshift)) { set_error("net_stream: the dense program carries its own output map and has no fused gradient"); return LINNA_ERR_INVALID; }
     if (mv && (nin > 64 || (!w && !dn))) { set_error("net_stream: fused sampler moves need <= 64 parameters and a log-likelihood in the launch"); return LINNA_ERR_UNSUPPORTED; }
@@ -1075,7 +1104,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
                             int B, float* const* y, const int* ldy, float* const* t, const int* ldt, const float* cscale,
                             const float* cshift, int rows, hipStream_t s) {
-    const NsProgram p = ns_build(layers, nl, in_size);
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 0);
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -1107,7 +1136,7 @@ int launch_net_stream_dx(const linna_layer_t* layers, int nl, int in_size, const
                          int B, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
                          float* const* dt, const int* lddt, const float* const* t, const int* ldt, int with_input, int rows,
                          hipStream_t s) {
-    const NsProgram p = ns_build_prog(layers, nl, in_size, with_input ? 2 : 1);
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, with_input ? 2 : 1);
     if (!p.ok) { set_error("net_stream: no dX-chain program for this network"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));

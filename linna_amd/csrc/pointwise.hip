@@ -4,6 +4,7 @@
 // All HBM-bound: coalesced row reads, 64-lane shuffle reductions, no LDS round trips
 // except the cross-wave column sum.
 #include "common.h"
+#include <string.h>
 #include <math.h>
 
 namespace linna {
@@ -722,6 +723,23 @@ int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int
     hipLaunchKernelGGL(slice_commit_kernel, grid1d((size_t)ns * ndim, 256), dim3(256), 0, s, coords, ldc, ndim, logp, S,
                        ns, DIR, ldd, Wacc, Zacc);
     LAUNCH_CHECK("slice_commit");
+}
+// Small host tables to device memory as KERNEL ARGUMENTS (1 KiB per launch): asynchronous on the caller's stream and
+// capturable into a hipGraph, unlike a copy from pageable host memory.
+struct TableChunk { unsigned char b[1024]; };
+__global__ void table_write_kernel(TableChunk c, unsigned char* __restrict__ dst, int n) {
+    const int i = threadIdx.x + blockIdx.x * blockDim.x;
+    if (i < n) dst[i] = c.b[i];
+}
+int launch_table_write(const void* host_src, size_t nbytes, void* dst, hipStream_t s) {
+    const unsigned char* src = static_cast<const unsigned char*>(host_src);
+    for (size_t off = 0; off < nbytes; off += sizeof(TableChunk)) {
+        TableChunk c;
+        const size_t n = nbytes - off < sizeof(TableChunk) ? nbytes - off : sizeof(TableChunk);
+        memcpy(c.b, src + off, n);
+        hipLaunchKernelGGL(table_write_kernel, dim3(4), dim3(256), 0, s, c, static_cast<unsigned char*>(dst) + off, (int)n);
+    }
+    LAUNCH_CHECK("table_write");
 }
 int launch_step_increment(int* step, hipStream_t s) {
     hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, step);

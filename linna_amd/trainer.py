@@ -62,6 +62,7 @@ class TrainEngine(object):
         self.rows = torch.zeros(B, dtype=torch.int32, device=dev)
         self.graph = None
         self.inv_batch = 1.0 / (B * self.world)          # the global batch is B per rank x ranks
+        _lib.call("linna_net_prepare", self.model.net_handle(with_grads=True), 1, 0)   # no allocation on the launch path
 
     def _chi2_md(self, Y):
         n = Y.shape[0]
@@ -131,9 +132,9 @@ class TrainEngine(object):
         if self.graph is not None:
             _lib.call("linna_graph_destroy", self.graph)
             self.graph = None
-        # one direct forward/backward first (no optimiser step: gradients and scratch only): the library
-        # uploads the descriptor table of its grouped parameter-gradient GEMMs outside a capture only
-        self._forward_loss_backward()
+        # nothing runs before the capture: linna_net_prepare (below, and in __init__) has allocated the weight streams,
+        # the descriptor table of the grouped parameter-gradient launch travels as kernel arguments
+        _lib.call("linna_net_prepare", self.model.net_handle(with_grads=True), 1, 0)
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

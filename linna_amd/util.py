@@ -368,11 +368,23 @@ class Log_prob(object):
             raise ValueError("expected %d parameters per walker, got %d" % (p["nin"], z.shape[1]))
         return z.contiguous(), one
 
+    @staticmethod
+    def _check_rows(z, p):
+        """The kernels take ``z[B, >= nin]`` float32 on the plan's device with unit column stride (any row stride)."""
+        if not (torch.is_tensor(z) and z.is_cuda and z.dtype == torch.float32 and z.dim() == 2):
+            raise _lib.LinnaHipError("expected a 2-D float32 device tensor of walker positions")
+        if z.device != p["dev"]:
+            raise _lib.LinnaHipError("walker positions on %s, log-probability on %s" % (z.device, p["dev"]))
+        if z.shape[1] < p["nin"] or (z.shape[0] > 1 and z.stride(1) != 1) or (z.shape[1] > 1 and z.stride(1) != 1):
+            raise _lib.LinnaHipError("walker rows must hold >= %d contiguous columns (got shape %s, strides %s)"
+                                     % (p["nin"], tuple(z.shape), tuple(z.stride())))
+
     # -------------------------------------------------------------- evaluation
     def evaluate(self, z, out=None, theta=None):
         """Device-to-device batch evaluation: ``z[B, nin]`` (cuda, fp32, row stride free) ->
         ``lnP[B]``.  No host synchronisation; graph-capturable."""
         p = self._ensure()
+        self._check_rows(z, p)
         B = z.shape[0]
         if out is None:
             out = torch.empty(B, dtype=torch.float32, device=z.device)
@@ -386,6 +398,7 @@ class Log_prob(object):
         """``(lnP[B], d lnP/d z [B, nin])`` -- what ``torch.autograd.grad(lnP, x)`` yields in
         HMCSampler.py:32, batched per walker."""
         p = self._ensure()
+        self._check_rows(z, p)
         B = z.shape[0]
         if out is None:
             out = torch.empty(B, dtype=torch.float32, device=z.device)

@@ -189,6 +189,16 @@ def test_nan_maps_to_minus_inf_and_empty_edge():
     from linna_amd import _lib
     with pytest.raises(_lib.LinnaHipError):                                         # the C ABI rejects B < 1 loudly
         lp.evaluate(torch.zeros((0, 6), device="cuda"))
+    # device entry points take float32 rows with unit column stride (any row stride): anything else is refused, not misread
+    zt = torch.randn(6, 8, device="cuda")
+    with pytest.raises(_lib.LinnaHipError):
+        lp.evaluate(zt.t())                                                         # a transposed view
+    with pytest.raises(_lib.LinnaHipError):
+        lp.evaluate(torch.zeros((4, 6), device="cuda", dtype=torch.float64))
+    with pytest.raises(_lib.LinnaHipError):
+        lp.evaluate_with_grad(zt.t())
+    wide = torch.randn(5, 12, device="cuda")                                        # rows of a wider buffer: row stride 12
+    np.testing.assert_array_equal(lp.evaluate(wide[:, :6]).cpu().numpy(), lp.evaluate(wide[:, :6].contiguous()).cpu().numpy())
 
 
 def test_whole_network_kernel_edges_and_agreement_with_layered_path():

@@ -151,6 +151,45 @@ def test_lr_range_test_runs_and_restores_weights(tmp_path):
     assert torch.equal(before, model.flat_params())
 
 
+def test_first_training_step_can_be_captured():
+    """A hipGraph capture of the VERY FIRST optimiser step (nothing launched before it on this network): the library
+    allocates at create / prepare time only, and the descriptor table of the grouped parameter-gradient launch is
+    uploaded as kernel arguments.  Replays give the parameters of the same steps launched directly."""
+    from linna_amd import nn, util, predictor_gpu, trainer
+    from linna_amd.predictor_gpu import _AdamWState
+    p = cases.training_problem("train_v2_12_40")
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    X = p["X"].reshape(-1, p["nin"]); Y = p["Y"].reshape(-1, p["nout"])
+    B = 50
+
+    def engine(use_graph):
+        model = nn.ChtoModelv2(p["nin"], p["nout"], None)
+        model.load_state_dict(p["weights"])
+        pred = predictor_gpu.Predictor(p["nin"], p["nout"], model=model, device="cuda",
+                                       X_transform=util.X_transform_class(t(p["X_mean"]), t(p["X_std"]), "cpu", None),
+                                       y_transform=util.Y_transform_class(t(p["y_mean"]), t(p["y_std"]), "cpu"))
+        ytd = util.Y_transform_data(p["sigma"], "cpu")
+        yinv = util.Y_invtransform_class(t(p["y_mean"]), t(p["y_std"]), t(p["data"]), "cpu")
+        lf = util.Loss_fn(t(p["data"]), torch.tensor(p["cov"], dtype=torch.float64),
+                          torch.tensor(np.linalg.inv(p["cov"]), dtype=torch.float64), ytd, yinv, "cpu")
+        loader = predictor_gpu.BatchLoader(util.ArrayDataset(X, Y), B, shuffle=False, drop_last=True)
+        eng = trainer.TrainEngine(pred, loader, lf, None, use_graph=use_graph)
+        return model, eng, _AdamWState(model, 1e-3, weight_decay=1e-4)
+
+    model_g, eng_g, opt_g = engine(True)
+    eng_g.prepare_graph(opt_g)                                   # capture: the first thing this network ever does
+    assert eng_g.graph is not None
+    assert model_g.stream_state()[0] == 1 and model_g.stream_state()[1] == 1      # the one-launch paths are in the graph
+    model_d, eng_d, opt_d = engine(False)
+    for s in range(3):
+        rows = torch.arange(s * B, (s + 1) * B, dtype=torch.int32, device="cuda")
+        eng_g.step(opt_g, rows)
+        eng_d.step(opt_d, rows)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(model_g.flat_params().cpu().numpy(), model_d.flat_params().cpu().numpy(), rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(float(eng_g.loss_mean), float(eng_d.loss_mean), rtol=1e-6)
+
+
 def test_train_gpu_process_shim(tmp_path):
     """linna/train_gpu.py:24-38: `python train_gpu.py <outdir> cuda` reads model_args.pkl, trains,
     writes finish.pkl -- here `python -m linna_amd.train_gpu`."""
