@@ -14,8 +14,10 @@ with no data-path collective (weak scaling: 4096 walkers per GPU).  Rank 0 print
 
 Besides the contract's fields the line carries: ``roofline`` (dominant kernel, HIP-event timing, p10/p50/p90 of
 single launches, PMC traffic from profiles/), ``cpu_baseline`` (N = 1), ``mcmc`` (ensemble iterations/s of the
-bare sampler loop), ``strong_scaling`` (N > 1: the same 4096 walkers split over the ranks) and ``training``
-(optimiser steps of ChtoModelv2(26,457), batch 500 per GPU, gradient all-reduce for N > 1).
+bare sampler loop), ``strong_scaling`` (N > 1: the same 4096 walkers split over the ranks), ``training``
+(optimiser steps of ChtoModelv2(26,457), batch 500 per GPU, gradient all-reduce for N > 1, with its own roofline
+object) and two more serving workloads timed by HIP events on rank 0: ``chto_v2`` (the reference's network class,
+ChtoModelv2(33,33)) and ``dense_1000`` (BASELINE configs[3]: ChtoModelv2(40,1000), dense inverse covariance).
 """
 import argparse
 import ctypes as C
@@ -142,6 +144,37 @@ def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
                 "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
+def driver_rate(lp, nwalkers, nsamp=5000):
+    """The reference's emcee driver end to end (sampler.py:458-554 -> linna_amd.sampler.HMCSampler.sample): 100 burn-in
+    iterations + restart, then `nsamp` iterations with everything a run does -- chain blocks device -> host, the
+    reference's HDF5 layout appended every 100 iterations (chain + chain_transformed + log_prob: 1.1 MB per iteration
+    at 4096 walkers), theta of every stored sample, integrated-autocorrelation checks -- into a temporary directory
+    that is removed afterwards.  The FFT plans of the checks are created beforehand (DeviceChain.prewarm, what
+    ml_sampler_core does while the emulator trains: 0.2-0.4 s per plan, once per process)."""
+    import shutil
+    import tempfile
+    import contextlib
+    import io
+    import torch
+    from linna_amd import sampler, util
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(NIN)]
+    sampler.DeviceChain.prewarm(nwalkers, NIN, torch.device("cuda", torch.cuda.current_device())).join()
+    x0 = 0.05 * np.random.RandomState(7).standard_normal((nwalkers, NIN))
+    out = tempfile.mkdtemp(prefix="linna_bench_chain_")
+    try:
+        drv = sampler.HMCSampler(lp, None, None, NIN, nwalkers, x0=x0, transform=util.Transform(priors))
+        with contextlib.redirect_stdout(io.StringIO()):
+            t0 = time.perf_counter()
+            store = drv.sample(None, nsamp, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True)   # never "converged": runs nsamp
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        n = sum(len(c) for c in store.chain)
+        size = os.path.getsize(os.path.join(out, "chemcee_256.h5"))
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return {"driver_steps_per_s": (n + 100) / dt, "driver_iterations": n + 100, "driver_seconds": dt, "driver_chain_file_bytes": size}
+
+
 def training_rate(device, world, rank, backend, nsteps=150):
     """BASELINE configs[2] shape: ChtoModelv2(26, 457) (3x2pt-like stand-in), dense covariance, batch 500 PER RANK,
     one all-reduce of the flat gradient per step when N > 1 (RCCL over xGMI), lr * N (predictor_gpu.py:246).
@@ -231,6 +264,57 @@ def training_rate(device, world, rank, backend, nsteps=150):
     return res
 
 
+def secondary_serving(device, kind, nin, nout, dense, nwalkers=4096, iters=400):
+    """One more serving workload in the driver's record, timed like the headline's dominant kernel (HIP events on the launch
+    stream around back-to-back launches, after a clock-ramp warm-up): the reference's own network class on the README
+    problem (ChtoModelv2(33,33), diagonal covariance) and BASELINE configs[3] (~1000-dim output, dense inverse
+    covariance; nin = 40 is SURVEY 8d's stand-in).  FLOP per evaluation from the network's MAC count (+ 2 nout^2 for the
+    dense quadratic form, 3 nout for the diagonal one), SURVEY 8d."""
+    import torch
+    from linna_amd import nn, util, predictor_gpu, _lib
+    rs = np.random.RandomState(11)
+    data = rs.uniform(size=nout)
+    if dense:
+        q, _ = np.linalg.qr(rs.standard_normal((nout, nout)))
+        cov = (q * (np.logspace(0, -2, nout) * 0.1)[None, :]) @ q.T
+        cov = 0.5 * (cov + cov.T)
+    else:
+        cov = np.diag(0.1 * rs.uniform(0.05, 1.0, size=nout))
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(nin)]
+    torch.manual_seed(1234)
+    model = getattr(nn, kind)(nin, nout, None)
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    sigma = np.sqrt(np.diag(cov))
+    pred = predictor_gpu.Predictor(nin, nout, model=model, device=device,
+                                   X_transform=util.X_transform_class(t(np.zeros(nin)), t(np.full(nin, 10.0 / np.sqrt(12.0))), "cpu", None),
+                                   y_transform=util.Y_transform_class(t(data / sigma), t(np.ones(nout)), "cpu"))
+    lp = util.Log_prob(t(data), t(np.linalg.inv(cov)), pred, util.Y_invtransform_data(sigma, "cpu"), util.Transform(priors), 1.0,
+                       util.gaussianlogliklihood, nograd=True)
+    z = torch.as_tensor(np.random.RandomState(5).standard_normal((nwalkers, nin)).astype(np.float32), device=device)
+    out = torch.empty(nwalkers, dtype=torch.float32, device=device)
+    t_end = time.perf_counter() + 0.3
+    while time.perf_counter() < t_end:
+        for _ in range(32):
+            lp.evaluate(z, out=out)
+        torch.cuda.synchronize()
+    st = _lib.stream()
+    e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+    _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
+    _lib.call("linna_event_record", e0, st)
+    for _ in range(iters):
+        lp.evaluate(z, out=out)
+    _lib.call("linna_event_record", e1, st)
+    _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+    _lib.call("linna_event_destroy", e0); _lib.call("linna_event_destroy", e1)
+    assert torch.isfinite(out).all()
+    us = 1e3 * ms.value / iters
+    flop_eval = 2.0 * model.macs_per_eval() + (2.0 * nout * nout + nout if dense else 3.0 * nout)
+    tf = nwalkers * flop_eval / (us * 1e-6) / 1e12
+    return {"workload": "%s(%d,%d), %s inverse covariance, %d walkers, one launch per step" % (kind, nin, nout, "dense" if dense else "diagonal", nwalkers),
+            "us_per_launch": us, "evals_per_s": nwalkers / (us * 1e-6), "flop_per_eval": flop_eval, "achieved": tf,
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+
+
 def time_dominant_kernel(lp, z, out, iters):
     """HIP-event timing (events recorded on the launch stream) of the dominant kernel: the
     whole-network serving kernel net_stream_kernel<6, 0, false, 0, 16> -- ONE launch per step evaluates prior map,
@@ -275,6 +359,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph instead of direct launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-training", action="store_true", help="skip the secondary training-throughput measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the chto_v2 / dense_1000 serving objects")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank path on a box with fewer GPUs)")
     args = ap.parse_args()
@@ -451,8 +536,19 @@ def main():
         if training is not None:
             res["training"] = training
         res["mcmc"] = mcmc
+        if world == 1 and isinstance(mcmc, dict) and "error" not in mcmc:
+            try:
+                res["mcmc"].update(driver_rate(lp, NWALKERS))
+            except Exception as e:                                  # noqa: BLE001
+                res["mcmc"]["driver_error"] = repr(e)[:300]
         if collectives is not None:
             res["collectives"] = collectives
+        if not args.no_secondary:
+            for key, spec in (("chto_v2", ("ChtoModelv2", 33, 33, False)), ("dense_1000", ("ChtoModelv2", 40, 1000, True))):
+                try:
+                    res[key] = secondary_serving(device, *spec)
+                except Exception as e:                              # noqa: BLE001
+                    res[key] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
             res["cpu_baseline"] = cpu_baseline(consts, z_host)
         print(json.dumps(res), flush=True)

@@ -111,6 +111,15 @@ class Dataset(_Object):
             raise H5Error("dataset datatype class not supported")
         self.dtype = self.dt.dtype
 
+    @property
+    def chunks(self):
+        """Chunk shape of a chunked dataset (h5py's ``Dataset.chunks``), None for compact / contiguous layouts."""
+        body = self._first(0x0008)
+        if body is None or body[0] != 3 or body[1] != 2:
+            return None
+        ndim = body[2]
+        return tuple(int(c) for c in struct.unpack_from("<%dI" % ndim, body, 11)[:-1])
+
     def _filters(self):
         body = self._first(0x000B)
         if body is None:
@@ -670,6 +679,39 @@ class Appender(object):
         self.data_off = {}                                          # fixed dataset name -> (offset, dtype, shape)
         self.fh.seek(0, 2)
         self.eof = self.fh.tell()
+        self._bulk, self._pool = [], None
+
+    # Bulk chunk data goes out by positional writes (os.pwrite releases the GIL) from a few threads: one thread copying
+    # into the page cache sustains ~4 GB/s, a 4096-walker chain produces 13 GB/s of samples at full sampling rate.
+    BULK_MIN = 4 << 20
+    BULK_PIECE = 32 << 20
+    BULK_THREADS = 4
+
+    def _write_at(self, addr, view):
+        if view.nbytes < self.BULK_MIN:
+            self.fh.seek(addr); self.fh.write(view)
+        else:
+            for off in range(0, view.nbytes, self.BULK_PIECE):
+                self._bulk.append((addr + off, view[off:off + self.BULK_PIECE]))
+
+    @staticmethod
+    def _pwrite_all(fd, addr, view):
+        done = 0
+        while done < view.nbytes:
+            done += os.pwrite(fd, view[done:], addr + done)
+
+    def _run_bulk(self):
+        if not self._bulk:
+            return
+        self.fh.flush()
+        fd = self.fh.fileno()
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=self.BULK_THREADS, thread_name_prefix="linna-h5-write")
+        jobs = [self._pool.submit(self._pwrite_all, fd, addr, view) for addr, view in self._bulk]
+        self._bulk = []
+        for j in jobs:
+            j.result()                                              # raises what a write raised
 
     # -- skeleton ------------------------------------------------------------------------------
     @staticmethod
@@ -832,16 +874,15 @@ class Appender(object):
             if fill:                                                # the last chunk is partial: continue inside it
                 take = min(len(a), st["chunk_rows"] - fill)
                 row_bytes = st["chunk_bytes"] // st["chunk_rows"]
-                self.fh.seek(st["path"][0]["children"][-1] + fill * row_bytes)
-                self.fh.write(memoryview(np.ascontiguousarray(a[:take]).reshape(-1)).cast("B"))
+                self._write_at(st["path"][0]["children"][-1] + fill * row_bytes, memoryview(np.ascontiguousarray(a[:take]).reshape(-1)).cast("B"))
                 st["nrows"] += take
                 a = a[take:]
             for r0 in range(0, len(a), st["chunk_rows"]):
                 part = a[r0:r0 + st["chunk_rows"]]
                 addr = self._alloc(st["chunk_bytes"])
-                self.fh.seek(addr); self.fh.write(memoryview(part.reshape(-1)).cast("B"))
+                self._write_at(addr, memoryview(part.reshape(-1)).cast("B"))
                 if part.nbytes < st["chunk_bytes"]:
-                    self.fh.write(b"\x00" * (st["chunk_bytes"] - part.nbytes))
+                    self.fh.seek(addr + part.nbytes); self.fh.write(b"\x00" * (st["chunk_bytes"] - part.nbytes))
                 row = st["nrows"]
                 st["nrows"] += len(part)
                 final = (row // st["chunk_rows"] + 1) * st["chunk_rows"]
@@ -850,6 +891,7 @@ class Appender(object):
                     st["path"].append(node)
                     self.fh.seek(st["btree_off"]); self.fh.write(struct.pack("<Q", node["addr"]))
                 self._insert(st, 0, (st["chunk_bytes"], row), addr, final)
+        self._run_bulk()                                            # chunk data is in the file before anything points at it
         for name in blocks:                                         # the new length becomes visible last
             st = self.ds[name]
             self.fh.seek(st["dims_off"]); self.fh.write(struct.pack("<Q", st["nrows"]))
@@ -877,6 +919,8 @@ class Appender(object):
         return self.ds[name]["nrows"]
 
     def close(self):
+        if self._pool is not None:
+            self._pool.shutdown(wait=True); self._pool = None
         if self.fh is not None:
             self.fh.close(); self.fh = None
 

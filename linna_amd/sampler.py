@@ -135,6 +135,32 @@ class DeviceChain(object):
             out[d0:d0 + per] = t.gather(1, win[:, None])[:, 0]
         return out.cpu().numpy()
 
+    @classmethod
+    def prewarm(cls, nwalkers, ndim, device, lengths=(4096, 8192, 16384)):
+        """Create the FFT plans ``integrated_time`` will ask for, on a background thread and a stream of its own, while
+        the sampler burns in: every new (transform length, batch) costs rocFFT 0.2-0.4 s the first time in a process --
+        3 s of a 10000-iteration run at 4096 walkers when paid at the checks.  Returns the thread."""
+        import threading
+        dev = torch.device(device)
+
+        def work():
+            try:
+                wstride = max(1, nwalkers // cls.MAX_WALKERS)
+                nw = len(range(0, nwalkers, wstride))
+                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
+                    for n in lengths:
+                        per = max(1, min(ndim, int((1 << 30) // max(1, 16 * 2 * n * nw))))
+                        for width in sorted({per, ndim % per} - {0}):
+                            x = torch.zeros((nw, width, 8), dtype=torch.float64, device=dev)
+                            f = torch.fft.rfft(x, n=2 * n, dim=2)
+                            torch.fft.irfft(f * f.conj(), n=2 * n, dim=2)
+                    torch.cuda.current_stream(dev).synchronize()
+            except Exception:                            # a warm-up only: the checks create what is missing
+                pass
+        t = threading.Thread(target=work, name="linna-fft-prewarm", daemon=True)
+        t.start()
+        return t
+
     def checkmeanstd(self, nlast, meanshift, stdshift):
         """sampler.py:370-387 on the last ``nlast`` steps: first-half / second-half drift."""
         s = self.last(nlast).to(torch.float64)
@@ -160,6 +186,17 @@ def checkmeanstd(samples, meanshift, stdshift):
 
 
 # ------------------------------------------------------------------ chain storage
+class _OnDisk(object):
+    """Placeholder for a chain block that lives in the HDF5 file only (ChainStore drops big blocks once written)."""
+    __slots__ = ("n",)
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __len__(self):
+        return self.n
+
+
 class ChainStore(object):
     """Chain backend in the reference's file formats: ``chemcee_256.h5`` as emcee's ``HDFBackend`` /
     ``Transformbackend`` lay it out (group ``mcmc``: ``chain``, ``chain_transformed``, ``log_prob``,
@@ -184,27 +221,47 @@ class ChainStore(object):
         self._events, self._copy_stream = {}, None
         self._appender, self._appended = None, 0
 
-    # The incremental part files are written by one background thread: zipping + writing 7 MB per convergence
-    # check (128 walkers) took as long as the 100 iterations between two checks.  numpy's file I/O and zlib's
-    # CRC release the GIL; the sampling thread spends its time inside ctypes calls, which release it too.
+    # Incremental flushes run on two background threads in a pipeline: the first brings a block from the device to the
+    # host (copy stream of its own, after the event recorded when the block was appended), the second appends it to the
+    # HDF5 file (whose bulk writes fan out over a few more threads, h5lite.Appender).  Zipping / writing 7 MB per
+    # convergence check (128 walkers) on the sampling thread took as long as the 100 iterations between two checks; at
+    # 4096 walkers a block is 2 x 54 MB and one thread doing copy + write in turn sustained a third of the sampling
+    # rate.  numpy's file I/O, os.pwrite and the device copies release the GIL; the sampling thread spends its time
+    # inside ctypes calls, which release it too.
     def _enqueue(self, path, arrays):
         import queue, threading
         if self._writer is None:
-            self._queue = queue.Queue()
+            self._queue, self._wqueue = queue.Queue(), queue.Queue(maxsize=8)
 
-            def work():
+            def fetch():
                 while True:
                     item = self._queue.get()
                     try:
+                        if item is not None and self._error is None:
+                            self._to_host(item[1])                    # device blocks come to the host HERE, off the sampling thread
+                            if torch.is_tensor(item[2]):
+                                item = (item[0], item[1], self._acc_host(item[2]))
+                    except Exception as e:          # surfaced by the next drain()
+                        self._error = e
+                    self._wqueue.put(item)
+                    if item is None:
+                        return
+
+            def work():
+                while True:
+                    item = self._wqueue.get()
+                    try:
                         if item is None:
                             return
-                        _, k, accepted = item
-                        self._append_block(k, accepted)               # device blocks come to the host HERE, off the sampling thread
-                    except Exception as e:          # surfaced by the next drain()
+                        if self._error is None:
+                            self._append_block(item[1], item[2])
+                    except Exception as e:
                         self._error = e
                     finally:
                         self._queue.task_done()
+            self._fetcher = threading.Thread(target=fetch, name="linna-chain-fetch", daemon=True)
             self._writer = threading.Thread(target=work, name="linna-chain-writer", daemon=True)
+            self._fetcher.start()
             self._writer.start()
         self._queue.put((path, arrays[0], arrays[1]))
 
@@ -218,7 +275,9 @@ class ChainStore(object):
 
     def _to_host(self, k):
         """Block k as numpy arrays (in place).  Blocks appended as device tensors are copied on a stream of their own,
-        after the event recorded when they were appended: the copy neither waits for nor delays the sampling stream."""
+        after the event recorded when they were appended: the copy neither waits for nor delays the sampling stream.
+        The host side is PINNED memory from torch's caching host allocator (54 MB in 1 ms against 6-11 ms into pageable
+        memory; the buffers are recycled once a written block has been dropped, see _append_block)."""
         if not torch.is_tensor(self.chain[k]):
             return
         ev = self._events.pop(k, None)
@@ -229,7 +288,13 @@ class ChainStore(object):
             with torch.cuda.stream(self._copy_stream):
                 if ev is not None:
                     self._copy_stream.wait_event(ev)
-                host = [t.to("cpu", non_blocking=False).numpy() for t in (self.chain[k], self.chain_transformed[k], self.log_prob[k])]
+                host = []
+                for t in (self.chain[k], self.chain_transformed[k], self.log_prob[k]):
+                    h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    host.append(h)
+                self._copy_stream.synchronize()
+            host = [h.numpy() for h in host]
         else:
             host = [t.numpy() for t in (self.chain[k], self.chain_transformed[k], self.log_prob[k])]
         self.chain[k], self.chain_transformed[k], self.log_prob[k] = host           # (frees the device copies)
@@ -282,26 +347,78 @@ class ChainStore(object):
         return (("samples", "chain_transformed", "logprob") if self.layout == "zeus"
                 else ("mcmc/chain", "mcmc/chain_transformed", "mcmc/log_prob"))
 
-    def _start_appender(self, k):
-        """Create the extensible file from block k's shapes; blocks before k (a resumed run) are appended first."""
-        self._to_host(k)
+    DROP_BYTES = 16 << 20           # blocks of at least this size are dropped from host memory once they are in the file
+    CHUNK_ROWS = 100                # steps per HDF5 chunk: the flush cadence (emcee's backend grows its file likewise),
+                                    # whatever the length of the first block -- a resumed chain arrives as ONE long block
+
+    def _spec(self, k):
         nw, nd = self.chain[k].shape[1], self.chain[k].shape[2]
         dt = lambda blocks: np.result_type(*[np.asarray(b).dtype for b in blocks if not torch.is_tensor(b)] or [np.float32])
-        rows = max(1, len(self.chain[k]))
+        tails = dict(zip(self._names(), (((nw, nd), dt(self.chain[:k + 1])), ((nw, nd), dt(self.chain_transformed[:k + 1])),
+                                         ((nw,), dt(self.log_prob[:k + 1])))))
+        for name, (tail, d) in tails.items():
+            if self.CHUNK_ROWS * int(np.prod(tail)) * np.dtype(d).itemsize >= 2 ** 32:
+                raise h5lite.H5Error("%s: a chunk of %d steps would reach 4 GiB (HDF5 chunk sizes are 32-bit)" % (name, self.CHUNK_ROWS))
+        return nw, nd, tails
+
+    def _adopt_existing(self, k):
+        """A resumed run: blocks 0..j of this store are the rows the chain file already holds (sampler drivers load the
+        file and append it as one block).  When the file is one of ours (extensible datasets) it simply keeps growing:
+        nothing is rewritten, nothing can be lost.  Returns True when adopted."""
+        if not os.path.isfile(self.h5):
+            return False
+        try:
+            ap = h5lite.Appender.open(self.h5)
+        except Exception:
+            return False
+        names = self._names()
+        try:
+            if not all(n in ap.ds for n in names) or any(ap.ds[n]["chunk_rows"] != self.CHUNK_ROWS for n in names):
+                raise ValueError
+            have = ap.nrows(names[0])
+            rows, j = 0, 0
+            while j <= k and rows < have:
+                rows += len(self.chain[j]); j += 1
+            if rows != have or have == 0:
+                raise ValueError
+            self._to_host(j - 1)
+            with h5lite.File(self.h5) as f:                      # the block really is what the file ends with
+                last = f[names[0]][have - 1:have]
+            if not np.array_equal(np.asarray(last)[0], np.asarray(self.chain[j - 1])[-1]):
+                raise ValueError
+        except Exception:
+            ap.close()
+            return False
+        self._appender, self._appended = ap, j
+        return True
+
+    def _start_appender(self, k):
+        """The extensible chain file.  A file of ours that already holds the leading blocks is continued in place;
+        otherwise a NEW file is built under ``<name>.h5.tmp`` -- the blocks before k (a resumed run: the old rows)
+        included -- and takes the old file's place only when it is complete, so a kill at any moment leaves a readable
+        chain behind."""
+        self._to_host(k)
+        if self._adopt_existing(k):
+            return
+        nw, nd, spec = self._spec(k)
+        names = self._names()
         tmp = self.h5 + ".tmp"
         if self.layout == "zeus":
-            ap = h5lite.Appender.create(tmp, {"samples": ((nw, nd), dt(self.chain[:k + 1])), "chain_transformed": ((nw, nd), dt(self.chain_transformed[:k + 1])),
-                                              "logprob": ((nw,), dt(self.log_prob[:k + 1]))}, chunk_rows=rows)
+            ap = h5lite.Appender.create(tmp, spec, chunk_rows=self.CHUNK_ROWS)
         else:
-            ap = h5lite.Appender.create(tmp, {"chain": ((nw, nd), dt(self.chain[:k + 1])), "chain_transformed": ((nw, nd), dt(self.chain_transformed[:k + 1])),
-                                              "log_prob": ((nw,), dt(self.log_prob[:k + 1]))}, group="mcmc",
+            ap = h5lite.Appender.create(tmp, {n.split("/")[1]: v for n, v in spec.items()}, group="mcmc",
                                         group_attrs=dict(version="3.0.2", nwalkers=np.int64(nw), ndim=np.int64(nd), has_blobs=False,
                                                          iteration=np.int64(0)),
-                                        fixed={"accepted": np.zeros(nw)}, chunk_rows=rows)
+                                        fixed={"accepted": np.zeros(nw)}, chunk_rows=self.CHUNK_ROWS)
+        for j in range(k):                                          # what came before block k goes in before the swap
+            self._to_host(j)
+            ap.append({names[0]: self.chain[j], names[1]: self.chain_transformed[j], names[2]: self.log_prob[j]})
+        if self.layout != "zeus" and k > 0:
+            ap.set_attr("mcmc", "iteration", ap.nrows(names[0]))
         ap.close()
         os.replace(tmp, self.h5)
         self._appender = h5lite.Appender.open(self.h5)
-        self._appended = 0
+        self._appended = k
 
     def _append_block(self, k, accepted):
         if self._appender is None:
@@ -313,6 +430,11 @@ class ChainStore(object):
             z, th, lp = self.chain[j], self.chain_transformed[j], self.log_prob[j]
             self._appender.append({names[0]: z, names[1]: th, names[2]: lp})
             self._appended += 1
+            if z.nbytes >= self.DROP_BYTES:
+                # a big block that is in the file does not stay in host memory as well (at 4096 walkers the chain grows
+                # by 1.1 MB per iteration): only its length remains here, readers go to the file; its pinned buffers
+                # return to the allocator for the next block
+                self.chain[j] = self.chain_transformed[j] = self.log_prob[j] = _OnDisk(len(z))
         if self.layout != "zeus":
             self._appender.set_attr("mcmc", "iteration", self._appender.nrows(names[0]))
             if accepted is not None:
@@ -322,6 +444,13 @@ class ChainStore(object):
         self.drain()
         for k in range(len(self.chain)):
             self._to_host(k)
+        if any(isinstance(b, _OnDisk) for b in self.chain):     # written blocks were dropped: the file has them (and
+            if self._appender is not None:                      # whatever is not in it yet goes there first)
+                if len(self.chain) > self._appended:
+                    self._append_block(len(self.chain) - 1, None)
+                self._appender.fh.flush()
+            d = self.read_h5(self.h5)
+            return d["chain"], d["chain_transformed"], d["log_prob"]
         return (np.concatenate(self.chain), np.concatenate(self.chain_transformed), np.concatenate(self.log_prob))
 
     def flush(self, final=True):
@@ -868,6 +997,7 @@ class HMCSampler(object):
                 store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])   # re-chunked into the new file at the first flush
         ens = EnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
         self.sampler = ens
+        DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)           # FFT plans of the convergence checks, off the critical path
         print("start", flush=True)
         if not resume:
             print("burnin...", flush=True)                                   # sampler.py:519-529
@@ -951,6 +1081,7 @@ class ZeusSampler(object):
             store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])   # re-chunked into the new file at the first flush
         ens = SliceEnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
         self.sampler = ens
+        DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)
         ens.set_state(x0)
         old_tau, done = np.inf, sum(len(c) for c in store.chain)
         dchain = DeviceChain()

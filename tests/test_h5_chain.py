@@ -169,6 +169,26 @@ def test_chainstore_resumes_from_reference_file(tmp_path):
     assert d2["iteration"] == 210 and os.path.getsize(path) < 40000       # rewritten without the pre-grown tail
     np.testing.assert_array_equal(d2["chain"][:200], d["chain"])
     np.testing.assert_array_equal(d2["accepted"], d["accepted"] + 1)
+    # the same resume with INCREMENTAL flushes (what the sampling drivers do): the reference's contiguous file cannot
+    # grow in place, so the extensible file is built under .tmp -- old rows included -- and swapped in when complete;
+    # until then the reference's file is untouched
+    path2 = str(tmp_path / "again" / "chemcee_256.h5")
+    os.makedirs(os.path.dirname(path2))
+    shutil.copy(FIXTURE, path2)
+    ino = os.stat(path2).st_ino
+    st = ChainStore(path2)
+    st.append(d["chain"], d["chain_transformed"], d["log_prob"], d["accepted"])
+    assert os.stat(path2).st_ino == ino
+    st.append(*_blocks(rs, 100, 4, 2), d["accepted"] + 5)
+    st.flush(final=False); st.drain()
+    assert os.stat(path2).st_ino != ino and not os.path.exists(path2 + ".tmp")
+    d3 = ChainStore.load(path2)
+    assert d3["iteration"] == 300
+    np.testing.assert_array_equal(d3["chain"][:200], d["chain"])
+    with h5lite.File(path2) as f:
+        assert f["mcmc/chain"].chunks[0] == 100                        # not the 200 rows of the resumed block
+    assert os.path.getsize(path2) < 3 * (300 * 4 * 2 * 8 * 2 + 300 * 4 * 8) + 16384
+    st.flush()
 
 
 def test_reader_rejects_what_it_does_not_implement(tmp_path):

@@ -268,6 +268,29 @@ def test_chainstore_grows_the_hdf5_file_in_place(tmp_path):
     d3 = ChainStore.load(name)
     np.testing.assert_array_equal(d3["chain"], d2["chain"])
     assert os.path.isfile(st2.base + ".txt")
+    # chunks hold CHUNK_ROWS steps whatever the first block's length (a resumed chain arrives as ONE long block), the
+    # resumed file kept growing IN PLACE (same inode, no rewrite, nothing to lose), and it grew by what was appended
+    with h5lite.File(st2.h5) as f:
+        assert f["mcmc/chain"].chunks[0] == ChainStore.CHUNK_ROWS == 100
+    ino, size = os.stat(name).st_ino, os.path.getsize(name)
+    d = ChainStore.load(name)
+    st4 = ChainStore(name)
+    st4.append(d["chain"], d["chain_transformed"], d["log_prob"], d["accepted"])
+    st4.append(*blocks[0], np.full(4, 9.0))
+    st4.flush(final=False); st4.drain()
+    assert os.stat(name).st_ino == ino and not os.path.exists(name + ".tmp")
+    assert os.path.getsize(name) - size < 8192
+    d5 = ChainStore.load(name)
+    assert d5["iteration"] == 23
+    np.testing.assert_array_equal(d5["chain"][:18], d2["chain"])
+    np.testing.assert_array_equal(d5["chain"][18:], blocks[0][0])
+    st4.flush()
+    # a chunk of 100 steps must stay below 4 GiB (32-bit chunk sizes): refused up front, not in the writer thread
+    big = ChainStore(str(tmp_path / "big" / "chemcee_256.h5"))
+    fake = np.lib.stride_tricks.as_strided(np.zeros(1), shape=(1, 1 << 22, 16), strides=(0, 0, 0))
+    big.chain.append(fake); big.chain_transformed.append(fake); big.log_prob.append(fake[:, :, 0])
+    with pytest.raises(h5lite.H5Error):
+        big._spec(0)
     # a store that is only flushed at the end writes contiguous datasets in one pass
     st3 = ChainStore(str(tmp_path / "zeus_256.h5"))
     for z, th, lp in blocks:
