@@ -81,11 +81,8 @@ def cpu_baseline(consts, z, budget_s=15.0):
                               consts["y_std"], consts["sigma"], width=WIDTH, depth=DEPTH)
     invcov = np.linalg.inv(consts["cov"])
     f = lambda zz: likelihood.log_prob(zz, emu, consts["priors"], consts["means"], invcov, 1.0)
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    from linna_amd.util import cpu_quota
+    cores = cpu_quota()                    # affinity capped by the container's CPU bandwidth quota (16 of 256 on the GPU box)
     best = (0.0, 0, 0)
     for nthreads in sorted({min(32, cores), cores}):
         with threadpool_limits(limits=nthreads):
@@ -105,7 +102,7 @@ def cpu_baseline(consts, z, budget_s=15.0):
         per_walker = m / (time.perf_counter() - t0)
     return {"value": best[0], "unit": "evals/s", "cores": best[1], "kind": "port",
             "sample": "numpy oracle (oracle/likelihood.log_prob), fp32: %d passes of the same %d-walker batch with a "
-                      "%d-thread BLAS pool (host has %d cores); reference-faithful per-walker loop (batch 1, one "
+                      "%d-thread BLAS pool (this process may use %d CPUs); reference-faithful per-walker loop (batch 1, one "
                       "thread): %.0f evals/s over %d calls" % (best[2], len(z), best[1], cores, per_walker, m)}
 
 
@@ -367,6 +364,8 @@ def main():
     import torch
     import torch.distributed as dist
     from linna_amd import _lib
+    from linna_amd.util import limit_threads_to_quota
+    limit_threads_to_quota()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from .nn import *  # noqa: F401,F403
-from .util import (Transform, invTransform, NN_samplerv1, generate_training_point, train_NN, retrieve_model, Log_prob,
+from .util import (limit_threads_to_quota, Transform, invTransform, NN_samplerv1, generate_training_point, train_NN, retrieve_model, Log_prob,
                    gaussianlogliklihood, run_mcmc, read_chain_and_cut, LogPrior, logp_theory_data)
 from . import nn as lnn
 
@@ -56,6 +56,7 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
         raise NotImplementedError("nbest (optimizer-seeded training points) is outside the hot path")
     if nnmodel_in is None:
         nnmodel_in = lnn.ChtoModelv2
+    limit_threads_to_quota()
     params = dict(params or {})
     ndim = len(init)
     data, cov = np.asarray(data, np.float64), np.asarray(cov, np.float64)

@@ -123,16 +123,38 @@ class BatchLoader(object):
         n = len(self.dataset)
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
-    def epoch_batches(self):
+    def epoch_order(self):
+        """This epoch's sample order (int64 tensor [n]); consumes torch's global RNG as iterating the DataLoader does."""
         n = len(self.dataset)
         torch.empty((), dtype=torch.int64).random_()                     # _BaseDataLoaderIter base seed
-        if self.shuffle:
-            seed = int(torch.empty((), dtype=torch.int64).random_().item())
-            g = torch.Generator()
-            g.manual_seed(seed)
-            order = torch.randperm(n, generator=g)
-        else:
-            order = torch.arange(n)
+        if not self.shuffle:
+            return torch.arange(n)
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        g = torch.Generator()
+        g.manual_seed(seed)
+        # ONE thread.  Above 32768 elements torch's CPU ops go through its intra-op thread pool, sized by the host's core
+        # count (256 on an MI355X box) whatever the CPU quota of the container (16): a parallel region then burns the
+        # cgroup's quota in a third of the scheduling period and the WHOLE process is frozen for the rest of it -- every
+        # epoch of more than 64 steps (66 x 500 rows) took 40 ms instead of 14 (and randperm(40000) itself 2-47 ms).
+        # The permutation is the same.
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            return torch.randperm(n, generator=g)
+        finally:
+            torch.set_num_threads(nt)
+
+    def epoch_rows(self):
+        """The epoch's batches as ONE int32 numpy array [batches, batch_size] (numpy: never multi-threaded, see
+        ``epoch_order``); the training loop's form of ``epoch_batches``."""
+        order = self.epoch_order().numpy()
+        nb, B = len(self), self.batch_size
+        if nb * B <= len(order):
+            return np.ascontiguousarray(order[:nb * B].reshape(nb, B), dtype=np.int32)
+        raise ValueError("epoch_rows needs equal batches (drop_last=True or a batch size dividing the set)")
+
+    def epoch_batches(self):
+        order = self.epoch_order()
         nb = len(self)
         return [order[i * self.batch_size:(i + 1) * self.batch_size] for i in range(nb)]
 

@@ -245,8 +245,9 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
 
     for i in range(num_epochs):
         from . import dist as ldist
-        mine = ldist.rank_batches(dataset.epoch_batches(), rank, size)   # same order on every rank (same seed)
-        perm = torch.stack(mine).to(torch.int32).to(engine.dev) if nsteps else None
+        # same order on every rank (same seed); step s of rank r takes global batch s * size + r (dist.rank_batches)
+        rows = dataset.epoch_rows()[rank::size][:nsteps]
+        perm = torch.from_numpy(np.ascontiguousarray(rows)).to(engine.dev) if nsteps else None
         for s in range(nsteps):
             engine.step(opt, perm[s], loss_hist[s:s + 1])                       # :273-288
         if val_dataset is not None:

@@ -29,6 +29,36 @@ from .nn import *  # noqa: F401,F403  (the reference re-exports its network clas
 SQRT2 = float(np.sqrt(2.0))
 
 
+def cpu_quota():
+    """CPUs this process may use: the scheduler affinity, capped by the cgroup bandwidth quota (cpu.max / cfs_quota_us)
+    when there is one -- a container on a 256-core MI355X host typically has 16."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1") and float(quota) > 0:
+                n = min(n, max(1, int(float(quota) / float(period))))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def limit_threads_to_quota():
+    """torch sizes its intra-op thread pool by the host's core count; with more threads than the container's CPU quota
+    every parallel CPU op over 32768 elements exhausts the quota within the scheduling period and the whole process --
+    the thread feeding the GPU included -- is frozen for the rest of it (measured: 65 ms of every 100).  Called by
+    ``ml_sampler_core``; lowers ``torch.get_num_threads()`` to the quota, never raises it."""
+    q = cpu_quota()
+    if torch.get_num_threads() > q:
+        torch.set_num_threads(q)
+    return torch.get_num_threads()
+
+
 # ------------------------------------------------------------------ prior map (util.py:291-381)
 def gauss2unif(x):
     return 0.5 * (1 + torch.erf(x / SQRT2))

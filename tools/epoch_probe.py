@@ -1,10 +1,11 @@
 """Per-epoch overhead of Predictor.train: wall time of N epochs against steps x (time per step)."""
 import sys, os, time, tempfile
+_args = sys.argv[1:]
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.argv = sys.argv[:1]
 import numpy as np, torch, bench_paths
 from bench_paths import *
 p = problem("ChtoModelv2", 33, 33, True)
-rs = np.random.RandomState(3); n = 10000; nv = 500; B = 500
+rs = np.random.RandomState(3); n = int(_args[0]) if _args else 10000; nv = int(_args[1]) if len(_args) > 1 else 500; B = 500
 def data(n):
     X = (p["X_mean"][None, :] + p["X_std"][None, :] * rs.standard_normal((n, 33))).astype(np.float32)
     Y = (p["data"][None, :] + 3 * p["sigma"][None, :] * rs.standard_normal((n, 33))).astype(np.float32)
@@ -24,11 +25,7 @@ for ne in (10, 100):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pred.train(loader, ne, lf, vloader, vf)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print("epochs %d (20 steps each): %.1f ms per epoch = %.0f us per step equivalent" % (ne, dt / ne * 1e3, dt / ne / 20 * 1e6), flush=True)
-import cProfile, pstats
-pr = cProfile.Profile(); pr.enable(); pred.train(loader, 60, lf, vloader, vf); pr.disable()
-pstats.Stats(pr).sort_stats("tottime").print_stats(14)
-# ---- where does the time of an epoch go: wrap the pieces with timers
+    print("n %d nv %d: epochs %d (%d steps each): %.1f ms per epoch = %.0f us per step equivalent" % (n, nv, ne, n // B, dt / ne * 1e3, dt / ne / (n // B) * 1e6), flush=True)
 import collections
 T = collections.Counter()
 def wrap(obj, name, key):
@@ -36,7 +33,8 @@ def wrap(obj, name, key):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); T[key] += time.perf_counter() - t0; return r
     setattr(obj, name, g)
-wrap(trainer.TrainEngine, "validate", "validate")
+wrap(trainer.TrainEngine, "validate_enqueue", "validate_enqueue")
+wrap(trainer.TrainEngine, "validate_finish", "validate_finish")
 wrap(trainer.TrainEngine, "step", "step (enqueue)")
 wrap(trainer._Checkpoints, "record", "ckpt.record")
 wrap(predictor_gpu.BatchLoader, "epoch_batches", "epoch_batches")
