@@ -73,7 +73,6 @@ int linna_ctx_device(const linna_ctx_t* ctx) { return ctx->device; }
 struct linna_graph { hipGraph_t graph; hipGraphExec_t exec; };
 // zeroed, self-resetting arrival counters of the context (allocated by linna_ctx_create)
 static unsigned* ctx_counters(linna_ctx* ctx, hipStream_t) { return ctx ? ctx->counters : nullptr; }
-constexpr size_t kGroupTableBytes = 32 * 1024;    // descriptor table of the grouped parameter-gradient launch (~5 KB used)
 
 // The whole-network kernel (net_stream.hip) reads the weights from a copy in MFMA fragment order.  Its 16-row
 // engine and its small-batch engines (8 / 4 rows per workgroup) read different orders, so there are two copies,
@@ -96,11 +95,7 @@ struct StreamCopy {
 
 struct linna_net {
     linna_ctx* ctx;
-    // descriptor table of the grouped parameter-gradient launch (gemm_launch_group), allocated by linna_net_create:
-    // [0] read by direct launches, `group_host` = what it holds; [1] read by captured launches, which carry their own
-    // upload (kernel arguments) so that a replay never depends on -- or disturbs -- what direct launches left there
-    void* group_dev[2] = {nullptr, nullptr};
-    std::vector<char> group_host;
+
     StreamCopy packed;                       // fragment-order weight streams for the one-launch training forward
     int stream_fwd = -1;
     StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
@@ -156,7 +151,7 @@ int linna_ctx_create(int device, linna_ctx_t** out) {
     if (!c) return LINNA_ERR_INVALID;
     c->device = device;
     // the context's device-side state is allocated HERE, so that no launch ever allocates: the arrival counters of the
-    // one-launch loss (networks hold the descriptor tables of their grouped parameter-gradient launch)
+    // one-launch loss
     int prev = 0;
     (void)hipGetDevice(&prev);
     int rc = check_hip(hipSetDevice(device), "hipSetDevice");
@@ -297,20 +292,12 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
         set_error("net_create: INSKIP needs a LINEAR first op"); delete n; return LINNA_ERR_INVALID;
     }
     n->out_size = width;
-    bool grads = false;
-    for (const linna_layer_t& l : n->L) grads = grads || l.gW || l.gW1;
-    for (int k = 0; k < 2 && grads; ++k)
-        if (hipMalloc(&n->group_dev[k], kGroupTableBytes) != hipSuccess) {
-            set_error("net_create: hipMalloc(gemm group table) failed");
-            (void)linna_net_destroy(n); return LINNA_ERR_HIP;
-        }
     *out = n;
     return LINNA_OK;
 }
 int linna_net_destroy(linna_net_t* net) {
     if (net) {
         net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release();
-        for (int k = 0; k < 2; ++k) if (net->group_dev[k]) (void)hipFree(net->group_dev[k]);
     }
     delete net;
     return LINNA_OK;
@@ -477,9 +464,9 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         ctx->group = (e && e[0] == '0') ? 0 : 1;
     }
     const bool grouping = pg && ctx && ctx->group == 1;
-    std::vector<GemmArgs> dwq;
-    std::vector<ColsumProb> csq;
-    int csblocks = 0;
+    GemmGroupArgs grp;                  // the grouped parameter-gradient launch: descriptors by value, filled as we go
+    grp.nprob = 0;
+    int grp_blocks = 0;
     bool aux_used = false;
     auto fork = [&]() -> int {       // work enqueued on aux after this sees everything enqueued on st so far
         if (!overlap) return LINNA_OK;
@@ -493,12 +480,14 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         GemmArgs a = gemm_zero();    // dW[n][k] = scale * sum_b dY[b][n] X[b][k]
         set_pair(a, 0, dY, lddy, LAY_MN, Xin, ldxin, LAY_MN, B);
         a.M = N; a.N = K; a.C = dW; a.ldc = lddw; a.alpha0 = scale;
-        if (grouping && gemm_group_ok(a)) dwq.push_back(a);
-        else { TRY(fork()); TRY(gemm_launch(a, S(aux))); }
-        if (db) {
-            if (grouping) { csq.push_back(ColsumProb{dY, db, lddy, N, csblocks, scale}); csblocks += (N + 63) / 64; }
-            else { TRY(fork()); TRY(launch_colsum(dY, lddy, B, N, scale, db, S(aux))); }
+        if (grouping && grp.nprob < GEMM_GROUP_MAX && gemm_group_ok(a)) {
+            // one tile grid for every dW of the step; the bias gradient (column sums of dY) rides in the same tiles
+            grp.p[grp.nprob++] = GemmGroupProb{dY, Xin, dW, db, lddy, ldxin, lddw, B, N, K, scale, grp_blocks};
+            grp_blocks += gemm_group_blocks(a);
+            return LINNA_OK;
         }
+        TRY(fork()); TRY(gemm_launch(a, S(aux)));
+        if (db) { TRY(fork()); TRY(launch_colsum(dY, lddy, B, N, scale, db, S(aux))); }
         return LINNA_OK;
     };
 
@@ -598,38 +587,7 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
         }
         dcur = dprev; ldd = ldp;
     }
-    if (!dwq.empty() || !csq.empty()) {
-        // every dY is on `st` by now: one grid over all the dW tiles.  The descriptor table is uploaded only when
-        // it changed (first step, new batch size); during a capture with a stale table the GEMMs go out one by one.
-        const int np = (int)dwq.size(), nc = (int)csq.size();
-        const size_t cs_off = (gemm_group_table_bytes(np) + 15) & ~(size_t)15;
-        std::vector<char> tab(cs_off + (size_t)nc * sizeof(ColsumProb));
-        std::memcpy(tab.data(), dwq.data(), (size_t)np * sizeof(GemmArgs));
-        int* first = reinterpret_cast<int*>(tab.data() + (size_t)np * sizeof(GemmArgs));
-        int nb = 0;
-        for (int i = 0; i < np; ++i) { first[i] = nb; nb += gemm_group_blocks(dwq[i]); }
-        first[np] = nb;
-        if (nc) std::memcpy(tab.data() + cs_off, csq.data(), (size_t)nc * sizeof(ColsumProb));
-        // uploaded only when it changed (first step, new batch size, new buffers) -- as kernel arguments, so the upload
-        // is asynchronous and part of a capture like everything else; a table beyond the context's capacity (never for
-        // the reference's networks) sends the GEMMs out one by one
-        hipStreamCaptureStatus capg = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &capg);
-        const int tk = capg != hipStreamCaptureStatusNone ? 1 : 0;
-        const bool ready = tab.size() <= kGroupTableBytes && n->group_dev[tk];
-        void* const table = n->group_dev[tk];
-        if (ready && (tk == 1 || n->group_host != tab)) {
-            TRY(launch_table_write(tab.data(), tab.size(), table, st));
-            if (tk == 0) n->group_host = tab;
-        }
-        if (ready) {
-            if (np) TRY(gemm_launch_group(table, np, nb, st));      // (none when every tile shape is the small one)
-            if (nc) TRY(launch_colsum_group(reinterpret_cast<const ColsumProb*>(static_cast<const char*>(table) + cs_off), nc, csblocks, B, st));
-        } else {
-            for (const GemmArgs& a : dwq) TRY(gemm_launch(a, st));
-            for (const ColsumProb& q : csq) TRY(launch_colsum(q.dZ, q.ld, B, q.N, q.scale, q.db, st));
-        }
-    }
+    if (grp.nprob) TRY(gemm_launch_group(grp, grp_blocks, st));     // every dY is on `st` by now: one grid over all the dW tiles
     if (overlap && aux_used) {       // join: the caller's stream continues only after every gradient is written
         hipEvent_t e = ctx->events[next_event++];
         TRY(check_hip(hipEventRecord(e, ctx->aux), "hipEventRecord"));

@@ -77,8 +77,6 @@ int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const
 int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg, const float* xmean,
                         const float* xstd, float* XB, int ldxb, hipStream_t s);
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s);
-struct ColsumProb { const float* dZ; float* db; int ld, N, first; float scale; };   // first: first 64-column block of this pair
-int launch_colsum_group(const ColsumProb* probs_dev, int nprob, int nblocks, int B, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,
                  float eps, hipStream_t s);
 int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const float* ccoords, int ldcc,
@@ -108,7 +106,6 @@ int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, co
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
                         const float* Wacc, const float* Zacc, hipStream_t s);
 int launch_step_increment(int* step, hipStream_t s);
-int launch_table_write(const void* host_src, size_t nbytes, void* dst, hipStream_t s);   // capturable small upload
 
 // Dense inverse covariance for the whole-network kernel: the output map d = raw * cscale + cshift is folded into the last
 // layer of the weight stream and S (symmetric, [nout][lds]) is appended as one more segment, chi2 = d . (d S).
@@ -154,10 +151,13 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);
-// several independent problems in ONE grid (gemm.hip: gemm_group_kernel)
-size_t gemm_group_table_bytes(int nprob);
+// several independent k-major x k-major problems in ONE grid (gemm.hip: gemm_group_kernel): C[M][N] = alpha * A^T B over
+// K (the batch), db[M] = alpha * column sums of A (null: none); descriptors by value in the kernel arguments
+struct GemmGroupProb { const float* A; const float* B; float* C; float* db; int lda, ldb, ldc, K, M, N; float alpha; int first; };
+constexpr int GEMM_GROUP_MAX = 48;
+struct GemmGroupArgs { GemmGroupProb p[GEMM_GROUP_MAX]; int nprob; };
 bool gemm_group_ok(const GemmArgs& a);
 int gemm_group_blocks(const GemmArgs& a);
-int gemm_launch_group(const void* table, int nprob, int nblocks, hipStream_t stream);
+int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream);
 
 }  // namespace linna

@@ -20,6 +20,7 @@
 //    products are never stored.
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 #include <map>
 #include <mutex>
 
@@ -134,7 +135,7 @@ struct Tile {
 struct KSplit { int kz; float* scratch; int* counters; };
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all, const KSplit ks) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all, const KSplit ks, float* const db = nullptr) {
     constexpr int NW = WM * WN, NT = NW * 64;                 // waves / threads of one K group
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using TA = Tile<BM, ALAY, NW>;
@@ -174,9 +175,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // Bias gradient fused into the parameter-gradient GEMM (db != null; k-major A = dY[batch][n], one K group): the column
+    // sums of the A tile over the batch rows, taken from LDS by the tiles of the first tile column -- wave w adds the
+    // k rows w, w + NW, ... of every K tile for column `lane` -- summed over the waves after the K loop.
+    float csum = 0.f;
+    const bool do_colsum = db != nullptr && ALAY == LAY_MN && KS == 1 && TM == 1 && BM == 64 && tn_ == 0 && ks.kz <= 1;
     auto compute = [&](const float* st) {
         const float* cA = st;
         const float* cB = st + TA::SIZE;
+        if (do_colsum) {
+#pragma unroll
+            for (int kk = 0; kk < BK / NW; ++kk) csum += cA[(wave + kk * NW) * BM + lane];
+        }
         f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = TA::frag(cA, (wm * TM + i) * 32, 0, lane);
@@ -269,6 +279,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = a.alpha0 * (acc[i][j][e] + b0);
+            }
+        }
+    }
+
+    if (db != nullptr && ALAY == LAY_MN && KS == 1 && TM == 1 && BM == 64 && ks.kz <= 1) {   // (block-uniform)
+        if (do_colsum) {
+            __syncthreads();
+            smem[wave * 64 + lane] = csum;
+            __syncthreads();
+            if (wave == 0 && m0 + lane < a.M) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += smem[w * 64 + lane];
+                db[m0 + lane] = a.alpha0 * t;
             }
         }
     }
@@ -389,16 +413,24 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a, KSp
 }
 
 // Grouped launch: ONE grid over the tiles of several independent problems that share the tile
-// configuration and the operand layouts (the 13 parameter-gradient GEMMs of a training step: 251
-// tiles that fill the chip once, instead of 13 launches of 1-128 tiles each).  `first[p]` = first
-// block of problem p, `first[nprob]` = grid size; the descriptors live in device memory.
+// configuration and the operand layouts (the 13 parameter-gradient GEMMs of a training step: 250-370
+// tiles that fill the chip once, instead of 13 launches of 1-128 tiles each), with the bias gradients
+// (column sums of dY) taken inside the tiles of the first tile column.  The descriptors travel BY VALUE as
+// kernel arguments (56 bytes per problem): no device table, nothing to upload, capturable as it is; the
+// search for a block's problem runs on the scalar unit over the kernarg segment.
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const GemmArgs* __restrict__ probs,
-                                                                       const int* __restrict__ first, int nprob) {
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const GemmGroupArgs g) {
     int p = 0;
-    while (p + 1 < nprob && (int)blockIdx.x >= first[p + 1]) ++p;
-    const GemmArgs a = probs[p];
-    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, (int)blockIdx.x - first[p], KSplit{1, nullptr, nullptr});
+    while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
+    const GemmGroupProb q = g.p[p];
+    GemmArgs a;
+    a.p[0].A = q.A; a.p[0].B = q.B; a.p[0].lda = q.lda; a.p[0].ldb = q.ldb; a.p[0].K = q.K; a.p[0].alay = ALAY; a.p[0].blay = BLAY;
+    a.p[1] = a.p[0];
+    a.npairs = 1; a.M = q.M; a.N = q.N; a.C = q.C; a.ldc = q.ldc;
+    a.bias0 = nullptr; a.bias1 = nullptr; a.alpha0 = q.alpha; a.R = nullptr; a.ldr = 0; a.relu = 0; a.mask = nullptr; a.ldmask = 0;
+    a.cscale = nullptr; a.cshift = nullptr; a.cexp = 0; a.cpost = nullptr; a.cshift2 = nullptr;
+    a.dotwith = nullptr; a.lddot = 0; a.dot_partial = nullptr; a.dot_slots = 0; a.flags = 0;
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db);
 }
 
 // ---------------------------------------------------------------------------- launcher
@@ -497,19 +529,16 @@ static int launch_lay(const GemmArgs& a, int cfg, hipStream_t stream) {
     }
 }
 
-// Grouped launch of problems that all take tile configuration 1 (64x64, 4-stage ring) and the k-major /
-// k-major layouts.  `table` is device memory for nprob descriptors followed by nprob+1 ints; the caller
-// has already copied `probs` and `first` there (gemm_group_table_bytes / gemm_group_fill).
-size_t gemm_group_table_bytes(int nprob) { return (size_t)nprob * sizeof(GemmArgs) + (size_t)(nprob + 1) * sizeof(int); }
+// Grouped launch of k-major x k-major problems on 64x64 tiles (4-stage ring); see gemm_group_kernel.
 bool gemm_group_ok(const GemmArgs& a) {
-    return a.npairs == 1 && a.p[0].alay == LAY_MN && a.p[0].blay == LAY_MN && pick_cfg(a.M, a.N, a.flags) == 1 && !a.dotwith;
+    const int cfg = pick_cfg(a.M, a.N, a.flags);
+    return a.npairs == 1 && a.p[0].alay == LAY_MN && a.p[0].blay == LAY_MN && (cfg == 1 || cfg == 2) && !a.dotwith &&
+           ((a.p[0].lda | a.p[0].ldb) & 3) == 0;
 }
 int gemm_group_blocks(const GemmArgs& a) { return ((a.M + 63) / 64) * ((a.N + 63) / 64); }
-int gemm_launch_group(const void* table, int nprob, int nblocks, hipStream_t stream) {
-    const GemmArgs* probs = static_cast<const GemmArgs*>(table);
-    const int* first = reinterpret_cast<const int*>(static_cast<const char*>(table) + (size_t)nprob * sizeof(GemmArgs));
+int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
-    hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks), dim3(256), lds, stream, probs, first, nprob);
+    hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks), dim3(256), lds, stream, g);
     return check_hip(hipGetLastError(), "gemm group launch");
 }
 

@@ -614,37 +614,6 @@ int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin
                        xmean, xstd, XB, ldxb);
     LAUNCH_CHECK("gather_xform");
 }
-// Grouped bias gradients: ONE grid over the 64-column blocks of several (dZ, db) pairs of the same batch.
-__global__ __launch_bounds__(1024) void colsum_group_kernel(const ColsumProb* __restrict__ probs, int nprob, int B) {
-    __shared__ float part[16][64];
-    int p = 0;
-    while (p + 1 < nprob && (int)blockIdx.x >= probs[p + 1].first) ++p;
-    const ColsumProb q = probs[p];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int col = ((int)blockIdx.x - q.first) * 64 + lane;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (col < q.N) {
-        const float* ptr = q.dZ + col;
-        int b = wave;
-        for (; b + 48 < B; b += 64) {
-            a0 += ptr[(size_t)b * q.ld]; a1 += ptr[(size_t)(b + 16) * q.ld];
-            a2 += ptr[(size_t)(b + 32) * q.ld]; a3 += ptr[(size_t)(b + 48) * q.ld];
-        }
-        for (; b < B; b += 16) a0 += ptr[(size_t)b * q.ld];
-    }
-    part[wave][lane] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    if (wave == 0 && col < q.N) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += part[w][lane];
-        q.db[col] = q.scale * t;
-    }
-}
-int launch_colsum_group(const ColsumProb* probs_dev, int nprob, int nblocks, int B, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_group_kernel, dim3(nblocks), dim3(1024), 0, s, probs_dev, nprob, B);
-    LAUNCH_CHECK("colsum_group");
-}
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s) {
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, s, dZ, ld, B, N, scale, db);
     LAUNCH_CHECK("colsum");
@@ -723,23 +692,6 @@ int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int
     hipLaunchKernelGGL(slice_commit_kernel, grid1d((size_t)ns * ndim, 256), dim3(256), 0, s, coords, ldc, ndim, logp, S,
                        ns, DIR, ldd, Wacc, Zacc);
     LAUNCH_CHECK("slice_commit");
-}
-// Small host tables to device memory as KERNEL ARGUMENTS (1 KiB per launch): asynchronous on the caller's stream and
-// capturable into a hipGraph, unlike a copy from pageable host memory.
-struct TableChunk { unsigned char b[1024]; };
-__global__ void table_write_kernel(TableChunk c, unsigned char* __restrict__ dst, int n) {
-    const int i = threadIdx.x + blockIdx.x * blockDim.x;
-    if (i < n) dst[i] = c.b[i];
-}
-int launch_table_write(const void* host_src, size_t nbytes, void* dst, hipStream_t s) {
-    const unsigned char* src = static_cast<const unsigned char*>(host_src);
-    for (size_t off = 0; off < nbytes; off += sizeof(TableChunk)) {
-        TableChunk c;
-        const size_t n = nbytes - off < sizeof(TableChunk) ? nbytes - off : sizeof(TableChunk);
-        memcpy(c.b, src + off, n);
-        hipLaunchKernelGGL(table_write_kernel, dim3(4), dim3(256), 0, s, c, static_cast<unsigned char*>(dst) + off, (int)n);
-    }
-    LAUNCH_CHECK("table_write");
 }
 int launch_step_increment(int* step, hipStream_t s) {
     hipLaunchKernelGGL(step_increment_kernel, dim3(1), dim3(1), 0, s, step);
