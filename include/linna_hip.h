@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 4   /* 3: + linna_net_stream_state; 4: + linna_comm_* / collectives (RCCL) */
+#define LINNA_ABI_VERSION 5   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -290,6 +290,17 @@ int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, 
                                   int ldp, const float* Y, int ldy, const float* den, const int* ROWS,
                                   int B, float* scratch, float* loss_rows, float* loss_mean,
                                   float* dPRED, int lddp, float inv_batch, void* stream);
+/* Minibatch gather + X transform + network forward (activations kept for linna_net_backward) + the loss above, its
+ * per-row values, batch mean and gradient -- predictor_gpu.py:274-285 up to loss.backward() -- in ONE launch of the
+ * whole-network kernel when the network and the loss fit it (LINNA_ERR_UNSUPPORTED otherwise: run linna_gather_xform,
+ * linna_net_forward and linna_chi2_ratio_loss_fwd_bwd instead).  X[n][ldx]: the resident, untransformed training
+ * inputs; XB[B][ldxb]: the transformed batch (out; the first layer's parameter gradient reads it); ws: forward
+ * workspace of linna_net_fwd_ws_bytes(net, B); PRED[B][ldp]: raw network output (out). */
+int linna_net_prepare_loss(linna_net_t* net, const linna_loss_desc_t* d);   /* allocates its weight stream (outside a capture) */
+int linna_net_forward_loss(linna_net_t* net, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                           const int* log10_flag, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws,
+                           float* PRED, int ldp, const float* Y, int ldy, const float* den, float inv_batch,
+                           float* loss_rows, float* loss_mean, float* dPRED, int lddp, void* stream);
 /* validation pieces (util.py:1124-1127): per-row loss and chisq_nnd/chisq_Md. */
 int linna_val_rows(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp,
                    const float* Y, int ldy, const float* den, int B, float* scratch, float* loss_rows,

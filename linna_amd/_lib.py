@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblinna_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
@@ -112,6 +112,8 @@ _SIGNATURES = {
     "linna_loss_scratch_bytes": (_SZ, [_I, _I]),
     "linna_chi2_md": (_I, [_V, C.POINTER(LossDesc), _V, _I, _I, _V, _V, _V]),
     "linna_chi2_ratio_loss_fwd_bwd": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _V, _I, _V, _V, _V, _V, _I, _F, _V]),
+    "linna_net_prepare_loss": (_I, [_V, C.POINTER(LossDesc)]),
+    "linna_net_forward_loss": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _V, _V, _V, _I, _V, _V, _I, _V, _I, _V, _F, _V, _V, _V, _I, _V]),
     "linna_val_rows": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _I, _V, _V, _V, _V]),
     "linna_gather_xform": (_I, [_V, _V, _I, _V, _I, _I, _V, _V, _V, _V, _I, _V]),
     "linna_adamw_step": (_I, [_V, _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _V]),

@@ -98,6 +98,9 @@ struct linna_net {
 
     StreamCopy packed;                       // fragment-order weight streams for the one-launch training forward
     int stream_fwd = -1;
+    StreamCopy packed_loss;                  // ... for forward + chi^2-ratio loss in one launch (linna_net_forward_loss)
+    NsDense loss_dn{nullptr, 0, nullptr, nullptr};   // the inverse covariance that stream ends in
+    int stream_loss = -1;                    // -1 unknown, 0 no (not eligible / LINNA_LOSS_STREAM=0), 1 yes
     StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
     int stream_bwd[2] = {-1, -1};            // -1 unknown, 0 no (network out of reach / LINNA_BWD_STREAM=0), 1 yes                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
     std::vector<linna_layer_t> L;   // without the trailing INSKIP
@@ -297,7 +300,7 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
 }
 int linna_net_destroy(linna_net_t* net) {
     if (net) {
-        net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release();
+        net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release(); net->packed_loss.release();
     }
     delete net;
     return LINNA_OK;
@@ -416,6 +419,65 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
         }
         hin = Y; ldh = ldy;
     }
+    return LINNA_OK;
+}
+
+static void net_ensure_loss(linna_net* n, const NsDense& dn) {
+    const int nl = (int)n->L.size();
+    const char* e = getenv("LINNA_LOSS_STREAM");
+    const bool ok = !n->has_inskip && !(e && e[0] == '0') && net_stream_dense_eligible(n->L.data(), nl, n->in_size, dn);
+    n->packed_loss.release();
+    n->stream_loss = 0; n->loss_dn = dn;
+    if (ok && n->packed_loss.alloc(net_stream_dense_packed_floats(n->L.data(), nl, n->in_size, dn)) == LINNA_OK) n->stream_loss = 1;
+}
+int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
+    if (!n || !d) { set_error("net_prepare_loss: null argument"); return LINNA_ERR_INVALID; }
+    const NsDense dn{d->Cinv, d->ldc, nullptr, nullptr};
+    if (n->stream_loss < 0 || n->loss_dn.S != dn.S || n->loss_dn.lds != dn.lds) net_ensure_loss(n, dn);
+    return LINNA_OK;
+}
+// Forward pass of a training step AND its loss in ONE launch (net_stream.hip, STORE == 3): the batch rows are gathered
+// from the resident set and X-transformed in the kernel's prologue, every activation the backward needs is stored, the
+// network's normalised-space inverse covariance is the program's last segment and the finish writes the per-row loss and
+// d loss / d pred.  Replaces linna_gather_xform + linna_net_forward + linna_chi2_ratio_loss_fwd_bwd (seven launches for
+// nout > 64) when the network + loss fit the whole-network kernel; LINNA_ERR_UNSUPPORTED otherwise (the caller then
+// runs that sequence).  The batch mean is a second, tiny launch (fixed summation order).
+int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                           const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
+                           int ldp, const float* Y, int ldy, const float* den, float inv_batch, float* loss_rows,
+                           float* loss_mean, float* dPRED, int lddp, void* stream) {
+    if (!n || !d || !X || !xmean || !xstd || !XB || !PRED || !Y || !den || !loss_rows || !dPRED || B < 1) {
+        set_error("net_forward_loss: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    if (d->nout != n->out_size) { set_error("net_forward_loss: loss for %d outputs, network has %d", d->nout, n->out_size); return LINNA_ERR_INVALID; }
+    const int nl = (int)n->L.size();
+    const NsDense dn{d->Cinv, d->ldc, nullptr, nullptr};
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(S(stream), &cap);
+    if (n->stream_loss < 0 || n->loss_dn.S != dn.S || n->loss_dn.lds != dn.lds) {
+        if (cap != hipStreamCaptureStatusNone) {
+            set_error("net_forward_loss: first use inside a stream capture (call linna_net_prepare_loss before)"); return LINNA_ERR_UNSUPPORTED;
+        }
+        net_ensure_loss(n, dn);
+    }
+    if (n->stream_loss != 1) { set_error("net_forward_loss: this network / loss does not run the whole-network kernel"); return LINNA_ERR_UNSUPPORTED; }
+    const FwdLayout f = fwd_layout(n, B);
+    float* w = static_cast<float*>(ws);
+    if (nl > 1 && !w) { set_error("net_forward_loss: workspace required"); return LINNA_ERR_INVALID; }
+    const int rows = net_stream_rows(B);
+    const float* packed = nullptr;
+    TRY(stream_copy_refresh(n->packed_loss, n, rows, stream, &packed, 0, &n->loss_dn));
+    std::vector<float*> y(nl), t(nl);
+    std::vector<int> ldy_(nl), ldt(nl);
+    for (int i = 0; i < nl; ++i) {
+        const bool last = i == nl - 1;
+        y[i] = last ? PRED : w + f.y_off[i]; ldy_[i] = last ? ldp : ld4(n->L[i].N);
+        t[i] = n->L[i].op == LINNA_OP_RESBLOCK ? w + f.t_off[i] : nullptr; ldt[i] = ld4(n->L[i].C);
+    }
+    const NsTrainLoss L{Y, ldy, d->sigma, d->ymean, d->ystd, d->data_norm, den, inv_batch, loss_rows, dPRED, lddp};
+    TRY(launch_net_stream_train(n->L.data(), nl, n->in_size, packed, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, y.data(),
+                                ldy_.data(), t.data(), ldt.data(), L, n->loss_dn, rows, S(stream)));
+    if (loss_mean) TRY(launch_sum_scale(loss_rows, B, inv_batch, loss_mean, S(stream)));
     return LINNA_OK;
 }
 

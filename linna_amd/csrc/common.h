@@ -140,6 +140,13 @@ struct NsMove {
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
                             int B, float* const* y, const int* ldy, float* const* t, const int* ldt, const float* cscale,
                             const float* cshift, int rows, hipStream_t s);
+// training forward + chi^2-ratio loss in one launch (STORE == 3)
+struct NsTrainLoss { const float* Y; int ldy; const float* sigma; const float* ymean; const float* ystd; const float* data_norm;
+                     const float* den; float inv_batch; float* loss_rows; float* dP; int lddp; };
+int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
+                            const int* ROWS, int B, const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb,
+                            float* const* y, const int* ldy, float* const* t, const int* ldt, const NsTrainLoss& L,
+                            const NsDense& dn, int rows, hipStream_t s);
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
 struct NsGrad { const float* gscale; float* G; int ldg; };
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);

@@ -100,6 +100,14 @@ struct NsArgs {
     // STORE == 2 (the dX chain of a training step): a segment's output is zeroed where gmask (the stored forward
     // activation whose gradient it is) is not positive, before it is stored and handed to the next segment
     const float* gmask[NS_MAXSEG]; int gmld[NS_MAXSEG];
+    // STORE == 3 (one launch = gather + input transform + training forward + chi^2-ratio loss and its gradient,
+    // predictor_gpu.py:274-285 with util.py:1070-1116): Z is the RESIDENT training set X[n][ldz], row `t_rows[b]` is
+    // transformed in the prologue (and stored to t_xb for the first layer's parameter gradient); the last network layer's
+    // epilogue turns pred into delta = mask ? 0 : ynorm - pred in LDS; the program's last segment is U = delta Cinv; the
+    // finish writes loss_b = delta.U / den and d loss / d pred = -2 U inv_batch / den
+    const int* t_rows; float* t_xb; int t_ldxb;
+    const float* t_Y; int t_ldy; const float* t_sigma; const float* t_ymean; const float* t_ystd; const float* t_dnorm;
+    const float* t_den; float t_inv_batch; float* t_loss_rows; float* t_dP; int t_lddp;
     // dense inverse covariance as the program's last segment: U = d S sits at column u_col of the current buffer
     // (u_same) or at column 0 with d in the other buffer; the finish takes chi2 = d . U
     int dense, u_col, u_same;
@@ -237,6 +245,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const bool prow = prt < ROWS;                   // (ROWS < 16: the thread rows past ROWS only keep the barriers company)
     const int pr = SM ? min(prt, ROWS - 1) : prt;
     const int grow = min(row0 + pr, a.B - 1);
+    int zsrc = grow;                                // STORE == 3: the row of the resident set this batch row is
+    float zden = 1.f;
+    if constexpr (STORE == 3) {
+        zsrc = a.t_rows ? a.t_rows[grow] : grow;
+        zden = a.t_den[zsrc];
+    }
     const int kpad0 = a.kpad0, nin = a.nin, nout = a.nout, nseg = a.nseg;
     constexpr int ZPRE = 2;
     float zr[ZPRE], za1[ZPRE], za2[ZPRE], zxm[ZPRE], zxs[ZPRE]; int zfl[ZPRE], zlg[ZPRE];
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
     for (int i = 0; i < ZPRE; ++i) {
         const int c = min(pc0 + i * RG, nin - 1);
-        if constexpr (MOVE == 0) zr[i] = a.Z[(size_t)grow * a.ldz + c];
+        if constexpr (MOVE == 0) zr[i] = a.Z[(size_t)(STORE == 3 ? zsrc : grow) * a.ldz + c];
         zfl[i] = a.is_flat[c]; za1[i] = a.a1[c]; za2[i] = a.a2[c];
         zlg[i] = lgp[c]; zxm[i] = a.xmean[c]; zxs[i] = a.xstd[c];
     }
@@ -339,7 +353,15 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         theta[i] = th;
         const float t = (a.lg && zlg[i]) ? lt : th;
         float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
-        if constexpr (STORE) x = z;                 // rows arrive transformed
+        if constexpr (STORE == 1 || STORE == 2) x = z;   // rows arrive transformed
+        if constexpr (STORE == 3) {                 // X_transform of a gathered row (util.py:483-497), as linna_gather_xform
+            float lz = log10f(z);
+            asm volatile("" : "+v"(lz));
+            const float tz = (a.lg && zlg[i]) ? lz : z;
+            x = in ? (tz - zxm[i]) / zxs[i] : 0.f;
+            if (prow && row0 + pr < a.B && c < a.t_ldxb)
+                asm volatile("global_store_dword %0, %1, off" :: "v"(a.t_xb + (size_t)(row0 + pr) * a.t_ldxb + c), "v"(x) : "memory");
+        }
         if (c < kpad0 && prow) act[pr * LD + c] = x;
     }
     // inputs wider than ZPRE*RG = 64 columns (none of the reference's models; <= 256 supported) and the zero
@@ -353,7 +375,15 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             const float th = ns_prior_theta(z, a.is_flat[c], a.a1[c], a.a2[c]);
             const float t = (a.lg && a.lg[c]) ? log10f(th) : th;
             x = (t - a.xmean[c]) / a.xstd[c];
-            if constexpr (STORE) x = z;
+            if constexpr (STORE == 1 || STORE == 2) x = z;
+            if constexpr (STORE == 3) {
+                const float zz3 = a.Z[(size_t)zsrc * a.ldz + c];
+                x = (((a.lg && a.lg[c]) ? log10f(zz3) : zz3) - a.xmean[c]) / a.xstd[c];
+            }
+        }
+        if constexpr (STORE == 3) {
+            if (prow && row0 + pr < a.B && c < a.t_ldxb)
+                asm volatile("global_store_dword %0, %1, off" :: "v"(a.t_xb + (size_t)(row0 + pr) * a.t_ldxb + c), "v"(x) : "memory");
         }
         if (prow) act[pr * LD + c] = x;
     }
@@ -367,6 +397,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     for (int i = 0; i < BMAX; ++i) {
         const int j = tid + i * 64 * NW;
         if (j < nb4) reinterpret_cast<f32x4*>(lbias)[j] = breg[i];
+    }
+    int* const lsrc = reinterpret_cast<int*>(lbias + ((a.bias_total + 3) & ~3));      // STORE == 3: [ROWS] set rows, [ROWS] den
+    float* const lden = reinterpret_cast<float*>(lsrc + 16);
+    if constexpr (STORE == 3) {
+        if (prow && pc0 == 0) { lsrc[pr] = zsrc; lden[pr] = zden; }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // raw: __syncthreads() would drain the weight stream
@@ -493,6 +528,31 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #define q_col(q) (SM ? lane : 16 * (q) + li)
             if (s_type == NS_WIDE) {
                 float* const nxt = act + (P ^ 1) * ABUF + s_dst + 512 * pass + 64 * wave;
+                // STORE == 3, last network layer: the targets and the per-column constants of delta, fetched by inline-asm
+                // loads the compiler does not count (a visible load in this loop body would turn its counted vmcnt waits
+                // for the weight ring into vmcnt(0) in EVERY step); one explicit wait for all of them
+                float ty[NQ][4], tdn[NQ], tsg[NQ], tym[NQ], tys[NQ];
+                if constexpr (STORE == 3) {
+                    if (si == nseg - 2) {
+#pragma unroll
+                        for (int t = 0; t < NQ; ++t) {
+                            const int dc = min(512 * pass + 64 * wave + q_col(t), nout - 1);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float* py = a.t_Y + (size_t)lsrc[q_row(t, e)] * a.t_ldy + dc;
+                                asm volatile("global_load_dword %0, %1, off" : "=v"(ty[t][e]) : "v"(py) : "memory");
+                            }
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(tdn[t]) : "v"(a.t_dnorm + dc) : "memory");
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(tsg[t]) : "v"(a.t_sigma + dc) : "memory");
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(tym[t]) : "v"(a.t_ymean + dc) : "memory");
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(tys[t]) : "v"(a.t_ystd + dc) : "memory");
+                        }
+#pragma unroll
+                        for (int t = 0; t < NQ; ++t)
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ty[t][0]), "+v"(ty[t][1]), "+v"(ty[t][2]), "+v"(ty[t][3]),
+                                         "+v"(tdn[t]), "+v"(tsg[t]), "+v"(tym[t]), "+v"(tys[t]) :: "memory");
+                    }
+                }
                 unsigned mbits = 0xFFFFu;
                 if constexpr (GRAD) {
                     if (s_mapply) mbits = lmask[(s_mapply - 1 + pass) * (64 * NW) + threadIdx.x];   // sign bits of this very (row, col)
@@ -518,7 +578,17 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                                 if (!(s_gmask[(size_t)mr * s_gmld + mc] > 0.f)) v = 0.f;
                             }
                         }
-                        nxt[q_row(t, e) * LD + q_col(t)] = v;
+                        float v_lds = v;
+                        if constexpr (STORE == 3) {
+                            if (si == nseg - 2) {              // the network's last layer: delta replaces pred in LDS
+                                const int dc = 512 * pass + 64 * wave + q_col(t);
+                                const float y = ty[t][e], dn = tdn[t];
+                                const bool masked = (y == 1e-30f) | (y == 1e10f) | (dn == 1e-30f);
+                                const float yn = (y / tsg[t] - tym[t]) / tys[t];
+                                v_lds = dc < nout ? (masked ? -0.f : (yn - v) + 0.f) : 0.f;   // -0: "masked", read back by the finish
+                            }
+                        }
+                        nxt[q_row(t, e) * LD + q_col(t)] = v_lds;
                         if constexpr (STORE) {
                             const int grow_ = row0 + q_row(t, e), gcol = 512 * pass + 64 * wave + q_col(t);
                             if (s_gout && grow_ < a.B && gcol < s_gn) {
@@ -580,6 +650,35 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     }
                     cur[c] = v;
                 }
+                if constexpr (STORE == 3) {
+                    if (si == nseg - 2) {
+                        // the network's last layer (nout <= 256): thread (row pr, lane pc0) turns its own columns
+                        // pc0 + 32 j of pred into delta, in place (asm loads: see the WIDE epilogue)
+                        constexpr int NJ = 8;
+                        float sy[NJ], sdn[NJ], ssg[NJ], sym[NJ], sys_[NJ];
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const int c = min(pc0 + RG * j, nout - 1);
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(sy[j]) : "v"(a.t_Y + (size_t)zsrc * a.t_ldy + c) : "memory");
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(sdn[j]) : "v"(a.t_dnorm + c) : "memory");
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(ssg[j]) : "v"(a.t_sigma + c) : "memory");
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(sym[j]) : "v"(a.t_ymean + c) : "memory");
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(sys_[j]) : "v"(a.t_ystd + c) : "memory");
+                        }
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sy[j]), "+v"(sdn[j]), "+v"(ssg[j]), "+v"(sym[j]), "+v"(sys_[j]) :: "memory");
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            const int c = pc0 + RG * j;
+                            if (c < nout && prow) {
+                                const bool masked = (sy[j] == 1e-30f) | (sy[j] == 1e10f) | (sdn[j] == 1e-30f);
+                                const float yn = (sy[j] / ssg[j] - sym[j]) / sys_[j];
+                                cur[c] = masked ? -0.f : (yn - cur[c]) + 0.f;
+                            }
+                        }
+                    }
+                }
                 lds_barrier();
                 NS_STAMP();
                 ++si;
@@ -632,7 +731,32 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[0]), "+v"(Aq[1]) :: "memory");
     NS_STAMP();
 
-    if constexpr (STORE) return;                    // every output is in global memory already
+    if constexpr (STORE == 1 || STORE == 2) return; // every output is in global memory already
+    if constexpr (STORE == 3) {
+        // ---- 5 (loss).  delta and U = delta Cinv sit in LDS (as d and U of the dense serving program): chi2 = delta . U,
+        // loss_b = chi2 / den (util.py:1086-1088), d loss / d pred = -2 U inv_batch / den, zero where delta was masked
+        const float* const F = act + P * ABUF + pr * LD;
+        const bool rok = prow && row0 + pr < a.B;
+        const float* const Dv = a.u_same ? F : act + (P ^ 1) * ABUF + pr * LD;
+        const float* const Uv = a.u_same ? F + a.u_col : F;
+        float chi = 0.f;
+        for (int c = pc0; c < nout; c += RG) chi += Dv[c] * Uv[c];
+#pragma unroll
+        for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
+        if (rok) {
+            const float dr = lden[pr];
+            if (pc0 == 0) a.t_loss_rows[row0 + pr] = chi / dr;
+            for (int c = pc0; c < a.t_lddp; c += RG) {
+                float g = 0.f;
+                if (c < nout) {
+                    const bool masked = __float_as_uint(Dv[c]) == 0x80000000u;
+                    g = masked ? 0.f : (-2.f * Uv[c]) * a.t_inv_batch / dr;
+                }
+                a.t_dP[(size_t)(row0 + pr) * a.t_lddp + c] = g;
+            }
+        }
+        return;
+    }
     // ---- 5 (GRAD). d lnP / d x sits in buffer P: the derivative of the input transform and of the prior map
     // (util.py:339-347, 483-497), minus z for the Gaussian prior term; lnP from the turnaround
     if constexpr (GRAD) {
@@ -721,7 +845,7 @@ struct NsProgram {
     size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;   // LDS of the 16-row engine (lds_for: any engine)
     int dense = 0, u_col = 0, u_same = 0;                   // dense inverse covariance appended as the last segment
     size_t lds_for(int rows, bool grad) const {
-        size_t b = (size_t)(2 * rows * LD + ((bias_total + 3) & ~3)) * sizeof(float);
+        size_t b = (size_t)(2 * rows * LD + ((bias_total + 3) & ~3)) * sizeof(float) + 128;   // + [16] set rows, [16] den (STORE == 3)
 #ifdef NS_STAMPS
         b += NS_NW * 32 * 8;
 #endif
@@ -934,7 +1058,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     p.bias_total = bias_off;
     p.LD = std::max(((maxext + 63) & ~63) + 4, 516);        // >= 516: SPLIT partials need [8][rows][64] floats in one buffer
     if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
-    p.lds_bytes = (size_t)(2 * NS_ROWS * p.LD + ((bias_off + 3) & ~3)) * sizeof(float);
+    p.lds_bytes = (size_t)(2 * NS_ROWS * p.LD + ((bias_off + 3) & ~3)) * sizeof(float) + 128;
 #ifdef NS_STAMPS
     p.lds_bytes += NS_NW * 32 * 8;
 #endif
@@ -1125,6 +1249,37 @@ int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, co
     return ns_launch_kernel<0, false, 1>(a, B, p, rows, s);
 }
 
+
+// Training forward + loss in one launch (STORE == 3): X[n][ldx] the resident set, ROWS the batch (null: rows 0..B-1);
+// `dn` = {Cinv, ldc, null, null}: the inverse covariance in the network's normalised output space as the last segment.
+int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
+                            const int* ROWS, int B, const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb,
+                            float* const* y, const int* ldy, float* const* t, const int* ldt, const NsTrainLoss& L,
+                            const NsDense& dn, int rows, hipStream_t s) {
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 0, &dn);
+    if (!p.ok || !p.dense) { set_error("net_stream: network + loss not eligible"); return LINNA_ERR_UNSUPPORTED; }
+    NsArgs a;
+    ::memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.Z = X; a.ldz = ldx; a.B = B; a.nin = in_size;
+    a.is_flat = reinterpret_cast<const int*>(xmean); a.a1 = xmean; a.a2 = xmean;     // loaded and ignored
+    a.lg = lg; a.xmean = xmean; a.xstd = xstd;
+    a.packed = packed;
+    a.Gstride = p.Gstride; a.nseg_f = p.nseg_f; a.G = p.G; a.nseg = p.nseg_f;
+    a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
+    a.T = 1.f;
+    a.dense = p.dense; a.u_col = p.u_col; a.u_same = p.u_same;
+    for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
+    for (int i = 0; i < p.nseg_f; ++i) {
+        const int op = p.seg_op[i];
+        if (op >= nl) continue;                                   // the loss segment stores nothing
+        if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
+        else { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
+    }
+    a.t_rows = ROWS; a.t_xb = XB; a.t_ldxb = ldxb;
+    a.t_Y = L.Y; a.t_ldy = L.ldy; a.t_sigma = L.sigma; a.t_ymean = L.ymean; a.t_ystd = L.ystd; a.t_dnorm = L.data_norm;
+    a.t_den = L.den; a.t_inv_batch = L.inv_batch; a.t_loss_rows = L.loss_rows; a.t_dP = L.dP; a.t_lddp = L.lddp;
+    return ns_launch_kernel<0, false, 3>(a, B, p, rows, s);
+}
 }  // namespace linna
 
 namespace linna {

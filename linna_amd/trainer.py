@@ -61,8 +61,10 @@ class TrainEngine(object):
             self.loss_mean = self.model.grad_tail()      # right behind the gradients: ONE all-reduce carries both
         self.rows = torch.zeros(B, dtype=torch.int32, device=dev)
         self.graph = None
+        self.one_launch = None                           # None: try linna_net_forward_loss on the first step
         self.inv_batch = 1.0 / (B * self.world)          # the global batch is B per rank x ranks
         _lib.call("linna_net_prepare", self.model.net_handle(with_grads=True), 1, 0)   # no allocation on the launch path
+        _lib.call("linna_net_prepare_loss", self.model.net_handle(with_grads=True), C.byref(self.desc))
 
     def _chi2_md(self, Y):
         n = Y.shape[0]
@@ -81,6 +83,24 @@ class TrainEngine(object):
         k, st = self.k, _lib.stream()
         rows = self.rows if rows is None else rows
         loss_out = self.loss_mean if loss_out is None else loss_out
+        if self.one_launch is not False:
+            # gather + transform + forward + loss + d loss / d pred in ONE launch when the network and the loss fit the
+            # whole-network kernel (seven launches otherwise)
+            m = self.model
+            rc = _lib.load().linna_net_forward_loss(
+                m.net_handle(with_grads=True), C.byref(self.desc), _lib.ptr(self.X), self.X.stride(0), _lib.iptr(rows), self.B,
+                _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]), _lib.ptr(self.xb),
+                self.xb.stride(0), _lib.ptr(m.workspace(self.B)), _lib.ptr(self.predb), self.predb.stride(0), _lib.ptr(self.Y),
+                self.Y.stride(0), _lib.ptr(self.den), self.inv_batch, _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
+                self.dpred.stride(0), st)
+            if rc == 0:
+                self.one_launch = True
+                m._last_input = self.xb
+                m.backward(self.dpred[:, :self.nout], param_grads=True)
+                return
+            if rc != _lib.ERR_UNSUPPORTED or self.one_launch is True:
+                _lib.check(rc)
+            self.one_launch = False
         _lib.call("linna_gather_xform", self.ctx, _lib.ptr(self.X), self.X.stride(0), _lib.iptr(rows), self.B, self.nin,
                   _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]),
                   _lib.ptr(self.xb), self.xb.stride(0), st)
@@ -135,6 +155,7 @@ class TrainEngine(object):
         # nothing runs before the capture: linna_net_prepare (below, and in __init__) has allocated the weight streams,
         # the descriptor table of the grouped parameter-gradient launch travels as kernel arguments
         _lib.call("linna_net_prepare", self.model.net_handle(with_grads=True), 1, 0)
+        _lib.call("linna_net_prepare_loss", self.model.net_handle(with_grads=True), C.byref(self.desc))
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
