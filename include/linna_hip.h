@@ -300,7 +300,11 @@ int linna_net_prepare_loss(linna_net_t* net, const linna_loss_desc_t* d);   /* a
 int linna_net_forward_loss(linna_net_t* net, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                            const int* log10_flag, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws,
                            float* PRED, int ldp, const float* Y, int ldy, const float* den, float inv_batch,
-                           float* loss_rows, float* loss_mean, float* dPRED, int lddp, void* stream);
+                           float* loss_rows, float* loss_mean, float* dPRED, int lddp,
+                           /* optional (NULL, NULL, 0, 0): the AdamW state of the update that follows this step's backward --
+                            * its step counter and bias corrections are then advanced here, in the launch that takes the
+                            * batch mean, and linna_adamw_step is called with prepared = 1 */
+                           float* hyper, int* step_dev, float beta1, float beta2, void* stream);
 /* validation pieces (util.py:1124-1127): per-row loss and chisq_nnd/chisq_Md. */
 int linna_val_rows(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp,
                    const float* Y, int ldy, const float* den, int B, float* scratch, float* loss_rows,
@@ -315,6 +319,7 @@ int linna_gather_xform(linna_ctx_t* ctx, const float* X, int ldx, const int* ROW
  * device int32 `step_dev` and refreshes the two bias-correction slots before the update. */
 int linna_adamw_step(linna_ctx_t* ctx, float* p, const float* g, float* m, float* v, size_t n,
                      float* hyper, int* step_dev, float beta1, float beta2, float eps,
+                     int prepared /* 1: linna_net_forward_loss already advanced step_dev / hyper[2..3] for this step */,
                      void* stream);
 
 /* ------------------------------------------------------------------ ensemble / HMC moves

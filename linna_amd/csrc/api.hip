@@ -445,7 +445,8 @@ int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
 int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                            const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
                            int ldp, const float* Y, int ldy, const float* den, float inv_batch, float* loss_rows,
-                           float* loss_mean, float* dPRED, int lddp, void* stream) {
+                           float* loss_mean, float* dPRED, int lddp, float* hyper, int* step_dev, float b1, float b2,
+                           void* stream) {
     if (!n || !d || !X || !xmean || !xstd || !XB || !PRED || !Y || !den || !loss_rows || !dPRED || B < 1) {
         set_error("net_forward_loss: bad arguments"); return LINNA_ERR_INVALID;
     }
@@ -477,6 +478,10 @@ int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const flo
     const NsTrainLoss L{Y, ldy, d->sigma, d->ymean, d->ystd, d->data_norm, den, inv_batch, loss_rows, dPRED, lddp};
     TRY(launch_net_stream_train(n->L.data(), nl, n->in_size, packed, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, y.data(),
                                 ldy_.data(), t.data(), ldt.data(), L, n->loss_dn, rows, S(stream)));
+    // the batch mean -- and, when the caller hands in its AdamW state, the step counter and bias corrections of the
+    // update that will follow this step's backward (linna_adamw_step(prepared = 1)): two single-thread jobs, one launch
+    if (loss_mean && hyper && step_dev) return launch_sum_scale_prepare(loss_rows, B, inv_batch, loss_mean, step_dev, hyper, b1, b2, S(stream));
+    if (hyper && step_dev) TRY(launch_adamw_prepare(hyper, step_dev, b1, b2, S(stream)));
     if (loss_mean) TRY(launch_sum_scale(loss_rows, B, inv_batch, loss_mean, S(stream)));
     return LINNA_OK;
 }
@@ -985,12 +990,13 @@ int linna_gather_xform(linna_ctx_t*, const float* X, int ldx, const int* ROWS, i
 }
 
 int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev,
-                     float b1, float b2, float eps, void* stream) {
+                     float b1, float b2, float eps, int prepared, void* stream) {
     if (!p || !g || !m || !v || !hyper || !step_dev) { set_error("adamw_step: null pointer"); return LINNA_ERR_INVALID; }
     g_weights_epoch.fetch_add(1);
-    // (The step counter and the bias corrections stay in a launch of their own: folding them into the update with an
-    //  arrival counter measured 5 us slower than the extra launch.)
-    return launch_adamw(p, g, m, v, n, hyper, step_dev, b1, b2, eps, S(stream));
+    // The step counter and the bias corrections are a single-thread launch of their own (folding them into the update
+    // with an arrival counter measured 5 us slower than the extra launch): in front of the update here, or -- `prepared`
+    // -- already advanced by linna_net_forward_loss, in the launch that takes the batch mean of the loss.
+    return launch_adamw(p, g, m, v, n, hyper, prepared ? nullptr : step_dev, b1, b2, eps, S(stream));
 }
 
 // ------------------------------------------------------------------ moves

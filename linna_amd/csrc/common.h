@@ -73,12 +73,15 @@ int launch_loss_rows(int mode, const float* partial, int slots_ld, int nslots, i
 int launch_loss_grad(const float* U, int ldu, const float* Y, int ldy, const int* ROWS, int B, int nout,
                      const float* data_norm, const float* den, float inv_batch, float* dP, int lddp, hipStream_t s);
 int launch_sum_scale(const float* v, int n, float scale, float* out, hipStream_t s);
+int launch_sum_scale_prepare(const float* v, int n, float scale, float* out, int* step_dev, float* hyper, float b1, float b2,
+                             hipStream_t s);
 int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const float* den, float* frac, hipStream_t s);
 int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg, const float* xmean,
                         const float* xstd, float* XB, int ldxb, hipStream_t s);
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s);
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,
                  float eps, hipStream_t s);
+int launch_adamw_prepare(float* hyper, int* step_dev, float b1, float b2, hipStream_t s);
 int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const float* ccoords, int ldcc,
                            const int* C, int nc, uint64_t seed, const int* step_dev, int stream_id, float a, float* Q,
                            int ldq, float* factors, hipStream_t s);

@@ -244,6 +244,27 @@ __global__ __launch_bounds__(1024) void sum_scale_kernel(const float* __restrict
         out[0] = t * scale;
     }
 }
+// The same with the AdamW step counter and bias corrections advanced on the side (adamw_prepare_kernel): both are
+// single-thread jobs of every optimiser step, one launch instead of two.
+__global__ __launch_bounds__(1024) void sum_scale_prepare_kernel(const float* __restrict__ v, int n, float scale, float* __restrict__ out,
+                                                                 int* step, float* hyper, float beta1, float beta2) {
+    __shared__ float part[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += v[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = t * scale;
+    }
+    if (threadIdx.x == 64) {
+        const int t = ++step[0];
+        hyper[2] = (float)(1.0 - pow((double)beta1, (double)t));
+        hyper[3] = (float)sqrt(1.0 - pow((double)beta2, (double)t));
+    }
+}
 
 // frac[b] = |nnd_b / den_b - 1|  (util.py:1126)
 __global__ void val_frac_kernel(const float* __restrict__ partial, int slots_ld, int nslots, int B,
@@ -604,6 +625,11 @@ int launch_sum_scale(const float* v, int n, float scale, float* out, hipStream_t
     hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(1024), 0, s, v, n, scale, out);
     LAUNCH_CHECK("sum_scale");
 }
+int launch_sum_scale_prepare(const float* v, int n, float scale, float* out, int* step_dev, float* hyper, float b1, float b2,
+                             hipStream_t s) {
+    hipLaunchKernelGGL(sum_scale_prepare_kernel, dim3(1), dim3(1024), 0, s, v, n, scale, out, step_dev, hyper, b1, b2);
+    LAUNCH_CHECK("sum_scale_prepare");
+}
 int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const float* den, float* frac, hipStream_t s) {
     hipLaunchKernelGGL(val_frac_kernel, grid1d(B, 256), dim3(256), 0, s, partial, slots_ld, nslots, B, den, frac);
     LAUNCH_CHECK("val_frac");
@@ -620,9 +646,13 @@ int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db,
 }
 int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev, float b1, float b2,
                  float eps, hipStream_t s) {
-    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, s, step_dev, hyper, b1, b2);
+    if (step_dev) hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, s, step_dev, hyper, b1, b2);   // null: already advanced
     hipLaunchKernelGGL(adamw_kernel, grid1d(n, 256), dim3(256), 0, s, p, g, m, v, n, hyper, b1, b2, eps);
     LAUNCH_CHECK("adamw");
+}
+int launch_adamw_prepare(float* hyper, int* step_dev, float b1, float b2, hipStream_t s) {
+    hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(1), 0, s, step_dev, hyper, b1, b2);
+    LAUNCH_CHECK("adamw_prepare");
 }
 int launch_stretch_propose(const float* coords, int ldc, int ndim, const int* S, int ns, const float* ccoords, int ldcc,
                            const int* C, int nc, uint64_t seed, const int* step_dev, int stream_id, float a, float* Q,

@@ -183,11 +183,12 @@ class _AdamWState(object):
     def push_hyper(self):
         self.hyper[:2].copy_(torch.tensor([self.lr, self.weight_decay], dtype=torch.float32))
 
-    def apply(self):
+    def apply(self, prepared=False):
+        """``prepared``: this step's counter / bias corrections were advanced by ``linna_net_forward_loss`` already."""
         n = self.model.flat_params().numel()
         _lib.call("linna_adamw_step", _lib.ctx(self.m.device.index), _lib.ptr(self.model.flat_params()),
                   _lib.ptr(self.model.flat_grads()), _lib.ptr(self.m), _lib.ptr(self.v), n, _lib.ptr(self.hyper),
-                  _lib.iptr(self.step_dev), self.betas[0], self.betas[1], self.eps, _lib.stream())
+                  _lib.iptr(self.step_dev), self.betas[0], self.betas[1], self.eps, 1 if prepared else 0, _lib.stream())
 
     def state_dict(self, snapshot=None):
         """torch.optim.AdamW-shaped state; ``snapshot`` = (m, v, step_dev, lr, weight_decay) device copies taken at

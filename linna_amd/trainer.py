@@ -76,7 +76,7 @@ class TrainEngine(object):
         return den
 
     # ------------------------------------------------------------------ one optimiser step
-    def _forward_loss_backward(self, rows=None, loss_out=None):
+    def _forward_loss_backward(self, rows=None, loss_out=None, opt=None):
         """``rows`` / ``loss_out``: device int32 row indices and a 1-float device slot for the mean loss; default the
         engine's own fixed buffers (what a captured graph needs).  Direct launches pass the caller's tensors and save
         two copy kernels per step."""
@@ -92,9 +92,12 @@ class TrainEngine(object):
                 _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]), _lib.ptr(self.xb),
                 self.xb.stride(0), _lib.ptr(m.workspace(self.B)), _lib.ptr(self.predb), self.predb.stride(0), _lib.ptr(self.Y),
                 self.Y.stride(0), _lib.ptr(self.den), self.inv_batch, _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
-                self.dpred.stride(0), st)
+                self.dpred.stride(0), _lib.ptr(opt.hyper) if opt is not None else None,
+                _lib.iptr(opt.step_dev) if opt is not None else None, opt.betas[0] if opt is not None else 0.0,
+                opt.betas[1] if opt is not None else 0.0, st)
             if rc == 0:
                 self.one_launch = True
+                self._prepared = opt is not None
                 m._last_input = self.xb
                 m.backward(self.dpred[:, :self.nout], param_grads=True)
                 return
@@ -114,21 +117,22 @@ class TrainEngine(object):
     def _step_body(self, opt, rows=None, loss_out=None, local=False):
         """``local``: this rank alone (no collective, gradient of its own batch) -- the learning-rate range test, which
         the reference runs on rank 0 only, on a private copy of the model (predictor_gpu.py:223-227)."""
+        self._prepared = False
         if self.world > 1 and not local:
             from . import dist as ldist
-            self._forward_loss_backward(rows, self.loss_mean)
+            self._forward_loss_backward(rows, self.loss_mean, opt)
             ldist.allreduce_grads(self.model.flat_grads(), self.loss_mean, self.group)        # RCCL over xGMI
             if loss_out is not None:
                 loss_out.copy_(self.loss_mean, non_blocking=True)
         elif local and self.world > 1:
             keep, self.inv_batch = self.inv_batch, 1.0 / self.B
             try:
-                self._forward_loss_backward(rows, loss_out)
+                self._forward_loss_backward(rows, loss_out, opt)
             finally:
                 self.inv_batch = keep
         else:
-            self._forward_loss_backward(rows, loss_out)
-        opt.apply()
+            self._forward_loss_backward(rows, loss_out, opt)
+        opt.apply(prepared=self._prepared)
 
     def step(self, opt, rows_dev, loss_out=None):
         """One optimiser step on the int32 device index vector ``rows_dev[B]``; the mean loss of the step lands in

@@ -318,7 +318,7 @@ def test_stream_kernel_follows_weight_updates():
     flat = model.flat_params()
     lp.evaluate(zd)                                      # copy is fresh here
     _lib.call("linna_adamw_step", _lib.ctx(0), _lib.ptr(flat), _lib.ptr(g), _lib.ptr(m), _lib.ptr(v),
-              C.c_size_t(n), _lib.ptr(hyper), _lib.iptr(step), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8),
+              C.c_size_t(n), _lib.ptr(hyper), _lib.iptr(step), C.c_float(0.9), C.c_float(0.999), C.c_float(1e-8), 0,
               _lib.stream())
     d = check()
     assert np.abs(d - c).max() > 1e-3
