@@ -295,11 +295,16 @@ int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, 
  * whole-network kernel when the network and the loss fit it (LINNA_ERR_UNSUPPORTED otherwise: run linna_gather_xform,
  * linna_net_forward and linna_chi2_ratio_loss_fwd_bwd instead).  X[n][ldx]: the resident, untransformed training
  * inputs; XB[B][ldxb]: the transformed batch (out; the first layer's parameter gradient reads it); ws: forward
- * workspace of linna_net_fwd_ws_bytes(net, B); PRED[B][ldp]: raw network output (out). */
+ * workspace of linna_net_fwd_ws_bytes(net, B); PRED[B][ldp]: raw network output (out); YN[n][ldyn]: the normalised
+ * targets of the resident set (linna_loss_targets). */
 int linna_net_prepare_loss(linna_net_t* net, const linna_loss_desc_t* d);   /* allocates its weight stream (outside a capture) */
+/* YN[i][j] = (Y[i][j]/sigma_j - ymean_j)/ystd_j, NaN where the element is masked (util.py:1072): the normalised targets
+ * of a whole data set, computed once; linna_net_forward_loss subtracts its prediction from them */
+int linna_loss_targets(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* YN, int ldyn,
+                       void* stream);
 int linna_net_forward_loss(linna_net_t* net, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                            const int* log10_flag, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws,
-                           float* PRED, int ldp, const float* Y, int ldy, const float* den, float inv_batch,
+                           float* PRED, int ldp, const float* YN, int ldyn, const float* den, float inv_batch,
                            float* loss_rows, float* loss_mean, float* dPRED, int lddp,
                            /* optional (NULL, NULL, 0, 0): the AdamW state of the update that follows this step's backward --
                             * its step counter and bias corrections are then advanced here, in the launch that takes the

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "linna_chi2_md": (_I, [_V, C.POINTER(LossDesc), _V, _I, _I, _V, _V, _V]),
     "linna_chi2_ratio_loss_fwd_bwd": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _V, _I, _V, _V, _V, _V, _I, _F, _V]),
     "linna_net_prepare_loss": (_I, [_V, C.POINTER(LossDesc)]),
+    "linna_loss_targets": (_I, [_V, C.POINTER(LossDesc), _V, _I, _I, _V, _I, _V]),
     "linna_net_forward_loss": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _V, _V, _V, _I, _V, _V, _I, _V, _I, _V, _F, _V, _V, _V, _I,
                                     _V, _V, _F, _F, _V]),
     "linna_val_rows": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _I, _V, _V, _V, _V]),

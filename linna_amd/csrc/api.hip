@@ -430,6 +430,10 @@ static void net_ensure_loss(linna_net* n, const NsDense& dn) {
     n->stream_loss = 0; n->loss_dn = dn;
     if (ok && n->packed_loss.alloc(net_stream_dense_packed_floats(n->L.data(), nl, n->in_size, dn)) == LINNA_OK) n->stream_loss = 1;
 }
+int linna_loss_targets(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* YN, int ldyn, void* stream) {
+    if (!d || !Y || !YN || nrows < 1 || ldyn < d->nout) { set_error("loss_targets: bad arguments"); return LINNA_ERR_INVALID; }
+    return launch_loss_targets(Y, ldy, nrows, *d, YN, ldyn, S(stream));
+}
 int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
     if (!n || !d) { set_error("net_prepare_loss: null argument"); return LINNA_ERR_INVALID; }
     const NsDense dn{d->Cinv, d->ldc, nullptr, nullptr};
@@ -444,10 +448,10 @@ int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
 // runs that sequence).  The batch mean is a second, tiny launch (fixed summation order).
 int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                            const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
-                           int ldp, const float* Y, int ldy, const float* den, float inv_batch, float* loss_rows,
+                           int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
                            float* loss_mean, float* dPRED, int lddp, float* hyper, int* step_dev, float b1, float b2,
                            void* stream) {
-    if (!n || !d || !X || !xmean || !xstd || !XB || !PRED || !Y || !den || !loss_rows || !dPRED || B < 1) {
+    if (!n || !d || !X || !xmean || !xstd || !XB || !PRED || !YN || !den || !loss_rows || !dPRED || B < 1) {
         set_error("net_forward_loss: bad arguments"); return LINNA_ERR_INVALID;
     }
     if (d->nout != n->out_size) { set_error("net_forward_loss: loss for %d outputs, network has %d", d->nout, n->out_size); return LINNA_ERR_INVALID; }
@@ -475,7 +479,7 @@ int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const flo
         y[i] = last ? PRED : w + f.y_off[i]; ldy_[i] = last ? ldp : ld4(n->L[i].N);
         t[i] = n->L[i].op == LINNA_OP_RESBLOCK ? w + f.t_off[i] : nullptr; ldt[i] = ld4(n->L[i].C);
     }
-    const NsTrainLoss L{Y, ldy, d->sigma, d->ymean, d->ystd, d->data_norm, den, inv_batch, loss_rows, dPRED, lddp};
+    const NsTrainLoss L{YN, ldyn, den, inv_batch, loss_rows, dPRED, lddp};
     TRY(launch_net_stream_train(n->L.data(), nl, n->in_size, packed, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, y.data(),
                                 ldy_.data(), t.data(), ldt.data(), L, n->loss_dn, rows, S(stream)));
     // the batch mean -- and, when the caller hands in its AdamW state, the step counter and bias corrections of the

@@ -144,8 +144,9 @@ int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, co
                             int B, float* const* y, const int* ldy, float* const* t, const int* ldt, const float* cscale,
                             const float* cshift, int rows, hipStream_t s);
 // training forward + chi^2-ratio loss in one launch (STORE == 3)
-struct NsTrainLoss { const float* Y; int ldy; const float* sigma; const float* ymean; const float* ystd; const float* data_norm;
+struct NsTrainLoss { const float* YN; int ldyn;      // normalised targets of the whole set, NaN where masked
                      const float* den; float inv_batch; float* loss_rows; float* dP; int lddp; };
+int launch_loss_targets(const float* Y, int ldy, int n, const linna_loss_desc_t& d, float* YN, int ldyn, hipStream_t s);
 int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
                             const int* ROWS, int B, const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb,
                             float* const* y, const int* ldy, float* const* t, const int* ldt, const NsTrainLoss& L,

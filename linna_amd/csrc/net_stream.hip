@@ -103,10 +103,11 @@ struct NsArgs {
     // STORE == 3 (one launch = gather + input transform + training forward + chi^2-ratio loss and its gradient,
     // predictor_gpu.py:274-285 with util.py:1070-1116): Z is the RESIDENT training set X[n][ldz], row `t_rows[b]` is
     // transformed in the prologue (and stored to t_xb for the first layer's parameter gradient); the last network layer's
-    // epilogue turns pred into delta = mask ? 0 : ynorm - pred in LDS; the program's last segment is U = delta Cinv; the
-    // finish writes loss_b = delta.U / den and d loss / d pred = -2 U inv_batch / den
+    // epilogue turns pred into delta = mask ? 0 : ynorm - pred in LDS (ynorm, with its mask, precomputed for the whole
+    // set: one load per element); the program's last segment is U = delta Cinv; the finish writes
+    // loss_b = delta.U / den and d loss / d pred = -2 U inv_batch / den
     const int* t_rows; float* t_xb; int t_ldxb;
-    const float* t_Y; int t_ldy; const float* t_sigma; const float* t_ymean; const float* t_ystd; const float* t_dnorm;
+    const float* t_Y; int t_ldy;            // NORMALISED targets of the whole set, NaN where masked (linna_loss_targets)
     const float* t_den; float t_inv_batch; float* t_loss_rows; float* t_dP; int t_lddp;
     // dense inverse covariance as the program's last segment: U = d S sits at column u_col of the current buffer
     // (u_same) or at column 0 with d in the other buffer; the finish takes chi2 = d . U
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 // STORE == 3, last network layer: the targets and the per-column constants of delta, fetched by inline-asm
                 // loads the compiler does not count (a visible load in this loop body would turn its counted vmcnt waits
                 // for the weight ring into vmcnt(0) in EVERY step); one explicit wait for all of them
-                float ty[NQ][4], tdn[NQ], tsg[NQ], tym[NQ], tys[NQ];
+                float ty[NQ][4];                        // STORE == 3: normalised targets; STORE == 2: gates
                 if constexpr (STORE == 3) {
                     if (si == nseg - 2) {
 #pragma unroll
@@ -542,15 +543,28 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                                 const float* py = a.t_Y + (size_t)lsrc[q_row(t, e)] * a.t_ldy + dc;
                                 asm volatile("global_load_dword %0, %1, off" : "=v"(ty[t][e]) : "v"(py) : "memory");
                             }
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(tdn[t]) : "v"(a.t_dnorm + dc) : "memory");
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(tsg[t]) : "v"(a.t_sigma + dc) : "memory");
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(tym[t]) : "v"(a.t_ymean + dc) : "memory");
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(tys[t]) : "v"(a.t_ystd + dc) : "memory");
                         }
 #pragma unroll
                         for (int t = 0; t < NQ; ++t)
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ty[t][0]), "+v"(ty[t][1]), "+v"(ty[t][2]), "+v"(ty[t][3]),
-                                         "+v"(tdn[t]), "+v"(tsg[t]), "+v"(tym[t]), "+v"(tys[t]) :: "memory");
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ty[t][0]), "+v"(ty[t][1]), "+v"(ty[t][2]), "+v"(ty[t][3]) :: "memory");
+                    }
+                }
+                if constexpr (STORE == 2) {
+                    // the gates (stored forward activations), by loads the compiler does not count -- a visible load in this
+                    // loop body makes every step's wait for the weight ring a vmcnt(0) -- with one explicit wait
+                    if (s_gmask) {
+#pragma unroll
+                        for (int t = 0; t < NQ; ++t) {
+                            const int mc = min(512 * pass + 64 * wave + q_col(t), s_gn - 1);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float* pg = s_gmask + (size_t)min(row0 + q_row(t, e), a.B - 1) * s_gmld + mc;
+                                asm volatile("global_load_dword %0, %1, off" : "=v"(ty[t][e]) : "v"(pg) : "memory");
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < NQ; ++t)
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ty[t][0]), "+v"(ty[t][1]), "+v"(ty[t][2]), "+v"(ty[t][3]) :: "memory");
                     }
                 }
                 unsigned mbits = 0xFFFFu;
@@ -573,19 +587,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
                         v = s_relu ? fmaxf(v, 0.f) : v;
                         if constexpr (STORE == 2) {
-                            if (s_gmask) {
-                                const int mr = min(row0 + q_row(t, e), a.B - 1), mc = min(512 * pass + 64 * wave + q_col(t), s_gn - 1);
-                                if (!(s_gmask[(size_t)mr * s_gmld + mc] > 0.f)) v = 0.f;
-                            }
+                            if (s_gmask && !(ty[t][e] > 0.f)) v = 0.f;
                         }
                         float v_lds = v;
                         if constexpr (STORE == 3) {
                             if (si == nseg - 2) {              // the network's last layer: delta replaces pred in LDS
                                 const int dc = 512 * pass + 64 * wave + q_col(t);
-                                const float y = ty[t][e], dn = tdn[t];
-                                const bool masked = (y == 1e-30f) | (y == 1e10f) | (dn == 1e-30f);
-                                const float yn = (y / tsg[t] - tym[t]) / tys[t];
-                                v_lds = dc < nout ? (masked ? -0.f : (yn - v) + 0.f) : 0.f;   // -0: "masked", read back by the finish
+                                const float yn = ty[t][e];
+                                v_lds = dc < nout ? (isnan(yn) ? -0.f : (yn - v) + 0.f) : 0.f;   // -0: "masked", read back by the finish
                             }
                         }
                         nxt[q_row(t, e) * LD + q_col(t)] = v_lds;
@@ -625,7 +634,21 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 float* const cur = act + P * ABUF + pr * LD + s_dst;
                 const int ncol = 64 << s_ncgl, nkp = NW >> s_ncgl;
                 const int sw = SM ? 32 * (pr & 1) : 16 * (pr >> 2);
-                for (int c = pc0; c < (prow ? s_zext : 0); c += RG) {
+                constexpr int NGJ = 8;                  // (SPLIT outputs are <= 256 columns: 8 per thread)
+                float sg[NGJ];
+                if constexpr (STORE == 2) {
+                    if (s_gmask) {
+#pragma unroll
+                        for (int j = 0; j < NGJ; ++j) {
+                            const float* pg = s_gmask + (size_t)min(row0 + pr, a.B - 1) * s_gmld + min(pc0 + RG * j, s_gn - 1);
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(sg[j]) : "v"(pg) : "memory");
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sg[0]), "+v"(sg[1]), "+v"(sg[2]), "+v"(sg[3]), "+v"(sg[4]), "+v"(sg[5]),
+                                     "+v"(sg[6]), "+v"(sg[7]) :: "memory");
+                    }
+                }
+                int gj = 0;
+                for (int c = pc0; c < (prow ? s_zext : 0); c += RG, ++gj) {
                     float v = 0.f;
                     if (c < ncol) {
                         const float* src = part + (c >> 6) * PW + pr * 64 + ((c & 63) ^ sw);
@@ -637,7 +660,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
                         if constexpr (STORE == 2) {
-                            if (s_gmask && !(s_gmask[(size_t)min(row0 + pr, a.B - 1) * s_gmld + min(c, s_gn - 1)] > 0.f)) v = 0.f;
+                            float gv = 1.f;             // (dynamic register-array index: a select chain)
+#pragma unroll
+                            for (int j = 0; j < NGJ; ++j) gv = gj == j ? sg[j] : gv;
+                            if (s_gmask && !(gv > 0.f)) v = 0.f;
                         }
                         if constexpr (STORE) {
                             if (s_gout && row0 + pr < a.B && c < s_gn) {
@@ -655,27 +681,18 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         // the network's last layer (nout <= 256): thread (row pr, lane pc0) turns its own columns
                         // pc0 + 32 j of pred into delta, in place (asm loads: see the WIDE epilogue)
                         constexpr int NJ = 8;
-                        float sy[NJ], sdn[NJ], ssg[NJ], sym[NJ], sys_[NJ];
+                        float sy[NJ];
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
                             const int c = min(pc0 + RG * j, nout - 1);
                             asm volatile("global_load_dword %0, %1, off" : "=v"(sy[j]) : "v"(a.t_Y + (size_t)zsrc * a.t_ldy + c) : "memory");
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(sdn[j]) : "v"(a.t_dnorm + c) : "memory");
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(ssg[j]) : "v"(a.t_sigma + c) : "memory");
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(sym[j]) : "v"(a.t_ymean + c) : "memory");
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(sys_[j]) : "v"(a.t_ystd + c) : "memory");
                         }
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(sy[j]), "+v"(sdn[j]), "+v"(ssg[j]), "+v"(sym[j]), "+v"(sys_[j]) :: "memory");
+                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sy[0]), "+v"(sy[1]), "+v"(sy[2]), "+v"(sy[3]), "+v"(sy[4]), "+v"(sy[5]),
+                                     "+v"(sy[6]), "+v"(sy[7]) :: "memory");
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
                             const int c = pc0 + RG * j;
-                            if (c < nout && prow) {
-                                const bool masked = (sy[j] == 1e-30f) | (sy[j] == 1e10f) | (sdn[j] == 1e-30f);
-                                const float yn = (sy[j] / ssg[j] - sym[j]) / sys_[j];
-                                cur[c] = masked ? -0.f : (yn - cur[c]) + 0.f;
-                            }
+                            if (c < nout && prow) cur[c] = isnan(sy[j]) ? -0.f : (sy[j] - cur[c]) + 0.f;
                         }
                     }
                 }
@@ -1276,7 +1293,7 @@ int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, co
         else { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
     }
     a.t_rows = ROWS; a.t_xb = XB; a.t_ldxb = ldxb;
-    a.t_Y = L.Y; a.t_ldy = L.ldy; a.t_sigma = L.sigma; a.t_ymean = L.ymean; a.t_ystd = L.ystd; a.t_dnorm = L.data_norm;
+    a.t_Y = L.YN; a.t_ldy = L.ldyn;
     a.t_den = L.den; a.t_inv_batch = L.inv_batch; a.t_loss_rows = L.loss_rows; a.t_dP = L.dP; a.t_lddp = L.lddp;
     return ns_launch_kernel<0, false, 3>(a, B, p, rows, s);
 }

@@ -155,6 +155,20 @@ __global__ void loss_delta_kernel(int mode, const float* __restrict__ PRED, int 
     DELTA[idx] = masked ? 0.f : v;
 }
 
+// Normalised targets of a whole data set, once: YN = (y / sigma - ymean) / ystd (loss_delta_kernel's formula), NaN where
+// the element is masked (util.py:1072) -- what the one-launch training forward subtracts its prediction from.
+__global__ void loss_targets_kernel(const float* __restrict__ Y, int ldy, int n, int nout, const float* __restrict__ sigma,
+                                    const float* __restrict__ ymean, const float* __restrict__ ystd,
+                                    const float* __restrict__ data_norm, float* __restrict__ YN, int ldyn) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * ldyn) return;
+    const int i = (int)(idx / ldyn), j = (int)(idx % ldyn);
+    if (j >= nout) { YN[idx] = 0.f; return; }
+    const float y = Y[(size_t)i * ldy + j];
+    const bool masked = (y == 1e-30f) | (y == 1e10f) | (data_norm[j] == 1e-30f);
+    YN[idx] = masked ? __builtin_nanf("") : (y / sigma[j] - ymean[j]) / ystd[j];
+}
+
 // chi2_b = sum_s partial[b][s]; mode 0: out[b] = max(chi2, floor) (denominator, util.py:1086)
 // mode 1: out[b] = chi2 / den[r]
 __global__ void loss_rows_kernel(int mode, const float* __restrict__ partial, int slots_ld, int nslots, int B,
@@ -601,6 +615,11 @@ int launch_loss_delta(int mode, const float* PRED, int ldp, const float* Y, int 
     hipLaunchKernelGGL(loss_delta_kernel, grid1d((size_t)B * ldd, 256), dim3(256), 0, s, mode, PRED, ldp, Y, ldy, ROWS,
                        B, d.nout, d.sigma, d.ymean, d.ystd, d.data_norm, DELTA, ldd);
     LAUNCH_CHECK("loss_delta");
+}
+int launch_loss_targets(const float* Y, int ldy, int n, const linna_loss_desc_t& d, float* YN, int ldyn, hipStream_t s) {
+    hipLaunchKernelGGL(loss_targets_kernel, grid1d((size_t)n * ldyn, 256), dim3(256), 0, s, Y, ldy, n, d.nout, d.sigma, d.ymean,
+                       d.ystd, d.data_norm, YN, ldyn);
+    LAUNCH_CHECK("loss_targets");
 }
 int launch_loss_fused_small(const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
                             const linna_loss_desc_t& d, const float* den, float inv_batch, float* loss_rows, float* loss_mean,

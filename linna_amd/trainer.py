@@ -62,6 +62,7 @@ class TrainEngine(object):
         self.rows = torch.zeros(B, dtype=torch.int32, device=dev)
         self.graph = None
         self.one_launch = None                           # None: try linna_net_forward_loss on the first step
+        self.YN = None
         self.inv_batch = 1.0 / (B * self.world)          # the global batch is B per rank x ranks
         _lib.call("linna_net_prepare", self.model.net_handle(with_grads=True), 1, 0)   # no allocation on the launch path
         _lib.call("linna_net_prepare_loss", self.model.net_handle(with_grads=True), C.byref(self.desc))
@@ -90,8 +91,8 @@ class TrainEngine(object):
             rc = _lib.load().linna_net_forward_loss(
                 m.net_handle(with_grads=True), C.byref(self.desc), _lib.ptr(self.X), self.X.stride(0), _lib.iptr(rows), self.B,
                 _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]), _lib.ptr(self.xb),
-                self.xb.stride(0), _lib.ptr(m.workspace(self.B)), _lib.ptr(self.predb), self.predb.stride(0), _lib.ptr(self.Y),
-                self.Y.stride(0), _lib.ptr(self.den), self.inv_batch, _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
+                self.xb.stride(0), _lib.ptr(m.workspace(self.B)), _lib.ptr(self.predb), self.predb.stride(0), _lib.ptr(self._targets()),
+                self.YN.stride(0), _lib.ptr(self.den), self.inv_batch, _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
                 self.dpred.stride(0), _lib.ptr(opt.hyper) if opt is not None else None,
                 _lib.iptr(opt.step_dev) if opt is not None else None, opt.betas[0] if opt is not None else 0.0,
                 opt.betas[1] if opt is not None else 0.0, st)
@@ -113,6 +114,14 @@ class TrainEngine(object):
                   _lib.ptr(self.scratch), _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
                   self.dpred.stride(0), self.inv_batch, st)
         self.model.backward(self.dpred[:, :self.nout], param_grads=True)
+
+    def _targets(self):
+        """Normalised targets of the whole training set with their mask (``linna_loss_targets``), computed once."""
+        if self.YN is None:
+            self.YN = torch.empty((self.Y.shape[0], _lib.ld4(self.nout)), dtype=torch.float32, device=self.dev)
+            _lib.call("linna_loss_targets", self.ctx, C.byref(self.desc), _lib.ptr(self.Y), self.Y.stride(0), self.Y.shape[0],
+                      _lib.ptr(self.YN), self.YN.stride(0), _lib.stream())
+        return self.YN
 
     def _step_body(self, opt, rows=None, loss_out=None, local=False):
         """``local``: this rank alone (no collective, gradient of its own batch) -- the learning-rate range test, which
