@@ -391,7 +391,7 @@ def main():
         from linna_amd import dist as ldist
         if args.backend == "nccl":
             try:
-                ldist.comm_init(dev_index)
+                ldist.comm_init(dev_index, timeout=120.0)
                 collectives = "RCCL %s through the C ABI (linna_comm_init / linna_allreduce_sum_f32 / linna_allgather_f32)" % (ldist.comm_info(dev_index)[2],)
             except Exception as e:                                  # noqa: BLE001
                 collectives = "torch.distributed nccl (linna_comm_init failed: %s)" % repr(e)[:200]

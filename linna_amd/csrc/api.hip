@@ -762,7 +762,7 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
     const linna_logprob_desc_t& d = lp->d;
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
     const linna_net* n = lp->net;
-    if (!keep_activations && fused_enabled() && lp->packed.ready() && !d.outmap.cexp) {
+    if (!keep_activations && fused_enabled() && lp->packed.ready() && (!d.outmap.cexp || (d.outmap.cpost && d.outmap.cshift2 && !lp->dense_fused))) {
         // whole-network kernel (net_stream.hip): prior map -> every layer -> output transform -> diagonal
         // log-likelihood in ONE launch, weights streamed from the fragment-order copy
         const float* packed = nullptr; int rows = 16;
@@ -778,7 +778,7 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
         TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                               d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
                               d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, rows, nullptr,
-                              S(stream)));
+                              S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr, d.outmap.cexp ? d.outmap.cshift2 : nullptr));
         if (d.w) return LINNA_OK;
         return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
@@ -855,7 +855,8 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
     }
     const linna_logprob_desc_t& d = lp->d;
     if (ndim != d.nin) { set_error("logprob_eval_slice_points: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
-    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || (!d.w && !lp->dense_fused) || d.nin > 64) {
+    if (!fused_enabled() || !lp->packed.ready() || (d.outmap.cexp && (!d.w || !d.outmap.cpost || !d.outmap.cshift2)) ||
+        (!d.w && !lp->dense_fused) || d.nin > 64) {
         set_error("logprob_eval_slice_points: this log-probability does not run the whole-network kernel");
         return LINNA_ERR_UNSUPPORTED;          // the caller falls back to linna_slice_points + linna_logprob_eval_if
     }
@@ -868,7 +869,8 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
     return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, df ? nullptr : d.outmap.cscale, df ? nullptr : d.outmap.cshift,
                              df ? nullptr : d.w, d.temperature, lnP, nullptr, 0, nullptr, 0, &mv, nullptr, gate, rows,
-                             df ? &dn : nullptr, S(stream));
+                             df ? &dn : nullptr, S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr,
+                             d.outmap.cexp ? d.outmap.cshift2 : nullptr);
 }
 
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
@@ -879,7 +881,8 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     }
     const linna_logprob_desc_t& d = lp->d;
     if (ndim != d.nin) { set_error("stretch_half_step: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
-    if (!fused_enabled() || !lp->packed.ready() || d.outmap.cexp || (!d.w && !lp->dense_fused) || d.nin > 64) {
+    if (!fused_enabled() || !lp->packed.ready() || (d.outmap.cexp && (!d.w || !d.outmap.cpost || !d.outmap.cshift2)) ||
+        (!d.w && !lp->dense_fused) || d.nin > 64) {
         set_error("stretch_half_step: this log-probability does not run the whole-network kernel");
         return LINNA_ERR_UNSUPPORTED;          // the caller falls back to propose / eval / accept
     }
@@ -892,7 +895,8 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, df ? nullptr : d.outmap.cscale, df ? nullptr : d.outmap.cshift,
                              df ? nullptr : d.w, d.temperature, nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, rows,
-                             df ? &dn : nullptr, S(stream));
+                             df ? &dn : nullptr, S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr,
+                             d.outmap.cexp ? d.outmap.cshift2 : nullptr);
 }
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,

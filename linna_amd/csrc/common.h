@@ -158,7 +158,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
-                      const NsDense* dn, hipStream_t s);
+                      const NsDense* dn, hipStream_t s, const float* cpost = nullptr, const float* cshift2 = nullptr);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);

@@ -91,6 +91,7 @@ struct NsArgs {
     int Gstride, nseg_f;                // steps per wave in the packed stream; forward segments (GRAD: the rest is the backward)
     const float* gscale; float* Gout; int ldg;   // GRAD: d(d)/d(raw output); d lnP / d z
     const float* cscale; const float* cshift; const float* w; float T;
+    const float* cpost; const float* cshift2;   // ypositive output map (util.py:540): d = exp(raw cscale + cshift) cpost + cshift2
     float* lnP; float* D; int ldd; float* TH; int ldt;
     unsigned long long* stamps;
     const int* gate;                    // optional: every workgroup leaves at once when gate[0] == 0 (speculatively queued rounds)
@@ -801,7 +802,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         const bool rok = prow && row0 + pr < a.B;
         float chi = 0.f;
         auto column = [&](int c, float cs, float ct, float ww) {
-            const float d = F[c] * cs + ct;
+            float d = F[c] * cs + ct;
+            if (a.cpost) d = expf(d) * a.cpost[c] + a.cshift2[c];
             if (a.D && rok) a.D[(size_t)(row0 + pr) * a.ldd + c] = d;
             chi += (d * ww) * d;
         };
@@ -1202,8 +1204,11 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
-                      const NsDense* dn, hipStream_t s) {
+                      const NsDense* dn, hipStream_t s, const float* cpost, const float* cshift2) {
     const NsProgram& p = ns_build_prog(layers, nl, in_size, 0, dn);
+    if ((cpost != nullptr) != (cshift2 != nullptr) || (cpost && (dn || gr))) {
+        set_error("net_stream: the exp output map needs cpost and cshift2, and has no dense / gradient program"); return LINNA_ERR_INVALID;
+    }
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     if (dn && (w || gr || cscale || cshift)) { set_error("net_stream: the dense program carries its own output map and has no fused gradient"); return LINNA_ERR_INVALID; }
     if (mv && (nin > 64 || (!w && !dn))) { set_error("net_stream: fused sampler moves need <= 64 parameters and a log-likelihood in the launch"); return LINNA_ERR_UNSUPPORTED; }
@@ -1218,6 +1223,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     a.nseg = gr ? (int)p.seg.size() : p.nseg_f;
     a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
+    a.cpost = cpost; a.cshift2 = cshift2;
     a.dense = p.dense; a.u_col = p.u_col; a.u_same = p.u_same;
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];

@@ -24,7 +24,7 @@ from . import _lib
 _comm = {}          # device index -> (rank, world) of the RCCL communicator held by that device's context
 
 
-def comm_init(device_index=None, group=None, rank=None, world=None, unique_id=None):
+def comm_init(device_index=None, group=None, rank=None, world=None, unique_id=None, timeout=None):
     """Create this rank's RCCL communicator (collective over the ranks of ``group``).  Rank 0 draws the unique id and
     every rank receives it through torch.distributed's object broadcast (any backend), unless ``unique_id`` bytes are
     handed in (a file, a store).  One rank per device: RCCL refuses two ranks on one GPU."""
@@ -44,8 +44,32 @@ def comm_init(device_index=None, group=None, rank=None, world=None, unique_id=No
         unique_id = box[0]
     if len(unique_id) != _lib.COMM_ID_BYTES:
         raise ValueError("an RCCL unique id is %d bytes" % _lib.COMM_ID_BYTES)
-    with torch.cuda.device(device_index):
-        _lib.call("linna_comm_init", _lib.ctx(device_index), int(rank), int(world), C.create_string_buffer(unique_id, _lib.COMM_ID_BYTES))
+    ctx = _lib.ctx(device_index)
+    idbuf = C.create_string_buffer(unique_id, _lib.COMM_ID_BYTES)
+
+    def init():
+        with torch.cuda.device(device_index):
+            _lib.call("linna_comm_init", ctx, int(rank), int(world), idbuf)
+    if timeout is None:
+        init()
+    else:
+        # ncclCommInitRank blocks until every rank has arrived; a rank that never does would hang the job.  Run it on a
+        # thread and give up after `timeout` seconds (the caller then keeps torch.distributed as the transport).
+        import threading
+        err = []
+
+        def run():
+            try:
+                init()
+            except Exception as e:                          # noqa: BLE001
+                err.append(e)
+        t = threading.Thread(target=run, name="linna-comm-init", daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            raise _lib.LinnaHipError("linna_comm_init did not return within %.0f s" % timeout)
+        if err:
+            raise err[0]
     _comm[device_index] = (int(rank), int(world))
     return _comm[device_index]
 

@@ -232,6 +232,32 @@ def test_whole_network_kernel_edges_and_agreement_with_layered_path():
     np.testing.assert_allclose(got, ref, rtol=6e-4)
 
 
+def test_ypositive_output_map_runs_in_the_whole_network_kernel(monkeypatch):
+    """``Y_transform_class(ypositive=True)`` (util.py:532-542: exp of the affine map) is evaluated in the finish of the
+    whole-network kernel, so such emulators keep the one-launch evaluation and the one-launch sampler moves: against the
+    reference's golden values, the layer-by-layer path and the three-launch half step (bit for bit)."""
+    from linna_amd import sampler
+    lp, pred, yinv, prob = build_logprob("v2_4_2_ypos")
+    g = cases.golden("v2_4_2_ypos")
+    got = lp(g["z"], returntorch=False)
+    np.testing.assert_allclose(got, g["loglike"][:, 0], rtol=6e-4, atol=1e-5)
+    z = torch.as_tensor(np.random.RandomState(4).standard_normal((777, 4)).astype(np.float32) * 0.4, device="cuda")
+    fused = lp.evaluate(z).cpu().numpy()
+    monkeypatch.setenv("LINNA_DISABLE_FUSED", "1")
+    lp2 = build_logprob("v2_4_2_ypos")[0]
+    layered = lp2.evaluate(z).cpu().numpy()
+    monkeypatch.delenv("LINNA_DISABLE_FUSED")
+    np.testing.assert_allclose(fused, layered, rtol=3e-4, atol=1e-5)
+    x0 = np.random.RandomState(1).standard_normal((64, 4)).astype(np.float32) * 0.3
+    a = sampler.EnsembleSampler(64, 4, lp, seed=3, randomize_split=False)
+    b = sampler.EnsembleSampler(64, 4, lp, seed=3, randomize_split=False, fused=False)
+    a.set_state(x0); b.set_state(x0)
+    for _ in range(5):
+        a.step(); b.step()
+    assert a.fused is True and b.fused is False
+    assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp)
+
+
 def _custom_problem(nin, nout, seed, width, depth, dense=False):
     """A serving problem outside cases.SERVING (no golden file: checked against the oracle)."""
     import synth
