@@ -104,6 +104,7 @@ struct linna_net {
     StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
     int stream_bwd[2] = {-1, -1};            // -1 unknown, 0 no (network out of reach / LINNA_BWD_STREAM=0), 1 yes                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
     std::vector<linna_layer_t> L;   // without the trailing INSKIP
+    std::vector<linna_layer_t> Lfull;   // with it: what the serving programs of the whole-network kernel are built from
     int in_size, out_size;
     bool has_inskip;
     linna_layer_t inskip;
@@ -295,6 +296,8 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
         set_error("net_create: INSKIP needs a LINEAR first op"); delete n; return LINNA_ERR_INVALID;
     }
     n->out_size = width;
+    n->Lfull = n->L;
+    if (n->has_inskip) n->Lfull.push_back(n->inskip);
     *out = n;
     return LINNA_OK;
 }
@@ -738,13 +741,14 @@ static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, voi
     const unsigned long long epoch = g_weights_epoch.load();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(S(stream), &cap);
+    const std::vector<linna_layer_t>& LL = prog == 0 ? n->Lfull : n->L;     // (the forward programs carry the input skip)
     if (cap != hipStreamCaptureStatusNone) {
         // a captured launch carries its own re-layout, so that every replay sees the weights of that
         // moment; the copy is not valid for direct launches until they redo it
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
+        TRY(launch_net_stream_pack(LL.data(), (int)LL.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
         sc.epoch[k] = 0;
     } else if (sc.epoch[k] != epoch) {
-        TRY(launch_net_stream_pack(n->L.data(), (int)n->L.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
+        TRY(launch_net_stream_pack(LL.data(), (int)LL.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
         sc.epoch[k] = epoch;
     }
     *out = sc.buf[k];
@@ -771,11 +775,11 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
             // dense covariance: the output map is folded into the stream's last layer and the inverse covariance is its
             // last segment -- lnP comes out of the same launch
             const NsDense dn = lp->dense();
-            return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+            return launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                                      d.log10_flag, d.xmean, d.xstd, nullptr, nullptr, nullptr, d.temperature, lnP, nullptr, 0,
                                      TH, ldt, nullptr, nullptr, gate, rows, &dn, S(stream));
         }
-        TRY(launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+        TRY(launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                               d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature,
                               d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, rows, nullptr,
                               S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr, d.outmap.cexp ? d.outmap.cshift2 : nullptr));
@@ -803,17 +807,17 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     if (!(desc->temperature > 0.f)) { set_error("logprob_create: temperature must be > 0"); return LINNA_ERR_INVALID; }
     linna_logprob* lp = new linna_logprob{ctx, net, *desc};
     const NsDense dn = lp->dense();
-    const bool want_dense = !desc->w && desc->S && !desc->outmap.cexp && !net->has_inskip &&
+    const bool want_dense = !desc->w && desc->S && !desc->outmap.cexp &&
                             !(getenv("LINNA_DENSE_FUSED") && getenv("LINNA_DENSE_FUSED")[0] == '0');
-    if (want_dense && net_stream_dense_eligible(net->L.data(), (int)net->L.size(), net->in_size, dn)) {
+    if (want_dense && net_stream_dense_eligible(net->Lfull.data(), (int)net->Lfull.size(), net->in_size, dn)) {
         lp->dense_fused = true;
-        if (lp->packed.alloc(net_stream_dense_packed_floats(net->L.data(), (int)net->L.size(), net->in_size, dn)) != LINNA_OK) {
+        if (lp->packed.alloc(net_stream_dense_packed_floats(net->Lfull.data(), (int)net->Lfull.size(), net->in_size, dn)) != LINNA_OK) {
             set_error("logprob_create: hipMalloc(weight stream) failed");
             delete lp; return LINNA_ERR_HIP;
         }
-    } else if (!net->has_inskip && net_stream_eligible(net->L.data(), (int)net->L.size(), net->in_size)) {
-        const size_t nf = net_stream_packed_floats(net->L.data(), (int)net->L.size(), net->in_size);
-        lp->grad_fused = net_stream_has_grad(net->L.data(), (int)net->L.size(), net->in_size) && !desc->outmap.cexp &&
+    } else if (net_stream_eligible(net->Lfull.data(), (int)net->Lfull.size(), net->in_size)) {
+        const size_t nf = net_stream_packed_floats(net->Lfull.data(), (int)net->Lfull.size(), net->in_size);
+        lp->grad_fused = net_stream_has_grad(net->Lfull.data(), (int)net->Lfull.size(), net->in_size) && !desc->outmap.cexp &&
                          !(getenv("LINNA_DISABLE_FUSED_GRAD") && getenv("LINNA_DISABLE_FUSED_GRAD")[0] == '1');
         if (lp->packed.alloc(nf) != LINNA_OK) {
             set_error("logprob_create: hipMalloc(weight stream) failed");
@@ -866,7 +870,7 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
     NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, nullptr, ns, 0ull, nullptr, 0, 0, 0.f, nullptr, 1};
     const NsDense dn = lp->dense();
     const bool df = lp->dense_fused;
-    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
+    return launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, df ? nullptr : d.outmap.cscale, df ? nullptr : d.outmap.cshift,
                              df ? nullptr : d.w, d.temperature, lnP, nullptr, 0, nullptr, 0, &mv, nullptr, gate, rows,
                              df ? &dn : nullptr, S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr,
@@ -892,7 +896,7 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
     NsMove mv{coords, ldc, logp, S_idx, ccoords, ldcc, C_idx, nc, seed, step_dev, step_offset, stream_id, a, naccept, 0};
     const NsDense dn = lp->dense();
     const bool df = lp->dense_fused;
-    return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
+    return launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
                              d.a2, d.log10_flag, d.xmean, d.xstd, df ? nullptr : d.outmap.cscale, df ? nullptr : d.outmap.cshift,
                              df ? nullptr : d.w, d.temperature, nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, rows,
                              df ? &dn : nullptr, S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr,
@@ -911,7 +915,7 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
         TRY(lp_refresh_stream(lp, B, stream, &packed, &rows));
         const linna_net* n = lp->net;
         NsGrad gr{d.gscale, G, ldg};
-        return launch_net_stream(n->L.data(), (int)n->L.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
+        return launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                                  d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP,
                                  nullptr, 0, nullptr, 0, nullptr, &gr, nullptr, rows, nullptr, S(stream));
     }

@@ -79,7 +79,10 @@ struct NsSeg {            // kernel-side view of a segment
     int type, steps, passes, bias_off;
     int dst_col, relu, kslice, zext;   // SPLIT: kslice = k offset between K parts (16*steps), zext = columns written
     int ncg_log2;                      // SPLIT: log2 of the number of 64-column groups
-    int mask_store, mask_apply, pad2;  // GRAD: 1 + LDS slot of the ReLU sign bits this WIDE segment records / applies (0: none)
+    int mask_store, mask_apply;        // GRAD: 1 + LDS slot of the ReLU sign bits this WIDE segment records / applies (0: none)
+    int x0_n;                          // ... that many columns of them (a multiple of 16)
+    int x0_col;                        // > 0: the network INPUT rows (kept aside in LDS) are copied to this column of the segment's
+                                       // input buffer before it runs (ChtoModelv2_linear's input skip, nn.py:160-163,195)
 };
 
 struct NsArgs {
@@ -113,6 +116,7 @@ struct NsArgs {
     // dense inverse covariance as the program's last segment: U = d S sits at column u_col of the current buffer
     // (u_same) or at column 0 with d in the other buffer; the finish takes chi2 = d . U
     int dense, u_col, u_same;
+    int x0_keep;                        // the program copies the input rows somewhere later (NsSeg::x0_col): keep them in LDS
     // stretch move fused around the evaluation (MOVE instantiation; emcee StretchMove behind sampler.py:493-495)
     float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
@@ -125,6 +129,7 @@ struct NsPackSeg {
     const float* Wa; int lda, Ka, Kapad;          // first K part (Wa NULL: identity)
     const float* Wb; int ldb, Kb; float alpha;    // second K part, scaled (residual blocks)
     const float* b; float bscale;
+    const float* b2; float b2scale;                // second bias term (input skip: alpha * bl)
     int N, type, steps, passes, bias_off, bias_pad, ncg;
     int transA;                                   // Wa is read transposed: value(n, k) = Wa[k][n] (backward segments)
     int transB;                                   // the same for Wb
@@ -186,6 +191,7 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
     const NsPackSeg& S = p.seg[si];
     const int c = (int)j - S.bias_off;
     float bv = (c < S.N && S.b) ? S.bscale * S.b[c] : 0.f;
+    if (c < S.N && S.b2) bv += S.b2scale * S.b2[c];
     if (c < S.N && S.rscale) bv *= S.rscale[c];
     if (c < S.N && S.rshift) bv += S.rshift[c];
     p.out[nw4 * 4 + j] = bv;
@@ -405,6 +411,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     if constexpr (STORE == 3) {
         if (prow && pc0 == 0) { lsrc[pr] = zsrc; lden[pr] = zden; }
     }
+    float* const lx0 = lden + 16;                  // [ROWS][64]: the input rows, for a later input-skip segment
+    if (a.x0_keep && prow) {
+#pragma unroll
+        for (int i = 0; i < ZPRE; ++i) lx0[pr * 64 + pc0 + i * RG] = (pc0 + i * RG < kpad0) ? act[pr * LD + pc0 + i * RG] : 0.f;
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // raw: __syncthreads() would drain the weight stream
     asm volatile("" ::: "memory");
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // 4x4x1 engine: block b = lane >> 2 of the A read holds row set b & 3 (rows wrap below ROWS: never selected), k chunk b >> 2
     const int sm_arow = (4 * ((lane >> 2) & 3) + (lane & 3)) % ROWS, sm_achunk = lane >> 4;
     int si = 0, pass = 0, P = 0, kleft;
-    int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl, s_mstore = 0, s_mapply = 0;
+    int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl, s_mstore = 0, s_mapply = 0, s_x0col = 0, s_x0n = 0;
     unsigned* const lmask = reinterpret_cast<unsigned*>(lbias + ((a.bias_total + 3) & ~3));   // GRAD: [slot][512 lanes]
     float lnp_grad = 0.f;                          // GRAD: lnP, stored at the very end (no store next to the weight loads)
     float* s_gout = nullptr; int s_gld = 0, s_gn = 0;   // STORE: global destination of the current segment's output
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     auto load_seg = [&]() {
         const NsSeg S = a.seg[si];
         s_type = S.type; kleft = s_steps = S.steps; s_passes = S.passes; s_bias = S.bias_off;
-        s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2;
+        s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2; s_x0col = S.x0_col; s_x0n = S.x0_n;
         if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
         if constexpr (STORE) { s_gout = a.gout[si]; s_gld = a.gld[si]; s_gn = a.gn[si]; }
         if constexpr (STORE == 2) { s_gmask = a.gmask[si]; s_gmld = a.gmld[si]; }
@@ -513,7 +524,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             const int cur_steps = s_steps;
             auto take_next = [&]() {
                 s_type = NX.type; s_steps = NX.steps; s_passes = NX.passes; s_bias = NX.bias_off;
-                s_dst = NX.dst_col; s_relu = NX.relu; s_kslice = NX.kslice; s_zext = NX.zext; s_ncgl = NX.ncg_log2;
+                s_dst = NX.dst_col; s_relu = NX.relu; s_kslice = NX.kslice; s_zext = NX.zext; s_ncgl = NX.ncg_log2; s_x0col = NX.x0_col; s_x0n = NX.x0_n;
                 if constexpr (GRAD) { s_mstore = NX.mask_store; s_mapply = NX.mask_apply; }
                 if constexpr (STORE) { s_gout = nx_gout; s_gld = nx_gld; s_gn = nx_gn; }
                 if constexpr (STORE == 2) { s_gmask = nx_gmask; s_gmld = nx_gmld; }
@@ -726,6 +737,16 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #undef fin
 #undef q_row
 #undef q_col
+            if (seg_done && si < nseg && s_x0col > 0) {
+                // input skip: the kept input rows go behind this segment's regular input (one GEMM over [h ; x0])
+                if (prow) {
+                    float* const dstp = act + P * ABUF + pr * LD + s_x0col;
+#pragma unroll
+                    for (int i = 0; i < ZPRE; ++i)
+                        if (pc0 + i * RG < s_x0n) dstp[pc0 + i * RG] = lx0[pr * 64 + pc0 + i * RG];
+                }
+                lds_barrier();
+            }
             if (si < nseg) {
                 begin_run();
                 a_read(Aq[(U + 1) & 1]);           // replaces the speculative fragment
@@ -863,8 +884,9 @@ struct NsProgram {
     int Gstride = 0, nseg_f = 0, mask_slots = 0;            // G: forward steps; Gstride: forward + backward steps
     size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;   // LDS of the 16-row engine (lds_for: any engine)
     int dense = 0, u_col = 0, u_same = 0;                   // dense inverse covariance appended as the last segment
+    int x0_keep = 0;                                        // an input-skip segment copies the network input later
     size_t lds_for(int rows, bool grad) const {
-        size_t b = (size_t)(2 * rows * LD + ((bias_total + 3) & ~3)) * sizeof(float) + 128;   // + [16] set rows, [16] den (STORE == 3)
+        size_t b = (size_t)(2 * rows * LD + ((bias_total + 3) & ~3)) * sizeof(float) + 128 + (x0_keep ? 4096 : 0);   // + [16] set rows, [16] den (STORE == 3), kept input rows
 #ifdef NS_STAMPS
         b += NS_NW * 32 * 8;
 #endif
@@ -901,7 +923,8 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     // 1. linear maps: [Wa | alpha Wb] over K = [Kapad ; Kb], N outputs, written to dst_col (same_buf: into the input's buffer)
     struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
                  int N, relu, dst_col; bool same_buf; int transA = 0; int force_wide = 0; int mask_apply_of = -1; int op = -1;
-                 int transB = 0; const float* rscale = nullptr; const float* rshift = nullptr; };
+                 int transB = 0; const float* rscale = nullptr; const float* rshift = nullptr;
+                 const float* b2 = nullptr; float b2scale = 0.f; int x0_col = 0; };
     std::vector<Lin> lins;
     int width = in_size;
     for (int i = 0; i < nl && dx_prog; ++i) {                   // shape checks as in the forward program
@@ -931,7 +954,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     width = in_size;
     for (int i = 0; i < nl && !dx_prog; ++i) {
         const linna_layer_t& l = layers[i];
-        if (l.K != width) return p;
+        if (l.K != width && l.op != LINNA_OP_INSKIP) return p;
         if (l.op == LINNA_OP_LINEAR) {
             if (l.alpha != 1.f || l.N < 1 || l.N > 1024) return p;
             lins.push_back(Lin{l.W, (l.K + 3) & ~3, l.K, ceil16(l.K), nullptr, 0, 0, 0.f, l.b, 1.f, l.N, l.relu, 0, false});
@@ -943,6 +966,16 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
             lins.back().op = i;
             lins.push_back(Lin{l.Ws, (l.K + 3) & ~3, l.K, inpad, l.W2, (l.C + 3) & ~3, l.C, 0.1f, l.b2, 0.1f, l.N, 1, 0, false});
             lins.back().op = i;
+        } else if (l.op == LINNA_OP_INSKIP) {
+            // out = last(h) + alpha (x0 Wl^T + bl) (nn.py:195): the last layer becomes ONE GEMM over [h ; x0] with [W | alpha Wl]
+            // and bias b + alpha bl; x0 (the network input, kept in LDS) is copied behind h before the segment runs
+            if (i != nl - 1 || lins.empty() || l.K != in_size || l.N != width || in_size > 64 || mode == NS_PROG_FWD) return p;
+            Lin& last = lins.back();
+            if (last.Wb || last.same_buf || last.relu || !last.Wa) return p;
+            last.Wb = l.W; last.ldb = (l.K + 3) & ~3; last.Kb = l.K; last.alpha = l.alpha;
+            last.b2 = l.b; last.b2scale = l.alpha; last.x0_col = last.Kapad;
+            p.x0_keep = 1;
+            continue;
         } else {
             return p;
         }
@@ -1009,7 +1042,8 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         }
         q.Wa = L.Wa; q.lda = L.lda; q.Ka = L.Ka; q.Kapad = L.Kapad; q.Wb = L.Wb; q.ldb = L.ldb; q.Kb = L.Kb; q.alpha = L.alpha;
         q.b = L.b; q.bscale = L.bscale; q.N = L.N; q.type = s.type; q.steps = s.steps; q.passes = s.passes; q.bias_off = bias_off;
-        q.transA = L.transA; q.transB = L.transB; q.rscale = L.rscale; q.rshift = L.rshift;
+        q.transA = L.transA; q.transB = L.transB; q.rscale = L.rscale; q.rshift = L.rshift; q.b2 = L.b2; q.b2scale = L.b2scale;
+        s.x0_col = L.x0_col; s.x0_n = L.x0_col ? ceil16(L.Kb) : 0;
         if (L.transA && !dx_prog) {                                     // backward segments have no bias: ONE shared block of zeros
             if (zero_off < 0) { zero_off = bias_off; zero_pad = 0; }
             s.bias_off = q.bias_off = zero_off;
@@ -1077,7 +1111,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     p.bias_total = bias_off;
     p.LD = std::max(((maxext + 63) & ~63) + 4, 516);        // >= 516: SPLIT partials need [8][rows][64] floats in one buffer
     if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
-    p.lds_bytes = (size_t)(2 * NS_ROWS * p.LD + ((bias_off + 3) & ~3)) * sizeof(float) + 128;
+    p.lds_bytes = (size_t)(2 * NS_ROWS * p.LD + ((bias_off + 3) & ~3)) * sizeof(float) + 128 + (p.x0_keep ? 4096 : 0);
 #ifdef NS_STAMPS
     p.lds_bytes += NS_NW * 32 * 8;
 #endif
@@ -1224,7 +1258,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
     a.cpost = cpost; a.cshift2 = cshift2;
-    a.dense = p.dense; a.u_col = p.u_col; a.u_same = p.u_same;
+    a.dense = p.dense; a.u_col = p.u_col; a.u_same = p.u_same; a.x0_keep = p.x0_keep;
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
     a.stamps = nullptr; a.gate = gate;

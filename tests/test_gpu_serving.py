@@ -258,6 +258,48 @@ def test_ypositive_output_map_runs_in_the_whole_network_kernel(monkeypatch):
     assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp)
 
 
+@pytest.mark.parametrize("nin,nout", [(5, 3), (26, 40), (33, 33)])
+def test_input_skip_network_runs_in_the_whole_network_kernel(nin, nout, monkeypatch):
+    """``ChtoModelv2_linear`` (nn.py:136-198: ``layer8(h) + 1e-3 linearlayer(x)``, the class cosmolike_run.py:193 can
+    select by name): the input skip is the second K part of the last layer's GEMM -- the network input rows are kept in
+    LDS and copied behind h -- so the model keeps the one-launch evaluation and sampler moves.  Against the oracle, the
+    layer-by-layer path, and the three-launch half step (bit for bit); the reference's golden values (dense covariance:
+    whole-network kernel + row-dot GEMM) are checked by test_predict_and_logprob_match_reference[v2lin_5_3_log10]."""
+    import synth
+    from oracle import likelihood
+    from linna_amd import sampler
+    seed = 300 + nin
+    data, cov, priors = synth.gaussian_problem(nin, nout, seed, dense=False)
+    X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
+    w = synth.weights("ChtoModelv2_linear", nin, nout, seed)
+    w["linearlayer.weight"] = (w["linearlayer.weight"] * 30).astype(np.float32)        # make the 1e-3 branch count
+    prob = dict(kind="ChtoModelv2_linear", nin=nin, nout=nout, kw={}, weights=w, priors=priors, data=data, cov=cov,
+                invcov=np.linalg.inv(cov), sigma=np.sqrt(np.diag(cov)), X_mean=X_mean, X_std=X_std, y_mean=y_mean, y_std=y_std,
+                dolog10=None, ypositive=False)
+    lp = build_logprob(None, 1.0, prob)[0]
+    z = np.random.RandomState(2).standard_normal((333, nin)).astype(np.float32) * 0.5
+    zd = torch.as_tensor(z, device="cuda")
+    fused = lp.evaluate(zd).cpu().numpy()
+    ref = likelihood.log_prob(z, cases.oracle_emulator(prob), priors, data, prob["invcov"], 1.0)
+    np.testing.assert_allclose(fused, ref, rtol=6e-4, atol=1e-4)
+    monkeypatch.setenv("LINNA_DISABLE_FUSED", "1")
+    layered = build_logprob(None, 1.0, prob)[0].evaluate(zd).cpu().numpy()
+    monkeypatch.delenv("LINNA_DISABLE_FUSED")
+    np.testing.assert_allclose(fused, layered, rtol=3e-4, atol=1e-4)
+    # without the skip the values differ: the branch is really in the kernel
+    w0 = dict(w); w0["linearlayer.weight"] = np.zeros_like(w["linearlayer.weight"]); w0["linearlayer.bias"] = np.zeros_like(w["linearlayer.bias"])
+    noskip = build_logprob(None, 1.0, dict(prob, weights=w0))[0].evaluate(zd).cpu().numpy()
+    assert np.abs(noskip - fused).max() > 1e-3 * np.abs(fused).max()
+    x0 = np.random.RandomState(1).standard_normal((64, nin)).astype(np.float32) * 0.3
+    a = sampler.EnsembleSampler(64, nin, lp, seed=3, randomize_split=False)
+    b = sampler.EnsembleSampler(64, nin, lp, seed=3, randomize_split=False, fused=False)
+    a.set_state(x0); b.set_state(x0)
+    for _ in range(4):
+        a.step(); b.step()
+    assert a.fused is True and b.fused is False
+    assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp)
+
+
 def _custom_problem(nin, nout, seed, width, depth, dense=False):
     """A serving problem outside cases.SERVING (no golden file: checked against the oracle)."""
     import synth
