@@ -707,6 +707,8 @@ struct linna_logprob {
     linna_logprob_desc_t d;
     StreamCopy packed;                       // fragment-order weight streams (net_stream.hip), or not allocated
     bool grad_fused = false;                 // the streams also hold the backward segments (ReLU MLPs)
+    StreamCopy packed_g2;                    // forward + dX chain down to the input in one stream (any network: residual blocks, ...)
+    bool grad2 = false;
     bool dense_fused = false;                // the streams end in the dense inverse covariance (output map folded in)
     NsDense dense() const { return NsDense{d.S, d.lds, d.outmap.cscale, d.outmap.cshift}; }
 };
@@ -824,11 +826,18 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
             delete lp; return LINNA_ERR_HIP;
         }
     }
+    // lnP + gradient in one launch for the networks the MLP-only fused gradient does not cover (residual blocks, SPLIT
+    // segments): forward program + dX chain in one weight stream, gates from the activations the same launch stored
+    if (!lp->grad_fused && desc->w && desc->gscale && !desc->outmap.cexp && !net->has_inskip &&
+        !(getenv("LINNA_DISABLE_FUSED_GRAD") && getenv("LINNA_DISABLE_FUSED_GRAD")[0] == '1') &&
+        net_stream_dxi_eligible(net->L.data(), (int)net->L.size(), net->in_size)) {
+        if (lp->packed_g2.alloc(net_stream_dxi_packed_floats(net->L.data(), (int)net->L.size(), net->in_size)) == LINNA_OK) lp->grad2 = true;
+    }
     *out = lp;
     return LINNA_OK;
 }
 int linna_logprob_destroy(linna_logprob_t* lp) {
-    if (lp) lp->packed.release();
+    if (lp) { lp->packed.release(); lp->packed_g2.release(); }
     delete lp;
     return LINNA_OK;
 }
@@ -922,6 +931,27 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
     const LpLayout L = lp_layout(lp, B, 1);
     float* w = static_cast<float*>(ws);
     const int ldx = ld4(d.nin), ldd = ld4(d.nout);
+    if (fused_enabled() && lp->grad2 && lp->packed_g2.ready() && d.w) {
+        // ONE launch for any network: forward segments (activations kept in the workspace), turnaround, dX chain down to
+        // the input, prior map's derivative (net_stream.hip, GRAD + STORE == 2) -- six launches otherwise
+        linna_net* n = lp->net;
+        const int nl = (int)n->L.size();
+        const int rows = net_stream_rows(B);
+        const float* packed = nullptr;
+        TRY(stream_copy_refresh(lp->packed_g2, n, rows, stream, &packed, 3));
+        const FwdLayout f = fwd_layout(n, B);
+        float* base = w + L.fwd;
+        std::vector<float*> y(nl, nullptr), t(nl, nullptr);
+        std::vector<int> ldy(nl, 0), ldt(nl, 0);
+        for (int i = 0; i < nl; ++i) {
+            if (i < nl - 1) { y[i] = base + f.y_off[i]; ldy[i] = ld4(n->L[i].N); }
+            if (n->L[i].op == LINNA_OP_RESBLOCK) { t[i] = base + f.t_off[i]; ldt[i] = ld4(n->L[i].C); }
+        }
+        const NsGrad gr{d.gscale, G, ldg};
+        return launch_net_stream_grad2(n->L.data(), nl, n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag,
+                                       d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP, gr, y.data(),
+                                       ldy.data(), t.data(), ldt.data(), rows, S(stream));
+    }
     TRY(lp_forward(lp, Z, ldz, B, w, L, lnP, nullptr, 0, stream, true));
     if (d.w) {
         TRY(launch_loglike_diag_grad(w + L.d, ldd, B, d.nout, d.w, d.gscale, d.temperature, w + L.dh, ldd, S(stream)));

@@ -154,6 +154,14 @@ int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, co
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
 struct NsGrad { const float* gscale; float* G; int ldg; };
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);
+// forward + dX chain down to the input in one stream (any network both programs cover; diagonal covariance)
+bool net_stream_dxi_eligible(const linna_layer_t* layers, int nl, int in_size);
+size_t net_stream_dxi_packed_floats(const linna_layer_t* layers, int nl, int in_size);
+int launch_net_stream_grad2(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
+                            int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
+                            const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
+                            const NsGrad& gr, float* const* y, const int* ldy, float* const* t, const int* ldt, int rows,
+                            hipStream_t s);
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         theta[i] = th;
         const float t = (a.lg && zlg[i]) ? lt : th;
         float x = in ? (t - zxm[i]) / zxs[i] : 0.f;
-        if constexpr (STORE == 1 || STORE == 2) x = z;   // rows arrive transformed
+        if constexpr ((STORE == 1 || STORE == 2) && !GRAD) x = z;   // rows arrive transformed
         if constexpr (STORE == 3) {                 // X_transform of a gathered row (util.py:483-497), as linna_gather_xform
             float lz = log10f(z);
             asm volatile("" : "+v"(lz));
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             const float th = ns_prior_theta(z, a.is_flat[c], a.a1[c], a.a2[c]);
             const float t = (a.lg && a.lg[c]) ? log10f(th) : th;
             x = (t - a.xmean[c]) / a.xstd[c];
-            if constexpr (STORE == 1 || STORE == 2) x = z;
+            if constexpr ((STORE == 1 || STORE == 2) && !GRAD) x = z;
             if constexpr (STORE == 3) {
                 const float zz3 = a.Z[(size_t)zsrc * a.ldz + c];
                 x = (((a.lg && a.lg[c]) ? log10f(zz3) : zz3) - a.xmean[c]) / a.xstd[c];
@@ -571,7 +571,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float* pg = s_gmask + (size_t)min(row0 + q_row(t, e), a.B - 1) * s_gmld + mc;
-                                asm volatile("global_load_dword %0, %1, off" : "=v"(ty[t][e]) : "v"(pg) : "memory");
+                                if constexpr (GRAD)     // written earlier in this very launch: served by the L2, not this CU's L1
+                                    asm volatile("global_load_dword %0, %1, off sc1" : "=v"(ty[t][e]) : "v"(pg) : "memory");
+                                else
+                                    asm volatile("global_load_dword %0, %1, off" : "=v"(ty[t][e]) : "v"(pg) : "memory");
                             }
                         }
 #pragma unroll
@@ -653,7 +656,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
                         for (int j = 0; j < NGJ; ++j) {
                             const float* pg = s_gmask + (size_t)min(row0 + pr, a.B - 1) * s_gmld + min(pc0 + RG * j, s_gn - 1);
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(sg[j]) : "v"(pg) : "memory");
+                            if constexpr (GRAD)
+                                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(sg[j]) : "v"(pg) : "memory");
+                            else
+                                asm volatile("global_load_dword %0, %1, off" : "=v"(sg[j]) : "v"(pg) : "memory");
                         }
                         asm volatile("s_waitcnt vmcnt(0)" : "+v"(sg[0]), "+v"(sg[1]), "+v"(sg[2]), "+v"(sg[3]), "+v"(sg[4]), "+v"(sg[5]),
                                      "+v"(sg[6]), "+v"(sg[7]) :: "memory");
@@ -715,6 +721,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
             if constexpr (GRAD) {
                 if (seg_done && si == a.nseg_f) {   // (seg_done: not again after a pass of the first backward segment)
+                    if constexpr (STORE == 2)       // the forward activations every wave stored are in memory before any gate load
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     // ---- turnaround: the output rows (bias added) sit in buffer P.  lnP as in the finish, and
                     // d lnP / d out = -(d w) gscale / T written over them: the input of the first backward segment
                     float* const F = act + P * ABUF + pr * LD;
@@ -770,7 +778,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[0]), "+v"(Aq[1]) :: "memory");
     NS_STAMP();
 
-    if constexpr (STORE == 1 || STORE == 2) return; // every output is in global memory already
+    if constexpr ((STORE == 1 || STORE == 2) && !GRAD) return; // every output is in global memory already
     if constexpr (STORE == 3) {
         // ---- 5 (loss).  delta and U = delta Cinv sit in LDS (as d and U of the dense serving program): chi2 = delta . U,
         // loss_b = chi2 / den (util.py:1086-1088), d loss / d pred = -2 U inv_batch / den, zero where delta was masked
@@ -893,6 +901,7 @@ struct NsProgram {
         return b + (grad ? (size_t)mask_slots * 64 * NS_NW * sizeof(unsigned) : 0);
     }
     bool ok = false, grad_ok = false;                       // grad_ok: backward segments appended (ReLU MLPs)
+    bool dxi_ok = false;                                    // the dX chain down to the input appended (NS_PROG_FWD_DXI)
     std::vector<int> seg_op, seg_hidden;                    // forward segments: op index; 1 = the hidden h of a residual block
                                                             // (dX-chain program: 1 = d/dh of a residual block, else d/d(input) of the op)
 };
@@ -900,7 +909,7 @@ struct NsProgram {
 static int ceil16(int k) { return (k + 15) & ~15; }
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
-enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4 };
+enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4, NS_PROG_FWD_DXI = 5 };
 static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn = nullptr);
 static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
     NsProgram p = ns_build_one(layers, nl, in_size, NS_PROG_FWD);
@@ -927,7 +936,11 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
                  const float* b2 = nullptr; float b2scale = 0.f; int x0_col = 0; };
     std::vector<Lin> lins;
     int width = in_size;
-    for (int i = 0; i < nl && dx_prog; ++i) {                   // shape checks as in the forward program
+    // NS_PROG_FWD_DXI: the forward program followed by the dX chain down to the network input in ONE stream -- lnP and
+    // d lnP / d z in one launch for ANY network (residual blocks, SPLIT segments): the forward segments store their
+    // activations, the backward segments gate on them (the kernel's GRAD + STORE == 2 instantiation)
+    const bool fwd_dxi = mode == NS_PROG_FWD_DXI;
+    for (int i = 0; i < nl && (dx_prog || fwd_dxi); ++i) {      // shape checks as in the forward program
         const linna_layer_t& l = layers[i];
         if (l.K != width || l.N < 1 || l.N > 1024 || l.K > 1024) return p;
         if (l.op == LINNA_OP_LINEAR) { if (l.alpha != 1.f) return p; }
@@ -935,7 +948,8 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         else return p;
         width = l.N;
     }
-    for (int i = nl - 1; i >= (mode == NS_PROG_DX_INPUT ? 0 : 1) && dx_prog; --i) {
+    auto push_dx = [&](int first) {
+      for (int i = nl - 1; i >= first; --i) {
         const linna_layer_t& l = layers[i];
         const int npad = ceil16(l.N);
         if (l.op == LINNA_OP_LINEAR) {
@@ -950,7 +964,9 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
             B.transA = 1; B.transB = 1; B.op = i;
             lins.push_back(B);
         }
-    }
+      }
+    };
+    if (dx_prog) push_dx(mode == NS_PROG_DX_INPUT ? 0 : 1);
     width = in_size;
     for (int i = 0; i < nl && !dx_prog; ++i) {
         const linna_layer_t& l = layers[i];
@@ -996,6 +1012,11 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         p.dense = 1; p.u_col = Q.dst_col; p.u_same = behind ? 1 : 0;
     }
     const int nfwd = (int)lins.size();
+    if (fwd_dxi) {
+        if (in_size > 64 || lins.back().N > 64) return p;      // (prologue / turnaround constants are held for <= 64 columns)
+        push_dx(0);
+        if ((int)lins.size() > NS_MAXSEG) return p;
+    }
     // Backward (d lnP / d z) for plain ReLU MLPs whose hidden layers come out as WIDE segments: the backward
     // GEMM of layer l is a forward-shaped segment over W_l^T (contraction N_l, K_l outputs); for l >= 1 it is
     // forced WIDE so that its lane <-> (row, column) map equals that of the layer whose sign bits it applies.
@@ -1107,7 +1128,8 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     if (p.kpad0 > (dx_prog ? 1024 : 256)) return p;
     p.nout = lins[nfwd - 1].N;
     p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
-    for (int i = 0; i < nfwd; ++i) { p.seg_op.push_back(lins[i].op); p.seg_hidden.push_back(lins[i].same_buf ? 1 : 0); }
+    for (size_t i = 0; i < lins.size(); ++i) { p.seg_op.push_back(lins[i].op); p.seg_hidden.push_back(lins[i].same_buf ? 1 : 0); }
+    p.dxi_ok = fwd_dxi;
     p.bias_total = bias_off;
     p.LD = std::max(((maxext + 63) & ~63) + 4, 516);        // >= 516: SPLIT partials need [8][rows][64] floats in one buffer
     if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
@@ -1148,6 +1170,7 @@ int net_stream_rows(int B) {
 
 static NsProgram ns_build_prog_uncached(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn) {
     if (prog == 0 && dn) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DENSE, dn);
+    if (prog == 3) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DXI);
     return prog == 0 ? ns_build(layers, nl, in_size) : ns_build_one(layers, nl, in_size, prog == 2 ? NS_PROG_DX_INPUT : NS_PROG_DX);
 }
 // Kernel-configuration cache: a program is a pure function of the op list (shapes AND parameter pointers:
@@ -1233,6 +1256,8 @@ static int ns_launch_kernel(const NsArgs& a, int B, const NsProgram& p, int rows
 }
 
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 0).grad_ok; }
+bool net_stream_dxi_eligible(const linna_layer_t* layers, int nl, int in_size) { const NsProgram& p = ns_build_prog(layers, nl, in_size, 3); return p.ok && p.dxi_ok; }
+size_t net_stream_dxi_packed_floats(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 3).packed_floats; }
 
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
@@ -1306,6 +1331,43 @@ int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, co
     return ns_launch_kernel<0, false, 1>(a, B, p, rows, s);
 }
 
+
+// lnP and d lnP / d z in ONE launch for any network the forward and dX-chain programs cover (GRAD + STORE == 2): forward
+// segments store the activations the gates need (`y[i]` / `t[i]`: output of op i / hidden h of residual block i, in the
+// caller's workspace), the turnaround forms d lnP / d out, the dX chain runs down to the network input gating on those
+// activations, the finish applies the prior map's derivative.  Diagonal covariance.
+int launch_net_stream_grad2(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
+                            int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
+                            const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
+                            const NsGrad& gr, float* const* y, const int* ldy, float* const* t, const int* ldt, int rows,
+                            hipStream_t s) {
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 3);
+    if (!p.ok || !p.dxi_ok) { set_error("net_stream: no forward + dX program for this network"); return LINNA_ERR_UNSUPPORTED; }
+    if (!w || !lnP || !gr.gscale || !gr.G) { set_error("net_stream: the one-launch gradient needs a diagonal covariance"); return LINNA_ERR_INVALID; }
+    NsArgs a;
+    ::memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.Z = Z; a.ldz = ldz; a.B = B; a.nin = nin;
+    a.is_flat = is_flat; a.a1 = a1; a.a2 = a2; a.lg = lg; a.xmean = xmean; a.xstd = xstd;
+    a.packed = packed;
+    a.Gstride = p.Gstride; a.nseg_f = p.nseg_f; a.G = p.Gstride; a.nseg = (int)p.seg.size();
+    a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
+    a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T; a.lnP = lnP;
+    a.gscale = gr.gscale; a.Gout = gr.G; a.ldg = gr.ldg;
+    for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
+    for (int i = 0; i < (int)p.seg.size(); ++i) {
+        const int op = p.seg_op[i];
+        if (i < p.nseg_f) {                                   // forward: keep what a gate will ask for
+            if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
+            else if (op < nl - 1) { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
+        } else if (p.seg_hidden[i]) {                         // d/dh of residual block op: gated by its stored h
+            a.gmask[i] = t[op]; a.gmld[i] = ldt[op]; a.gn[i] = layers[op].C;
+        } else {                                              // d/d(input of op): gated by the producing op's output, if it went through a ReLU
+            const bool relu_in = op > 0 && (layers[op - 1].op == LINNA_OP_RESBLOCK || layers[op - 1].relu);
+            a.gmask[i] = relu_in ? y[op - 1] : nullptr; a.gmld[i] = relu_in ? ldy[op - 1] : 0; a.gn[i] = layers[op].K;
+        }
+    }
+    return ns_launch_kernel<0, true, 2>(a, B, p, rows, s);
+}
 
 // Training forward + loss in one launch (STORE == 3): X[n][ldx] the resident set, ROWS the batch (null: rows 0..B-1);
 // `dn` = {Cinv, ldc, null, null}: the inverse covariance in the network's normalised output space as the last segment.
