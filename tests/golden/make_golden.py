@@ -135,11 +135,32 @@ def gen_serving(out):
 
 
 # ------------------------------------------------------------------ fixture (2-D)
+def _fixture_model():
+    """The reference's ``retrieve_model`` (util.py:611-639) on its own fixture directory, with the FILES read by loaders
+    that execute nothing: the checkpoint through ``torch.load(weights_only=True)``, the three transform pickles through
+    this package's closed allow-list unpickler (their tensors move into the reference's transform classes)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from linna_amd import util as putil, nnutils as pnnutils
+    src = FIX_SRC + "/"
+
+    def safe(name):
+        with open(src + name, "rb") as f:
+            return putil.CPU_Unpickler(f).load()
+    xt, yt, yid = safe("X_transform.pkl"), safe("y_transform.pkl"), safe("y_invtransform_data.pkl")
+    X_transform = rutil.X_transform_class(xt.X_mean, xt.X_std, "cpu", xt.dolog10index)
+    y_transform = rutil.Y_transform_class(yt.y_mean, yt.y_std, "cpu", ypositive=yt.ypositive)
+    yinv = rutil.Y_invtransform_data(yid.sigma.detach().numpy(), "cpu")
+    net = rnn.ChtoModelv2(2, 2, None)
+    net.load_state_dict(pnnutils.read_checkpoint(src + "best.pth.tar")["state_dict"])
+    model = rpred.Predictor(2, 2, X_transform=X_transform, y_transform=y_transform, device="cpu", outdir=src, model=net)
+    return model, yinv
+
+
 def gen_fixture(out):
     os.makedirs(FIX_DST, exist_ok=True)
     for f in FIX_FILES:
         shutil.copyfile(os.path.join(FIX_SRC, f), os.path.join(FIX_DST, f))
-    model, yinv = rutil.retrieve_model(FIX_SRC + "/", 2, 2, rnn.ChtoModelv2)
+    model, yinv = _fixture_model()
     priors = [{"param": "test_%d" % i, "dist": "flat", "arg1": -2.0, "arg2": 2.0} for i in range(2)]
     cov = np.diag([0.5, 0.2])
     data = np.array([0.1, 1.0])
