@@ -141,7 +141,7 @@ def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
                 "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
-def driver_rate(lp, nwalkers, nsamp=5000):
+def driver_rate(lp, nwalkers, nsamp=10000):
     """The reference's emcee driver end to end (sampler.py:458-554 -> linna_amd.sampler.HMCSampler.sample): 100 burn-in
     iterations + restart, then `nsamp` iterations with everything a run does -- chain blocks device -> host, the
     reference's HDF5 layout appended every 100 iterations (chain + chain_transformed + log_prob: 1.1 MB per iteration
@@ -356,7 +356,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the step as a hipGraph instead of direct launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-training", action="store_true", help="skip the secondary training-throughput measurement")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the chto_v2 / dense_1000 serving objects")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the chto_v2 / dense_1000 serving objects (they run the "
+                    "same kernel instantiation as the headline: profile the headline without them)")
+    ap.add_argument("--no-driver", action="store_true", help="skip mcmc.driver_steps_per_s (an 11 GB chain file in the temporary directory)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank path on a box with fewer GPUs)")
     args = ap.parse_args()
@@ -535,7 +537,7 @@ def main():
         if training is not None:
             res["training"] = training
         res["mcmc"] = mcmc
-        if world == 1 and isinstance(mcmc, dict) and "error" not in mcmc:
+        if world == 1 and not args.no_driver and isinstance(mcmc, dict) and "error" not in mcmc:
             try:
                 res["mcmc"].update(driver_rate(lp, NWALKERS))
             except Exception as e:                                  # noqa: BLE001
