@@ -110,7 +110,7 @@ def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if not collected."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None
