@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 5   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss */
+#define LINNA_ABI_VERSION 6   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -326,6 +326,14 @@ int linna_adamw_step(linna_ctx_t* ctx, float* p, const float* g, float* m, float
                      float* hyper, int* step_dev, float beta1, float beta2, float eps,
                      int prepared /* 1: linna_net_forward_loss already advanced step_dev / hyper[2..3] for this step */,
                      void* stream);
+/* The same update over the flat buffer `p[n]` that holds exactly `net`'s tensors back to back (weights with rows padded
+ * to 4 floats, biases padded to 4), AND the re-layout of the updated weights into the two fragment-order weight streams
+ * a training step reads (linna_net_forward_loss's, the backward's dX chain) -- one launch instead of the update plus the
+ * two lazy re-layouts of the next step.  `B`: the batch size the steps run at (selects the engine, hence the stream
+ * layout).  LINNA_ERR_UNSUPPORTED when the network does not train through those two streams or the buffer is laid out
+ * differently: use linna_adamw_step then (the streams re-lay themselves).  (predictor_gpu.py:287 `optim.step()`.) */
+int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, float* m, float* v, size_t n,
+                         float* hyper, int* step_dev, float beta1, float beta2, float eps, int prepared, void* stream);
 
 /* ------------------------------------------------------------------ ensemble / HMC moves
  * Stretch move (emcee StretchMove, called at sampler.py:493-495,530): for the active half

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblinna_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
@@ -119,6 +119,7 @@ _SIGNATURES = {
     "linna_val_rows": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _I, _V, _V, _V, _V]),
     "linna_gather_xform": (_I, [_V, _V, _I, _V, _I, _I, _V, _V, _V, _V, _I, _V]),
     "linna_adamw_step": (_I, [_V, _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _I, _V]),
+    "linna_net_adamw_step": (_I, [_V, _I, _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _I, _V]),
     "linna_stretch_propose": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _F, _V, _I, _V, _V]),
     "linna_stretch_accept": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _V, _U64, _V, _I, _V, _V]),
     "linna_logprob_eval_if": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V, _V]),

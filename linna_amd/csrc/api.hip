@@ -102,6 +102,8 @@ struct linna_net {
     NsDense loss_dn{nullptr, 0, nullptr, nullptr};   // the inverse covariance that stream ends in
     int stream_loss = -1;                    // -1 unknown, 0 no (not eligible / LINNA_LOSS_STREAM=0), 1 yes
     StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
+    AsArgs as_args;                          // linna_net_adamw_step's descriptor table, valid for (as_params, as_n, as_k)
+    const float* as_params = nullptr; size_t as_n = 0; int as_k = -1; int as_state = -1;   // as_state: -1 unknown, 0 unsupported, 1 ready
     int stream_bwd[2] = {-1, -1};            // -1 unknown, 0 no (network out of reach / LINNA_BWD_STREAM=0), 1 yes                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
     std::vector<linna_layer_t> L;   // without the trailing INSKIP
     std::vector<linna_layer_t> Lfull;   // with it: what the serving programs of the whole-network kernel are built from
@@ -1039,6 +1041,38 @@ int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v,
     // with an arrival counter measured 5 us slower than the extra launch): in front of the update here, or -- `prepared`
     // -- already advanced by linna_net_forward_loss, in the launch that takes the batch mean of the loss.
     return launch_adamw(p, g, m, v, n, hyper, prepared ? nullptr : step_dev, b1, b2, eps, S(stream));
+}
+
+// AdamW over the network's flat parameter buffer AND the re-layout of the updated weights into the two weight streams a
+// training step reads (linna_net_forward_loss's and the backward's dX chain), in ONE launch: what linna_adamw_step
+// followed by the two lazy re-layouts of the next step does in three.  `B`: the batch size the step runs at (it
+// selects the engine, hence the stream layout).  LINNA_ERR_UNSUPPORTED when the network does not train through those
+// two streams, or `params[n]` is not exactly its tensors back to back: the caller then uses linna_adamw_step.
+int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, float* m, float* v, size_t n, float* hyper,
+                         int* step_dev, float b1, float b2, float eps, int prepared, void* stream) {
+    if (!net || !p || !g || !m || !v || !hyper || !step_dev || B < 1) { set_error("net_adamw_step: bad arguments"); return LINNA_ERR_INVALID; }
+    static const bool off = getenv("LINNA_ADAMW_STREAMS") && getenv("LINNA_ADAMW_STREAMS")[0] == '0';
+    if (off || net->stream_loss != 1 || net->stream_bwd[0] != 1 || !net->packed_loss.ready() || !net->packed_dx[0].ready()) {
+        set_error("net_adamw_step: the network does not train through the whole-network streams"); return LINNA_ERR_UNSUPPORTED;
+    }
+    const int rows = net_stream_rows(B), k = rows < 16 ? 1 : 0;
+    if (net->as_state < 0 || net->as_params != p || net->as_n != n || net->as_k != k) {
+        net->as_params = p; net->as_n = n; net->as_k = k;
+        net->as_state = net_stream_adamw_args(net->L.data(), (int)net->L.size(), net->in_size, rows, p, n, net->packed_loss.buf[k],
+                                              &net->loss_dn, net->packed_dx[0].buf[k], &net->as_args) == LINNA_OK ? 1 : 0;
+    }
+    if (net->as_state != 1) return LINNA_ERR_UNSUPPORTED;          // (the error text is net_stream_adamw_args')
+    // both streams must hold the CURRENT weights and their constant parts before they are patched in place
+    const float* dummy = nullptr;
+    TRY(stream_copy_refresh(net->packed_loss, net, rows, stream, &dummy, 0, &net->loss_dn));
+    TRY(stream_copy_refresh(net->packed_dx[0], net, rows, stream, &dummy, 1, nullptr));
+    if (!prepared) TRY(launch_adamw_prepare(hyper, step_dev, b1, b2, S(stream)));
+    TRY(launch_adamw_streams(net->as_args, p, g, m, v, hyper, b1, b2, eps, S(stream)));
+    const unsigned long long epoch = g_weights_epoch.fetch_add(1) + 1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(S(stream), &cap);
+    if (cap == hipStreamCaptureStatusNone) { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
+    return LINNA_OK;
 }
 
 // ------------------------------------------------------------------ moves

@@ -153,6 +153,17 @@ int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, co
                             const NsDense& dn, int rows, hipStream_t s);
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
 struct NsGrad { const float* gscale; float* G; int ldg; };
+// AdamW that also writes the two weight streams of a training step (net_stream.hip: adamw_streams_kernel)
+constexpr int AS_MAXR = 26, AS_MAXW = 14, AS_MAXB = 12;
+struct AsPlace { float* out; float scale; int trans, koff, ncols, type, ncg, steps, G, first0, first1; };
+struct AsMat { int N, ld; AsPlace pl[2]; };            // pl[0]: forward(+loss) stream, pl[1]: dX-chain stream
+struct AsBias { float* out; float scale; int N; };
+struct AsRange { unsigned off4, n4, blk0; short kind, idx; };   // a tensor of the flat buffer, in units of 4 floats
+struct AsArgs { AsRange r[AS_MAXR]; AsMat w[AS_MAXW]; AsBias b[AS_MAXB]; int nr, small; unsigned nblocks; };
+int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int rows, const float* params, size_t nflat,
+                          float* s_fwd, const NsDense* dn, float* s_dx, AsArgs* out);
+int launch_adamw_streams(const AsArgs& a, float* p, const float* g, float* m, float* v, const float* hyper, float b1, float b2,
+                         float eps, hipStream_t s);
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);
 // forward + dX chain down to the input in one stream (any network both programs cover; diagonal covariance)
 bool net_stream_dxi_eligible(const linna_layer_t* layers, int nl, int in_size);

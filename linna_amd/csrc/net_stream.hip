@@ -239,12 +239,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const int row0 = blockIdx.x * ROWS;
     if (a.gate && a.gate[0] == 0) return;
 #ifdef NS_STAMPS
-    unsigned long long* const lstamp = reinterpret_cast<unsigned long long*>(lbias + ((a.bias_total + 3) & ~3)) + wave * 32;
+    unsigned long long* const lstamp = reinterpret_cast<unsigned long long*>(lbias + ((a.bias_total + 3) & ~3) + 32 + (a.x0_keep ? 1024 : 0)) + wave * 32;   // (not for GRAD: its masks live there)
     int nstamp = 0;
 #define NS_STAMP() do { const unsigned long long t_ = __builtin_readcyclecounter(); \
         if (lane == 0 && nstamp < 32) lstamp[nstamp] = t_; ++nstamp; } while (0)
+#define NS_STAMPS_FLUSH() do { if (lane < 32) a.stamps[((size_t)blockIdx.x * NW + wave) * 32 + lane] = lane < nstamp ? lstamp[lane] : 0ull; } while (0)
 #else
 #define NS_STAMP() do {} while (0)
+#define NS_STAMPS_FLUSH() do {} while (0)
 #endif
     NS_STAMP();
 
@@ -374,6 +376,31 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     }
     // inputs wider than ZPRE*RG = 64 columns (none of the reference's models; <= 256 supported) and the zero
     // pad of a SPLIT first segment: plain loop, loads waited in place
+    if constexpr ((STORE == 1 || STORE == 2) && !GRAD) {
+        // rows arrive transformed (the dX chain's input is d loss / d pred, 457 or 1000 columns wide): every thread of the
+        // workgroup copies, four independent loads in flight each -- the per-row loop below waits for every load in place
+        const int wcols = kpad0 - ZPRE * RG;
+        if (wcols > 0) {
+            constexpr int CP = 4;
+            for (int base = 0; base < ROWS * wcols; base += CP * 64 * NW) {
+                float v[CP];
+#pragma unroll
+                for (int u = 0; u < CP; ++u) {
+                    const int idx = min(base + u * 64 * NW + tid, ROWS * wcols - 1);
+                    const int r = idx / wcols, c = ZPRE * RG + idx % wcols;
+                    v[u] = a.Z[(size_t)min(row0 + r, a.B - 1) * a.ldz + min(c, nin - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < CP; ++u) {
+                    const int idx = base + u * 64 * NW + tid;
+                    if (idx < ROWS * wcols) {
+                        const int r = idx / wcols, c = ZPRE * RG + idx % wcols;
+                        act[r * LD + c] = c < nin ? v[u] : 0.f;
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll 1
     for (int c = pc0 + ZPRE * RG; c < kpad0; c += RG) {
         float x = 0.f;
@@ -778,7 +805,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[0]), "+v"(Aq[1]) :: "memory");
     NS_STAMP();
 
-    if constexpr ((STORE == 1 || STORE == 2) && !GRAD) return; // every output is in global memory already
+    if constexpr ((STORE == 1 || STORE == 2) && !GRAD) { NS_STAMPS_FLUSH(); return; }   // every output is in global memory already
     if constexpr (STORE == 3) {
         // ---- 5 (loss).  delta and U = delta Cinv sit in LDS (as d and U of the dense serving program): chi2 = delta . U,
         // loss_b = chi2 / den (util.py:1086-1088), d loss / d pred = -2 U inv_batch / den, zero where delta was masked
@@ -802,6 +829,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 a.t_dP[(size_t)(row0 + pr) * a.t_lddp + c] = g;
             }
         }
+        NS_STAMP();
+        NS_STAMPS_FLUSH();
         return;
     }
     // ---- 5 (GRAD). d lnP / d x sits in buffer P: the derivative of the input transform and of the prior map
@@ -878,10 +907,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         }
     }
     NS_STAMP();
-#ifdef NS_STAMPS
-    if (lane < 32) a.stamps[((size_t)blockIdx.x * NW + wave) * 32 + lane] = lane < nstamp ? lstamp[lane] : 0ull;
-#endif
+    NS_STAMPS_FLUSH();
 #undef NS_STAMP
+#undef NS_STAMPS_FLUSH
 }
 
 // ---------------------------------------------------------------------------- host side: the program
@@ -1246,13 +1274,180 @@ static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t 
     return check_hip(hipGetLastError(), "net_stream launch");
 }
 template <int MOVE, bool GRAD, int STORE = 0>
-static int ns_launch_kernel(const NsArgs& a, int B, const NsProgram& p, int rows, hipStream_t s) {
+static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int rows, hipStream_t s) {
     const size_t lds = p.lds_for(rows, GRAD);
+#ifdef NS_STAMPS
+    // diagnostic build: every launch writes its phase stamps to the buffer LINNA_FUSED_STAMPS names (tools/ns_stamps*.py)
+    NsArgs a = a0;
+    a.stamps = getenv("LINNA_FUSED_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LINNA_FUSED_STAMPS"), nullptr, 16)) : nullptr;
+    if (!a.stamps) { set_error("net_stream: NS_STAMPS build needs LINNA_FUSED_STAMPS"); return LINNA_ERR_INVALID; }
+#else
+    const NsArgs& a = a0;
+#endif
     if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s);
     if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s);
     if (rows == 16) return ns_launch_rows<MOVE, GRAD, STORE, 16>(a, B, lds, s);
     set_error("net_stream: %d rows per workgroup", rows);
     return LINNA_ERR_INVALID;
+}
+
+// ------------------------------------------------------------------ AdamW that writes the weight streams itself
+// A training step ends with AdamW over the flat parameter buffer and begins with two re-layouts of the updated weights
+// (ns_pack_kernel: the forward + loss stream and the dX-chain stream): three launches that each read or write every
+// parameter.  Here the update runs once, in the flat buffer's own order, and every thread puts its four updated values
+// where the two streams want them: the forward stream holds four consecutive k of one weight row as ONE 16-byte vector
+// (one store), the dX-chain stream holds the transposed matrix (four 4-byte stores; neighbouring lanes fill
+// neighbouring vectors).  Biases go to the forward stream's bias block.  Constant parts of a stream (zero padding, the
+// loss's inverse covariance) are written by the ordinary re-layout once and never touched here.
+__device__ __forceinline__ size_t as_slot(const AsPlace& q, int small, int nn, int kk) {
+    const int nl = nn & 63, ks = kk >> 4, kr = kk & 15;
+    int w, g;
+    if (q.type == NS_WIDE) { w = (nn & 511) >> 6; g = ((nn >> 9) ? q.first1 : q.first0) + ks; }
+    else { const int kp = ks / q.steps; w = kp * q.ncg + (nn >> 6); g = q.first0 + (ks - kp * q.steps); }
+    const int t = small ? kr >> 2 : nl >> 4, lane = small ? nl : (nl & 15) + 16 * (kr >> 2);
+    return ((((size_t)w * q.G + g) * NS_NT + t) * 64 + lane) * 4 + (kr & 3);          // float index
+}
+
+__global__ __launch_bounds__(256) void adamw_streams_kernel(AsArgs a, float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+    int ri = 0;
+    while (ri + 1 < a.nr && blockIdx.x >= a.r[ri + 1].blk0) ++ri;
+    const AsRange R = a.r[ri];
+    const unsigned i4 = (blockIdx.x - R.blk0) * 256 + threadIdx.x;
+    if (i4 >= R.n4) return;
+    const size_t i = ((size_t)R.off4 + i4) * 4;
+    const float lr = hyper[0], wd = hyper[1], bc1 = hyper[2], sbc2 = hyper[3];
+    const f32x4 G4 = *reinterpret_cast<const f32x4*>(g + i);
+    f32x4 P4 = *reinterpret_cast<const f32x4*>(p + i), M4 = *reinterpret_cast<const f32x4*>(m + i), V4 = *reinterpret_cast<const f32x4*>(v + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {                   // adamw_kernel's arithmetic, operation for operation
+        const float gi = G4[e];
+        float pi = P4[e] * (1.f - lr * wd);
+        float mi = M4[e];
+        mi = mi + (gi - mi) * (1.f - beta1);
+        const float vi = V4[e] * beta2 + (1.f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / sbc2 + eps;
+        pi = pi - (lr / bc1) * (mi / denom);
+        P4[e] = pi; M4[e] = mi; V4[e] = vi;
+    }
+    *reinterpret_cast<f32x4*>(p + i) = P4; *reinterpret_cast<f32x4*>(m + i) = M4; *reinterpret_cast<f32x4*>(v + i) = V4;
+    if (R.kind == 1) {
+        const AsBias B = a.b[R.idx];
+        if (B.out) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if ((int)(4 * i4) + e < B.N) B.out[4 * i4 + e] = B.scale * P4[e];
+        }
+        return;
+    }
+    const AsMat& W = a.w[R.idx];
+    const int ld4 = W.ld >> 2;
+    const int n = (int)(i4 / (unsigned)ld4), k0 = 4 * (int)(i4 % (unsigned)ld4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const AsPlace& q = W.pl[j];
+        if (!q.out) continue;
+        if (!q.trans) {
+            // (n, k0..k0+3): one vector of the stream (koff and k0 are multiples of 4; pad columns hold zeros)
+            const size_t o = as_slot(q, a.small, n, q.koff + k0);
+            *reinterpret_cast<f32x4*>(q.out + o) = f32x4{q.scale * P4[0], q.scale * P4[1], q.scale * P4[2], q.scale * P4[3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k0 + e < q.ncols) q.out[as_slot(q, a.small, k0 + e, q.koff + n)] = q.scale * P4[e];
+        }
+    }
+}
+
+// Descriptor table of adamw_streams_kernel for the flat buffer `params[nflat]` the layers' parameters live in, the
+// forward(+loss) stream `s_fwd` (program 0 with `dn`) and the dX-chain stream `s_dx` (program 1).  LINNA_ERR_UNSUPPORTED
+// when the buffer is not exactly the layers' tensors back to back, or a stream folds something into the weights that
+// an element-wise scatter cannot reproduce (output maps, a second bias).
+int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int rows, const float* params, size_t nflat,
+                          float* s_fwd, const NsDense* dn, float* s_dx, AsArgs* out) {
+    const NsProgram& pf = ns_build_prog(layers, nl, in_size, 0, dn);
+    const NsProgram& pd = ns_build_prog(layers, nl, in_size, 1);
+    if (!pf.ok || !pd.ok || !s_fwd || !s_dx) { set_error("adamw_streams: no forward / dX-chain program"); return LINNA_ERR_UNSUPPORTED; }
+    ::memset(static_cast<void*>(out), 0, sizeof(*out));
+    out->small = rows < 16;
+    struct T { const float* ptr; int N, K, bias; };
+    std::vector<T> ts;
+    for (int i = 0; i < nl; ++i) {
+        const linna_layer_t& l = layers[i];
+        if (l.op == LINNA_OP_LINEAR) { ts.push_back({l.W, l.N, l.K, 0}); ts.push_back({l.b, l.N, 0, 1}); }
+        else if (l.op == LINNA_OP_RESBLOCK) {
+            ts.push_back({l.W1, l.C, l.K, 0}); ts.push_back({l.b1, l.C, 0, 1});
+            ts.push_back({l.W2, l.N, l.C, 0}); ts.push_back({l.b2, l.N, 0, 1});
+            if (l.Ws) ts.push_back({l.Ws, l.N, l.K, 0});
+        } else { set_error("adamw_streams: op %d", l.op); return LINNA_ERR_UNSUPPORTED; }
+    }
+    std::sort(ts.begin(), ts.end(), [](const T& x, const T& y) { return x.ptr < y.ptr; });
+    if ((int)ts.size() > AS_MAXR) { set_error("adamw_streams: %d tensors", (int)ts.size()); return LINNA_ERR_UNSUPPORTED; }
+    auto runs_first = [](const NsProgram& p, int seg, int pass) {
+        int first = 0;
+        for (int i = 0; i < seg; ++i) first += p.seg[i].steps * p.seg[i].passes;
+        return first + pass * p.seg[seg].steps;
+    };
+    auto place = [&](const NsProgram& p, float* base, const float* W, AsPlace* q) -> int {
+        for (size_t i = 0; i < p.pack.size(); ++i) {
+            const NsPackSeg& S = p.pack[i];
+            const bool isA = S.Wa == W, isB = S.Wb == W;
+            if (!isA && !isB) continue;
+            if (q->out) { set_error("adamw_streams: a weight matrix twice in one stream"); return LINNA_ERR_UNSUPPORTED; }
+            if (S.rscale || S.rshift || S.b2) { set_error("adamw_streams: folded output map"); return LINNA_ERR_UNSUPPORTED; }
+            q->out = base; q->scale = isA ? 1.f : S.alpha; q->trans = isA ? S.transA : S.transB; q->koff = isA ? 0 : S.Kapad;
+            q->ncols = S.N; q->type = S.type; q->ncg = S.ncg; q->steps = S.steps; q->G = p.Gstride;
+            q->first0 = runs_first(p, (int)i, 0); q->first1 = p.seg[i].passes > 1 ? runs_first(p, (int)i, 1) : q->first0;
+            if (p.seg[i].passes > 2) { set_error("adamw_streams: %d passes", p.seg[i].passes); return LINNA_ERR_UNSUPPORTED; }
+        }
+        return LINNA_OK;
+    };
+    size_t off = 0;
+    unsigned blk = 0;
+    int nw = 0, nb = 0;
+    for (size_t i = 0; i < ts.size(); ++i) {
+        const T& t = ts[i];
+        if (!t.ptr || t.ptr != params + off) { set_error("adamw_streams: the parameters are not one contiguous buffer"); return LINNA_ERR_UNSUPPORTED; }
+        const int ld = t.bias ? 0 : (t.K + 3) & ~3;
+        const size_t nf = t.bias ? (size_t)((t.N + 3) & ~3) : (size_t)t.N * ld;
+        AsRange& R = out->r[i];
+        R.off4 = (unsigned)(off / 4); R.n4 = (unsigned)(nf / 4); R.blk0 = blk; R.kind = (short)t.bias;
+        blk += (R.n4 + 255) / 256;
+        if (t.bias) {
+            if (nb >= AS_MAXB) { set_error("adamw_streams: biases"); return LINNA_ERR_UNSUPPORTED; }
+            R.idx = (short)nb;
+            AsBias& B = out->b[nb++];
+            B.N = t.N;
+            for (size_t j = 0; j < pf.pack.size(); ++j) {
+                const NsPackSeg& S = pf.pack[j];
+                if (S.b != t.ptr) continue;
+                if (B.out || S.rscale || S.rshift || S.b2) { set_error("adamw_streams: bias folded or used twice"); return LINNA_ERR_UNSUPPORTED; }
+                B.out = s_fwd + (size_t)NS_NW * pf.Gstride * NS_NT * 256 + S.bias_off; B.scale = S.bscale;
+            }
+            for (const NsPackSeg& S : pd.pack) if (S.b == t.ptr) { set_error("adamw_streams: bias in the dX program"); return LINNA_ERR_UNSUPPORTED; }
+        } else {
+            if (nw >= AS_MAXW) { set_error("adamw_streams: weight matrices"); return LINNA_ERR_UNSUPPORTED; }
+            R.idx = (short)nw;
+            AsMat& W = out->w[nw++];
+            W.N = t.N; W.ld = ld;
+            int rc = place(pf, s_fwd, t.ptr, &W.pl[0]);
+            if (rc == LINNA_OK) rc = place(pd, s_dx, t.ptr, &W.pl[1]);
+            if (rc != LINNA_OK) return rc;
+            if (!W.pl[0].out) { set_error("adamw_streams: a weight matrix outside the forward stream"); return LINNA_ERR_UNSUPPORTED; }
+        }
+        off += nf;
+    }
+    if (off != nflat) { set_error("adamw_streams: %zu of %zu floats covered", off, nflat); return LINNA_ERR_UNSUPPORTED; }
+    // every pack segment's weights must have been found among the tensors (the loss's constant matrix excepted)
+    out->nr = (int)ts.size(); out->nblocks = blk;
+    return LINNA_OK;
+}
+
+int launch_adamw_streams(const AsArgs& a, float* p, const float* g, float* m, float* v, const float* hyper, float b1, float b2,
+                         float eps, hipStream_t s) {
+    hipLaunchKernelGGL(adamw_streams_kernel, dim3(a.nblocks), dim3(256), 0, s, a, p, g, m, v, hyper, b1, b2, eps);
+    return check_hip(hipGetLastError(), "adamw_streams launch");
 }
 
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 0).grad_ok; }
@@ -1287,10 +1482,6 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
     a.stamps = nullptr; a.gate = gate;
-#ifdef NS_STAMPS
-    a.stamps = getenv("LINNA_FUSED_STAMPS") ? reinterpret_cast<unsigned long long*>(strtoull(getenv("LINNA_FUSED_STAMPS"), nullptr, 16)) : nullptr;
-    if (!a.stamps) { set_error("net_stream: NS_STAMPS build needs LINNA_FUSED_STAMPS"); return LINNA_ERR_INVALID; }
-#endif
     if (mv) {
         a.mv_coords = mv->coords; a.mv_ldc = mv->ldc; a.mv_logp = mv->logp; a.mv_S = mv->S;
         a.mv_cc = mv->cc; a.mv_ldcc = mv->ldcc; a.mv_C = mv->C; a.mv_nc = mv->nc;

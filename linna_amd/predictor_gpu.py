@@ -171,6 +171,7 @@ class _AdamWState(object):
         self.v = torch.zeros_like(flat)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=flat.device)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=flat.device)
+        self._streams = None         # None: try linna_net_adamw_step when apply() is told the batch size
         self.push_hyper()
 
     @property
@@ -183,10 +184,24 @@ class _AdamWState(object):
     def push_hyper(self):
         self.hyper[:2].copy_(torch.tensor([self.lr, self.weight_decay], dtype=torch.float32))
 
-    def apply(self, prepared=False):
-        """``prepared``: this step's counter / bias corrections were advanced by ``linna_net_forward_loss`` already."""
-        n = self.model.flat_params().numel()
-        _lib.call("linna_adamw_step", _lib.ctx(self.m.device.index), _lib.ptr(self.model.flat_params()),
+    def apply(self, prepared=False, batch=None):
+        """``prepared``: this step's counter / bias corrections were advanced by ``linna_net_forward_loss`` already.
+        ``batch``: the batch size of the training steps around this update -- the update then also writes the two weight
+        streams those steps read (``linna_net_adamw_step``, one launch for three) where the network trains through them."""
+        flat = self.model._flat          # (not flat_params(): the entries below announce the change themselves)
+        n = flat.numel()
+        if batch is not None and self._streams is not False:
+            rc = _lib.load().linna_net_adamw_step(
+                self.model.net_handle(with_grads=True), int(batch), _lib.ptr(flat),
+                _lib.ptr(self.model.flat_grads()), _lib.ptr(self.m), _lib.ptr(self.v), n, _lib.ptr(self.hyper),
+                _lib.iptr(self.step_dev), self.betas[0], self.betas[1], self.eps, 1 if prepared else 0, _lib.stream())
+            if rc == 0:
+                self._streams = True
+                return
+            if rc != _lib.ERR_UNSUPPORTED or self._streams is True:
+                _lib.check(rc)
+            self._streams = False
+        _lib.call("linna_adamw_step", _lib.ctx(self.m.device.index), _lib.ptr(flat),
                   _lib.ptr(self.model.flat_grads()), _lib.ptr(self.m), _lib.ptr(self.v), n, _lib.ptr(self.hyper),
                   _lib.iptr(self.step_dev), self.betas[0], self.betas[1], self.eps, 1 if prepared else 0, _lib.stream())
 

@@ -141,7 +141,7 @@ class TrainEngine(object):
                 self.inv_batch = keep
         else:
             self._forward_loss_backward(rows, loss_out, opt)
-        opt.apply(prepared=self._prepared)
+        opt.apply(prepared=self._prepared, batch=self.B)
 
     def step(self, opt, rows_dev, loss_out=None):
         """One optimiser step on the int32 device index vector ``rows_dev[B]``; the mean loss of the step lands in

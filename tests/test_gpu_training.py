@@ -82,6 +82,35 @@ def test_chi2_denominator_and_masks():
     assert dp[1, 0] == 0.0                 # masked sentinel entry (1e10) carries no gradient (util.py:1072-1084)
 
 
+@pytest.mark.parametrize("name", ["train_v2_33_33", "train_v2_26_457", "train_v2_5_3", "train_mlp_7_5"])
+def test_adamw_writing_the_weight_streams_equals_update_plus_relayout(name):
+    """``linna_net_adamw_step`` (the update AND both weight streams of the next step in one launch) against
+    ``linna_adamw_step`` followed by the lazy re-layouts: parameters, moments and every step's loss bit for bit over six
+    steps (a wrong slot in either stream would show in the next step's loss or gradients), and the validation pass after
+    them, which reads a stream of its own."""
+    from linna_amd.predictor_gpu import _AdamWState
+    res = []
+    for fused in (True, False):
+        p, model, pred, eng, B = make_engine(name)
+        opt = _AdamWState(model, 2e-3)
+        if not fused:
+            opt._streams = False
+        losses = []
+        for s in range(6):
+            out = torch.zeros(1, device="cuda")
+            eng.step(opt, torch.arange((s % 3) * B, (s % 3 + 1) * B, dtype=torch.int32, device="cuda"), loss_out=out)
+            losses.append(out)
+        torch.cuda.synchronize()
+        eng.validate()
+        res.append((model._flat.cpu().numpy().copy(), opt.m.cpu().numpy().copy(), opt.v.cpu().numpy().copy(),
+                    torch.cat(losses).cpu().numpy(), eng.val["loss_rows"].cpu().numpy().copy(), opt._streams))
+    assert np.isfinite(res[0][3]).all()
+    for a, b in zip(res[0][:5], res[1][:5]):
+        np.testing.assert_array_equal(a, b)
+    if name in ("train_v2_33_33", "train_v2_26_457"):
+        assert res[0][5] is True                    # the reference's network trains through the one-launch update
+
+
 def test_graph_replay_equals_direct_launches():
     from linna_amd.predictor_gpu import _AdamWState
     from linna_amd import trainer
