@@ -392,11 +392,24 @@ def main():
         # shares a GPU between ranks keeps torch.distributed as the transport.
         from linna_amd import dist as ldist
         if args.backend == "nccl":
+            why = ""
             try:
                 ldist.comm_init(dev_index, timeout=120.0)
-                collectives = "RCCL %s through the C ABI (linna_comm_init / linna_allreduce_sum_f32 / linna_allgather_f32)" % (ldist.comm_info(dev_index)[2],)
+                ok = ldist.comm_selftest(dev_index, timeout=60.0)   # one all-reduce on a side stream, checked, bounded wait
+                why = "" if ok else "self-test all-reduce wrong or late"
             except Exception as e:                                  # noqa: BLE001
-                collectives = "torch.distributed nccl (linna_comm_init failed: %s)" % repr(e)[:200]
+                ok, why = False, repr(e)[:200]
+            # every rank takes the same transport: RCCL through the C ABI only if it came up and answered on ALL of them
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                collectives = "RCCL %s through the C ABI (linna_comm_init / linna_allreduce_sum_f32 / linna_allgather_f32)" % (ldist.comm_info(dev_index)[2],)
+            else:
+                if ok:
+                    ldist.comm_destroy(dev_index)
+                else:
+                    ldist.comm_forget(dev_index)                    # (never tear down a communicator that may be stuck)
+                collectives = "torch.distributed nccl (the library's communicator did not come up on every rank%s)" % (": " + why if why else "")
         else:
             collectives = "torch.distributed %s (rehearsal)" % args.backend
 

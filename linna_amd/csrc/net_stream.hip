@@ -1299,6 +1299,7 @@ static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int row
 // (one store), the dX-chain stream holds the transposed matrix (four 4-byte stores; neighbouring lanes fill
 // neighbouring vectors).  Biases go to the forward stream's bias block.  Constant parts of a stream (zero padding, the
 // loss's inverse covariance) are written by the ordinary re-layout once and never touched here.
+constexpr int AS_BLOCK = 64;               // one wave per block: ~1200 blocks for 1.3 M parameters, five per CU
 __device__ __forceinline__ size_t as_slot(const AsPlace& q, int small, int nn, int kk) {
     const int nl = nn & 63, ks = kk >> 4, kr = kk & 15;
     int w, g;
@@ -1308,18 +1309,8 @@ __device__ __forceinline__ size_t as_slot(const AsPlace& q, int small, int nn, i
     return ((((size_t)w * q.G + g) * NS_NT + t) * 64 + lane) * 4 + (kr & 3);          // float index
 }
 
-__global__ __launch_bounds__(256) void adamw_streams_kernel(AsArgs a, float* __restrict__ p, const float* __restrict__ g,
-                                                            float* __restrict__ m, float* __restrict__ v,
-                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps) {
-    int ri = 0;
-    while (ri + 1 < a.nr && blockIdx.x >= a.r[ri + 1].blk0) ++ri;
-    const AsRange R = a.r[ri];
-    const unsigned i4 = (blockIdx.x - R.blk0) * 256 + threadIdx.x;
-    if (i4 >= R.n4) return;
-    const size_t i = ((size_t)R.off4 + i4) * 4;
-    const float lr = hyper[0], wd = hyper[1], bc1 = hyper[2], sbc2 = hyper[3];
-    const f32x4 G4 = *reinterpret_cast<const f32x4*>(g + i);
-    f32x4 P4 = *reinterpret_cast<const f32x4*>(p + i), M4 = *reinterpret_cast<const f32x4*>(m + i), V4 = *reinterpret_cast<const f32x4*>(v + i);
+__device__ __forceinline__ void as_update(f32x4& P4, const f32x4& G4, f32x4& M4, f32x4& V4, float lr, float wd, float bc1,
+                                          float sbc2, float beta1, float beta2, float eps) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {                   // adamw_kernel's arithmetic, operation for operation
         const float gi = G4[e];
@@ -1331,31 +1322,71 @@ __global__ __launch_bounds__(256) void adamw_streams_kernel(AsArgs a, float* __r
         pi = pi - (lr / bc1) * (mi / denom);
         P4[e] = pi; M4[e] = mi; V4[e] = vi;
     }
-    *reinterpret_cast<f32x4*>(p + i) = P4; *reinterpret_cast<f32x4*>(m + i) = M4; *reinterpret_cast<f32x4*>(v + i) = V4;
+}
+
+// One work item = a 4 x 4 block of a weight matrix (rows n0..n0+3, columns k0..k0+3; 16-byte loads and stores throughout:
+// the forward stream takes the block's rows as four vectors, the dX-chain stream its columns) or four bias elements.
+__global__ __launch_bounds__(AS_BLOCK) void adamw_streams_kernel(AsArgs a, float* __restrict__ p, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            const float* __restrict__ hyper, float beta1, float beta2, float eps) {
+    int ri = 0;
+    while (ri + 1 < a.nr && blockIdx.x >= a.r[ri + 1].blk0) ++ri;
+    const AsRange R = a.r[ri];
+    const unsigned it = (blockIdx.x - R.blk0) * AS_BLOCK + threadIdx.x;
+    if (it >= R.n4) return;
+    const float lr = hyper[0], wd = hyper[1], bc1 = hyper[2], sbc2 = hyper[3];
     if (R.kind == 1) {
+        const size_t i = ((size_t)R.off4 + it) * 4;
+        const f32x4 G4 = *reinterpret_cast<const f32x4*>(g + i);
+        f32x4 P4 = *reinterpret_cast<const f32x4*>(p + i), M4 = *reinterpret_cast<const f32x4*>(m + i), V4 = *reinterpret_cast<const f32x4*>(v + i);
+        as_update(P4, G4, M4, V4, lr, wd, bc1, sbc2, beta1, beta2, eps);
+        *reinterpret_cast<f32x4*>(p + i) = P4; *reinterpret_cast<f32x4*>(m + i) = M4; *reinterpret_cast<f32x4*>(v + i) = V4;
         const AsBias B = a.b[R.idx];
         if (B.out) {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if ((int)(4 * i4) + e < B.N) B.out[4 * i4 + e] = B.scale * P4[e];
+                if ((int)(4 * it) + e < B.N) B.out[4 * it + e] = B.scale * P4[e];
         }
         return;
     }
     const AsMat& W = a.w[R.idx];
-    const int ld4 = W.ld >> 2;
-    const int n = (int)(i4 / (unsigned)ld4), k0 = 4 * (int)(i4 % (unsigned)ld4);
+    const unsigned ld4 = (unsigned)W.ld >> 2;
+    const int n0 = 4 * (int)(it / ld4), k0 = 4 * (int)(it % ld4);
+    f32x4 P4[4], G4[4], M4[4], V4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t i = (size_t)R.off4 * 4 + (size_t)min(n0 + r, W.N - 1) * W.ld + k0;     // (rows past N: reread the last, not stored)
+        G4[r] = *reinterpret_cast<const f32x4*>(g + i); P4[r] = *reinterpret_cast<const f32x4*>(p + i);
+        M4[r] = *reinterpret_cast<const f32x4*>(m + i); V4[r] = *reinterpret_cast<const f32x4*>(v + i);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        as_update(P4[r], G4[r], M4[r], V4[r], lr, wd, bc1, sbc2, beta1, beta2, eps);
+        if (n0 + r < W.N) {
+            const size_t i = (size_t)R.off4 * 4 + (size_t)(n0 + r) * W.ld + k0;
+            *reinterpret_cast<f32x4*>(p + i) = P4[r]; *reinterpret_cast<f32x4*>(m + i) = M4[r]; *reinterpret_cast<f32x4*>(v + i) = V4[r];
+        } else {
+            P4[r] = f32x4{0.f, 0.f, 0.f, 0.f};      // the streams' padding
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const AsPlace& q = W.pl[j];
         if (!q.out) continue;
         if (!q.trans) {
-            // (n, k0..k0+3): one vector of the stream (koff and k0 are multiples of 4; pad columns hold zeros)
-            const size_t o = as_slot(q, a.small, n, q.koff + k0);
-            *reinterpret_cast<f32x4*>(q.out + o) = f32x4{q.scale * P4[0], q.scale * P4[1], q.scale * P4[2], q.scale * P4[3]};
+            // row n0 + r, columns k0..k0+3: one vector of the stream (koff and k0 are multiples of 4; pad columns hold zeros)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < W.N)
+                    *reinterpret_cast<f32x4*>(q.out + as_slot(q, a.small, n0 + r, q.koff + k0)) =
+                        f32x4{q.scale * P4[r][0], q.scale * P4[r][1], q.scale * P4[r][2], q.scale * P4[r][3]};
         } else {
+            // column k0 + e, rows n0..n0+3: one vector of the transposed stream (rows past N: the zeros of its padding)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (k0 + e < q.ncols) q.out[as_slot(q, a.small, k0 + e, q.koff + n)] = q.scale * P4[e];
+                if (k0 + e < q.ncols)
+                    *reinterpret_cast<f32x4*>(q.out + as_slot(q, a.small, k0 + e, q.koff + n0)) =
+                        f32x4{q.scale * P4[0][e], q.scale * P4[1][e], q.scale * P4[2][e], q.scale * P4[3][e]};
         }
     }
 }
@@ -1412,8 +1443,9 @@ int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int 
         const int ld = t.bias ? 0 : (t.K + 3) & ~3;
         const size_t nf = t.bias ? (size_t)((t.N + 3) & ~3) : (size_t)t.N * ld;
         AsRange& R = out->r[i];
-        R.off4 = (unsigned)(off / 4); R.n4 = (unsigned)(nf / 4); R.blk0 = blk; R.kind = (short)t.bias;
-        blk += (R.n4 + 255) / 256;
+        R.off4 = (unsigned)(off / 4); R.blk0 = blk; R.kind = (short)t.bias;
+        R.n4 = t.bias ? (unsigned)(nf / 4) : (unsigned)((t.N + 3) / 4) * (unsigned)(ld / 4);      // work items (see the kernel)
+        blk += (R.n4 + AS_BLOCK - 1) / AS_BLOCK;
         if (t.bias) {
             if (nb >= AS_MAXB) { set_error("adamw_streams: biases"); return LINNA_ERR_UNSUPPORTED; }
             R.idx = (short)nb;
@@ -1446,7 +1478,7 @@ int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int 
 
 int launch_adamw_streams(const AsArgs& a, float* p, const float* g, float* m, float* v, const float* hyper, float b1, float b2,
                          float eps, hipStream_t s) {
-    hipLaunchKernelGGL(adamw_streams_kernel, dim3(a.nblocks), dim3(256), 0, s, a, p, g, m, v, hyper, b1, b2, eps);
+    hipLaunchKernelGGL(adamw_streams_kernel, dim3(a.nblocks), dim3(AS_BLOCK), 0, s, a, p, g, m, v, hyper, b1, b2, eps);
     return check_hip(hipGetLastError(), "adamw_streams launch");
 }
 

@@ -95,6 +95,38 @@ def comm_destroy(device_index=None):
             del _comm[d]
 
 
+def comm_forget(device_index=None):
+    """Stop routing collectives through a communicator WITHOUT destroying it (one that timed out may still be blocked in
+    RCCL: tearing it down could block as well)."""
+    for d in ([device_index] if device_index is not None else list(_comm)):
+        _comm.pop(d, None)
+
+
+def comm_selftest(device_index=None, timeout=60.0):
+    """One ``linna_allreduce_sum_f32`` of 1024 floats on a side stream, waited for at most ``timeout`` seconds and
+    checked against the closed form: True when this rank's communicator works.  (A launcher calls this before it
+    commits the data path to the communicator; every rank must then agree, e.g. by a MIN all-reduce of the answers.)"""
+    import time
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index not in _comm:
+        return False
+    r, w = _comm[device_index]
+    dev = torch.device("cuda", device_index)
+    side = torch.cuda.Stream(device=dev)
+    done = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        t = torch.full((1024,), float(r + 1), dtype=torch.float32, device=dev)
+        _lib.call("linna_allreduce_sum_f32", _lib.ctx(device_index), _f32(t), t.numel(), C.c_void_p(side.cuda_stream))
+        done.record(side)
+    t0 = time.perf_counter()
+    while not done.query():
+        if time.perf_counter() - t0 > timeout:
+            return False
+        time.sleep(0.005)
+    return bool((t == float(w * (w + 1) // 2)).all().item())
+
+
 def _f32(t):
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise _lib.LinnaHipError("RCCL entries take contiguous float32 device tensors")

@@ -113,6 +113,7 @@ def test_rccl_single_rank_through_the_c_abi():
         assert (r, n) == (0, 1)
         rank, nranks, ver = ldist.comm_info(dev)
         assert (rank, nranks) == (0, 1) and ver > 20000              # RCCL 2.x reports 2xxyy
+        assert ldist.comm_selftest(dev, timeout=30.0)                   # what bench.py asks before it commits to the communicator
         g = torch.arange(1000003, dtype=torch.float32, device="cuda")
         ref = g.clone()
         side = torch.cuda.Stream()
