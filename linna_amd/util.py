@@ -705,19 +705,34 @@ class NN_samplerv1(object):
         return np.array(list(mapper(m, samples)))
 
     def gensample_flat(self, Nsamples, omegab2cut=None):
-        """Centred Latin hypercube over the prior box (util.py:775-814 uses pyDOE2.lhs(criterion=
-        "center"), a third-party package absent here: same design family, own permutations)."""
-        rs = np.random.RandomState(self.seed)
+        """util.py:775-814: ``pyDOE2.lhs(ndim, samples=n, criterion="center", iterations=5, random_state=seed)`` scaled to
+        the prior box, grown by 1000 points until enough survive the cuts.  pyDOE2 (third party, absent here) is
+        restated from its published algorithm -- ``_lhscentered``: cell centres ``(cut[i] + cut[i+1]) / 2`` of
+        ``linspace(0, 1, n + 1)``, one unused ``rand(n, ndim)`` draw, then one ``permutation`` of the centres per
+        column, all from ``RandomState(seed)`` (``iterations`` does not enter the centred design) -- and PINNED: with
+        the reference's seed it reproduces the training and validation designs its own fixture holds
+        (tests/test_data/.../train_samples_x.txt, val_samples_x.txt) bit for bit (tests/test_host_api.py)."""
         n_in, samples = int(Nsamples), np.zeros((0, len(self.prior_range)))
+        ndim = len(self.prior_range)
         while len(samples) < Nsamples:
-            u = np.stack([(rs.permutation(n_in) + 0.5) / n_in for _ in self.prior_range], axis=1)
-            s = np.empty_like(u)
+            rs = np.random.RandomState(self.seed)
+            cut = np.linspace(0, 1, n_in + 1)
+            rs.rand(n_in, ndim)                                         # drawn and dropped by pyDOE2's _lhscentered
+            centre = (cut[:n_in] + cut[1:n_in + 1]) / 2
+            s = np.zeros((n_in, ndim))
+            for j in range(ndim):
+                s[:, j] = rs.permutation(centre)
+            s -= 0.5
+            s *= 2
+            shift_as = False
             for ind, prior in enumerate(self.prior_range):
-                lo, hi = prior
-                if ind == 1 and self.prior_range[1][1] < 1e-5:        # A_s sampled in log (util.py:795-803)
-                    s[:, ind] = np.exp(np.log(lo) + u[:, ind] * (np.log(hi) - np.log(lo)))
-                else:
-                    s[:, ind] = lo + u[:, ind] * (hi - lo)
+                if ind == 1 and self.prior_range[1][1] < 1e-5:          # A_s sampled in log (util.py:795-803)
+                    prior = np.log(prior)
+                    shift_as = True
+                scaled, mean = (prior[1] - prior[0]) / 2, (prior[1] + prior[0]) / 2
+                s[:, ind] = s[:, ind] * scaled + mean
+                if shift_as and ind == 1:
+                    s[:, ind] = np.exp(s[:, ind])
             samples = _apply_cuts(s, omegab2cut)
             n_in += 1000
         return samples[:Nsamples]

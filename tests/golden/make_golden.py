@@ -421,15 +421,13 @@ def gen_train33(out, nep=None):
     epochs with a fixed ``lr.npy``.  Stored: per-step training losses, per-epoch validation metrics, the messages of
     the epoch controller, and the residual of the trained emulator at points of the tempered posterior."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-    from linna_amd import util as putil                     # point design only (CPU): pyDOE2 is absent
     import readme33
     nep = int(os.environ.get("GOLDEN_TRAIN33_EPOCHS", "300")) if nep is None else nep
     prob = readme33.problem()
     ndim, means, cov = prob["ndim"], prob["means"], prob["cov"]
     sigma = np.sqrt(np.diag(cov))
     tmp = tempfile.mkdtemp(prefix="linna_golden33_") + "/"
-    ns = putil.NN_samplerv1(tmp, [[-5.0, 5.0]] * ndim)
-    train_x, val_x = ns.gensample_flat(10000), ns.gensample_flat(500)
+    train_x, val_x = readme33.design(10000, ndim), readme33.design(500, ndim)      # frozen input design (see readme33.design)
     np.savetxt(tmp + "train_samples_x.txt", train_x); np.save(tmp + "train_samples_y.npy", train_x.copy())
     np.savetxt(tmp + "val_samples_x.txt", val_x); np.save(tmp + "val_samples_y.npy", val_x.copy())
     np.save(tmp + "lr.npy", readme33.LR)

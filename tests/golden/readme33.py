@@ -18,3 +18,12 @@ def problem(seed=0):
 
 def theory(x, outdirs):
     return np.array(x[1], copy=True)
+
+
+def design(n, ndim, lo=-5.0, hi=5.0, seed=123456):
+    """The point design ``train33_run.npz`` was generated on: a centred Latin hypercube with one ``permutation(n)`` per
+    column.  Kept here, frozen, as an INPUT of that golden run -- the product's ``gensample_flat`` has since become the
+    exact restatement of pyDOE2's design (pinned by the reference's own fixture), which orders the cells differently."""
+    rs = np.random.RandomState(seed)
+    u = np.stack([(rs.permutation(int(n)) + 0.5) / int(n) for _ in range(ndim)], axis=1)
+    return lo + u * (hi - lo)

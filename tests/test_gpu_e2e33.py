@@ -29,8 +29,7 @@ pytestmark = pytest.mark.gpu
 def _write_iteration0(tmp):
     from linna_amd import util
     prob = readme33.problem()
-    ns = util.NN_samplerv1(tmp, [[-5.0, 5.0]] * prob["ndim"])
-    tx, vx = ns.gensample_flat(10000), ns.gensample_flat(500)
+    tx, vx = readme33.design(10000, prob["ndim"]), readme33.design(500, prob["ndim"])     # the golden run's input design
     np.savetxt(tmp + "train_samples_x.txt", tx); np.save(tmp + "train_samples_y.npy", tx.copy())
     np.savetxt(tmp + "val_samples_x.txt", vx); np.save(tmp + "val_samples_y.npy", vx.copy())
     np.save(tmp + "lr.npy", readme33.LR)

@@ -121,6 +121,59 @@ def test_emcee_layout_roundtrip_and_structure(tmp_path):
     assert ohdr % 8 == 0 and mine[ohdr] == 1
 
 
+def test_appended_file_encodes_its_datasets_as_libhdf5_did_in_the_fixture(tmp_path):
+    """No HDF5 library is importable here, so the writer cannot be read back by one.  The next best witness is the file
+    libhdf5 itself wrote for the reference (h5py under emcee's HDFBackend): the extensible datasets the appender creates
+    must carry the SAME object-header messages, field for field, wherever the two files describe the same thing --
+    datatype byte for byte; dataspace version / rank / flags / unlimited first dimension; chunked layout message
+    version 3 with rank + 1 chunk dimensions ending in the element size; fill-value message version 2 with incremental
+    allocation; version-1 chunk B-tree nodes of the right node type with keys of rank + 1 offsets."""
+    d = ChainStore.read_h5(FIXTURE)
+    nw, nd = d["chain"].shape[1:]
+    path = str(tmp_path / "chemcee_256.h5")
+    spec = {"chain": ((nw, nd), np.float64), "chain_transformed": ((nw, nd), np.float64), "log_prob": ((nw,), np.float64)}
+    ap = h5lite.Appender.create(path, spec, group="mcmc", fixed={"accepted": np.zeros(nw)}, chunk_rows=100,
+                                group_attrs=dict(version="3.0.2", nwalkers=np.int64(nw), ndim=np.int64(nd), has_blobs=False,
+                                                 iteration=np.int64(0)))
+    for lo in (0, 100):
+        ap.append({"mcmc/" + k: d[k][lo:lo + 100] for k in spec})
+    ap.set_attr("mcmc", "iteration", 200)
+    ap.close()
+
+    def messages(fpath):
+        out = {}
+        with h5lite.File(fpath) as f:
+            g = f["mcmc"]
+            for k in spec:
+                out[k] = {t: bytes(b) for t, b in f._read_header(g[k].addr) if t}
+                # the chunk index: a version-1 B-tree, node type 1 (raw data chunks)
+                lay = out[k][0x8]
+                addr = struct.unpack_from("<Q", lay, 3)[0]
+                node = f._at(addr, 8)
+                out[k]["tree"] = (bytes(node[:4]), node[4], node[5])
+        return out
+    ref, mine = messages(FIXTURE), messages(path)
+    for k in spec:
+        r, m = ref[k], mine[k]
+        assert sorted(t for t in r if t != "tree") == sorted(t for t in m if t != "tree") == [0x1, 0x3, 0x5, 0x8], k
+        assert m[0x3] == r[0x3]                                            # IEEE float64 little endian, byte for byte
+        rank = len(spec[k][0]) + 1
+        assert m[0x1][:8] == r[0x1][:8] == bytes([1, rank, 1, 0, 0, 0, 0, 0])            # version 1, rank, flags: max dims present
+        assert len(m[0x1]) == len(r[0x1]) == 8 + 16 * rank
+        rdims, mdims = struct.unpack_from("<%dQ" % (2 * rank), r[0x1], 8), struct.unpack_from("<%dQ" % (2 * rank), m[0x1], 8)
+        assert mdims[0] == 200 and rdims[1:rank] == mdims[1:rank] == spec[k][0]
+        assert rdims[rank] == mdims[rank] == 0xFFFFFFFFFFFFFFFF and rdims[rank + 1:] == mdims[rank + 1:] == spec[k][0]
+        assert m[0x8][:3] == r[0x8][:3] == bytes([3, 2, rank + 1])            # layout version 3, class 2 (chunked), rank + 1
+        assert len(m[0x8]) == len(r[0x8])
+        assert struct.unpack_from("<I", m[0x8], 11 + 4 * rank)[0] == struct.unpack_from("<I", r[0x8], 11 + 4 * rank)[0] == 8
+        assert m[0x5][:2] == r[0x5][:2] == bytes([2, 3])                     # fill value v2, space allocated incrementally
+        assert m["tree"][:2] == r["tree"][:2] == (b"TREE", 1)
+    # and libhdf5's file read through the same reader gives the rows this one holds
+    got = ChainStore.read_h5(path)
+    for k in spec:
+        np.testing.assert_array_equal(got[k], d[k])
+
+
 def test_zeus_layout_roundtrip_gzip_chunks(tmp_path):
     rs = np.random.RandomState(1)
     z, th, lp = _blocks(rs, 1037, 10, 2)

@@ -123,6 +123,29 @@ def test_reference_fixture_artefacts_load_on_cpu():
         np.testing.assert_array_equal(model.model.state_dict()[k].numpy(), v.numpy())
 
 
+def test_latin_hypercube_reproduces_the_reference_fixture_designs():
+    """``NN_samplerv1.gensample_flat`` (util.py:775-814 over pyDOE2's centred Latin hypercube, restated) against the
+    designs the reference's own run directory holds: 20 training and 5 validation points in [-2, 2]^2, written by the
+    reference with pyDOE2 and its seed 123456 -- bit for bit, row order included."""
+    from linna_amd import util
+    ns = util.NN_samplerv1("/nonexistent/", [[-2.0, 2.0], [-2.0, 2.0]])
+    for n, name in ((20, "train_samples_x.txt"), (5, "val_samples_x.txt")):
+        ref = np.loadtxt(os.path.join(cases.GOLDEN, "2dgaussian_Fulltconn/iter_0", name))
+        got = ns.gensample_flat(n)
+        assert got.shape == ref.shape == (n, 2)
+        np.testing.assert_array_equal(got, ref)
+    # the design family: every column visits every one of the n cells exactly once; cuts make it grow by 1000 and keep n rows
+    x = util.NN_samplerv1("/nonexistent/", [[0.0, 1.0]] * 5).gensample_flat(333)
+    for j in range(5):
+        np.testing.assert_array_equal(np.sort(np.floor(x[:, j] * 333).astype(int)), np.arange(333))
+    cut = util.NN_samplerv1("/nonexistent/", [[0.0, 1.0]] * 3).gensample_flat(200, omegab2cut=[0, 1, 0.01, 0.5])
+    assert cut.shape == (200, 3) and np.all((cut[:, 0] * cut[:, 1] ** 2 > 0.01) & (cut[:, 0] * cut[:, 1] ** 2 < 0.5))
+    # A_s (second parameter, upper limit < 1e-5) is spread uniformly in its logarithm (util.py:795-803)
+    a = util.NN_samplerv1("/nonexistent/", [[0.0, 1.0], [1e-9, 5e-9]]).gensample_flat(100)[:, 1]
+    la = np.sort(np.log(a))
+    np.testing.assert_allclose(np.diff(la), np.diff(la)[0], rtol=1e-9)
+
+
 def test_artefact_readers_execute_nothing(tmp_path):
     """Transform pickles and checkpoints of a run directory go through closed allow-lists: a file naming any
     other global (here os.system / builtins.eval) is refused before anything is imported or called."""

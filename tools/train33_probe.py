@@ -13,8 +13,7 @@ prob = readme33.problem()
 ndim, means, cov = prob["ndim"], prob["means"], prob["cov"]
 sigma = np.sqrt(np.diag(cov))
 tmp = tempfile.mkdtemp() + "/"
-ns = util.NN_samplerv1(tmp, [[-5.0, 5.0]] * ndim)
-tx, vx = ns.gensample_flat(10000), ns.gensample_flat(500)
+tx, vx = readme33.design(10000, ndim), readme33.design(500, ndim)
 np.savetxt(tmp + "train_samples_x.txt", tx); np.save(tmp + "train_samples_y.npy", tx.copy())
 np.savetxt(tmp + "val_samples_x.txt", vx); np.save(tmp + "val_samples_y.npy", vx.copy())
 np.save(tmp + "lr.npy", readme33.LR)
