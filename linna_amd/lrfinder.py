@@ -13,7 +13,8 @@ import torch
 from .predictor_gpu import _AdamWState
 
 
-def range_test(pred, engine, start_lr=1e-4, end_lr=5e-3, num_iter=100, smooth_f=0.05, diverge_th=5.0):
+def range_test(pred, engine, start_lr=1e-4, end_lr=5e-3, num_iter=100, smooth_f=0.05, diverge_th=5.0, history=None):
+    """``history``: a dict that receives the recorded curve (``lr``, ``loss``), as ``LRFinder.history`` holds it."""
     model = pred.model
     saved = model.flat_params().clone()
     rng = torch.get_rng_state()
@@ -46,6 +47,8 @@ def range_test(pred, engine, start_lr=1e-4, end_lr=5e-3, num_iter=100, smooth_f=
             break
     model.flat_params().copy_(saved)
     torch.set_rng_state(rng)
+    if history is not None:
+        history["lr"], history["loss"] = list(lrs), list(losses)
     if len(losses) < 2:
         return start_lr
     lr = lrs[int(np.gradient(np.array(losses)).argmin())]          # predictor_gpu.py:234-235

@@ -137,3 +137,45 @@ def train_step(params, opt_state, X, y, stats, kind, in_size, out_size, lr, weig
 def new_opt_state(params):
     return {"step": 0, "m": {k: np.zeros_like(v) for k, v in params.items()},
             "v": {k: np.zeros_like(v) for k, v in params.items()}}
+
+
+def lr_range_test(params, batches, val, stats, kind, in_size, out_size, start_lr=1e-4, end_lr=5e-3, num_iter=100,
+                  smooth_f=0.05, diverge_th=5.0, weight_decay=1e-4, **topo_kw):
+    """The learning-rate range test predictor_gpu.py:222-238 runs before training: ``torch_lr_finder.LRFinder
+    .range_test(dataset, val_loader=val_dataset, end_lr=5e-3, num_iter=100)`` on a COPY of the model with
+    AdamW(lr=1e-4, weight_decay=1e-4), then the learning rate of steepest descent of the recorded loss curve.
+    torch_lr_finder (third party, requirements.txt; absent from the reference tree and from this image) is restated
+    from its published algorithm -- PARITY UNPINNED for that part: per iteration one optimiser step on the next
+    training batch at lr_i = start (end / start)^(i / (num_iter - 1)), the loss over the validation set (sample-weighted
+    mean of the batch losses), exponential smoothing ``smooth_f`` against the previous RECORDED value, stop once the
+    loss exceeds ``diverge_th`` x the best.  ``batches``: [(X, y)] cycled; ``val``: [(X, y)].  Returns (lr, lrs, losses)."""
+    params = {k: v.copy() for k, v in params.items()}
+    opt = new_opt_state(params)
+    lrs, losses, best = [], [], None
+    for it in range(num_iter):
+        lr = start_lr * (end_lr / start_lr) ** (it / max(num_iter - 1, 1))
+        X, y = batches[it % len(batches)]
+        train_step(params, opt, X, y, stats, kind, in_size, out_size, lr, weight_decay=weight_decay, **topo_kw)
+        tot, cnt = 0.0, 0
+        for Xv, yv in val:
+            x = (np.asarray(Xv, np.float32) - stats["X_mean"][None, :]) / stats["X_std"][None, :]
+            pred = emulator.forward(params, x, kind, in_size, out_size, **topo_kw)
+            tot += float(loss(pred, yv, stats["data_norm"], stats["icov_norm"], stats["sigma"], stats["y_mean"], stats["y_std"])) * len(Xv)
+            cnt += len(Xv)
+        l = tot / cnt
+        lrs.append(lr)
+        if it == 0:
+            best = l
+        else:
+            if smooth_f > 0:
+                l = smooth_f * l + (1 - smooth_f) * losses[-1]
+            best = min(best, l)
+        losses.append(l)
+        if not np.isfinite(l) or l > diverge_th * best:
+            break
+    if len(losses) < 2:
+        return start_lr, lrs, losses
+    lr = lrs[int(np.gradient(np.array(losses)).argmin())]          # predictor_gpu.py:234-235
+    if lr > 1e0:
+        lr = lr / 1e2
+    return float(lr), lrs, losses

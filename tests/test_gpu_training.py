@@ -180,6 +180,30 @@ def test_lr_range_test_runs_and_restores_weights(tmp_path):
     assert torch.equal(before, model.flat_params())
 
 
+@pytest.mark.parametrize("name", ["train_v2_5_3", "train_v2_12_40"])
+def test_lr_range_test_matches_the_oracle_curve(name):
+    """The range test on the HIP training step against the oracle's restatement of it (oracle/training.lr_range_test: the
+    published algorithm of the third-party finder the reference calls at predictor_gpu.py:222-238, on the oracle's numpy
+    training step): the same learning-rate schedule, the same recorded loss curve within float32 training noise, the same
+    selected learning rate, and the model untouched afterwards."""
+    from oracle import training
+    from linna_amd import lrfinder
+    g = cases.golden(name)
+    p, model, pred, eng, B = make_engine(name)
+    before = model.flat_params().clone()
+    hist = {}
+    lr = lrfinder.range_test(pred, eng, num_iter=30, history=hist)
+    assert torch.equal(before, model.flat_params())
+    stats = dict(X_mean=p["X_mean"], X_std=p["X_std"], y_mean=p["y_mean"], y_std=p["y_std"],
+                 sigma=p["sigma"].astype(np.float32), data_norm=g["data_norm"].reshape(-1), icov_norm=g["icov_norm"])
+    batches = [(p["X"][s], p["Y"][s]) for s in range(3)]          # the loader of make_engine: unshuffled, three batches
+    lr_ref, lrs, losses = training.lr_range_test(p["weights"], batches, batches, stats, p["kind"], p["nin"], p["nout"], num_iter=30, **p["kw"])
+    np.testing.assert_allclose(hist["lr"], lrs, rtol=1e-12)
+    assert len(hist["loss"]) == len(losses)
+    np.testing.assert_allclose(hist["loss"], losses, rtol=5e-3)
+    assert lr == lr_ref and 1e-4 <= lr <= 5e-3
+
+
 def test_first_training_step_can_be_captured():
     """A hipGraph capture of the VERY FIRST optimiser step (nothing launched before it on this network): the library
     allocates at create / prepare time only, and the descriptor table of the grouped parameter-gradient launch is
