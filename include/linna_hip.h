@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 6   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step */
+#define LINNA_ABI_VERSION 6   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -310,6 +310,16 @@ int linna_net_forward_loss(linna_net_t* net, const linna_loss_desc_t* d, const f
                             * its step counter and bias corrections are then advanced here, in the launch that takes the
                             * batch mean, and linna_adamw_step is called with prepared = 1 */
                            float* hyper, int* step_dev, float beta1, float beta2, void* stream);
+/* The optimiser step up to its gradients in ONE call (predictor_gpu.py:274-285): linna_net_forward_loss, then
+ * linna_net_backward(param_grads = 1) on the gathered rows XB and the stored activations (`fwd_ws`, scratch `bwd_ws` of
+ * linna_net_bwd_ws_bytes).  The batch mean of the loss and the AdamW step constants ride in the backward's dX-chain launch
+ * as one extra workgroup (no launch of their own); follow with linna_net_adamw_step / linna_adamw_step(prepared = 1).
+ * LINNA_ERR_UNSUPPORTED exactly when linna_net_forward_loss is. */
+int linna_net_train_step(linna_net_t* net, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                         const int* log10_flag, const float* xmean, const float* xstd, float* XB, int ldxb, void* fwd_ws,
+                         float* PRED, int ldp, const float* YN, int ldyn, const float* den, float inv_batch,
+                         float* loss_rows, float* loss_mean, float* dPRED, int lddp, void* bwd_ws,
+                         float* hyper, int* step_dev, float beta1, float beta2, void* stream);
 /* validation pieces (util.py:1124-1127): per-row loss and chisq_nnd/chisq_Md. */
 int linna_val_rows(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp,
                    const float* Y, int ldy, const float* den, int B, float* scratch, float* loss_rows,

@@ -451,11 +451,42 @@ int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
 // d loss / d pred.  Replaces linna_gather_xform + linna_net_forward + linna_chi2_ratio_loss_fwd_bwd (seven launches for
 // nout > 64) when the network + loss fit the whole-network kernel; LINNA_ERR_UNSUPPORTED otherwise (the caller then
 // runs that sequence).  The batch mean is a second, tiny launch (fixed summation order).
+static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
+                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post);
+static int net_forward_loss_impl(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                                 const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
+                                 int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
+                                 float* loss_mean, float* dPRED, int lddp, float* hyper, int* step_dev, float b1, float b2,
+                                 void* stream, bool defer_post);
 int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                            const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
                            int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
                            float* loss_mean, float* dPRED, int lddp, float* hyper, int* step_dev, float b1, float b2,
                            void* stream) {
+    return net_forward_loss_impl(n, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, ws, PRED, ldp, YN, ldyn, den, inv_batch, loss_rows,
+                                 loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, false);
+}
+// One optimiser step up to the gradients in ONE call: linna_net_forward_loss followed by linna_net_backward(param_grads = 1)
+// on the rows it gathered, with the step's two single-thread jobs (batch mean of the loss, AdamW step counter and bias
+// corrections) riding in the backward's dX-chain launch as one extra workgroup instead of a launch of their own between
+// the two whole-network launches.  LINNA_ERR_UNSUPPORTED exactly when linna_net_forward_loss is.
+int linna_net_train_step(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                         const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* fwd_ws, float* PRED,
+                         int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
+                         float* loss_mean, float* dPRED, int lddp, void* bwd_ws, float* hyper, int* step_dev, float b1, float b2,
+                         void* stream) {
+    if (!bwd_ws) { set_error("net_train_step: backward workspace required"); return LINNA_ERR_INVALID; }
+    TRY(net_forward_loss_impl(n, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, fwd_ws, PRED, ldp, YN, ldyn, den, inv_batch,
+                              loss_rows, loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, true));
+    const bool prep = hyper && step_dev;
+    const NsPost post{loss_rows, (loss_mean || prep) ? B : 0, inv_batch, loss_mean, prep ? step_dev : nullptr, prep ? hyper : nullptr, b1, b2};
+    return net_backward_impl(n, XB, ldxb, B, fwd_ws, bwd_ws, dPRED, lddp, nullptr, 0, 1, stream, post.n ? &post : nullptr);
+}
+static int net_forward_loss_impl(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                                 const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
+                                 int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
+                                 float* loss_mean, float* dPRED, int lddp, float* hyper, int* step_dev, float b1, float b2,
+                                 void* stream, bool defer_post) {
     if (!n || !d || !X || !xmean || !xstd || !XB || !PRED || !YN || !den || !loss_rows || !dPRED || B < 1) {
         set_error("net_forward_loss: bad arguments"); return LINNA_ERR_INVALID;
     }
@@ -487,6 +518,7 @@ int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const flo
     const NsTrainLoss L{YN, ldyn, den, inv_batch, loss_rows, dPRED, lddp};
     TRY(launch_net_stream_train(n->L.data(), nl, n->in_size, packed, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, y.data(),
                                 ldy_.data(), t.data(), ldt.data(), L, n->loss_dn, rows, S(stream)));
+    if (defer_post) return LINNA_OK;                 // linna_net_train_step: they ride in the backward's dX launch
     // the batch mean -- and, when the caller hands in its AdamW state, the step counter and bias corrections of the
     // update that will follow this step's backward (linna_adamw_step(prepared = 1)): two single-thread jobs, one launch
     if (loss_mean && hyper && step_dev) return launch_sum_scale_prepare(loss_rows, B, inv_batch, loss_mean, step_dev, hyper, b1, b2, S(stream));
@@ -503,8 +535,16 @@ int linna_net_stream_state(const linna_net_t* n, int* fwd, int* dx, int* dx_inpu
     return LINNA_OK;
 }
 
+static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
+                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post);
 int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
                        int lddo, float* dX, int lddx, int pg, void* stream) {
+    return net_backward_impl(n, X, ldx, B, fwd_ws, bwd_ws, dOUT, lddo, dX, lddx, pg, stream, nullptr);
+}
+// `post`: the loss mean / AdamW step constants of this step (linna_net_train_step): they ride in the one-launch dX chain
+// as an extra workgroup, or run as the launch of their own they otherwise are, in front of the GEMM chain
+static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
+                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post) {
     if (!n || !X || !dOUT || !bwd_ws || B < 1) { set_error("net_backward: bad arguments"); return LINNA_ERR_INVALID; }
     const FwdLayout f = fwd_layout(n, B);
     const float* w = static_cast<const float*>(fwd_ws);
@@ -601,9 +641,14 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
                 }
             }
             TRY(launch_net_stream_dx(n->L.data(), nl, n->in_size, packed, dOUT, lddo, B, dprev.data(), ldpv.data(), hinp.data(),
-                                     ldhv.data(), dt.data(), lddt.data(), tp.data(), ldtv.data(), wi, rows, st));
+                                     ldhv.data(), dt.data(), lddt.data(), tp.data(), ldtv.data(), wi, rows, st, post));
             fused_dx = true;
         }
+    }
+    if (post && !fused_dx) {
+        if (post->out && post->step) TRY(launch_sum_scale_prepare(post->rows, post->n, post->scale, post->out, post->step, post->hyper, post->b1, post->b2, st));
+        else if (post->out) TRY(launch_sum_scale(post->rows, post->n, post->scale, post->out, st));
+        else if (post->step) TRY(launch_adamw_prepare(post->hyper, post->step, post->b1, post->b2, st));
     }
     const float* dcur = dOUT; int ldd = lddo;
     float* cursor = bw;

@@ -126,10 +126,13 @@ size_t net_stream_dense_packed_floats(const linna_layer_t* layers, int nl, int i
 // the dX chain of a training step as a program of the same kernel (prog 1: ops nl-1..1, prog 2: down to op 0)
 bool net_stream_dx_eligible(const linna_layer_t* layers, int nl, int in_size, int with_input);
 size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_size, int with_input);
+// A small job that rides in the dX-chain launch as one extra workgroup (linna_net_train_step): the batch mean of the loss
+// rows (out = scale * sum rows[n], sum_scale_prepare_kernel's order) and AdamW's step counter / bias corrections
+struct NsPost { const float* rows; int n; float scale; float* out; int* step; float* hyper; float b1, b2; };
 int launch_net_stream_dx(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* dOUT, int lddo,
                          int B, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
                          float* const* dt, const int* lddt, const float* const* t, const int* ldt, int with_input, int rows,
-                         hipStream_t s);
+                         hipStream_t s, const NsPost* post = nullptr);
 // sampler moves fused around the evaluation.  slice == 0: stretch half step, rows of the batch are the walkers
 // S[0..B).  slice == 1: rows are the slice sampler's trial points coords[S[k]] + cc[row] * DIR[k], k = row % nc
 // (DIR is passed as the launch's Z / ldz; cc = w[nrep * ns], nc = ns; nothing is written back).

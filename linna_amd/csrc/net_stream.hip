@@ -117,6 +117,10 @@ struct NsArgs {
     // (u_same) or at column 0 with d in the other buffer; the finish takes chi2 = d . U
     int dense, u_col, u_same;
     int x0_keep;                        // the program copies the input rows somewhere later (NsSeg::x0_col): keep them in LDS
+    // STORE == 2 rider (linna_net_train_step): ONE extra workgroup of the launch takes the batch mean of the loss rows the
+    // forward + loss launch wrote and advances AdamW's step counter / bias corrections -- sum_scale_prepare_kernel's job,
+    // on a CU the dX chain leaves idle instead of a launch of its own between the two
+    const float* p_rows; int p_n; float p_scale; float* p_out; int* p_step; float* p_hyper; float p_b1, p_b2;
     // stretch move fused around the evaluation (MOVE instantiation; emcee StretchMove behind sampler.py:493-495)
     float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
@@ -238,6 +242,31 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const int li = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.x * ROWS;
     if (a.gate && a.gate[0] == 0) return;
+    if constexpr (STORE == 2 && !GRAD) {
+        if (a.p_n > 0 && blockIdx.x == gridDim.x - 1) {
+            // sum_scale_prepare_kernel's arithmetic in its order: 1024 strided partial sums (two per thread here),
+            // sixteen wave sums, added in wave order
+            float* const part = smem;
+            float acc0 = 0.f, acc1 = 0.f;
+            for (int i = tid; i < a.p_n; i += 1024) acc0 += a.p_rows[i];
+            for (int i = tid + 512; i < a.p_n; i += 1024) acc1 += a.p_rows[i];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { acc0 += __shfl_xor(acc0, o, 64); acc1 += __shfl_xor(acc1, o, 64); }
+            if (lane == 0) { part[wave] = acc0; part[8 + wave] = acc1; }
+            __syncthreads();
+            if (tid == 0 && a.p_out) {
+                float t = 0.f;
+                for (int w = 0; w < 16; ++w) t += part[w];
+                a.p_out[0] = t * a.p_scale;
+            }
+            if (tid == 64 && a.p_step) {
+                const int t = ++a.p_step[0];
+                a.p_hyper[2] = (float)(1.0 - pow((double)a.p_b1, (double)t));
+                a.p_hyper[3] = (float)sqrt(1.0 - pow((double)a.p_b2, (double)t));
+            }
+            return;
+        }
+    }
 #ifdef NS_STAMPS
     unsigned long long* const lstamp = reinterpret_cast<unsigned long long*>(lbias + ((a.bias_total + 3) & ~3) + 32 + (a.x0_keep ? 1024 : 0)) + wave * 32;   // (not for GRAD: its masks live there)
     int nstamp = 0;
@@ -1262,7 +1291,7 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
 }
 
 template <int MOVE, bool GRAD, int STORE, int ROWS>
-static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s) {
+static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t s, int extra = 0) {
     static bool attr_set = false;
     if (!attr_set) {
         const int rc = check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(&net_stream_kernel<NS_R, MOVE, GRAD, STORE, ROWS>),
@@ -1270,11 +1299,11 @@ static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t 
         if (rc != LINNA_OK) return rc;
         attr_set = true;
     }
-    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD, STORE, ROWS>), dim3((B + ROWS - 1) / ROWS), dim3(64 * NS_NW), lds_bytes, s, a);
+    hipLaunchKernelGGL((net_stream_kernel<NS_R, MOVE, GRAD, STORE, ROWS>), dim3((B + ROWS - 1) / ROWS + extra), dim3(64 * NS_NW), lds_bytes, s, a);
     return check_hip(hipGetLastError(), "net_stream launch");
 }
 template <int MOVE, bool GRAD, int STORE = 0>
-static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int rows, hipStream_t s) {
+static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int rows, hipStream_t s, int extra = 0) {
     const size_t lds = p.lds_for(rows, GRAD);
 #ifdef NS_STAMPS
     // diagnostic build: every launch writes its phase stamps to the buffer LINNA_FUSED_STAMPS names (tools/ns_stamps*.py)
@@ -1284,9 +1313,9 @@ static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int row
 #else
     const NsArgs& a = a0;
 #endif
-    if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s);
-    if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s);
-    if (rows == 16) return ns_launch_rows<MOVE, GRAD, STORE, 16>(a, B, lds, s);
+    if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s, extra);
+    if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s, extra);
+    if (rows == 16) return ns_launch_rows<MOVE, GRAD, STORE, 16>(a, B, lds, s, extra);
     set_error("net_stream: %d rows per workgroup", rows);
     return LINNA_ERR_INVALID;
 }
@@ -1632,7 +1661,7 @@ namespace linna {
 int launch_net_stream_dx(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* dOUT, int lddo,
                          int B, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
                          float* const* dt, const int* lddt, const float* const* t, const int* ldt, int with_input, int rows,
-                         hipStream_t s) {
+                         hipStream_t s, const NsPost* post) {
     const NsProgram& p = ns_build_prog(layers, nl, in_size, with_input ? 2 : 1);
     if (!p.ok) { set_error("net_stream: no dX-chain program for this network"); return LINNA_ERR_UNSUPPORTED; }
     NsArgs a;
@@ -1649,6 +1678,11 @@ int launch_net_stream_dx(const linna_layer_t* layers, int nl, int in_size, const
         const int op = p.seg_op[i];
         if (p.seg_hidden[i]) { a.gout[i] = dt[op]; a.gld[i] = lddt[op]; a.gn[i] = layers[op].C; a.gmask[i] = t[op]; a.gmld[i] = ldt[op]; }
         else { a.gout[i] = dprev[op]; a.gld[i] = ldp[op]; a.gn[i] = layers[op].K; a.gmask[i] = hin[op]; a.gmld[i] = ldh[op]; }
+    }
+    if (post && post->n > 0) {                    // the rider (see NsArgs::p_rows): one more workgroup
+        a.p_rows = post->rows; a.p_n = post->n; a.p_scale = post->scale; a.p_out = post->out;
+        a.p_step = post->step; a.p_hyper = post->hyper; a.p_b1 = post->b1; a.p_b2 = post->b2;
+        return ns_launch_kernel<0, false, 2>(a, B, p, rows, s, 1);
     }
     return ns_launch_kernel<0, false, 2>(a, B, p, rows, s);
 }

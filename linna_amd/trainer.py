@@ -87,20 +87,21 @@ class TrainEngine(object):
         if self.one_launch is not False:
             # gather + transform + forward + loss + d loss / d pred in ONE launch when the network and the loss fit the
             # whole-network kernel (seven launches otherwise)
+            # (linna_net_train_step: that launch AND the backward in one call, the batch mean of the loss and AdamW's step
+            # constants riding in the backward's dX-chain launch)
             m = self.model
-            rc = _lib.load().linna_net_forward_loss(
+            rc = _lib.load().linna_net_train_step(
                 m.net_handle(with_grads=True), C.byref(self.desc), _lib.ptr(self.X), self.X.stride(0), _lib.iptr(rows), self.B,
                 _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]), _lib.ptr(self.xb),
                 self.xb.stride(0), _lib.ptr(m.workspace(self.B)), _lib.ptr(self.predb), self.predb.stride(0), _lib.ptr(self._targets()),
                 self.YN.stride(0), _lib.ptr(self.den), self.inv_batch, _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
-                self.dpred.stride(0), _lib.ptr(opt.hyper) if opt is not None else None,
+                self.dpred.stride(0), _lib.ptr(m.workspace(self.B, "bwd")), _lib.ptr(opt.hyper) if opt is not None else None,
                 _lib.iptr(opt.step_dev) if opt is not None else None, opt.betas[0] if opt is not None else 0.0,
                 opt.betas[1] if opt is not None else 0.0, st)
             if rc == 0:
                 self.one_launch = True
                 self._prepared = opt is not None
                 m._last_input = self.xb
-                m.backward(self.dpred[:, :self.nout], param_grads=True)
                 return
             if rc != _lib.ERR_UNSUPPORTED or self.one_launch is True:
                 _lib.check(rc)

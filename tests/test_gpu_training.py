@@ -111,6 +111,42 @@ def test_adamw_writing_the_weight_streams_equals_update_plus_relayout(name):
         assert res[0][5] is True                    # the reference's network trains through the one-launch update
 
 
+@pytest.mark.parametrize("name", ["train_v2_33_33", "train_v2_26_457"])
+def test_train_step_entry_equals_forward_loss_plus_backward(name):
+    """``linna_net_train_step`` (forward + loss + backward in one call, the batch mean and AdamW's step constants riding
+    in the dX-chain launch) against ``linna_net_forward_loss`` + ``linna_net_backward``: loss rows, batch mean, every
+    parameter gradient, the step counter and the bias corrections, bit for bit."""
+    import ctypes as C
+    from linna_amd import _lib
+    from linna_amd.predictor_gpu import _AdamWState
+    got = []
+    for one_call in (True, False):
+        p, model, pred, eng, B = make_engine(name)
+        opt = _AdamWState(model, 1e-3)
+        rows = torch.arange(B, 2 * B, dtype=torch.int32, device="cuda")
+        out = torch.zeros(1, device="cuda")
+        for _ in range(2):                                   # (twice: the second step finds the counter at 1)
+            if one_call:
+                eng._forward_loss_backward(rows, out, opt)
+                assert eng.one_launch is True
+            else:
+                k, m = eng.k, model
+                _lib.call("linna_net_forward_loss", m.net_handle(with_grads=True), C.byref(eng.desc), _lib.ptr(eng.X), eng.X.stride(0),
+                          _lib.iptr(rows), B, _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]),
+                          _lib.ptr(k["xstd"]), _lib.ptr(eng.xb), eng.xb.stride(0), _lib.ptr(m.workspace(B)), _lib.ptr(eng.predb),
+                          eng.predb.stride(0), _lib.ptr(eng._targets()), eng.YN.stride(0), _lib.ptr(eng.den), eng.inv_batch,
+                          _lib.ptr(eng.loss_rows), _lib.ptr(out), _lib.ptr(eng.dpred), eng.dpred.stride(0), _lib.ptr(opt.hyper),
+                          _lib.iptr(opt.step_dev), opt.betas[0], opt.betas[1], _lib.stream())
+                m._last_input = eng.xb
+                m.backward(eng.dpred[:, :p["nout"]], param_grads=True)
+        torch.cuda.synchronize()
+        got.append([eng.loss_rows.cpu().numpy().copy(), out.cpu().numpy().copy(), model.flat_grads().cpu().numpy().copy(),
+                    opt.step_dev.cpu().numpy().copy(), opt.hyper.cpu().numpy().copy()])
+    assert int(got[0][3][0]) == 2 and np.isfinite(got[0][1]).all() and np.abs(got[0][2]).max() > 0
+    for a, b in zip(*got):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_graph_replay_equals_direct_launches():
     from linna_amd.predictor_gpu import _AdamWState
     from linna_amd import trainer
