@@ -162,6 +162,30 @@ def test_oracle_agrees_at_large_batch():
     np.testing.assert_allclose(got, ref, rtol=5e-4)
 
 
+def test_very_large_ragged_batch():
+    """70 001 walkers in one call (4376 workgroups of the 16-row engine, the last one a single row; row indices past
+    2^16): every row against the oracle on a sample, and the rows of the first and last workgroups bit for bit against
+    the same rows evaluated as a batch of their own on the same engine."""
+    from oracle import likelihood
+    lp, pred, yinv, prob = build_logprob("v2_33_33")
+    emu = cases.oracle_emulator(prob)
+    n = 70001
+    z = np.random.RandomState(11).standard_normal((n, 33)).astype(np.float32)
+    zd = torch.as_tensor(z, device="cuda")
+    out = torch.empty(n, device="cuda")
+    lp.evaluate(zd, out=out)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    idx = np.r_[0:64, 65500:65600, n - 64:n]
+    ref = likelihood.log_prob(z[idx], emu, prob["priors"], prob["data"], prob["invcov"], 1.0, dtype=np.float64)
+    np.testing.assert_allclose(got[idx], ref, rtol=6e-4)
+    # a batch of 8192 rows runs the same 16-row engine: same rows, same bits, wherever they sit in the big batch
+    lo = 61440                                                    # a multiple of 16: the same row <-> lane map
+    part = torch.empty(8192, device="cuda")
+    lp.evaluate(zd[lo:lo + 8192].contiguous(), out=part)
+    np.testing.assert_array_equal(part.cpu().numpy(), got[lo:lo + 8192])
+
+
 def test_reference_fixture_known_answers():
     """The reference's own test fixture (tests/test_main.py:47-51 reads it): checkpoint and
     transform pickles load through the product's retrieve_model; log-probabilities match."""
