@@ -19,7 +19,12 @@ Parity status
   lives in emcee (requirements.txt:14 pins emcee==3.0.2), which is neither vendored in the
   reference tree nor installed here; it is restated from emcee's published algorithm
   (Goodman & Weare 2010; emcee ``RedBlueMove``/``StretchMove``) and anchored on the
-  reference's call sites sampler.py:493-495, 519-530.
+  reference's call sites sampler.py:493-495, 519-530.  Its GEOMETRY (red/blue halves, the line
+  through the complementary walker, the stretch range, the (ndim - 1) ln z factor) is pinned by the
+  reference-held emcee 3.0.2 chain ``chemcee_256.h5`` (tests/test_stretch_fixture.py); emcee's random
+  stream is not.
+* ``oracle.training.lr_range_test``: PARITY UNPINNED (torch_lr_finder, third party, absent), restated
+  from its published algorithm; anchored on predictor_gpu.py:222-238.
 
 Every function cites the reference file:line it follows (paths relative to the
 reference root).

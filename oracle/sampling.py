@@ -8,7 +8,8 @@ TEST INFRASTRUCTURE ONLY.
 * ``stretch_half_step`` restates emcee 3.0.2 ``RedBlueMove.propose`` /
   ``StretchMove.get_proposal`` (Goodman & Weare 2010, a = 2): PARITY UNPINNED -- emcee is
   a third-party dependency (requirements.txt:14) absent from the reference tree and from
-  this image; anchored on the reference call sites sampler.py:493-495, 519-530.
+  this image; anchored on the reference call sites sampler.py:493-495, 519-530, its geometry pinned by
+  the reference-held emcee chain (tests/test_stretch_fixture.py).
 * ``philox4x32`` is the published Philox4x32-10 generator (Salmon et al. 2011); the HIP
   sampler kernels use the same counter layout so draws can be replayed here.
 """

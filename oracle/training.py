@@ -2,7 +2,10 @@
 
 TEST INFRASTRUCTURE ONLY.  Restates linna/util.py:1055-1127 (Auxilleryfunc, Loss_fn,
 Val_metric_fn), :1308-1313, :1410-1460 (train_NN statistics) and the torch.optim.AdamW
-update used at linna/predictor_gpu.py:267,287.
+update used at linna/predictor_gpu.py:267,287.  ``lr_range_test`` (last function) restates the
+third-party learning-rate finder the reference calls at predictor_gpu.py:222-238 (torch_lr_finder:
+absent from the reference tree and from this image) from its published algorithm -- PARITY UNPINNED
+for that function; the selection rule behind it is the reference's.
 """
 import numpy as np
 
