@@ -701,31 +701,36 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         part[wave * PW + rr * 64 + (q_col(t) ^ (SM ? 32 * (rr & 1) : 16 * kq))] = fin[t][e];
                     }
                 lds_barrier();
-                // thread (row pr, lane pc0 of 32): columns pc0, pc0+32, ...; wave of (K part kp, group cg) = kp*ncg + cg
-                float* const cur = act + P * ABUF + pr * LD + s_dst;
+                // thread (row sr, lane sc0 of RGS): columns sc0, sc0+RGS, ...; wave of (K part kp, group cg) = kp*ncg + cg.
+                // 16 rows: the prologue's 32 threads per row; 8 / 4 rows: ALL 512 threads, 64 / 128 per row (with 32 per row
+                // three quarters of a 4-row workgroup watched the other quarter reduce)
+                constexpr int RGS = SM ? 64 * NW / ROWS : RG;
+                const int sr = SM ? tid / RGS : pr, sc0 = SM ? tid % RGS : pc0;
+                const bool srow = SM ? true : prow;
+                float* const cur = act + P * ABUF + sr * LD + s_dst;
                 const int ncol = 64 << s_ncgl, nkp = NW >> s_ncgl;
-                const int sw = SM ? 32 * (pr & 1) : 16 * (pr >> 2);
-                constexpr int NGJ = 8;                  // (SPLIT outputs are <= 256 columns: 8 per thread)
+                const int sw = SM ? 32 * (sr & 1) : 16 * (sr >> 2);
+                constexpr int NGJ = 256 / RGS;          // (SPLIT outputs are <= 256 columns: 8 / 4 / 2 per thread)
                 float sg[NGJ];
                 if constexpr (STORE == 2) {
                     if (s_gmask) {
 #pragma unroll
                         for (int j = 0; j < NGJ; ++j) {
-                            const float* pg = s_gmask + (size_t)min(row0 + pr, a.B - 1) * s_gmld + min(pc0 + RG * j, s_gn - 1);
+                            const float* pg = s_gmask + (size_t)min(row0 + sr, a.B - 1) * s_gmld + min(sc0 + RGS * j, s_gn - 1);
                             if constexpr (GRAD)
                                 asm volatile("global_load_dword %0, %1, off sc1" : "=v"(sg[j]) : "v"(pg) : "memory");
                             else
                                 asm volatile("global_load_dword %0, %1, off" : "=v"(sg[j]) : "v"(pg) : "memory");
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sg[0]), "+v"(sg[1]), "+v"(sg[2]), "+v"(sg[3]), "+v"(sg[4]), "+v"(sg[5]),
-                                     "+v"(sg[6]), "+v"(sg[7]) :: "memory");
+#pragma unroll
+                        for (int j = 0; j < NGJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sg[j]) :: "memory");
                     }
                 }
                 int gj = 0;
-                for (int c = pc0; c < (prow ? s_zext : 0); c += RG, ++gj) {
+                for (int c = sc0; c < (srow ? s_zext : 0); c += RGS, ++gj) {
                     float v = 0.f;
                     if (c < ncol) {
-                        const float* src = part + (c >> 6) * PW + pr * 64 + ((c & 63) ^ sw);
+                        const float* src = part + (c >> 6) * PW + sr * 64 + ((c & 63) ^ sw);
                         float x[NW];
 #pragma unroll
                         for (int kp = 0; kp < NW; ++kp) x[kp] = src[((kp & (nkp - 1)) << s_ncgl) * PW];   // 8 reads in flight
@@ -740,11 +745,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             if (s_gmask && !(gv > 0.f)) v = 0.f;
                         }
                         if constexpr (STORE) {
-                            if (s_gout && row0 + pr < a.B && c < s_gn) {
+                            if (s_gout && row0 + sr < a.B && c < s_gn) {
                                 float vs = v;
                                 if constexpr (STORE == 1)
                                     if (si == nseg - 1) vs = vs * (a.cscale ? a.cscale[c] : 1.f) + (a.cshift ? a.cshift[c] : 0.f);
-                                gstore(s_gout + (size_t)(row0 + pr) * s_gld + c, vs);
+                                gstore(s_gout + (size_t)(row0 + sr) * s_gld + c, vs);
                             }
                         }
                     }
@@ -752,21 +757,22 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 }
                 if constexpr (STORE == 3) {
                     if (si == nseg - 2) {
-                        // the network's last layer (nout <= 256): thread (row pr, lane pc0) turns its own columns
-                        // pc0 + 32 j of pred into delta, in place (asm loads: see the WIDE epilogue)
-                        constexpr int NJ = 8;
+                        // the network's last layer (nout <= 256): thread (row sr, lane sc0) turns its own columns
+                        // sc0 + RGS j of pred into delta, in place (asm loads: see the WIDE epilogue)
+                        constexpr int NJ = NGJ;
+                        const int ysrc = lsrc[sr];
                         float sy[NJ];
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            const int c = min(pc0 + RG * j, nout - 1);
-                            asm volatile("global_load_dword %0, %1, off" : "=v"(sy[j]) : "v"(a.t_Y + (size_t)zsrc * a.t_ldy + c) : "memory");
+                            const int c = min(sc0 + RGS * j, nout - 1);
+                            asm volatile("global_load_dword %0, %1, off" : "=v"(sy[j]) : "v"(a.t_Y + (size_t)ysrc * a.t_ldy + c) : "memory");
                         }
-                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sy[0]), "+v"(sy[1]), "+v"(sy[2]), "+v"(sy[3]), "+v"(sy[4]), "+v"(sy[5]),
-                                     "+v"(sy[6]), "+v"(sy[7]) :: "memory");
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(sy[j]) :: "memory");
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            const int c = pc0 + RG * j;
-                            if (c < nout && prow) cur[c] = isnan(sy[j]) ? -0.f : (sy[j] - cur[c]) + 0.f;
+                            const int c = sc0 + RGS * j;
+                            if (c < nout && srow) cur[c] = isnan(sy[j]) ? -0.f : (sy[j] - cur[c]) + 0.f;
                         }
                     }
                 }
@@ -846,16 +852,25 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         for (int c = pc0; c < nout; c += RG) chi += Dv[c] * Uv[c];
 #pragma unroll
         for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
-        if (rok) {
-            const float dr = lden[pr];
-            if (pc0 == 0) a.t_loss_rows[row0 + pr] = chi / dr;
-            for (int c = pc0; c < a.t_lddp; c += RG) {
-                float g = 0.f;
-                if (c < nout) {
-                    const bool masked = __float_as_uint(Dv[c]) == 0x80000000u;
-                    g = masked ? 0.f : (-2.f * Uv[c]) * a.t_inv_batch / dr;
+        if (rok && pc0 == 0) a.t_loss_rows[row0 + pr] = chi / lden[pr];
+        {
+            // d loss / d pred by ALL threads of the workgroup, 512 / ROWS per row (the row's 32 threads alone walked a
+            // 457-wide row in 15 rounds while three quarters of the workgroup waited: 8 k cycles at the kernel's tail)
+            constexpr int TPR = 64 * NW / ROWS;
+            const int fr = tid / TPR, fc = tid % TPR;
+            if (row0 + fr < a.B) {
+                const float* const Fr = act + P * ABUF + fr * LD;
+                const float* const Dr = a.u_same ? Fr : act + (P ^ 1) * ABUF + fr * LD;
+                const float* const Ur = a.u_same ? Fr + a.u_col : Fr;
+                const float dr = lden[fr];
+                for (int c = fc; c < a.t_lddp; c += TPR) {
+                    float g = 0.f;
+                    if (c < nout) {
+                        const bool masked = __float_as_uint(Dr[c]) == 0x80000000u;
+                        g = masked ? 0.f : (-2.f * Ur[c]) * a.t_inv_batch / dr;
+                    }
+                    a.t_dP[(size_t)(row0 + fr) * a.t_lddp + c] = g;
                 }
-                a.t_dP[(size_t)(row0 + pr) * a.t_lddp + c] = g;
             }
         }
         NS_STAMP();
