@@ -587,6 +587,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 kleft = NX.steps;
             };
             bool seg_done = true;
+#ifdef NS_STAMPS_FINE
+            const bool fine = si >= NS_STAMPS_FINE && si < NS_STAMPS_FINE + 4;
+            if (fine) NS_STAMP();                  // run end reached (last MFMA issued)
+#endif
             // result quads: fin[q][e] is (row, column) = SM ? (4 q + e, lane) : (4 kq + e, 16 q + li) of the wave's 64 columns
             if constexpr (SM) {
 #pragma unroll
@@ -679,6 +683,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             }
                         }
                     }
+#ifdef NS_STAMPS_FINE
+                if (fine) NS_STAMP();              // epilogue done (LDS writes and stores issued)
+#endif
                 if (++pass == s_passes) {
                     lds_barrier();
                     NS_STAMP();
@@ -821,6 +828,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 begin_run();
                 a_read(Aq[(U + 1) & 1]);           // replaces the speculative fragment
             }
+#ifdef NS_STAMPS_FINE
+            if (fine) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); NS_STAMP(); }   // next run ready to issue
+#endif
         }
     };
     using T_ = std::true_type; using F_ = std::false_type;
