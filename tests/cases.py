@@ -27,6 +27,8 @@ TRAIN = [
     ("train_v2_33_33", "ChtoModelv2", 33, 33, 203, 100, {}, False),
     ("train_v2_12_40", "ChtoModelv2", 12, 40, 204, 50, {}, False),
     ("train_v2_26_457", "ChtoModelv2", 26, 457, 205, 64, {}, False),      # BASELINE config 3 shape
+    ("train_v2lin_5_3", "ChtoModelv2_linear", 5, 3, 206, 40, {}, True),
+    ("train_simple_6_4", "ChtoModelsimple", 6, 4, 207, 40, {}, True),
 ]
 
 

@@ -187,6 +187,8 @@ TRAIN = [
     ("train_v2_33_33", "ChtoModelv2", 33, 33, 203, 100, {}, False),
     ("train_v2_12_40", "ChtoModelv2", 12, 40, 204, 50, {}, False),
     ("train_v2_26_457", "ChtoModelv2", 26, 457, 205, 64, {}, False),      # BASELINE config 3 shape
+    ("train_v2lin_5_3", "ChtoModelv2_linear", 5, 3, 206, 40, {}, True),    # nn.py:136-198: the input skip trains too
+    ("train_simple_6_4", "ChtoModelsimple", 6, 4, 207, 40, {}, True),      # nn.py:300-374
 ]
 
 
@@ -203,7 +205,10 @@ def training_problem(nin, nout, seed, B):
 
 
 def gen_training(out):
+    only = [n for n in os.environ.get("GOLDEN_TRAIN_ONLY", "").split(",") if n]     # (add a case without rewriting the others)
     for name, kind, nin, nout, seed, B, kw, full in TRAIN:
+        if only and name not in only:
+            continue
         data, cov, sigma, X_mean, X_std, y_mean, y_std, X, Y = training_problem(nin, nout, seed, B)
         model = build_model(kind, nin, nout, seed, **kw)
         ytd = rutil.Y_transform_data(sigma, device="cpu")

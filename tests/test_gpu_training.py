@@ -16,7 +16,8 @@ torch = pytest.importorskip("torch")
 def make_engine(name, steps_as_dataset=True):
     from linna_amd import nn, util, predictor_gpu, trainer
     p = cases.training_problem(name)
-    cls = {"ChtoModelv2": nn.ChtoModelv2, "MLP": nn.MLP}[p["kind"]]
+    cls = {"ChtoModelv2": nn.ChtoModelv2, "MLP": nn.MLP, "ChtoModelv2_linear": nn.ChtoModelv2_linear,
+           "ChtoModelsimple": nn.ChtoModelsimple}[p["kind"]]
     model = cls(p["nin"], p["nout"], None, **p["kw"])
     model.load_state_dict(p["weights"])
     t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
