@@ -4,7 +4,8 @@ TEST INFRASTRUCTURE ONLY.
 
 * ``hmc_chain`` restates linna/HMCSampler.py:19-68 (PINNED by tests/golden/hmc_trace.npz).
 * ``hmc_batched_step`` is the same leapfrog applied independently per walker (the
-  per-walker semantics of sampler.py:67-98).
+  per-walker semantics of sampler.py:67-98): PINNED by tests/golden/hmc_move.npz,
+  the output of the reference's own ``_hmc_wrapper`` called directly.
 * ``stretch_half_step`` restates emcee 3.0.2 ``RedBlueMove.propose`` /
   ``StretchMove.get_proposal`` (Goodman & Weare 2010, a = 2): PARITY UNPINNED -- emcee is
   a third-party dependency (requirements.txt:14) absent from the reference tree and from
@@ -131,7 +132,7 @@ def hmc_chain(lnp_and_grad, x0, mass, num_samps, num_steps, step_size, momenta, 
     return np.array(xs, f), np.array(lnps, f), np.array(accs)
 
 
-def hmc_batched_step(lnp_and_grad_rows, x, lnp, grad, mass, num_steps, step_size, p0, u):
+def hmc_batched_step(lnp_and_grad_rows, x, lnp, grad, mass, num_steps, step_size, p0, u, details=None):
     """One HMC transition for every row of ``x[B, nin]`` independently.
 
     ``lnp_and_grad_rows(x[B,nin]) -> (lnP[B], grad[B,nin])``; ``p0`` standard-normal draws,
@@ -153,6 +154,8 @@ def hmc_batched_step(lnp_and_grad_rows, x, lnp, grad, mass, num_steps, step_size
             p = p + eps * g
     p = p + f(0.5) * eps * g
     H1 = f(0.5) * np.sum(p * p / mass, -1) - l
+    if details is not None:      # the proposal itself and the kinetic-energy factor of sampler.py:95-97 (K0 - K1)
+        details.update(q=q.copy(), lnp_new=np.asarray(l).copy(), factor=(H0 + lnp) - (H1 + l))
     with np.errstate(invalid="ignore", over="ignore"):
         acc = u < np.exp(np.minimum(H0 - H1, 0))
     acc &= np.isfinite(l)

@@ -392,6 +392,36 @@ def gen_hmc(out):
     print("hmc accepted", int(sum(c["accepted"] for c in chain)), "of", num_samps, flush=True)
 
 
+def gen_hmc_move(out):
+    """The per-walker HMC move the reference WROTE but cannot reach through emcee (sampler.py:59-98 ``_hmc_wrapper``,
+    :311-320 ``_hmc_matrix``): its integrator called directly, walker by walker, with the gradient of the
+    reference's own ``Log_prob`` (autograd) -- proposal q and kinetic-energy factor for given momenta, plus the
+    log-probabilities the Metropolis test of ``HamiltonianMove.propose`` (:141-143) would use."""
+    import linna.sampler as rsamp
+    name, kind, nin, nout, seed, dense, n, dolog10, ypos, kw = SERVING[5]   # simple_6_4
+    lp = make_logprob(kind, nin, nout, seed, dense, dolog10, ypos, kw, 1.0, nograd=False)[0]
+
+    def lnp_and_grad(x):
+        xt = torch.tensor(np.asarray(x, np.float32), requires_grad=True)
+        v = lp(xt, inputnumpy=False)
+        g, = torch.autograd.grad(v, xt)
+        return float(v), g.numpy().astype(np.float64)
+    rs = np.random.RandomState(91)
+    nw, nsteps, eps = 24, 4, 0.002
+    var = np.linspace(0.6, 1.8, nin)                           # diagonal mass (the move's `cov`)
+    coords = 0.3 * rs.standard_normal((nw, nin))
+    integ = rsamp._hmc_wrapper(rs, lambda q: lnp_and_grad(q)[1], var, eps, nsteps)
+    momenta = integ.cov.sample(np.random.RandomState(92), nw, nin)
+    q, fac = np.zeros((nw, nin)), np.zeros(nw)
+    for k in range(nw):
+        q[k], fac[k] = integ((coords[k], momenta[k]))
+    out["hmc_move"] = dict(case=np.array(name), coords=coords, momenta=momenta, var=var, epsilon=np.float64(eps),
+                           nsteps=np.int64(nsteps), q=q, factor=fac,
+                           lnp_old=np.array([lnp_and_grad(c)[0] for c in coords]),
+                           lnp_new=np.array([lnp_and_grad(c)[0] for c in q]))
+    print("hmc move: max |q - coords|", float(np.abs(q - coords).max()), "factor range", float(fac.min()), float(fac.max()), flush=True)
+
+
 # ------------------------------------------------------------------ initial weights (torch RNG parity)
 INIT_CASES = [("ChtoModelv2", 33, 33, 11), ("ChtoModelv2", 26, 457, 12), ("ChtoModelsimple", 6, 4, 13),
               ("ChtoModelv2_linear", 5, 3, 14)]
@@ -506,8 +536,34 @@ def gen_train33(out, nep=None):
           "messages", messages[:12], flush=True)
 
 
-GENERATORS = [("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
-              ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc),
+# ------------------------------------------------------------------ host-side point designs
+def host_design_inputs():
+    """Deterministic inputs of ``gen_host_designs`` (the tests rebuild them): a synthetic 4-parameter chain that
+    overshoots its prior box, and three forms of the reference's ``omegab2cut`` argument."""
+    rs = np.random.RandomState(77)
+    chain = rs.standard_normal((6000, 4)) * np.array([0.6, 0.5, 1.4, 0.8]) + np.array([0.3, 0.6, 0.0, 0.1])
+    prior = [[-0.8, 1.4], [-0.4, 1.6], [-2.0, 2.0], [-1.0, 1.2]]
+    # (a 7-element cut -- one extra parameter range -- raises IndexError in the reference: its second range is tested with
+    # ``len > 6`` but read from elements 7..9, util.py:890-891; the forms that work have 4 or 10 elements)
+    cuts = {"none": None, "ombh2": [0, 1, 0.01, 0.9], "ombh2_p2_p3": [0, 1, 0.01, 0.9, 2, -1.5, 1.5, 3, -0.5, 1.0]}
+    return chain, prior, cuts
+
+
+def gen_host_designs(out):
+    """``NN_samplerv1.gensample_chain_randomsample`` of the LIVE reference (util.py:864-897: the training points of
+    iterations >= 1 are drawn from the previous chain): inside-the-prior and omega_b h^2 cuts, seed 123456."""
+    chain, prior, cuts = host_design_inputs()
+    ns = rutil.NN_samplerv1("/nonexistent/", prior)
+    rec = {}
+    for tag, cut in cuts.items():
+        for n in (300, 17):
+            rec["%s/%d" % (tag, n)] = np.asarray(ns.gensample_chain_randomsample(n, chain, None, omegab2cut=cut), np.float64)
+    out["host_designs"] = rec
+    print("host designs", {k: v.shape for k, v in rec.items()}, flush=True)
+
+
+GENERATORS = [("host_designs", gen_host_designs), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
+              ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc), ("hmc_move", gen_hmc_move),
               ("init_parity", gen_init_parity), ("train33", gen_train33)]
 
 

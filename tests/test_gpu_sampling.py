@@ -106,6 +106,35 @@ def test_batched_hmc_step_matches_oracle():
     np.testing.assert_allclose(h.lnp.cpu().numpy()[ok], ln[ok], rtol=2e-3)
 
 
+def test_batched_hmc_proposals_match_the_references_integrator():
+    """The per-walker HMC move of the reference (sampler.py:59-98 ``_hmc_wrapper``, :141-143 the Metropolis test; code it
+    never reaches through emcee, called directly for tests/golden/hmc_move.npz with the autograd gradient of its own
+    ``Log_prob``): ``BatchedHMC`` with the same momenta proposes the same points, and with given uniforms accepts exactly
+    where ``log u < lnP(q) - lnP(x) + factor`` of the reference's numbers says so."""
+    from linna_amd import sampler
+    g = cases.golden("hmc_move")
+    lp = build_logprob(str(g["case"]), 1.0)[0]
+    x0 = g["coords"].astype(np.float32)
+    nw, nd = x0.shape
+    mass = g["var"].astype(np.float32)
+    p0 = (g["momenta"] / np.sqrt(g["var"])[None, :]).astype(np.float32)
+    h = sampler.BatchedHMC(lp, x0, mass=mass)
+    np.testing.assert_allclose(h.lnp.cpu().numpy(), g["lnp_old"], rtol=6e-4)
+    h.step(int(g["nsteps"]), float(g["epsilon"]), p0=p0, u=np.zeros(nw, np.float32))       # u = 0: every finite proposal is taken
+    assert h.naccept.cpu().numpy().all()
+    np.testing.assert_allclose(h.x[:, :nd].cpu().numpy(), g["q"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(h.lnp.cpu().numpy(), g["lnp_new"], rtol=2e-3)
+    # the acceptance rule on the reference's own numbers
+    u = np.random.RandomState(3).uniform(size=nw).astype(np.float32)
+    want = np.log(u) < (g["lnp_new"] - g["lnp_old"] + g["factor"])
+    margin = np.abs(np.log(u) - (g["lnp_new"] - g["lnp_old"] + g["factor"])) > 0.05      # (float32 energies: skip the knife edges)
+    h2 = sampler.BatchedHMC(lp, x0, mass=mass)
+    h2.step(int(g["nsteps"]), float(g["epsilon"]), p0=p0, u=u)
+    got = h2.naccept.cpu().numpy().astype(bool)
+    assert margin.sum() >= nw - 4 and (got[margin] == want[margin]).all()
+    assert 0 < want.sum() < nw                                                              # both outcomes occur
+
+
 def _gaussian_33():
     rs = np.random.RandomState(0)                                    # README.rst:69-80 shaped
     ndim = 33

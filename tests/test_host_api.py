@@ -146,6 +146,28 @@ def test_latin_hypercube_reproduces_the_reference_fixture_designs():
     np.testing.assert_allclose(np.diff(la), np.diff(la)[0], rtol=1e-9)
 
 
+def test_chain_resampling_matches_the_live_reference():
+    """``NN_samplerv1.gensample_chain_randomsample`` (util.py:864-897: training points of iterations >= 1 are drawn from
+    the previous chain, inside the prior box and the omega_b h^2 cuts, seed 123456) against the live reference on the
+    same synthetic chain (tests/golden/host_designs.npz), bit for bit; the 7-element cut the reference cannot read
+    fails here in the same way."""
+    from linna_amd import util
+    g = cases.golden("host_designs")
+    rs = np.random.RandomState(77)                                   # make_golden.host_design_inputs
+    chain = rs.standard_normal((6000, 4)) * np.array([0.6, 0.5, 1.4, 0.8]) + np.array([0.3, 0.6, 0.0, 0.1])
+    prior = [[-0.8, 1.4], [-0.4, 1.6], [-2.0, 2.0], [-1.0, 1.2]]
+    cuts = {"none": None, "ombh2": [0, 1, 0.01, 0.9], "ombh2_p2_p3": [0, 1, 0.01, 0.9, 2, -1.5, 1.5, 3, -0.5, 1.0]}
+    ns = util.NN_samplerv1("/nonexistent/", prior)
+    keep = chain.copy()
+    for tag, cut in cuts.items():
+        for n in (300, 17):
+            got = ns.gensample_chain_randomsample(n, chain, None, omegab2cut=cut)
+            np.testing.assert_array_equal(got, g["%s/%d" % (tag, n)])
+    np.testing.assert_array_equal(chain, keep)                       # the caller's chain is not modified
+    with pytest.raises(IndexError):
+        ns.gensample_chain_randomsample(10, chain, None, omegab2cut=[0, 1, 0.01, 0.9, 2, -1.5, 1.5])
+
+
 def test_artefact_readers_execute_nothing(tmp_path):
     """Transform pickles and checkpoints of a run directory go through closed allow-lists: a file naming any
     other global (here os.system / builtins.eval) is refused before anything is imported or called."""

@@ -159,3 +159,24 @@ def test_stretch_move_detailed_balance_gaussian():
     s = np.concatenate(keep)
     assert np.all(np.abs(s.mean(0)) < 0.08)
     np.testing.assert_allclose(s.var(0), var, rtol=0.08)
+
+
+def test_per_walker_hmc_move_matches_the_references_integrator():
+    """sampler.py:59-98 (``_hmc_wrapper``: the per-walker leapfrog of the HMC move the reference wrote but never reaches
+    through emcee) called directly in the live reference with the autograd gradient of its own ``Log_prob``
+    (tests/golden/hmc_move.npz): the oracle's batched step proposes the same points with the same kinetic-energy factor."""
+    from oracle import sampling
+    g = cases.golden("hmc_move")
+    prob = cases.serving_problem(str(g["case"]))
+    emu = cases.oracle_emulator(prob)
+    fg = lambda q: likelihood.grad_log_prob(q, emu, prob["priors"], prob["data"], prob["invcov"], 1.0)
+    x0 = g["coords"].astype(np.float32)
+    l0, g0 = fg(x0)
+    np.testing.assert_allclose(l0, g["lnp_old"], rtol=2e-4)
+    mass = g["var"].astype(np.float32)
+    p0 = (g["momenta"] / np.sqrt(g["var"])[None, :]).astype(np.float32)
+    det = {}
+    sampling.hmc_batched_step(fg, x0, l0, g0, mass, int(g["nsteps"]), float(g["epsilon"]), p0, np.zeros(len(x0), np.float32), details=det)
+    np.testing.assert_allclose(det["q"], g["q"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(det["lnp_new"], g["lnp_new"], rtol=5e-4)
+    np.testing.assert_allclose(det["factor"], g["factor"], rtol=5e-3, atol=5e-3)
