@@ -549,6 +549,19 @@ def host_design_inputs():
     return chain, prior, cuts
 
 
+MEANSTD_THRESHOLDS = [(0.1, 0.1), (0.02, 0.1), (0.1, 0.01), (1.0, 1.0)]
+
+
+def meanstd_inputs():
+    """Synthetic chains [nstep, nwalker, nparam]: stationary, drifting mean, growing spread, odd length."""
+    rs = np.random.RandomState(55)
+    a = rs.standard_normal((400, 6, 5))
+    b = a + np.linspace(0, 0.6, 400)[:, None, None]
+    c = a * np.linspace(0.7, 1.4, 400)[:, None, None]
+    d = rs.standard_normal((301, 4, 3)) * np.array([1.0, 2.0, 0.5])
+    return [(a, "stationary"), (b, "drift"), (c, "spread"), (d, "odd")]
+
+
 def gen_host_designs(out):
     """``NN_samplerv1.gensample_chain_randomsample`` of the LIVE reference (util.py:864-897: the training points of
     iterations >= 1 are drawn from the previous chain): inside-the-prior and omega_b h^2 cuts, seed 123456."""
@@ -558,6 +571,17 @@ def gen_host_designs(out):
     for tag, cut in cuts.items():
         for n in (300, 17):
             rec["%s/%d" % (tag, n)] = np.asarray(ns.gensample_chain_randomsample(n, chain, None, omegab2cut=cut), np.float64)
+    # checkmeanstd (sampler.py:370-387) of the live reference on synthetic chains: the two drift statistics it prints and
+    # its verdict for thresholds on either side of them
+    import contextlib
+    import io
+    import linna.sampler as rsamp
+    for i, (chain3, _) in enumerate(meanstd_inputs()):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            verdicts = [bool(rsamp.checkmeanstd(chain3, a, b)) for a, b in MEANSTD_THRESHOLDS]
+        vals = [float(x) for x in buf.getvalue().split()[:2]]
+        rec["checkmeanstd/%d" % i] = np.array(vals + [float(v) for v in verdicts])
     out["host_designs"] = rec
     print("host designs", {k: v.shape for k, v in rec.items()}, flush=True)
 

@@ -168,6 +168,24 @@ def test_chain_resampling_matches_the_live_reference():
         ns.gensample_chain_randomsample(10, chain, None, omegab2cut=[0, 1, 0.01, 0.9, 2, -1.5, 1.5])
 
 
+def test_checkmeanstd_matches_the_live_reference(capsys):
+    """sampler.py:370-387 on four synthetic chains (stationary, drifting mean, growing spread, odd length): the two
+    drift statistics the reference prints and its verdicts for four threshold pairs (tests/golden/host_designs.npz)."""
+    from linna_amd import sampler
+    g = cases.golden("host_designs")
+    rs = np.random.RandomState(55)                                   # make_golden.meanstd_inputs
+    a = rs.standard_normal((400, 6, 5))
+    chains = [a, a + np.linspace(0, 0.6, 400)[:, None, None], a * np.linspace(0.7, 1.4, 400)[:, None, None],
+              rs.standard_normal((301, 4, 3)) * np.array([1.0, 2.0, 0.5])]
+    for i, c in enumerate(chains):
+        ref = g["checkmeanstd/%d" % i]
+        capsys.readouterr()
+        verdicts = [bool(sampler.checkmeanstd(c, x, y)) for x, y in [(0.1, 0.1), (0.02, 0.1), (0.1, 0.01), (1.0, 1.0)]]
+        printed = [float(v) for v in capsys.readouterr().out.split()[:2]]
+        np.testing.assert_allclose(printed, ref[:2], rtol=1e-12, atol=1e-15)
+        assert verdicts == [bool(v) for v in ref[2:]]
+
+
 def test_artefact_readers_execute_nothing(tmp_path):
     """Transform pickles and checkpoints of a run directory go through closed allow-lists: a file naming any
     other global (here os.system / builtins.eval) is refused before anything is imported or called."""
