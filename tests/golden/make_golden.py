@@ -549,6 +549,43 @@ def host_design_inputs():
     return chain, prior, cuts
 
 
+def importance_inputs():
+    """Deterministic inputs of ``gen_importance`` (the tests rebuild them)."""
+    rs = np.random.RandomState(88)
+    nout, ndim, n = 7, 4, 60
+    A = rs.standard_normal((nout, nout))
+    cov = A @ A.T / nout + 0.3 * np.eye(nout)
+    data = rs.uniform(0.5, 1.5, nout)
+    theory = np.concatenate([data, [9.0, 9.0]])[None, :] + rs.standard_normal((n, nout + 2)) * 0.4    # two extra columns: the reference cuts to len(data)
+    samples = rs.uniform(-1.5, 1.5, (n, ndim))
+    priors = [{"param": "a", "dist": "flat", "arg1": -1.0, "arg2": 1.2}, {"param": "b", "dist": "gauss", "arg1": 0.2, "arg2": 0.7},
+              {"param": "c", "dist": "flat", "arg1": -1.4, "arg2": 1.4}, {"param": "d", "dist": "gauss", "arg1": -0.3, "arg2": 1.1}]
+    return data, cov, theory, samples, priors
+
+
+def gen_importance(out):
+    """Host helpers of the importance-sampling post step and of training-set clean-up, LIVE reference: ``LogPrior``
+    (util.py:1129-1157), ``logp_theory_data`` (:1506-1517), ``chisqcut_all`` (:1260-1270: note y^T invcov y of the theory
+    vector itself), ``median_absolute_deviation`` (:1308-1313)."""
+    data, cov, theory, samples, priors = importance_inputs()
+    invcov = np.linalg.inv(cov)
+    lpr = rutil.LogPrior(priors)
+    rec = dict(logprior=np.array([lpr(s) for s in samples], np.float64),
+               logp=np.array(rutil.logp_theory_data(samples, theory, data, invcov, lpr), np.float64))
+    tmp = tempfile.mkdtemp(prefix="linna_golden_imp_")
+    y = theory[:, :len(data)]
+    cutv = float(np.median([v.dot(invcov).dot(v) for v in y]))
+    np.save(os.path.join(tmp, "y.npy"), y); np.savetxt(os.path.join(tmp, "x.txt"), samples)
+    rutil.chisqcut_all(data, invcov, cutv, os.path.join(tmp, "y.npy"), os.path.join(tmp, "x.txt"))
+    rec.update(chisqcut=np.float64(cutv), cut_y=np.load(os.path.join(tmp, "y.npy")), cut_x=np.loadtxt(os.path.join(tmp, "x.txt")))
+    shutil.rmtree(tmp, ignore_errors=True)
+    t = torch.tensor(theory[:, :len(data)], dtype=torch.float32)
+    med = t.median(axis=0).values
+    rec["mad"] = rutil.median_absolute_deviation(t, med, 0).numpy()
+    out["importance_helpers"] = rec
+    print("importance helpers: kept %d of %d rows; %d points outside the flat priors" % (len(rec["cut_x"]), len(samples), int(np.isinf(rec["logprior"]).sum())), flush=True)
+
+
 MEANSTD_THRESHOLDS = [(0.1, 0.1), (0.02, 0.1), (0.1, 0.01), (1.0, 1.0)]
 
 
@@ -586,7 +623,7 @@ def gen_host_designs(out):
     print("host designs", {k: v.shape for k, v in rec.items()}, flush=True)
 
 
-GENERATORS = [("host_designs", gen_host_designs), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
+GENERATORS = [("host_designs", gen_host_designs), ("importance", gen_importance), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
               ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc), ("hmc_move", gen_hmc_move),
               ("init_parity", gen_init_parity), ("train33", gen_train33)]
 

@@ -186,6 +186,29 @@ def test_checkmeanstd_matches_the_live_reference(capsys):
         assert verdicts == [bool(v) for v in ref[2:]]
 
 
+def test_logprior_and_mad_match_the_live_reference():
+    """``LogPrior`` (util.py:1129-1157) and ``median_absolute_deviation`` (:1308-1313) against the live reference
+    (tests/golden/importance_helpers.npz)."""
+    from linna_amd import util
+    g = cases.golden("importance_helpers")
+    rs = np.random.RandomState(88)                                   # make_golden.importance_inputs
+    nout, ndim, n = 7, 4, 60
+    A = rs.standard_normal((nout, nout))
+    cov = A @ A.T / nout + 0.3 * np.eye(nout)
+    data = rs.uniform(0.5, 1.5, nout)
+    theory = np.concatenate([data, [9.0, 9.0]])[None, :] + rs.standard_normal((n, nout + 2)) * 0.4
+    samples = rs.uniform(-1.5, 1.5, (n, ndim))
+    priors = [{"param": "a", "dist": "flat", "arg1": -1.0, "arg2": 1.2}, {"param": "b", "dist": "gauss", "arg1": 0.2, "arg2": 0.7},
+              {"param": "c", "dist": "flat", "arg1": -1.4, "arg2": 1.4}, {"param": "d", "dist": "gauss", "arg1": -0.3, "arg2": 1.1}]
+    lpr = util.LogPrior(priors)
+    got = np.array([lpr(s_) for s_ in samples], np.float64)
+    np.testing.assert_array_equal(np.isinf(got), np.isinf(g["logprior"]))
+    ok = np.isfinite(got)
+    np.testing.assert_allclose(got[ok], g["logprior"][ok], rtol=1e-14)
+    t = torch.tensor(theory[:, :nout], dtype=torch.float32)
+    np.testing.assert_array_equal(util.median_absolute_deviation(t, t.median(axis=0).values, 0).numpy(), g["mad"])
+
+
 def test_artefact_readers_execute_nothing(tmp_path):
     """Transform pickles and checkpoints of a run directory go through closed allow-lists: a file naming any
     other global (here os.system / builtins.eval) is refused before anything is imported or called."""
