@@ -567,6 +567,10 @@ class ChainStore(object):
 
 def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee", flat=False):
     """util.py:68-94: last ``nk`` autocorrelation times of the stored chain (theta space)."""
+    if walkercut:
+        # util.py:57-66 selects walkers with an unseeded sklearn KMeans over integer-cast mean log-probabilities; no caller
+        # in the reference ever passes walkercut=True (main.py:164,290,303), and its np.int no longer exists in numpy
+        raise NotImplementedError("walkercut=True (KMeans walker selection, util.py:57-66) is not part of the hot path")
     d = ChainStore.load(chainname)
     if nk > ntimes:
         print("Error: keep number greater then chain samples. nk: {0}, ntimes: {1}. This will lead to inclusion of all "

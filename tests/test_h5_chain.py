@@ -59,6 +59,12 @@ def test_read_chain_and_cut_reproduces_reference_test():
     assert int(np.median(tau)) * 4 == len(chain) == lp.size
 
 
+def test_walkercut_is_refused_not_ignored():
+    from linna_amd import util
+    with pytest.raises(NotImplementedError):
+        util.read_chain_and_cut(FIXTURE, 2, walkercut=True)
+
+
 def test_ml_sampler_core_reads_a_reference_run_directory(tmp_path):
     """The whole of ``test_reading``: with every artefact of iteration 0 in place, ``ml_sampler_core``
     trains nothing, samples nothing and returns the cut chain of the reference's HDF5 file."""
