@@ -45,7 +45,9 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
                     data, cov, init, pool, nwalkers, device, dolog10index, ypositive, temperatureArr, omegab2cut=None,
                     docuda=False, tsize=1, gpunode=None, nnmodel_in=None, params=None, method="emcee", nbest=None,
                     chisqcut=None, loglikelihoodfunc=None, nsigma=3, externalloglike=None):
-    """main.py:77-335.  Returns ``(chain[nsamp, ndim] in theta space, log_prob)``."""
+    """main.py:77-335.  Returns ``(chain[nsamp, ndim] in theta space, log_prob)``.
+    ``gpunode`` / ``docuda`` / ``device`` (main.py:193-245: which Slurm node runs ``train_gpu.py`` under srun) keep their
+    places in the signature; the emulator always trains in this process on the local GPU."""
     if method == "emcee":
         filename = "chemcee_256.h5"
     elif method == "zeus":
