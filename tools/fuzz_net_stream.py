@@ -71,7 +71,21 @@ def run(ncfg, seed0):
             # finite amount while lnP agrees; at most one such row (or 0.5 % of the rows) is not counted as a failure
             rowerr_all = np.abs(g.cpu().numpy()[:, :nin] - gref).max(1) / (np.abs(gref).max() + 1e-9)
             kinks = int((rowerr_all > 5e-3).sum())
-            ok = e1 < 1e-3 and e2 < 1e-3 and kinks <= max(1, B // 200) and e4 < 2e-3 and e5 < 2e-3
+            # ... and a row whose forward path passes within 1e-6 of a ReLU kink is not counted at all: the float64 and the
+            # float32 forward of the oracle disagree on which units are zero there, or a positive unit is that small
+            def near_kink(r):
+                pats = []
+                for dt in (np.float64, np.float32):
+                    zz = z[r:r + 1].astype(dt)
+                    xx = likelihood.x_transform(likelihood.prior_map(zz, prob["priors"]), emu.X_mean, emu.X_std, emu.dolog10index)
+                    _, caches = emu.network(xx, keep=True)
+                    acts = [a[0] for c in caches for a in c[1:]]
+                    if any((a > 0).any() and a[a > 0].min() < 1e-6 * np.abs(a).max() for a in acts):
+                        return True
+                    pats.append(np.concatenate([a == 0 for a in acts]))
+                return bool((pats[0] != pats[1]).any())
+            explained = sum(1 for r in np.where(rowerr_all > 5e-3)[0] if near_kink(int(r)))
+            ok = e1 < 1e-3 and e2 < 1e-3 and kinks - explained <= max(1, B // 200) and e4 < 2e-3 and e5 < 2e-3
             if kinks:
                 rowerr = np.abs(g.cpu().numpy()[:, :nin] - gref).max(1) / (np.abs(gref).max() + 1e-9)
                 worst = int(np.argmax(rowerr))
@@ -79,8 +93,8 @@ def run(ncfg, seed0):
                 _, g32 = likelihood.grad_log_prob(z[worst:worst + 1], emu, prob["priors"], prob["data"], prob["invcov"], 2.0, dtype=np.float32)
                 zn = z[worst:worst + 1].astype(np.float64) * (1 + 1e-6)
                 _, gn = likelihood.grad_log_prob(zn, emu, prob["priors"], prob["data"], prob["invcov"], 2.0, dtype=np.float64)
-                print("     rows > 5e-3: %d of %d; worst row %d: |gpu-ref64| %.2e |ref32-ref64| %.2e |ref64(z(1+1e-6))-ref64| %.2e (of max|g|)" % (
-                    int((rowerr > 5e-3).sum()), B, worst, rowerr[worst], np.abs(g32[0] - gref[worst]).max() / np.abs(gref).max(),
+                print("     rows > 5e-3: %d of %d (%d on a ReLU kink); worst row %d: |gpu-ref64| %.2e |ref32-ref64| %.2e |ref64(z(1+1e-6))-ref64| %.2e (of max|g|)" % (
+                    int((rowerr > 5e-3).sum()), B, explained, worst, rowerr[worst], np.abs(g32[0] - gref[worst]).max() / np.abs(gref).max(),
                     np.abs(gn[0] - gref[worst]).max() / np.abs(gref).max()), flush=True)
             print(("ok   " if ok else "BAD  ") + tag + "  eval %.1e grad-lnP %.1e grad %.1e dX %.1e dW %.1e  states %s" % (e1, e2, e3, e4, e5, ma.stream_state()), flush=True)
             bad += 0 if ok else 1
