@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 6   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step */
+#define LINNA_ABI_VERSION 6   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -344,6 +344,19 @@ int linna_adamw_step(linna_ctx_t* ctx, float* p, const float* g, float* m, float
  * differently: use linna_adamw_step then (the streams re-lay themselves).  (predictor_gpu.py:287 `optim.step()`.) */
 int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, float* m, float* v, size_t n,
                          float* hyper, int* step_dev, float beta1, float beta2, float eps, int prepared, void* stream);
+/* ONE optimiser step (predictor_gpu.py:274-287: forward, loss, backward, optim.step()) in ONE call and THREE launches:
+ * linna_net_train_step with AdamW in the epilogue of its grouped parameter-gradient launch -- every gradient tile updates
+ * its block of `params` / `m` / `v` (flat buffers laid out like the gradient buffer the layer table points into) and writes
+ * the updated block into both weight streams of the next step.  One rank only: data-parallel training all-reduces the
+ * gradients between backward and update (linna_net_train_step + linna_net_adamw_step).  LINNA_ERR_UNSUPPORTED, before
+ * anything is launched, when linna_net_train_step / linna_net_adamw_step would be, or some parameter gradient of this
+ * network does not fit the grouped launch. */
+int linna_net_train_step_update(linna_net_t* net, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                                const int* log10_flag, const float* xmean, const float* xstd, float* XB, int ldxb,
+                                void* fwd_ws, float* PRED, int ldp, const float* YN, int ldyn, const float* den,
+                                float inv_batch, float* loss_rows, float* loss_mean, float* dPRED, int lddp, void* bwd_ws,
+                                float* params, float* m, float* v, size_t n, float* hyper, int* step_dev, float beta1,
+                                float beta2, float eps, void* stream);
 
 /* ------------------------------------------------------------------ ensemble / HMC moves
  * Stretch move (emcee StretchMove, called at sampler.py:493-495,530): for the active half

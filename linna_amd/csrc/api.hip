@@ -104,6 +104,7 @@ struct linna_net {
     StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
     AsArgs as_args;                          // linna_net_adamw_step's descriptor table, valid for (as_params, as_n, as_k)
     const float* as_params = nullptr; size_t as_n = 0; int as_k = -1; int as_state = -1;   // as_state: -1 unknown, 0 unsupported, 1 ready
+    int upd_state = -1; int upd_B = 0;       // linna_net_train_step_update: -1 unknown, 0 unsupported, 1 every parameter gradient of the step is in the grouped launch
     int stream_bwd[2] = {-1, -1};            // -1 unknown, 0 no (network out of reach / LINNA_BWD_STREAM=0), 1 yes                     // -1 unknown, 0 no (network out of reach / LINNA_FWD_STREAM=0), 1 yes
     std::vector<linna_layer_t> L;   // without the trailing INSKIP
     std::vector<linna_layer_t> Lfull;   // with it: what the serving programs of the whole-network kernel are built from
@@ -451,8 +452,9 @@ int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
 // d loss / d pred.  Replaces linna_gather_xform + linna_net_forward + linna_chi2_ratio_loss_fwd_bwd (seven launches for
 // nout > 64) when the network + loss fit the whole-network kernel; LINNA_ERR_UNSUPPORTED otherwise (the caller then
 // runs that sequence).  The batch mean is a second, tiny launch (fixed summation order).
+struct NetUpdate { float* params; float* m; float* v; size_t n; float* hyper; float b1, b2, eps; };
 static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
-                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post);
+                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post, const NetUpdate* upd = nullptr);
 static int net_forward_loss_impl(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                                  const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
                                  int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
@@ -535,16 +537,16 @@ int linna_net_stream_state(const linna_net_t* n, int* fwd, int* dx, int* dx_inpu
     return LINNA_OK;
 }
 
-static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
-                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post);
 int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
                        int lddo, float* dX, int lddx, int pg, void* stream) {
     return net_backward_impl(n, X, ldx, B, fwd_ws, bwd_ws, dOUT, lddo, dX, lddx, pg, stream, nullptr);
 }
 // `post`: the loss mean / AdamW step constants of this step (linna_net_train_step): they ride in the one-launch dX chain
 // as an extra workgroup, or run as the launch of their own they otherwise are, in front of the GEMM chain
+// `upd`: the optimiser rides in the grouped parameter-gradient launch (linna_net_train_step_update; the caller has checked
+// net_update_supported: every parameter gradient of the step goes into that launch)
 static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
-                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post) {
+                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post, const NetUpdate* upd) {
     if (!n || !X || !dOUT || !bwd_ws || B < 1) { set_error("net_backward: bad arguments"); return LINNA_ERR_INVALID; }
     const FwdLayout f = fwd_layout(n, B);
     const float* w = static_cast<const float*>(fwd_ws);
@@ -582,6 +584,25 @@ static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, voi
     const bool grouping = pg && ctx && ctx->group == 1;
     GemmGroupArgs grp;                  // the grouped parameter-gradient launch: descriptors by value, filled as we go
     grp.nprob = 0;
+    GemmGroupArgsS grpu;                // ... and its form with the optimiser in the epilogue
+    GemmUpdate gu;
+    grpu.nprob = 0;
+    long long pdiff = 0;
+    if (upd) {
+        ::memset(static_cast<void*>(&gu), 0, sizeof(gu));
+        const linna_layer_t& l0 = n->L[0];
+        const float* w0 = l0.op == LINNA_OP_RESBLOCK ? l0.W1 : l0.W;
+        const float* g0 = l0.op == LINNA_OP_RESBLOCK ? l0.gW1 : l0.gW;
+        pdiff = w0 - g0;
+        gu.pdiff = pdiff; gu.mdiff = (upd->m - upd->params) + pdiff; gu.vdiff = (upd->v - upd->params) + pdiff;
+        gu.hyper = upd->hyper; gu.beta1 = upd->b1; gu.beta2 = upd->b2; gu.eps = upd->eps; gu.small = n->as_args.small;
+    }
+    auto as_range_of = [&](const float* param, int kind) -> const AsRange* {     // the flat-buffer tensor that starts at `param`
+        const long long off = param - upd->params;
+        for (int i = 0; i < n->as_args.nr; ++i)
+            if (n->as_args.r[i].kind == kind && (long long)n->as_args.r[i].off4 * 4 == off) return &n->as_args.r[i];
+        return nullptr;
+    };
     int grp_blocks = 0;
     bool aux_used = false;
     auto fork = [&]() -> int {       // work enqueued on aux after this sees everything enqueued on st so far
@@ -596,6 +617,18 @@ static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, voi
         GemmArgs a = gemm_zero();    // dW[n][k] = scale * sum_b dY[b][n] X[b][k]
         set_pair(a, 0, dY, lddy, LAY_MN, Xin, ldxin, LAY_MN, B);
         a.M = N; a.N = K; a.C = dW; a.ldc = lddw; a.alpha0 = scale;
+        if (upd) {
+            if (!(grouping && grpu.nprob < GEMM_UPD_MAX && gemm_group_ok(a))) { set_error("net_backward: update outside the grouped launch"); return LINNA_ERR_INVALID; }
+            const AsRange* rw = as_range_of(dW + pdiff, 0);
+            const AsRange* rb = db ? as_range_of(db + pdiff, 1) : nullptr;
+            if (!rw || (db && !rb)) { set_error("net_backward: update of a tensor outside the flat parameter buffer"); return LINNA_ERR_INVALID; }
+            const int i = grpu.nprob++;
+            grpu.p[i] = GemmGroupProb{dY, Xin, dW, db, lddy, ldxin, lddw, B, N, K, scale, grp_blocks};
+            gu.pl[i][0] = n->as_args.w[rw->idx].pl[0]; gu.pl[i][1] = n->as_args.w[rw->idx].pl[1];
+            if (rb) gu.bias[i] = n->as_args.b[rb->idx];
+            grp_blocks += gemm_group_blocks(a);
+            return LINNA_OK;
+        }
         if (grouping && grp.nprob < GEMM_GROUP_MAX && gemm_group_ok(a)) {
             // one tile grid for every dW of the step; the bias gradient (column sums of dY) rides in the same tiles
             grp.p[grp.nprob++] = GemmGroupProb{dY, Xin, dW, db, lddy, ldxin, lddw, B, N, K, scale, grp_blocks};
@@ -709,6 +742,7 @@ static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, voi
         dcur = dprev; ldd = ldp;
     }
     if (grp.nprob) TRY(gemm_launch_group(grp, grp_blocks, st));     // every dY is on `st` by now: one grid over all the dW tiles
+    if (grpu.nprob) TRY(gemm_launch_group_update(grpu, gu, grp_blocks, st));
     if (overlap && aux_used) {       // join: the caller's stream continues only after every gradient is written
         hipEvent_t e = ctx->events[next_event++];
         TRY(check_hip(hipEventRecord(e, ctx->aux), "hipEventRecord"));
@@ -1093,26 +1127,87 @@ int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v,
 // followed by the two lazy re-layouts of the next step does in three.  `B`: the batch size the step runs at (it
 // selects the engine, hence the stream layout).  LINNA_ERR_UNSUPPORTED when the network does not train through those
 // two streams, or `params[n]` is not exactly its tensors back to back: the caller then uses linna_adamw_step.
-int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, float* m, float* v, size_t n, float* hyper,
-                         int* step_dev, float b1, float b2, float eps, int prepared, void* stream) {
-    if (!net || !p || !g || !m || !v || !hyper || !step_dev || B < 1) { set_error("net_adamw_step: bad arguments"); return LINNA_ERR_INVALID; }
+// The placement tables of the flat parameter buffer `p[n]` in the two training streams (net_stream_adamw_args), cached.
+static int net_ensure_as_args(linna_net_t* net, int B, const float* p, size_t n) {
     static const bool off = getenv("LINNA_ADAMW_STREAMS") && getenv("LINNA_ADAMW_STREAMS")[0] == '0';
     if (off || net->stream_loss != 1 || net->stream_bwd[0] != 1 || !net->packed_loss.ready() || !net->packed_dx[0].ready()) {
-        set_error("net_adamw_step: the network does not train through the whole-network streams"); return LINNA_ERR_UNSUPPORTED;
+        set_error("the network does not train through the whole-network streams"); return LINNA_ERR_UNSUPPORTED;
     }
     const int rows = net_stream_rows(B), k = rows < 16 ? 1 : 0;
     if (net->as_state < 0 || net->as_params != p || net->as_n != n || net->as_k != k) {
         net->as_params = p; net->as_n = n; net->as_k = k;
         net->as_state = net_stream_adamw_args(net->L.data(), (int)net->L.size(), net->in_size, rows, p, n, net->packed_loss.buf[k],
                                               &net->loss_dn, net->packed_dx[0].buf[k], &net->as_args) == LINNA_OK ? 1 : 0;
+        net->upd_state = -1;
     }
-    if (net->as_state != 1) return LINNA_ERR_UNSUPPORTED;          // (the error text is net_stream_adamw_args')
+    return net->as_state == 1 ? LINNA_OK : LINNA_ERR_UNSUPPORTED;   // (the error text is net_stream_adamw_args')
+}
+
+int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, float* m, float* v, size_t n, float* hyper,
+                         int* step_dev, float b1, float b2, float eps, int prepared, void* stream) {
+    if (!net || !p || !g || !m || !v || !hyper || !step_dev || B < 1) { set_error("net_adamw_step: bad arguments"); return LINNA_ERR_INVALID; }
+    TRY(net_ensure_as_args(net, B, p, n));
+    const int rows = net_stream_rows(B), k = rows < 16 ? 1 : 0;
     // both streams must hold the CURRENT weights and their constant parts before they are patched in place
     const float* dummy = nullptr;
     TRY(stream_copy_refresh(net->packed_loss, net, rows, stream, &dummy, 0, &net->loss_dn));
     TRY(stream_copy_refresh(net->packed_dx[0], net, rows, stream, &dummy, 1, nullptr));
     if (!prepared) TRY(launch_adamw_prepare(hyper, step_dev, b1, b2, S(stream)));
     TRY(launch_adamw_streams(net->as_args, p, g, m, v, hyper, b1, b2, eps, S(stream)));
+    const unsigned long long epoch = g_weights_epoch.fetch_add(1) + 1;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(S(stream), &cap);
+    if (cap == hipStreamCaptureStatusNone) { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
+    return LINNA_OK;
+}
+
+// ONE optimiser step in ONE call and THREE launches: linna_net_train_step with AdamW in the epilogue of its grouped
+// parameter-gradient launch -- every 64 x 64 gradient tile updates its block of the weight matrix (and its moments) as soon as
+// it exists and writes the updated block into the two weight streams the next step reads.  For one rank (data-parallel
+// training all-reduces the gradients between backward and update: linna_net_train_step + linna_net_adamw_step).
+// LINNA_ERR_UNSUPPORTED -- before anything is launched -- when the network does not train through the streams, `params[n]`
+// is not its tensors back to back, or some parameter gradient of the step falls outside the grouped launch.
+int linna_net_train_step_update(linna_net_t* net, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                                const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* fwd_ws, float* PRED,
+                                int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
+                                float* loss_mean, float* dPRED, int lddp, void* bwd_ws, float* params, float* m, float* v,
+                                size_t n, float* hyper, int* step_dev, float b1, float b2, float eps, void* stream) {
+    if (!net || !params || !m || !v || !hyper || !step_dev || !bwd_ws || B < 1) { set_error("net_train_step_update: bad arguments"); return LINNA_ERR_INVALID; }
+    static const bool off = getenv("LINNA_ADAMW_IN_GEMM") && getenv("LINNA_ADAMW_IN_GEMM")[0] == '0';
+    if (off || net->has_inskip) { set_error("net_train_step_update: switched off / input-skip network"); return LINNA_ERR_UNSUPPORTED; }
+    TRY(net_ensure_as_args(net, B, params, n));
+    if (net->upd_state < 0 || net->upd_B != B) {
+        // every parameter gradient of the step must be a problem of the grouped launch, and the gradient pointers of the layer
+        // table must mirror the parameter buffer (same distance for every tensor)
+        linna_ctx* ctx = net->ctx;
+        if (ctx && ctx->group < 0) { const char* e = getenv("LINNA_BWD_GROUP"); ctx->group = (e && e[0] == '0') ? 0 : 1; }
+        bool ok = ctx && ctx->group == 1;
+        int nprob = 0;
+        long long diff = 0; bool have = false;
+        auto same = [&](const float* w, const float* g) { if (!w) return; if (!g) { ok = false; return; } if (!have) { diff = w - g; have = true; } else if (w - g != diff) ok = false; };
+        auto prob = [&](int M, int N) {
+            GemmArgs a = gemm_zero();
+            a.npairs = 1; a.p[0].alay = LAY_MN; a.p[0].blay = LAY_MN; a.p[0].lda = ld4(M); a.p[0].ldb = ld4(N); a.p[0].K = B; a.M = M; a.N = N;
+            if (!gemm_group_ok(a)) ok = false;
+            ++nprob;
+        };
+        for (const linna_layer_t& l : net->L) {
+            if (l.op == LINNA_OP_LINEAR) { prob(l.N, l.K); same(l.W, l.gW); same(l.b, l.gb); }
+            else if (l.op == LINNA_OP_RESBLOCK) {
+                prob(l.N, l.C); prob(l.C, l.K); if (l.Ws) prob(l.N, l.K);
+                same(l.W1, l.gW1); same(l.b1, l.gb1); same(l.W2, l.gW2); same(l.b2, l.gb2); same(l.Ws, l.gWs);
+            } else ok = false;
+        }
+        net->upd_state = (ok && nprob <= GEMM_UPD_MAX) ? 1 : 0;
+        net->upd_B = B;
+    }
+    if (net->upd_state != 1) { set_error("net_train_step_update: a parameter gradient of this network falls outside the grouped launch"); return LINNA_ERR_UNSUPPORTED; }
+    TRY(net_forward_loss_impl(net, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, fwd_ws, PRED, ldp, YN, ldyn, den, inv_batch,
+                              loss_rows, loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, true));
+    const NsPost post{loss_rows, B, inv_batch, loss_mean, step_dev, hyper, b1, b2};
+    const NetUpdate upd{params, m, v, n, hyper, b1, b2, eps};
+    TRY(net_backward_impl(net, XB, ldxb, B, fwd_ws, bwd_ws, dPRED, lddp, nullptr, 0, 1, stream, &post, &upd));
+    const int k = net_stream_rows(B) < 16 ? 1 : 0;
     const unsigned long long epoch = g_weights_epoch.fetch_add(1) + 1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(S(stream), &cap);

@@ -156,13 +156,33 @@ int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, co
                             const NsDense& dn, int rows, hipStream_t s);
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
 struct NsGrad { const float* gscale; float* G; int ldg; };
-// AdamW that also writes the two weight streams of a training step (net_stream.hip: adamw_streams_kernel)
+// AdamW that also writes the two weight streams of a training step (net_stream.hip: adamw_streams_kernel; gemm.hip: the
+// update epilogue of the grouped parameter-gradient launch).  An AsPlace says where the elements of a weight matrix sit
+// in one fragment-order stream (segment type 0 = WIDE, 1 = SPLIT; see net_stream.hip).
 constexpr int AS_MAXR = 26, AS_MAXW = 14, AS_MAXB = 12;
 struct AsPlace { float* out; float scale; int trans, koff, ncols, type, ncg, steps, G, first0, first1; };
 struct AsMat { int N, ld; AsPlace pl[2]; };            // pl[0]: forward(+loss) stream, pl[1]: dX-chain stream
 struct AsBias { float* out; float scale; int N; };
 struct AsRange { unsigned off4, n4, blk0; short kind, idx; };   // a tensor of the flat buffer, in units of 4 floats
 struct AsArgs { AsRange r[AS_MAXR]; AsMat w[AS_MAXW]; AsBias b[AS_MAXB]; int nr, small; unsigned nblocks; };
+// float index of element (column nn, depth kk) of a segment in its stream (4 step tiles per wave and step, 64 lanes x 4 floats each)
+__device__ __forceinline__ size_t as_slot(const AsPlace& q, int small, int nn, int kk) {
+    const int nl = nn & 63, ks = kk >> 4, kr = kk & 15;
+    int w, g;
+    if (q.type == 0) { w = (nn & 511) >> 6; g = ((nn >> 9) ? q.first1 : q.first0) + ks; }
+    else { const int kp = ks / q.steps; w = kp * q.ncg + (nn >> 6); g = q.first0 + (ks - kp * q.steps); }
+    const int t = small ? kr >> 2 : nl >> 4, lane = small ? nl : (nl & 15) + 16 * (kr >> 2);
+    return ((((size_t)w * q.G + g) * 4 + t) * 64 + lane) * 4 + (kr & 3);
+}
+// torch.optim.AdamW's single-tensor update of one element (pointwise.hip adamw_kernel's arithmetic, operation for operation)
+__device__ __forceinline__ void adamw_one(float& pi, float gi, float& mi, float& vi, float lr, float wd, float bc1, float sbc2,
+                                          float beta1, float beta2, float eps) {
+    pi = pi * (1.f - lr * wd);
+    mi = mi + (gi - mi) * (1.f - beta1);
+    vi = vi * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) / sbc2 + eps;
+    pi = pi - (lr / bc1) * (mi / denom);
+}
 int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int rows, const float* params, size_t nflat,
                           float* s_fwd, const NsDense* dn, float* s_dx, AsArgs* out);
 int launch_adamw_streams(const AsArgs& a, float* p, const float* g, float* m, float* v, const float* hyper, float b1, float b2,
@@ -189,6 +209,16 @@ int gemm_launch(const GemmArgs& a, hipStream_t stream);
 struct GemmGroupProb { const float* A; const float* B; float* C; float* db; int lda, ldb, ldc, K, M, N; float alpha; int first; };
 constexpr int GEMM_GROUP_MAX = 48;
 struct GemmGroupArgs { GemmGroupProb p[GEMM_GROUP_MAX]; int nprob; };
+// The same launch with the optimiser in its epilogue (linna_net_train_step_update): every tile applies AdamW to the block of
+// the weight matrix whose gradient it has just formed (parameters / moments at fixed distances from the gradient buffer)
+// and puts the updated block into the two weight streams of the next step -- no AdamW launch, no re-layout.
+constexpr int GEMM_UPD_MAX = 16;
+struct GemmGroupArgsS { GemmGroupProb p[GEMM_UPD_MAX]; int nprob; };
+struct GemmUpdate { long long pdiff, mdiff, vdiff;           // parameter / moment pointers = gradient pointer + these (floats)
+                    const float* hyper; float beta1, beta2, eps; int small;
+                    AsPlace pl[GEMM_UPD_MAX][2]; AsBias bias[GEMM_UPD_MAX]; };
+struct GemmUpd1 { long long pdiff, mdiff, vdiff; const float* hyper; float beta1, beta2, eps; int small; AsPlace pl[2]; AsBias bias; };
+int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream);
 bool gemm_group_ok(const GemmArgs& a);
 int gemm_group_blocks(const GemmArgs& a);
 int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream);

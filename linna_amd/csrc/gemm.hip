@@ -134,8 +134,9 @@ struct Tile {
 // as one serial MFMA chain per tile on 8-64 of the 256 CUs.
 struct KSplit { int kz; float* scratch; int* counters; };
 
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all, const KSplit ks, float* const db = nullptr) {
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS, bool UPD = false>
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all, const KSplit ks, float* const db = nullptr,
+                                          const GemmUpd1* const up = nullptr) {
     constexpr int NW = WM * WN, NT = NW * 64;                 // waves / threads of one K group
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using TA = Tile<BM, ALAY, NW>;
@@ -292,7 +293,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
                 float t = 0.f;
 #pragma unroll
                 for (int w = 0; w < NW; ++w) t += smem[w * 64 + lane];
-                db[m0 + lane] = a.alpha0 * t;
+                const float gb = a.alpha0 * t;
+                db[m0 + lane] = gb;
+                if constexpr (UPD) {                // the bias element's AdamW step, and its slot in the forward stream's bias block
+                    float* const gp = db + m0 + lane;
+                    float pi = gp[up->pdiff], mi = gp[up->mdiff], vi = gp[up->vdiff];
+                    adamw_one(pi, gb, mi, vi, up->hyper[0], up->hyper[1], up->hyper[2], up->hyper[3], up->beta1, up->beta2, up->eps);
+                    gp[up->pdiff] = pi; gp[up->mdiff] = mi; gp[up->vdiff] = vi;
+                    if (up->bias.out) up->bias.out[m0 + lane] = up->bias.scale * pi;
+                }
             }
         }
     }
@@ -361,6 +370,62 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
     // ---------------------------------------------------------------- epilogue
     // C/D layout of v_mfma_f32_32x32x2_f32: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5).
     const int h = lane >> 5;
+    if constexpr (UPD) {
+        // Parameter-gradient tile with the optimiser behind it: C = alpha acc is the gradient of W[row][col]; AdamW on that
+        // element (parameters and moments sit at fixed distances from the gradient), then the updated 4-row groups into the
+        // weight streams -- one 16-byte vector per group where the stream holds the matrix transposed, single floats where it
+        // holds rows (neighbouring lanes complete the vector).
+        static_assert(TM == 1 && TN == 1, "update epilogue: 64 x 64 workgroups");
+        const int col = n0 + wn * 32 + (lane & 31);
+        const bool cok = col < a.N;
+        const float lr = up->hyper[0], wd = up->hyper[1], bc1 = up->hyper[2], sbc2 = up->hyper[3];
+        // three phases -- every load, then the arithmetic, then every store: parameters and moments are reached through one
+        // pointer plus offsets, so a store of element e and a load of element e + 1 may alias as far as the compiler knows, and
+        // an element-by-element loop turns into sixteen dependent memory round trips per lane
+        float pv[16], mv[16], vv[16];
+        bool okv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            okv[e] = cok && row < a.M;
+            const float* const gp = a.C + (size_t)min(row, a.M - 1) * a.ldc + min(col, a.N - 1);
+            pv[e] = gp[up->pdiff]; mv[e] = gp[up->mdiff]; vv[e] = gp[up->vdiff];
+        }
+        float gv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            gv[e] = a.alpha0 * acc[0][0][e];
+            adamw_one(pv[e], gv[e], mv[e], vv[e], lr, wd, bc1, sbc2, up->beta1, up->beta2, up->eps);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (okv[e]) {
+                const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                float* const gp = a.C + (size_t)row * a.ldc + col;
+                *gp = gv[e]; gp[up->pdiff] = pv[e]; gp[up->mdiff] = mv[e]; gp[up->vdiff] = vv[e];
+            } else {
+                pv[e] = 0.f;                        // the streams' padding
+            }
+        }
+#pragma unroll
+        for (int eg = 0; eg < 4; ++eg) {
+            const int r0 = m0 + wm * 32 + 8 * eg + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const AsPlace& q = up->pl[j];
+                if (!q.out || !cok || r0 >= a.M) continue;
+                if (q.trans) {
+                    *reinterpret_cast<f32x4*>(q.out + as_slot(q, up->small, col, q.koff + r0)) =
+                        f32x4{q.scale * pv[4 * eg], q.scale * pv[4 * eg + 1], q.scale * pv[4 * eg + 2], q.scale * pv[4 * eg + 3]};
+                } else {
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4)
+                        if (r0 + e4 < a.M) q.out[as_slot(q, up->small, r0 + e4, q.koff + col)] = q.scale * pv[4 * eg + e4];
+                }
+            }
+        }
+        return;
+    }
     float dot[TM][16];
     if (a.dotwith) {
 #pragma unroll
@@ -431,6 +496,24 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const Gem
     a.cscale = nullptr; a.cshift = nullptr; a.cexp = 0; a.cpost = nullptr; a.cshift2 = nullptr;
     a.dotwith = nullptr; a.lddot = 0; a.dot_partial = nullptr; a.dot_slots = 0; a.flags = 0;
     gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db);
+}
+
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_update_kernel(const GemmGroupArgsS g, const GemmUpdate u) {
+    int p = 0;
+    while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
+    const GemmGroupProb q = g.p[p];
+    GemmArgs a;
+    a.p[0].A = q.A; a.p[0].B = q.B; a.p[0].lda = q.lda; a.p[0].ldb = q.ldb; a.p[0].K = q.K; a.p[0].alay = ALAY; a.p[0].blay = BLAY;
+    a.p[1] = a.p[0];
+    a.npairs = 1; a.M = q.M; a.N = q.N; a.C = q.C; a.ldc = q.ldc;
+    a.bias0 = nullptr; a.bias1 = nullptr; a.alpha0 = q.alpha; a.R = nullptr; a.ldr = 0; a.relu = 0; a.mask = nullptr; a.ldmask = 0;
+    a.cscale = nullptr; a.cshift = nullptr; a.cexp = 0; a.cpost = nullptr; a.cshift2 = nullptr;
+    a.dotwith = nullptr; a.lddot = 0; a.dot_partial = nullptr; a.dot_slots = 0; a.flags = 0;
+    GemmUpd1 up;
+    up.pdiff = u.pdiff; up.mdiff = u.mdiff; up.vdiff = u.vdiff; up.hyper = u.hyper; up.beta1 = u.beta1; up.beta2 = u.beta2;
+    up.eps = u.eps; up.small = u.small; up.pl[0] = u.pl[p][0]; up.pl[1] = u.pl[p][1]; up.bias = u.bias[p];
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS, true>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db, &up);
 }
 
 // ---------------------------------------------------------------------------- launcher
@@ -540,6 +623,12 @@ int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
     hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks), dim3(256), lds, stream, g);
     return check_hip(hipGetLastError(), "gemm group launch");
+}
+
+int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream) {
+    constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
+    hipLaunchKernelGGL((gemm_group_update_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks), dim3(256), lds, stream, g, u);
+    return check_hip(hipGetLastError(), "gemm group update launch");
 }
 
 int gemm_launch(const GemmArgs& a, hipStream_t stream) {

@@ -1354,15 +1354,6 @@ static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int row
 // neighbouring vectors).  Biases go to the forward stream's bias block.  Constant parts of a stream (zero padding, the
 // loss's inverse covariance) are written by the ordinary re-layout once and never touched here.
 constexpr int AS_BLOCK = 64;               // one wave per block: ~1200 blocks for 1.3 M parameters, five per CU
-__device__ __forceinline__ size_t as_slot(const AsPlace& q, int small, int nn, int kk) {
-    const int nl = nn & 63, ks = kk >> 4, kr = kk & 15;
-    int w, g;
-    if (q.type == NS_WIDE) { w = (nn & 511) >> 6; g = ((nn >> 9) ? q.first1 : q.first0) + ks; }
-    else { const int kp = ks / q.steps; w = kp * q.ncg + (nn >> 6); g = q.first0 + (ks - kp * q.steps); }
-    const int t = small ? kr >> 2 : nl >> 4, lane = small ? nl : (nl & 15) + 16 * (kr >> 2);
-    return ((((size_t)w * q.G + g) * NS_NT + t) * 64 + lane) * 4 + (kr & 3);          // float index
-}
-
 __device__ __forceinline__ void as_update(f32x4& P4, const f32x4& G4, f32x4& M4, f32x4& V4, float lr, float wd, float bc1,
                                           float sbc2, float beta1, float beta2, float eps) {
 #pragma unroll

@@ -62,6 +62,8 @@ class TrainEngine(object):
         self.rows = torch.zeros(B, dtype=torch.int32, device=dev)
         self.graph = None
         self.one_launch = None                           # None: try linna_net_forward_loss on the first step
+        self.one_update = None                           # None: try linna_net_train_step_update (one rank) on the first step
+        self._updated = False
         self.YN = None
         self.inv_batch = 1.0 / (B * self.world)          # the global batch is B per rank x ranks
         _lib.call("linna_net_prepare", self.model.net_handle(with_grads=True), 1, 0)   # no allocation on the launch path
@@ -77,7 +79,7 @@ class TrainEngine(object):
         return den
 
     # ------------------------------------------------------------------ one optimiser step
-    def _forward_loss_backward(self, rows=None, loss_out=None, opt=None):
+    def _forward_loss_backward(self, rows=None, loss_out=None, opt=None, update=False):
         """``rows`` / ``loss_out``: device int32 row indices and a 1-float device slot for the mean loss; default the
         engine's own fixed buffers (what a captured graph needs).  Direct launches pass the caller's tensors and save
         two copy kernels per step."""
@@ -88,8 +90,26 @@ class TrainEngine(object):
             # gather + transform + forward + loss + d loss / d pred in ONE launch when the network and the loss fit the
             # whole-network kernel (seven launches otherwise)
             # (linna_net_train_step: that launch AND the backward in one call, the batch mean of the loss and AdamW's step
-            # constants riding in the backward's dX-chain launch)
+            # constants riding in the backward's dX-chain launch; `update`: AdamW too, in the epilogue of the grouped
+            # parameter-gradient launch -- the whole optimiser step in one call and three launches)
             m = self.model
+            self._updated = False
+            if update and opt is not None and self.one_update is not False:
+                rc = _lib.load().linna_net_train_step_update(
+                    m.net_handle(with_grads=True), C.byref(self.desc), _lib.ptr(self.X), self.X.stride(0), _lib.iptr(rows), self.B,
+                    _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]), _lib.ptr(self.xb),
+                    self.xb.stride(0), _lib.ptr(m.workspace(self.B)), _lib.ptr(self.predb), self.predb.stride(0), _lib.ptr(self._targets()),
+                    self.YN.stride(0), _lib.ptr(self.den), self.inv_batch, _lib.ptr(self.loss_rows), _lib.ptr(loss_out), _lib.ptr(self.dpred),
+                    self.dpred.stride(0), _lib.ptr(m.workspace(self.B, "bwd")), _lib.ptr(m._flat), _lib.ptr(opt.m), _lib.ptr(opt.v),
+                    m._flat.numel(), _lib.ptr(opt.hyper), _lib.iptr(opt.step_dev), opt.betas[0], opt.betas[1], opt.eps, st)
+                if rc == 0:
+                    self.one_launch = self.one_update = self._updated = True
+                    self._prepared = True
+                    m._last_input = self.xb
+                    return
+                if rc != _lib.ERR_UNSUPPORTED or self.one_update is True:
+                    _lib.check(rc)
+                self.one_update = False
             rc = _lib.load().linna_net_train_step(
                 m.net_handle(with_grads=True), C.byref(self.desc), _lib.ptr(self.X), self.X.stride(0), _lib.iptr(rows), self.B,
                 _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]), _lib.ptr(self.xb),
@@ -127,7 +147,7 @@ class TrainEngine(object):
     def _step_body(self, opt, rows=None, loss_out=None, local=False):
         """``local``: this rank alone (no collective, gradient of its own batch) -- the learning-rate range test, which
         the reference runs on rank 0 only, on a private copy of the model (predictor_gpu.py:223-227)."""
-        self._prepared = False
+        self._prepared = self._updated = False
         if self.world > 1 and not local:
             from . import dist as ldist
             self._forward_loss_backward(rows, self.loss_mean, opt)
@@ -137,12 +157,13 @@ class TrainEngine(object):
         elif local and self.world > 1:
             keep, self.inv_batch = self.inv_batch, 1.0 / self.B
             try:
-                self._forward_loss_backward(rows, loss_out, opt)
+                self._forward_loss_backward(rows, loss_out, opt, update=True)
             finally:
                 self.inv_batch = keep
         else:
-            self._forward_loss_backward(rows, loss_out, opt)
-        opt.apply(prepared=self._prepared, batch=self.B)
+            self._forward_loss_backward(rows, loss_out, opt, update=True)       # one rank: the optimiser rides in the backward
+        if not self._updated:
+            opt.apply(prepared=self._prepared, batch=self.B)
 
     def step(self, opt, rows_dev, loss_out=None):
         """One optimiser step on the int32 device index vector ``rows_dev[B]``; the mean loss of the step lands in

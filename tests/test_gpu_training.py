@@ -91,11 +91,13 @@ def test_adamw_writing_the_weight_streams_equals_update_plus_relayout(name):
     them, which reads a stream of its own."""
     from linna_amd.predictor_gpu import _AdamWState
     res = []
-    for fused in (True, False):
+    for fused in (True, False, "gemm"):
         p, model, pred, eng, B = make_engine(name)
         opt = _AdamWState(model, 2e-3)
-        if not fused:
+        if fused is False:
             opt._streams = False
+        if fused != "gemm":
+            eng.one_update = False                   # "gemm": linna_net_train_step_update, AdamW in the gradient tiles' epilogue
         losses = []
         for s in range(6):
             out = torch.zeros(1, device="cuda")
@@ -104,12 +106,14 @@ def test_adamw_writing_the_weight_streams_equals_update_plus_relayout(name):
         torch.cuda.synchronize()
         eng.validate()
         res.append((model._flat.cpu().numpy().copy(), opt.m.cpu().numpy().copy(), opt.v.cpu().numpy().copy(),
-                    torch.cat(losses).cpu().numpy(), eng.val["loss_rows"].cpu().numpy().copy(), opt._streams))
+                    torch.cat(losses).cpu().numpy(), eng.val["loss_rows"].cpu().numpy().copy(), opt._streams, eng.one_update))
     assert np.isfinite(res[0][3]).all()
-    for a, b in zip(res[0][:5], res[1][:5]):
-        np.testing.assert_array_equal(a, b)
+    for other in (res[1], res[2]):
+        for a, b in zip(res[0][:5], other[:5]):
+            np.testing.assert_array_equal(a, b)
     if name in ("train_v2_33_33", "train_v2_26_457"):
         assert res[0][5] is True                    # the reference's network trains through the one-launch update
+        assert res[2][6] is True                    # ... and through the update in the gradient launch
 
 
 @pytest.mark.parametrize("name", ["train_v2_33_33", "train_v2_26_457"])
