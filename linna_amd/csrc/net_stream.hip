@@ -376,6 +376,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #define NS_PF_ALL(LO, HI) NS_PF(0, LO, HI) NS_PF(1, LO, HI) NS_PF(2, LO, HI) NS_PF(3, LO, HI) NS_PF(4, LO, HI) NS_PF(5, LO, HI) \
     NS_PF(6, LO, HI) NS_PF(7, LO, HI)
     NS_PF_ALL(0, PRE)
+#ifdef NS_STAMPS_FINE
+    NS_STAMP();                                    // every small load and the first weight slots requested
+#endif
 
     // ---- 3. network input x = X_transform(Transform(z)) into buffer 0, zero padded to kpad0; biases to LDS
     float zz = 0.f;
@@ -403,6 +406,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         }
         if (c < kpad0 && prow) act[pr * LD + c] = x;
     }
+#ifdef NS_STAMPS_FINE
+    NS_STAMP();                                    // first 64 input columns transformed and in LDS
+#endif
     // inputs wider than ZPRE*RG = 64 columns (none of the reference's models; <= 256 supported) and the zero
     // pad of a SPLIT first segment: plain loop, loads waited in place
     if constexpr ((STORE == 1 || STORE == 2) && !GRAD) {
@@ -452,6 +458,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         if (prow) act[pr * LD + c] = x;
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef NS_STAMPS_FINE
+    NS_STAMP();                                    // the rest of the input in LDS
+#endif
     NS_PF_ALL(PRE, R)
 #undef NS_PF_ALL
 #undef NS_PF
