@@ -392,6 +392,34 @@ def gen_hmc(out):
     print("hmc accepted", int(sum(c["accepted"] for c in chain)), "of", num_samps, flush=True)
 
 
+def callback_student_t(m, data, invcov):
+    """A user likelihood in the reference's calling convention (util.py:953-955 is the default of this shape)."""
+    d = m - data
+    chi2 = (d @ invcov @ d.T)[0][0]
+    return -0.5 * 5.0 * torch.log1p(chi2 / 4.0)
+
+
+def callback_external(theta):
+    return -0.25 * float(np.sum(np.asarray(theta) ** 2))
+
+
+def gen_callbacks(out):
+    """The callback surface of ``Log_prob`` (util.py:990-1021) in the LIVE reference, walker by walker: a user
+    ``loglikelihoodfunc`` (Student-t) with an ``externalloglike`` of the theta-space parameters at T = 4, and the Gaussian
+    default with the same ``externalloglike``."""
+    name, kind, nin, nout, seed, dense, n, dolog10, ypos, kw = SERVING[5]   # simple_6_4
+    lp, pred, yinv, transform, prob = make_logprob(kind, nin, nout, seed, dense, dolog10, ypos, kw, 4.0)
+    z = (np.random.RandomState(3).standard_normal((40, nin)) * 0.5).astype(np.float32)
+    lps = rutil.Log_prob(lp.data_new, lp.invcov_new, pred, yinv, transform, 4.0, callback_student_t, nograd=True,
+                         externalloglike=callback_external)
+    lpg = rutil.Log_prob(lp.data_new, lp.invcov_new, pred, yinv, transform, 4.0, rutil.gaussianlogliklihood, nograd=True,
+                         externalloglike=callback_external)
+    out["callbacks"] = dict(case=np.array(name), z=z,
+                            student=np.array([float(lps(zi, returntorch=False)) for zi in z]),
+                            gauss_ext=np.array([float(lpg(zi, returntorch=False)) for zi in z]))
+    print("callbacks", out["callbacks"]["student"][:3], out["callbacks"]["gauss_ext"][:3], flush=True)
+
+
 def gen_hmc_move(out):
     """The per-walker HMC move the reference WROTE but cannot reach through emcee (sampler.py:59-98 ``_hmc_wrapper``,
     :311-320 ``_hmc_matrix``): its integrator called directly, walker by walker, with the gradient of the
@@ -624,7 +652,7 @@ def gen_host_designs(out):
 
 
 GENERATORS = [("host_designs", gen_host_designs), ("importance", gen_importance), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
-              ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc), ("hmc_move", gen_hmc_move),
+              ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc), ("hmc_move", gen_hmc_move), ("callbacks", gen_callbacks),
               ("init_parity", gen_init_parity), ("train33", gen_train33)]
 
 

@@ -47,6 +47,21 @@ def test_user_loglikelihoodfunc_and_externalloglike():
     assert np.all(np.isneginf(lpn(z[:4], returntorch=False)))
 
 
+def test_callback_surface_matches_the_live_reference():
+    """The same user ``loglikelihoodfunc`` (Student-t) and ``externalloglike`` handed to the LIVE reference's ``Log_prob``
+    (util.py:990-1021), walker by walker at T = 4 (tests/golden/callbacks.npz): the host-callback path and the fused
+    Gaussian path with an external term return the reference's numbers."""
+    from linna_amd import util
+    g = cases.golden("callbacks")
+    lp0, pred, yinv, prob = build_logprob(str(g["case"]), 4.0)
+    ext = lambda theta: -0.25 * float(np.sum(np.asarray(theta) ** 2))
+    lps = util.Log_prob(lp0.data_new, lp0.invcov_new, pred, yinv, lp0.transform, 4.0, loglikelihoodfunc=_student_t, externalloglike=ext)
+    lpg = util.Log_prob(lp0.data_new, lp0.invcov_new, pred, yinv, lp0.transform, 4.0, externalloglike=ext)
+    np.testing.assert_allclose(lps(g["z"], returntorch=False), g["student"], rtol=5e-4, atol=5e-4)
+    np.testing.assert_allclose(lpg(g["z"], returntorch=False), g["gauss_ext"], rtol=6e-4)
+    np.testing.assert_allclose(float(lps(g["z"][7], returntorch=False)), g["student"][7], rtol=5e-4, atol=5e-4)   # one walker, scalar
+
+
 class _Pool(object):
     """The surface ``ml_sampler_core`` uses of the reference's MPI pool (util.py:99-289)."""
 
