@@ -123,13 +123,20 @@ class invTransform(object):
 # ------------------------------------------------------------------ data-vector transforms
 class _Picklable(object):
     def pickle(self, path):
+        """The reference's ``pickle()`` methods (util.py:424, 464, 499, 544, 592): a CPU copy of the object.  The stream names
+        the class as ``linna.util.<Class>`` -- same attributes as the reference's class of that name -- so that a run
+        directory written here continues under the reference as well (its unpickler finds its own class); this package's
+        ``CPU_Unpickler`` maps either module name to the classes here."""
         with open(path, "wb") as f:
             new = deepcopy(self)
             new.dev = "cpu"
             for k, v in list(new.__dict__.items()):
                 if torch.is_tensor(v):
                     new.__dict__[k] = v.detach().cpu()
-            pickle.dump(new, f, pickle.HIGHEST_PROTOCOL)
+            data = pickle.dumps(new, 3)                 # protocol 3: the class travels as a GLOBAL text record, bytes natively, no frames
+            tag = ("c%s\n%s\n" % (type(self).__module__, type(self).__name__)).encode()
+            assert data.count(tag) == 1
+            f.write(data.replace(tag, ("clinna.util\n%s\n" % type(self).__name__).encode()))
 
 
 class Y_transform_data(_Picklable):

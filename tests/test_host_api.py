@@ -1,6 +1,7 @@
 """CPU: host-side logic of the product (no GPU compute): EarlyStopping traces, batch order,
 checkpoint formats, reference-artefact loading, parameter layout."""
 import os
+import sys
 import pickle
 
 import numpy as np
@@ -249,6 +250,50 @@ def _npy(tmp_path, v):
     p = os.path.join(str(tmp_path), "v.npy")
     np.save(p, v)
     return p
+
+
+def test_transform_pickles_name_the_references_classes(tmp_path):
+    """``X_transform.pkl`` & co. written here name ``linna.util.<Class>`` (identical attribute sets), so a run directory
+    continues under the reference without this package; this package's own reader maps the name back.  Where the
+    reference tree is present (the build container), its own unpickler loads the files as ITS classes and they transform
+    like ours."""
+    from linna_amd import util
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    objs = {"X_transform": util.X_transform_class(t(np.arange(4.0)), t(np.full(4, 2.0)), "cpu", [0, 2]),
+            "y_transform": util.Y_transform_class(t(np.zeros(3)), t(np.ones(3)), "cpu"),
+            "y_invtransform": util.Y_invtransform_class(t(np.zeros(3)), t(np.ones(3)), t(np.ones(3)), "cpu"),
+            "y_transform_data": util.Y_transform_data(np.array([1.0, 2.0, 3.0]), "cpu"),
+            "y_invtransform_data": util.Y_invtransform_data(np.array([1.0, 2.0, 3.0]), "cpu")}
+    for k, o in objs.items():
+        path = os.path.join(str(tmp_path), k + ".pkl")
+        o.pickle(path)
+        raw = open(path, "rb").read()
+        assert b"clinna.util\n" + type(o).__name__.encode() + b"\n" in raw and b"linna_amd" not in raw
+        with open(path, "rb") as f:
+            back = util.CPU_Unpickler(f).load()
+        assert type(back) is type(o)
+    if not os.path.isdir("/root/reference/linna"):
+        pytest.skip("reference tree not present: the reference-side half of this check runs in the build container")
+    # in a process of its own: the reference import installs stand-ins for its absent third-party modules
+    x, y = torch.rand(5, 4) + 0.5, torch.rand(5, 3)
+    torch.save({"x": x, "y": y, "want": {k: o(x if k == "X_transform" else y) for k, o in objs.items()}},
+               os.path.join(str(tmp_path), "io.pt"))
+    code = (
+        "import sys, os, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import _ref_import\n"
+        "_, rutil, _, _ = _ref_import.import_reference()\n"
+        "d = %r\n"
+        "io = torch.load(os.path.join(d, 'io.pt'))\n"
+        "for k, want in io['want'].items():\n"
+        "    with open(os.path.join(d, k + '.pkl'), 'rb') as f:\n"
+        "        r = rutil.CPU_Unpickler(f).load()\n"
+        "    assert type(r).__module__ == 'linna.util', type(r)\n"
+        "    assert torch.equal(r(io['x'] if k == 'X_transform' else io['y']), want), k\n"
+        "print('REFERENCE_READS_OK')\n") % (cases.GOLDEN, str(tmp_path))
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFERENCE_READS_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_checkpoint_written_in_reference_layout(tmp_path):
