@@ -236,7 +236,10 @@ def training_rate(device, world, rank, backend, nsteps=150):
     loss = float(eng.loss_mean.item())
     res = {"workload": "ChtoModelv2(26,457), dense covariance, batch 500 per GPU, AdamW, gradient all-reduce per step for N > 1",
            "samples_per_s": world * B * nsteps / dt, "ms_per_step": 1e3 * dt / nsteps, "global_batch": world * B, "steps": nsteps,
-           "loss_finite": bool(np.isfinite(loss))}
+           "loss_finite": bool(np.isfinite(loss)),
+           # one rank: one C call, three launches (forward + loss, dX chain, parameter gradients with AdamW in the epilogue);
+           # data parallel: the all-reduce sits between backward and update, AdamW is a launch of its own
+           "launches_per_step": 3 if (world == 1 and getattr(eng, "one_update", None) is True) else None}
     # algorithmic work of one step on one rank: 3 x forward MLP FLOP per sample + the loss's 3 x 2 nout^2
     flop = B * (3 * 2.0 * model.macs_per_eval() + 6.0 * nout * nout)
     res["roofline"] = {"bound": "mfma", "flop_per_step": flop, "achieved": flop / (dt / nsteps) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
