@@ -152,6 +152,50 @@ def test_train_step_entry_equals_forward_loss_plus_backward(name):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize("B", [1200, 2304])
+def test_update_forms_agree_on_every_stream_layout(B):
+    """Batch 1200 trains on the 8-row engine, 2304 on the 16-row engine, whose weight streams are laid out differently
+    (lane = column against 16-column tiles): AdamW in the gradient tiles' epilogue, AdamW writing the streams and plain AdamW
+    with the lazy re-layouts leave the same parameters, moments and losses, bit for bit."""
+    from linna_amd import nn, util, predictor_gpu, trainer
+    p = cases.training_problem("train_v2_12_40")
+    rs = np.random.RandomState(9)
+    base_x, base_y = p["X"].reshape(-1, p["nin"]), p["Y"].reshape(-1, p["nout"])
+    idx = rs.randint(0, len(base_x), 3 * B)
+    X = (base_x[idx] + 0.05 * rs.standard_normal((3 * B, p["nin"]))).astype(np.float32)
+    Y = (base_y[idx] * (1 + 0.01 * rs.standard_normal((3 * B, p["nout"])))).astype(np.float32)
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    res = []
+    for mode in ("gemm", "streams", "plain"):
+        model = nn.ChtoModelv2(p["nin"], p["nout"], None)
+        model.load_state_dict(p["weights"])
+        pred = predictor_gpu.Predictor(p["nin"], p["nout"], model=model, device="cuda",
+                                       X_transform=util.X_transform_class(t(p["X_mean"]), t(p["X_std"]), "cpu", None),
+                                       y_transform=util.Y_transform_class(t(p["y_mean"]), t(p["y_std"]), "cpu"))
+        ytd = util.Y_transform_data(p["sigma"], "cpu")
+        yinv = util.Y_invtransform_class(t(p["y_mean"]), t(p["y_std"]), t(p["data"]), "cpu")
+        lf = util.Loss_fn(t(p["data"]), torch.tensor(p["cov"], dtype=torch.float64),
+                          torch.tensor(np.linalg.inv(p["cov"]), dtype=torch.float64), ytd, yinv, "cpu")
+        loader = predictor_gpu.BatchLoader(util.ArrayDataset(X, Y), B, shuffle=False, drop_last=True)
+        eng = trainer.TrainEngine(pred, loader, lf, None, use_graph=False)
+        opt = predictor_gpu._AdamWState(model, 1e-3)
+        if mode != "gemm":
+            eng.one_update = False
+        if mode == "plain":
+            opt._streams = False
+        losses = []
+        for s_ in range(4):
+            out = torch.zeros(1, device="cuda")
+            eng.step(opt, torch.arange((s_ % 3) * B, (s_ % 3 + 1) * B, dtype=torch.int32, device="cuda"), loss_out=out)
+            losses.append(out)
+        res.append((model._flat.cpu().numpy().copy(), opt.m.cpu().numpy().copy(), opt.v.cpu().numpy().copy(),
+                    torch.cat(losses).cpu().numpy(), eng.one_update, opt._streams))
+    assert res[0][4] is True and res[1][5] is True and np.isfinite(res[0][3]).all()
+    for other in res[1:]:
+        for a, b in zip(res[0][:4], other[:4]):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_graph_replay_equals_direct_launches():
     from linna_amd.predictor_gpu import _AdamWState
     from linna_amd import trainer
