@@ -684,8 +684,8 @@ class Appender(object):
     # Bulk chunk data goes out by positional writes (os.pwrite releases the GIL) from a few threads: one thread copying
     # into the page cache sustains ~4 GB/s, a 4096-walker chain produces 13 GB/s of samples at full sampling rate.
     BULK_MIN = 4 << 20
-    BULK_PIECE = 32 << 20
-    BULK_THREADS = 4
+    BULK_PIECE = int(os.environ.get("LINNA_H5_PIECE_MB", "32")) << 20
+    BULK_THREADS = int(os.environ.get("LINNA_H5_WRITERS", "4"))
 
     def _write_at(self, addr, view):
         if view.nbytes < self.BULK_MIN:

@@ -15,6 +15,7 @@ for nw in sizes:
     raw = 1000 / (time.perf_counter() - t0)
     t0 = time.perf_counter(); ens.run(1000, store=True); torch.cuda.synchronize()
     raw_store = 1000 / (time.perf_counter() - t0)
+    sampler.DeviceChain.prewarm(nw, 33, torch.device("cuda", 0)).join()      # (ml_sampler_core does this while the emulator trains)
     out = tempfile.mkdtemp(dir=os.environ.get("LINNA_PROBE_DIR"))
     drv = sampler.HMCSampler(lp, None, None, 33, nw, x0=x0, transform=util.Transform(priors))
     nsamp = int(os.environ.get("LINNA_PROBE_NSAMP", "3000" if nw > 1000 else "20000"))
