@@ -196,12 +196,13 @@ def test_update_forms_agree_on_every_stream_layout(B):
             np.testing.assert_array_equal(a, b)
 
 
-def test_graph_replay_equals_direct_launches():
+@pytest.mark.parametrize("name", ["train_mlp_7_5", "train_v2_33_33"])
+def test_graph_replay_equals_direct_launches(name):
     from linna_amd.predictor_gpu import _AdamWState
     from linna_amd import trainer
     res = []
     for use_graph in (False, True):
-        p, model, pred, eng, B = make_engine("train_mlp_7_5")
+        p, model, pred, eng, B = make_engine(name)
         eng.use_graph = use_graph
         opt = _AdamWState(model, 1e-3)
         if use_graph:
