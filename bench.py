@@ -351,6 +351,35 @@ def time_dominant_kernel(lp, z, out, iters):
     return ms_avg, float(z.shape[0]) * (2.0 * MACS_PER_EVAL + 3 * NOUT), [float(v) for v in q]
 
 
+def self_launch(ngpus, argv):
+    """`python bench.py --gpus N` from a bare shell: N ranks through torch.distributed.run as a CHILD process (this
+    process has not touched a GPU and never will), rendezvous on 127.0.0.1 at a free port.  Rank 0's JSON line is the
+    only thing relayed to stdout; the ranks' stderr passes through.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{"):
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1                                              # the ranks ended without a result line
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,57 +393,51 @@ def main():
     ap.add_argument("--no-driver", action="store_true", help="skip mcmc.driver_steps_per_s (an 11 GB chain file in the temporary directory)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank path on a box with fewer GPUs)")
+    ap.add_argument("--launch-check", action="store_true", help="ranks only rendezvous (linna_amd.dist.init), sum their ranks over "
+                    "the process group and rank 0 prints that: what the CPU test of the self-launcher runs (no GPU needed)")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1:
+        # a bare `python bench.py --gpus N`: start the N ranks as fresh child processes BEFORE anything here touches a GPU
+        # (never exec from a process that has initialised HIP), relay rank 0's JSON line, exit with the launcher's code
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
+    if args.launch_check:
+        from linna_amd import dist as ldist
+        w = ldist.init(backend=args.backend if args.backend != "nccl" or torch.cuda.device_count() else "gloo", comm=False)
+        if os.environ.get("LINNA_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):
+            sys.exit(3)                                     # (the test of "a failing rank fails the launcher")
+        t = torch.tensor([ldist.rank() + 1.0])
+        ldist.allreduce_grads(t)
+        if ldist.rank() == 0:
+            print(json.dumps({"launch_check": True, "world": w, "rank_sum": float(t.item()), "collectives": ldist.collectives()}), flush=True)
+        ldist.shutdown()
+        return
     from linna_amd import _lib
     from linna_amd.util import limit_threads_to_quota
     limit_threads_to_quota()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
+    if args.gpus != world and world > 1:
+        sys.exit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     ndev = torch.cuda.device_count()
     if args.backend == "nccl" and world > 1 and local_rank >= ndev:
         sys.exit("rank %d has no GPU (%d visible): one rank per GPU" % (local_rank, ndev))
     dev_index = local_rank % max(ndev, 1)           # (gloo rehearsal may share a GPU between ranks)
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    collectives = None
+    collectives, comm_ranks = None, 0
     if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
-        else:
-            dist.init_process_group(args.backend)
-        # data-path collectives: the library's own RCCL communicator (C ABI); torch.distributed stays the control plane
-        # (rendezvous, unique-id hand-off, barriers).  One rank per device is what RCCL needs; a gloo rehearsal that
-        # shares a GPU between ranks keeps torch.distributed as the transport.
+        # rendezvous, then the library's own RCCL communicator behind the C ABI (bounded bring-up, self-test all-reduce,
+        # MIN-agreement over the ranks, fall back to torch.distributed as the transport): linna_amd.dist.init()
         from linna_amd import dist as ldist
-        if args.backend == "nccl":
-            why = ""
-            try:
-                ldist.comm_init(dev_index, timeout=120.0)
-                ok = ldist.comm_selftest(dev_index, timeout=60.0)   # one all-reduce on a side stream, checked, bounded wait
-                why = "" if ok else "self-test all-reduce wrong or late"
-            except Exception as e:                                  # noqa: BLE001
-                ok, why = False, repr(e)[:200]
-            # every rank takes the same transport: RCCL through the C ABI only if it came up and answered on ALL of them
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 1:
-                collectives = "RCCL %s through the C ABI (linna_comm_init / linna_allreduce_sum_f32 / linna_allgather_f32)" % (ldist.comm_info(dev_index)[2],)
-            else:
-                if ok:
-                    ldist.comm_destroy(dev_index)
-                else:
-                    ldist.comm_forget(dev_index)                    # (never tear down a communicator that may be stuck)
-                collectives = "torch.distributed nccl (the library's communicator did not come up on every rank%s)" % (": " + why if why else "")
-        else:
-            collectives = "torch.distributed %s (rehearsal)" % args.backend
+        ldist.init(backend=args.backend, device=device)
+        collectives = ldist.collectives()
+        comm_ranks = ldist.comm_info(dev_index)[1]
 
     _stage("process group up: %s" % collectives)
     lp, model, consts = build_problem(device)
@@ -560,6 +583,7 @@ def main():
                 res["mcmc"]["driver_error"] = repr(e)[:300]
         if collectives is not None:
             res["collectives"] = collectives
+            res["rccl_ranks"] = comm_ranks          # linna_comm_info: ranks of the library's communicator (0 = torch.distributed carries the data path)
         if not args.no_secondary:
             for key, spec in (("chto_v2", ("ChtoModelv2", 33, 33, False)), ("dense_1000", ("ChtoModelv2", 40, 1000, True))):
                 try:
@@ -570,10 +594,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline(consts, z_host)
         print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
         from linna_amd import dist as ldist
-        ldist.comm_destroy()
-        dist.destroy_process_group()
+        ldist.shutdown()
 
 
 if __name__ == "__main__":

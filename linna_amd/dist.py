@@ -133,15 +133,89 @@ def _f32(t):
     return C.c_void_p(t.data_ptr())
 
 
-def init(backend=None, device=None):
-    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*); no-op for 1 rank."""
+_state = {"collectives": None}
+
+
+def collectives():
+    """What carries the data-path collectives of this process (a sentence for logs and the bench line); None = single rank
+    or ``init()`` not called."""
+    return _state["collectives"]
+
+
+def init(backend=None, device=None, comm=None, timeout=120.0):
+    """Bring a multi-rank run up from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); no-op for one
+    rank.  What `hvd.init()` / the DDP wrap would be in the reference (predictor_gpu.py:240-252, 265-266):
+
+    1. rendezvous through ``torch.distributed`` (``backend``: nccl when this rank has a GPU of its own, else gloo);
+    2. the library's own RCCL communicator through the C ABI (``linna_comm_init``, the unique id handed over the
+       process group), bounded by ``timeout``;
+    3. one self-test all-reduce on a side stream (``comm_selftest``), bounded as well;
+    4. a MIN all-reduce of the answers: the data path runs on RCCL through the C ABI only if it came up and answered on
+       EVERY rank; otherwise every rank falls back to ``torch.distributed`` as the transport (a communicator that may
+       be stuck is forgotten, never torn down).
+
+    ``comm``: True / False force or skip steps 2-4; None = attempt them when the backend is nccl (one rank per device;
+    a gloo rehearsal that shares one GPU between ranks cannot form an RCCL communicator).  Returns the world size;
+    ``collectives()`` tells which transport was agreed."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1 or dist.is_initialized():
+    if world == 1:
         return world
-    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-    kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-    dist.init_process_group(backend, **kw)
+    local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    ndev = torch.cuda.device_count()
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if (ndev >= 1 and local_rank < ndev and int(os.environ.get("LOCAL_WORLD_SIZE", world)) <= ndev) else "gloo"
+        if backend == "nccl":
+            if local_rank >= ndev:
+                raise _lib.LinnaHipError("rank %d has no GPU (%d visible): one rank per GPU" % (local_rank, ndev))
+            if device is None:
+                device = torch.device("cuda", local_rank)
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device(device))
+        else:
+            if ndev:
+                torch.cuda.set_device(local_rank % ndev if device is None else device)
+            dist.init_process_group(backend)
+    backend = dist.get_backend()
+    if _state["collectives"] is not None:
+        return world
+    if comm is None:
+        comm = backend == "nccl" and os.environ.get("LINNA_COMM", "rccl") != "torch"
+    if not comm or not torch.cuda.is_available():
+        _state["collectives"] = "torch.distributed %s%s" % (backend, " (rehearsal: ranks may share a GPU)" if backend != "nccl" else "")
+        return world
+    dev_index = torch.cuda.current_device() if device is None else torch.device(device).index
+    why = ""
+    try:
+        comm_init(dev_index, timeout=timeout)
+        ok = comm_selftest(dev_index, timeout=min(60.0, timeout))
+        why = "" if ok else "self-test all-reduce wrong or late"
+    except Exception as e:                                          # noqa: BLE001
+        ok, why = False, repr(e)[:200]
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=torch.device("cuda", dev_index) if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        r, n, v = comm_info(dev_index)
+        _state["collectives"] = ("RCCL %s, %d ranks, through the C ABI (linna_comm_init / linna_allreduce_sum_f32 / "
+                                 "linna_allgather_f32 / linna_broadcast_f32)" % (v, n))
+    else:
+        if ok:
+            comm_destroy(dev_index)
+        else:
+            comm_forget(dev_index)                                  # (never tear down a communicator that may be stuck)
+        _state["collectives"] = "torch.distributed %s (the library's communicator did not come up on every rank%s)" % (
+            backend, ": " + why if why else "")
     return world
+
+
+def shutdown():
+    """Tear down what ``init()`` brought up (communicator first, then the process group)."""
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    comm_destroy()
+    _state["collectives"] = None
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 def world_size(group=None):
@@ -154,6 +228,22 @@ def rank(group=None):
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(group)
     return max([r for r, _ in _comm.values()] + [0])
+
+
+def barrier(group=None):
+    """Host-side barrier of the control plane; no-op for one rank."""
+    if world_size(group) > 1 and dist.is_available() and dist.is_initialized():
+        dist.barrier(group=group)
+
+
+def agree(flag, group=None):
+    """Rank 0's boolean on every rank (decisions read from the file system are taken once, by the rank that owns the
+    files, so that no rank can see a different answer and leave the others in a collective)."""
+    if world_size(group) == 1 or not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    box = [bool(flag)]
+    dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
+    return bool(box[0])
 
 
 def rank_batches(batches, rank, size):

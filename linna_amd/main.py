@@ -59,6 +59,15 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
     if nnmodel_in is None:
         nnmodel_in = lnn.ChtoModelv2
     limit_threads_to_quota()
+    # one process per GPU under torchrun (WORLD_SIZE > 1): rendezvous + the library's RCCL communicator; the emulator then
+    # trains data-parallel (predictor_gpu.py:246,265-266: `tsize` ranks, lr * size) and the walkers of the ONE ensemble
+    # shard over the ranks (the reference's MPI pool, util.py:99-256).  Rank 0 designs the training points, calls the
+    # user's theory and owns every file; the others wait at the barriers below.
+    from . import dist as ldist
+    world = ldist.init()
+    rank = ldist.rank() if world > 1 else 0
+    if world > 1:
+        print("rank %d of %d: %s" % (rank, world, ldist.collectives()), flush=True)
     params = dict(params or {})
     ndim = len(init)
     data, cov = np.asarray(data, np.float64), np.asarray(cov, np.float64)
@@ -78,7 +87,7 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
         # the FFT plans of the convergence checks are created while the points are designed and the emulator trains
         from .sampler import DeviceChain
         DeviceChain.prewarm(nwalkers, ndim, torch.device("cuda", torch.cuda.current_device()))
-    master = pool is None or pool.is_master()
+    master = (pool is None or pool.is_master()) and rank == 0
     store = None
     nk = ntimes = None
     for i, (nt, nv, nk, ntimes, tautol, temperature, meanshift, stdshift) in enumerate(
@@ -93,23 +102,27 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
             prev = os.path.join(outdir, "iter_{0}/".format(i - 1), filename[:-3])
             chain, _, _ = read_chain_and_cut(prev, nk, ntimes, method=method)
         nnsampler = NN_samplerv1(outdir_in, prior_range)
-        generate_training_point(theory, nnsampler, pool, outdir_in, nt, nv, data, inv_cov, chain, nsigma=nsigma,
-                                omegab2cut=omegab2cut, options=params.get("trainingoption", 0), chisqcut=chisqcut)
+        if rank == 0:
+            generate_training_point(theory, nnsampler, pool, outdir_in, nt, nv, data, inv_cov, chain, nsigma=nsigma,
+                                    omegab2cut=omegab2cut, options=params.get("trainingoption", 0), chisqcut=chisqcut)
         chain = None
         gc.collect()
+        ldist.barrier()                                                          # the training points are on disk
+        outdir_list = [os.path.join(outdir, "iter_{0}/".format(m)) for m in range(i + 1)]
+        args = [None, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog10index, ypositive, False, 2, temperature,
+                True, None, world, None, params, False]
         if master:
-            outdir_list = [os.path.join(outdir, "iter_{0}/".format(m)) for m in range(i + 1)]
-            args = [None, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog10index, ypositive, False, 2, temperature,
-                    True, None, 1, None, params, False]
             with open(os.path.join(outdir_in, "model_args.pkl"), "wb") as f:     # main.py:192-198 (artefact parity)
                 pickle.dump(args, f)
-            if not os.path.isfile(os.path.join(outdir_in, "finish.pkl")):
-                args[15] = nnmodel_in
-                train_NN(*args, device=device if str(device).startswith("cuda") else "cuda")
+        if (master or world > 1) and not ldist.agree(os.path.isfile(os.path.join(outdir_in, "finish.pkl"))):
+            args[15] = nnmodel_in
+            train_NN(*args, device=device if str(device).startswith("cuda") else "cuda", rank=rank)   # every rank: data parallel
+            if master:
                 with open(os.path.join(outdir_in, "finish.pkl"), "wb") as f:     # train_gpu.py:36-38
                     pickle.dump([True], f)
+        ldist.barrier()                                                          # checkpoints and transform pickles are on disk
         model, y_invtransform_data = retrieve_model(outdir_in, len(init), len(data), nnmodel_in)
-        if any(os.path.isfile(os.path.join(outdir_in, filename[:-3] + ext)) for ext in (".h5", ".npz")):   # main.py:273-274
+        if ldist.agree(any(os.path.isfile(os.path.join(outdir_in, filename[:-3] + ext)) for ext in (".h5", ".npz"))):   # main.py:273-274
             continue
         log_prob = Log_prob(data.astype(np.float32), inv_cov.astype(np.float32), model, y_invtransform_data, transform,
                             temperature, nograd=True, loglikelihoodfunc=loglikelihoodfunc or gaussianlogliklihood,
@@ -123,7 +136,7 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
     last = os.path.join(outdir, "iter_{0}/".format(len(ntrainArr) - 1), filename[:-3])
     chain, _, d = read_chain_and_cut(last, nk, ntimes, method=method)
     log_prob_samples_x = d["log_prob"].reshape(-1)                               # main.py:291
-    if "nimp" in params:                                                         # main.py:297-334
+    if "nimp" in params and rank == 0:                                           # main.py:297-334 (rank 0 owns the files)
         f_samples, f_lp = os.path.join(outdir, "samples_im.npy"), os.path.join(outdir, "log_prob_samples_x.npy")
         if not os.path.isfile(f_samples):
             chain, lp_flat, _ = read_chain_and_cut(last, nk, ntimes, method=method, flat=True)
@@ -151,4 +164,9 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
             w[np.abs(lw - np.mean(lw)) > 2 * np.std(lw)] = 0
         w = w / np.sum(w)
         np.save(os.path.join(outdir, "weight_im.npy"), [log_prob_samples_x.flatten(), logp, w])
+    if "nimp" in params and world > 1:
+        import torch.distributed as tdist
+        box = [(chain, log_prob_samples_x) if rank == 0 else None]
+        tdist.broadcast_object_list(box, src=0)
+        chain, log_prob_samples_x = box[0]
     return chain, log_prob_samples_x

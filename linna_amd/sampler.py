@@ -969,9 +969,51 @@ class BatchedHMC(object):
 
 
 # ------------------------------------------------------------------ drivers with the reference's names
+class _Ranks(object):
+    """How a driver's ensemble is split over the ranks of a run (``linna_amd.dist.init()``; the reference farms the
+    walkers' log-probability calls out over its MPI pool, util.py:99-256): the ``nwalkers`` walkers of the ONE ensemble
+    are sharded, ``nwalkers / world`` per GPU; every half step draws its stretch / slice partners from the
+    complementary walkers of ALL ranks (one all-gather per half step), chain blocks are all-gathered per convergence
+    check, rank 0 alone keeps the chain file and the convergence statistics and tells the others when to stop."""
+
+    def __init__(self, nwalkers, group):
+        from . import dist as ldist
+        self.group, self.world, self.rank = group, ldist.world_size(group), ldist.rank(group)
+        if self.world > 1 and nwalkers % (2 * self.world):
+            raise ValueError("nwalkers = %d cannot be split into even halves over %d ranks" % (nwalkers, self.world))
+        self.nw = nwalkers // self.world
+        self.exchange = "allgather" if self.world > 1 else "none"
+
+    def mine(self, x0):
+        return np.asarray(x0)[self.rank * self.nw:(self.rank + 1) * self.nw]
+
+    def bcast(self, obj):
+        """A host object of rank 0 on every rank (control plane)."""
+        if self.world == 1:
+            return obj
+        import torch.distributed as tdist
+        box = [obj]
+        tdist.broadcast_object_list(box, src=0 if self.group is None else tdist.get_global_rank(self.group, 0), group=self.group)
+        return box[0]
+
+    def gather(self, ens, c, l):
+        """(chain block, log-probabilities, acceptance counts) of the whole ensemble on every rank."""
+        if self.world == 1:
+            return c, l, ens.naccept
+        from . import dist as ldist
+        c, l = ens.gather_chain(c, l)
+        return c, l, ldist.gather_rows(ens.naccept.float(), self.group)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as tdist
+            tdist.barrier(group=self.group)
+
+
 class HMCSampler(object):
     """The reference's emcee driver (sampler.py:389-554): burn-in, restart from the best region,
-    sample until the integrated autocorrelation time and the mean/std drift have converged."""
+    sample until the integrated autocorrelation time and the mean/std drift have converged.
+    Multi-rank runs shard the walkers (``_Ranks``)."""
 
     def __init__(self, lnp, dlnp, ddlnp, ndim, nwalkers, x0=None, m=None, transform=None, torchspeed=False, seed=0,
                  dist_group=None):
@@ -987,11 +1029,12 @@ class HMCSampler(object):
         if method != "emcee":
             # sampler.py's "hmc"/"nuts" branches are unreachable in the reference
             raise NotImplementedError(method)
+        rk = _Ranks(self.nwalkers, self.group)
         filename = os.path.join(outdir, "chemcee_256.h5")
         store = ChainStore(filename, self.transform)
         x0 = self.x0
         resume = False
-        if store.exists():
+        if rk.rank == 0 and store.exists():
             if overwrite:
                 store.remove()
             else:
@@ -999,52 +1042,53 @@ class HMCSampler(object):
                 prev = ChainStore.load(filename)
                 x0, resume = prev["chain"][-1], True
                 store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])   # re-chunked into the new file at the first flush
-        ens = EnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
+        x0, resume = rk.bcast((x0, resume))
+        ens = EnsembleSampler(rk.nw, self.nparams, self.lnp, seed=self.seed, dist_group=self.group, exchange=rk.exchange)
         self.sampler = ens
-        DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)           # FFT plans of the convergence checks, off the critical path
+        if rk.rank == 0:
+            DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)       # FFT plans of the convergence checks, off the critical path
         print("start", flush=True)
         if not resume:
             print("burnin...", flush=True)                                   # sampler.py:519-529
-            ens.set_state(x0)
+            ens.set_state(rk.mine(x0))
             c, l = ens.run(burnin)
-            flat, lp = c.reshape(-1, self.nparams).cpu().numpy(), l.reshape(-1).cpu().numpy()
-            pos = flat[np.argsort(lp)[::-1][:int(50 * self.nwalkers)]]
-            x0 = pos[np.random.randint(0, len(pos), self.nwalkers), :]
+            c, l, _ = rk.gather(ens, c, l)
+            if rk.rank == 0:
+                flat, lp = c.reshape(-1, self.nparams).cpu().numpy(), l.reshape(-1).cpu().numpy()
+                pos = flat[np.argsort(lp)[::-1][:int(50 * self.nwalkers)]]
+                x0 = pos[np.random.randint(0, len(pos), self.nwalkers), :]
+            x0 = rk.bcast(x0)
             print("burnin done...", flush=True)
             ens.naccept.zero_()
-        ens.set_state(x0)
-        old_tau = np.inf
+        ens.set_state(rk.mine(x0))
+        st = {"old_tau": np.inf, "next": 0, "last": -1}
         done = 0 if not resume else sum(len(c) for c in store.chain)
+        done = rk.bcast(done)
         dchain = DeviceChain()                                               # convergence statistics stay on the GPU
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
-        next_check, last_check = 0, -1
-        while done < nsamp:
-            c, l = ens.run(ncheck)
-            th = ens.theta_of(c)
-            store.append(c, th, l, ens.naccept)                               # device tensors: copied off this thread
-            dchain.append(c)
-            done += ncheck
-            if incremental:
-                store.flush(final=False)
-            # The reference evaluates its criterion every `ncheck` iterations on the whole chain -- quadratic in
-            # the chain length (a 270 k-iteration run spent 15 of 17 minutes here).  Same criterion, evaluated at
-            # every check up to 2000 iterations and then whenever the chain has grown by 2 %: tau now against tau
-            # `ncheck` iterations earlier, exactly the pair the reference compares at that iteration.
-            # A check is also skipped while the chain is shorter than 0.9 x ntimes x the last tau estimate: the
-            # criterion's first clause cannot hold there unless the estimate drops by more than 10 % (each check is
-            # a batch of FFTs over the whole chain, and every new chain length costs rocFFT a new plan).
-            if done < next_check:
-                continue
+
+        def check(done):
+            """True = stop.  The reference evaluates its criterion every `ncheck` iterations on the whole chain --
+            quadratic in the chain length (a 270 k-iteration run spent 15 of 17 minutes here).  Same criterion, evaluated
+            at every check up to 2000 iterations and then whenever the chain has grown by 2 %: tau now against tau
+            `ncheck` iterations earlier, exactly the pair the reference compares at that iteration.  A check is also
+            skipped while the chain is shorter than 0.9 x ntimes x the last tau estimate: the criterion's first clause
+            cannot hold there unless the estimate drops by more than 10 % (each check is a batch of FFTs over the whole
+            chain, and every new chain length costs rocFFT a new plan)."""
+            if done < st["next"]:
+                return False
             tau = dchain.integrated_time()                                    # sampler.py:538
-            if last_check != done - ncheck and done > ncheck:
+            old_tau = st["old_tau"]
+            if st["last"] != done - ncheck and done > ncheck:
                 old_tau = dchain.integrated_time(upto=done - ncheck)
-            last_check = done
-            next_check = int(done * 1.02) if done > 2000 else done + ncheck
+            st["last"] = done
+            nxt = int(done * 1.02) if done > 2000 else done + ncheck
             if np.all(np.isfinite(tau)):
-                next_check = max(next_check, min(int(0.9 * ntimes * float(np.max(tau))), nsamp - nsamp % ncheck))
+                nxt = max(nxt, min(int(0.9 * ntimes * float(np.max(tau))), nsamp - nsamp % ncheck))
+            st["next"] = nxt
             if np.isnan(np.sum(tau)) and done > 10:
-                break
+                return True
             converged = np.all(tau * ntimes < done)                           # :545-547
             converged &= np.all(np.abs(old_tau - tau) / tau < tautol)
             if converged and self.nwalkers > dchain.MAX_WALKERS:
@@ -1055,17 +1099,34 @@ class HMCSampler(object):
             converged = converged and dchain.checkmeanstd(max(2, int(nk * np.mean(tau))), meanshift, stdshift)
             print("max, min tau diff, max tau, ninter: {0}, {1}, {2}, {3}\n".format(
                 np.max(np.abs(old_tau - tau) / tau), np.min(np.abs(old_tau - tau) / tau), np.max(tau), done), flush=True)
-            if converged:
+            st["old_tau"] = tau
+            return bool(converged)
+
+        while done < nsamp:
+            c, l = ens.run(ncheck)
+            c, l, acc = rk.gather(ens, c, l)
+            done += ncheck
+            stop = False
+            if rk.rank == 0:
+                th = ens.theta_of(c)
+                store.append(c, th, l, acc)                                   # device tensors: copied off this thread
+                dchain.append(c)
+                if incremental:
+                    store.flush(final=False)
+                stop = check(done)
+            if rk.bcast(stop):
                 break
-            old_tau = tau
-        store.flush()
+        if rk.rank == 0:
+            store.flush()
+        rk.barrier()                                                          # the file is complete before any rank reads it
         self.sampler = None
         return store
 
 
 class ZeusSampler(object):
     """sampler.py:699-737: zeus' ensemble slice sampler (``SliceEnsembleSampler``) with the reference's
-    convergence callback (IAT on the last 80 %, sampler.py:684,729; mean/std drift) and file names."""
+    convergence callback (IAT on the last 80 %, sampler.py:684,729; mean/std drift) and file names.
+    Multi-rank runs shard the walkers (``_Ranks``)."""
 
     def __init__(self, lnp, ndim, nwalkers, x0=None, transform=None, seed=0, dist_group=None):
         self.lnp, self.transform, self.x0, self.nparams, self.nwalkers = lnp, transform, x0, ndim, nwalkers
@@ -1074,41 +1135,42 @@ class ZeusSampler(object):
 
     def sample(self, pool, nsamp, outdir="./", progress=False, overwrite=False, ntimes=10, tautol=0.01, incremental=True,
                meanshift=0.1, stdshift=0.1, nk=2, ncheck=100):
+        rk = _Ranks(self.nwalkers, self.group)
         store = ChainStore(os.path.join(outdir, "zeus_256.h5"), self.transform)
         x0 = self.x0
-        if store.exists() and overwrite:
-            store.remove()
-        if store.exists():
-            print("init from previous")
-            prev = ChainStore.load(store.base)
-            x0 = prev["chain"][-1]
-            store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])   # re-chunked into the new file at the first flush
-        ens = SliceEnsembleSampler(self.nwalkers, self.nparams, self.lnp, seed=self.seed, dist_group=self.group)
+        if rk.rank == 0:
+            if store.exists() and overwrite:
+                store.remove()
+            if store.exists():
+                print("init from previous")
+                prev = ChainStore.load(store.base)
+                x0 = prev["chain"][-1]
+                store.append(prev["chain"], prev["chain_transformed"], prev["log_prob"], prev["accepted"])   # re-chunked into the new file at the first flush
+        x0 = rk.bcast(x0)
+        ens = SliceEnsembleSampler(rk.nw, self.nparams, self.lnp, seed=self.seed, dist_group=self.group, exchange=rk.exchange)
         self.sampler = ens
-        DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)
-        ens.set_state(x0)
-        old_tau, done = np.inf, sum(len(c) for c in store.chain)
+        if rk.rank == 0:
+            DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)
+        ens.set_state(rk.mine(x0))
+        st = {"old_tau": np.inf, "next": 0, "last": -1}
+        done = rk.bcast(sum(len(c) for c in store.chain))
         dchain = DeviceChain()
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
-        next_check, last_check = 0, -1
-        while done < min(nsamp, 100000):
-            c, l = ens.run(ncheck)
-            store.append(c, ens.theta_of(c), l, ens.naccept)
-            dchain.append(c)
-            done += ncheck
-            if incremental:
-                store.flush(final=False)
-            if done < next_check:                           # checks thin out as in HMCSampler.sample (same criterion)
-                continue
-            if last_check != done - ncheck and done > ncheck:
+
+        def check(done):                                    # checks thin out as in HMCSampler.sample (same criterion)
+            if done < st["next"]:
+                return False
+            old_tau = st["old_tau"]
+            if st["last"] != done - ncheck and done > ncheck:
                 prev = done - ncheck
                 old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev)))
             tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2))))   # discard=0.2, sampler.py:684,729
-            last_check = done
-            next_check = int(done * 1.02) if done > 2000 else done + ncheck
+            st["last"] = done
+            nxt = int(done * 1.02) if done > 2000 else done + ncheck
             if np.isfinite(tau):
-                next_check = max(next_check, int(0.9 * ntimes * tau))
+                nxt = max(nxt, int(0.9 * ntimes * tau))
+            st["next"] = nxt
             converged = tau * ntimes < done
             converged &= abs(old_tau - tau) / tau < tautol
             if converged and self.nwalkers > dchain.MAX_WALKERS:      # decide on all walkers (the routine checks use a subset)
@@ -1118,8 +1180,23 @@ class ZeusSampler(object):
                     old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev, all_walkers=True)))
                 converged = tau * ntimes < done and abs(old_tau - tau) / tau < tautol
             converged = converged and bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
-            old_tau = tau
-            if converged:
+            st["old_tau"] = tau
+            return bool(converged)
+
+        while done < min(nsamp, 100000):
+            c, l = ens.run(ncheck)
+            c, l, acc = rk.gather(ens, c, l)
+            done += ncheck
+            stop = False
+            if rk.rank == 0:
+                store.append(c, ens.theta_of(c), l, acc)
+                dchain.append(c)
+                if incremental:
+                    store.flush(final=False)
+                stop = check(done)
+            if rk.bcast(stop):
                 break
-        store.flush()
+        if rk.rank == 0:
+            store.flush()
+        rk.barrier()
         return store

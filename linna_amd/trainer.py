@@ -261,6 +261,9 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     progress = progress or os.environ.get("LINNA_TRAIN_PROGRESS", "0") == "1"   # per-epoch train / validation loss
     torch.manual_seed(1234)                                                     # predictor_gpu.py:221
     size = max(int(size), 1)
+    if size > 1:
+        from . import dist as ldist
+        ldist.init()        # rendezvous + the library's RCCL communicator (no-op when the launcher already did; predictor_gpu.py:240-252)
     model = pred.model
     engine = TrainEngine(pred, dataset, loss_fn, val_dataset, world_size=size, dist_group=dist_group)
     if pred.optim == "automatic" or pred.optim is None:

@@ -105,3 +105,27 @@ def test_single_rank_helpers_are_noops():
     assert torch.equal(x, torch.ones(3))
     c, l = ldist.gather_chain(torch.zeros(2, 2, 2), torch.zeros(2, 2))
     assert c.shape == (2, 2, 2)
+
+
+def _bench(*argv, **env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), capture_output=True, text=True, env=e, timeout=300)
+
+
+def test_bench_launches_its_own_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's N > 1 form): bench.py starts the two
+    ranks itself as child processes, they rendezvous through linna_amd.dist.init() and rank 0's JSON line comes back on
+    stdout -- alone.  A rank that dies makes the launcher exit non-zero."""
+    import json
+    r = _bench("--gpus", "2", "--backend", "gloo", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["launch_check"] and d["world"] == 2 and d["rank_sum"] == 3.0 and "gloo" in d["collectives"]
+    bad = _bench("--gpus", "2", "--backend", "gloo", "--launch-check", LINNA_BENCH_FAIL_RANK="1")
+    assert bad.returncode != 0 and not bad.stdout.strip()

@@ -28,19 +28,18 @@ def _free_port():
 
 
 def _worker(rank, world, port, fn, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
     two = torch.cuda.device_count() >= world
     torch.cuda.set_device(rank if two else 0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from linna_amd import dist as ldist
+    # the product's own bring-up: rendezvous (gloo here), then -- one rank per device only -- the RCCL communicator through
+    # the C ABI with its bounded self-test and the MIN-agreement over the ranks (linna_amd.dist.init)
+    assert ldist.init(backend="gloo", device=torch.device("cuda", rank if two else 0), comm=two) == world
     try:
-        if two:
-            from linna_amd import dist as ldist
-            ldist.comm_init()                               # RCCL communicator through the C ABI (id via gloo)
+        assert ldist.collectives() is not None and (("RCCL" in ldist.collectives()) == two)
         ret[rank] = fn(rank, world)
     finally:
-        if two:
-            ldist.comm_destroy()
-        dist.destroy_process_group()
+        ldist.shutdown()
 
 
 def _run(fn, world=2):
@@ -207,3 +206,37 @@ def test_ensemble_with_complement_exchange_and_chain_gather():
         np.testing.assert_allclose(r[1], sig, rtol=0.2)
     np.testing.assert_array_equal(res[0][0], res[1][0])              # the gathered chain is the same on both ranks
     assert res[0][3] != res[1][3]                                    # ... while their own walkers differ
+
+
+def _driver_job(rank, world):
+    import contextlib
+    import io
+    from linna_amd import sampler, util
+    from test_gpu_sampling import identity_emulator_logprob, _gaussian_33
+    ndim, means, cov, priors = _gaussian_33()
+    lp = identity_emulator_logprob(ndim, means, cov, priors)
+    out = os.environ["LINNA_TEST_SHARED_DIR"]
+    nw = 256                                                          # walkers of the ONE ensemble: 128 per rank
+    x0 = util.invTransform(priors)(means)[None, :] + 0.01 * np.random.RandomState(10 + rank).standard_normal((nw, ndim))
+    drv = sampler.HMCSampler(lp, None, None, ndim, nw, x0=x0, transform=util.Transform(priors), seed=5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        drv.sample(None, 600, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True)       # never "converged": 600 iterations
+    d = sampler.ChainStore.load(os.path.join(out, "chemcee_256.h5"))                        # every rank reads rank 0's file
+    th = np.asarray(d["chain_transformed"])[300:]
+    return d["chain"].shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), np.asarray(d["accepted"]).sum()
+
+
+def test_emcee_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
+    """The reference's emcee driver on two ranks: 256 walkers of ONE ensemble, 128 per rank, partners drawn from both
+    ranks' complementary halves, chain blocks all-gathered per check, rank 0 alone writes chemcee_256.h5 (the layout the
+    one-rank run writes: [iterations, 256, ndim]) and decides when to stop; both ranks read the same file afterwards."""
+    from test_gpu_sampling import _gaussian_33
+    monkeypatch.setenv("LINNA_TEST_SHARED_DIR", str(tmp_path))
+    ndim, means, cov, priors = _gaussian_33()
+    res = _run(_driver_job)
+    sig = np.sqrt(np.diag(cov))
+    assert res[0][0] == res[1][0] == (600, 256, ndim)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert np.max(np.abs(res[0][1] - means) / sig) < 0.15 and res[0][3] > 0
+    np.testing.assert_allclose(res[0][2], sig, rtol=0.2)
+    assert sorted(os.listdir(tmp_path)) == ["chemcee_256.h5"]

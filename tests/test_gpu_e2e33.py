@@ -25,6 +25,11 @@ import readme33
 
 pytestmark = pytest.mark.gpu
 
+# Tolerances of the inference-level checks (fp32 emulator trained for 600 epochs per iteration, 4096 walkers):
+CORR_TOL = 0.05           # max |corr - I|: Monte-Carlo error of a correlation at ~16 k independent samples is 0.008, x 4 for the largest of 528
+LNP_MEDIAN_TOL = 0.5      # |median(stored lnP - exact lnP)| at the returned samples (chi^2 of 33 terms: emulator error of a few 0.01 sigma per output)
+LNP_P99_TOL = 2.0         # 99th percentile of |stored lnP - exact lnP|
+
 
 def _write_iteration0(tmp):
     from linna_amd import util
@@ -118,18 +123,26 @@ def test_ml_sampler_core_33d_posterior_through_a_trained_emulator(tmp_path):
     # no walker in a hole of the emulator: the largest excursion of a row is that of a 33-D Gaussian
     dev = np.abs((chain - means) / sig).max(1)
     assert np.median(dev) < 2.8 and (dev > 6).mean() < 1e-4
-    # the stored log-probability is the emulator's: against the exact posterior (theory = identity) at the same points
-    sub = np.random.RandomState(1).randint(0, len(chain), 20000)
-    exact = -0.5 * np.sum(((chain[sub] - means) / sig) ** 2, axis=1)
+    # the posterior's correlation matrix (north_star: "means/covariances"): the exact one is the identity
+    corr = np.corrcoef(chain.T)
+    assert np.abs(corr - np.eye(ndim)).max() < CORR_TOL, np.abs(corr - np.eye(ndim)).max()
+    # the stored log-probability (main.py:291: the whole chain's, flat; its tail belongs to the returned rows) is the
+    # emulator's lnP = -chi^2/2 - |z|^2/2 at T = 1: against the exact posterior (theory = identity) at a sub-sample
+    from linna_amd import util
     lp = np.asarray(logp).reshape(-1)
     assert lp.shape[0] >= len(chain)
+    sub = np.random.RandomState(1).randint(0, len(chain), 20000)
+    z = np.asarray(util.invTransform(prob["priors"])(chain[sub]))
+    exact = -0.5 * np.sum(((chain[sub] - means) / sig) ** 2, axis=1) - 0.5 * np.sum(z ** 2, axis=1)
+    err = lp[-len(chain):][sub] - exact
+    print("stored lnP - exact: median %.3f, p1 %.3f, p99 %.3f, max |.| %.3f" % (np.median(err), np.percentile(err, 1), np.percentile(err, 99), np.abs(err).max()))
+    assert abs(np.median(err)) < LNP_MEDIAN_TOL and np.percentile(np.abs(err), 99) < LNP_P99_TOL, (np.median(err), np.percentile(np.abs(err), 99))
     for k in range(4):
         d = os.path.join(out, "iter_%d" % k)
         for f in ("train_samples_x.txt", "train_samples_y.npy", "val_samples_x.txt", "val_samples_y.npy", "lr.npy",
                   "model_args.pkl", "finish.pkl", "best.pth.tar", "last.pth.tar", "X_transform.pkl", "y_transform.pkl",
                   "y_invtransform.pkl", "y_transform_data.pkl", "y_invtransform_data.pkl", "chemcee_256.h5"):
             assert os.path.isfile(os.path.join(d, f)), (k, f)
-    assert np.isfinite(exact).all()
     import shutil
     shutil.rmtree(out, ignore_errors=True)              # (the four chain files are a few GB each at 4096 walkers)
 
