@@ -106,11 +106,16 @@ def cpu_baseline(consts, z, budget_s=15.0):
                       "thread): %.0f evals/s over %d calls" % (best[2], len(z), best[1], cores, per_walker, m)}
 
 
+TRAFFIC_FILE = "r03_pmc_traffic.json"
+
+
 def pmc_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None if not collected."""
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside the timed process (rocprofv3
+    wraps the program): the figure comes from the committed rocprofv3 --pmc passes of THIS round's kernel
+    (tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes) and is labelled as
+    such in the line (``traffic_source``); None if not collected."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)) as f:
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None
@@ -141,7 +146,7 @@ def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
                 "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
-def driver_rate(lp, nwalkers, nsamp=10000):
+def driver_rate(lp, nwalkers, nsamp=2000):
     """The reference's emcee driver end to end (sampler.py:458-554 -> linna_amd.sampler.HMCSampler.sample): 100 burn-in
     iterations + restart, then `nsamp` iterations with everything a run does -- chain blocks device -> host, the
     reference's HDF5 layout appended every 100 iterations (chain + chain_transformed + log_prob: 1.1 MB per iteration
@@ -169,7 +174,24 @@ def driver_rate(lp, nwalkers, nsamp=10000):
         size = os.path.getsize(os.path.join(out, "chemcee_256.h5"))
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    return {"driver_steps_per_s": (n + 100) / dt, "driver_iterations": n + 100, "driver_seconds": dt, "driver_chain_file_bytes": size}
+    return {"driver_steps_per_s": (n + 100) / dt, "driver_iterations": n + 100, "driver_seconds": dt, "driver_chain_file_bytes": size,
+            "driver_tmp_fs": _fs_type(tempfile.gettempdir())}
+
+
+def _fs_type(path):
+    """File-system type of the mount that holds ``path`` (/proc/mounts, longest matching mount point)."""
+    best = ("", "?")
+    try:
+        path = os.path.realpath(path)
+        with open("/proc/mounts") as f:
+            for ln in f:
+                parts = ln.split()
+                mp = parts[1]
+                if (path == mp or path.startswith(mp.rstrip("/") + "/")) and len(mp) > len(best[0]):
+                    best = (mp, parts[2])
+    except Exception:                                               # noqa: BLE001
+        pass
+    return "%s on %s" % (best[1], best[0] or "?")
 
 
 def training_rate(device, world, rank, backend, nsteps=150):
@@ -180,7 +202,7 @@ def training_rate(device, world, rank, backend, nsteps=150):
     import torch
     import torch.distributed as dist
     from linna_amd import nn, util, predictor_gpu, trainer
-    nin, nout, B, n = 26, 457, 500, 20000
+    nin, nout, B, n = 26, 457, 500, 100000             # configs[2]: "MLP training 100k samples" resident in HBM (193 MB per rank)
     rs = np.random.RandomState(5)
     q, _ = np.linalg.qr(rs.standard_normal((nout, nout)))
     cov = (q * (np.logspace(0, -2, nout) * 0.1)[None, :]) @ q.T
@@ -234,7 +256,8 @@ def training_rate(device, world, rank, backend, nsteps=150):
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dt = float(tm.item())
     loss = float(eng.loss_mean.item())
-    res = {"workload": "ChtoModelv2(26,457), dense covariance, batch 500 per GPU, AdamW, gradient all-reduce per step for N > 1",
+    res = {"workload": "ChtoModelv2(26,457), dense covariance, resident training set of %d rows per GPU, shuffled batches of 500 per GPU, AdamW, gradient all-reduce per step for N > 1" % n,
+           "resident_rows": n,
            "samples_per_s": world * B * nsteps / dt, "ms_per_step": 1e3 * dt / nsteps, "global_batch": world * B, "steps": nsteps,
            "loss_finite": bool(np.isfinite(loss)),
            # one rank: one C call, three launches (forward + loss, dX chain, parameter gradients with AdamW in the epilogue);
@@ -315,6 +338,98 @@ def secondary_serving(device, kind, nin, nout, dense, nwalkers=4096, iters=400):
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS}
 
 
+def _problem33(device, kind):
+    """README problem (33-D Gaussian, flat priors [-5, 5], diagonal covariance) behind `kind`(33, 33), random-init weights."""
+    import torch
+    from linna_amd import nn, util, predictor_gpu
+    rs = np.random.RandomState(11)
+    data = rs.uniform(size=NOUT)
+    cov = np.diag(0.1 * rs.uniform(0.05, 1.0, size=NOUT))
+    sigma = np.sqrt(np.diag(cov))
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(NIN)]
+    torch.manual_seed(1234)
+    model = getattr(nn, kind)(NIN, NOUT, None)
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    pred = predictor_gpu.Predictor(NIN, NOUT, model=model, device=device,
+                                   X_transform=util.X_transform_class(t(np.zeros(NIN)), t(np.full(NIN, 10.0 / np.sqrt(12.0))), "cpu", None),
+                                   y_transform=util.Y_transform_class(t(data / sigma), t(np.ones(NOUT)), "cpu"))
+    lp = util.Log_prob(t(data), t(np.linalg.inv(cov)), pred, util.Y_invtransform_data(sigma, "cpu"), util.Transform(priors), 1.0,
+                       util.gaussianlogliklihood, nograd=True)
+    return lp, model
+
+
+def _events_us(fn, iters, warm_s=0.3):
+    """Average time of `fn` in microseconds: HIP events on the launch stream around `iters` back-to-back calls, after a
+    clock-ramp warm-up."""
+    import torch
+    from linna_amd import _lib
+    t_end = time.perf_counter() + warm_s
+    while time.perf_counter() < t_end:
+        for _ in range(8):
+            fn()
+        torch.cuda.synchronize()
+    st = _lib.stream()
+    e0, e1, ms = C.c_void_p(), C.c_void_p(), C.c_float()
+    _lib.call("linna_event_create", C.byref(e0)); _lib.call("linna_event_create", C.byref(e1))
+    _lib.call("linna_event_record", e0, st)
+    for _ in range(iters):
+        fn()
+    _lib.call("linna_event_record", e1, st)
+    _lib.call("linna_event_elapsed_ms", e0, e1, C.byref(ms))
+    _lib.call("linna_event_destroy", e0); _lib.call("linna_event_destroy", e1)
+    return 1e3 * ms.value / iters
+
+
+def hmc_rate(device, nchains=4096, nleap=5):
+    """BASELINE configs[4] (HMCSampler.py:19-68 batched over walkers; one process per GPU, chains are independent: no
+    collective): lnP + d lnP / d z per launch (linna_logprob_grad), and whole HMC transitions of `nleap` leapfrog steps
+    (momentum draw, half kick, nleap x (drift, gradient, kick), Metropolis test).  For the reference's network class
+    ChtoModelv2(33,33) and the 4 x 512 MLP.  One gradient evaluation = forward + dX-only backward = 2 x the forward FLOP
+    (SURVEY 8d)."""
+    import torch
+    from linna_amd import sampler
+    out = {"chains": nchains, "leapfrog_per_sample": nleap, "workload": "33-D Gaussian, %d independent chains, lnP and its gradient in one launch" % nchains}
+    for key, kind in (("chto_v2", "ChtoModelv2"), ("mlp4x512", "MLP")):
+        lp, model = _problem33(device, kind)
+        z = torch.as_tensor(np.random.RandomState(5).standard_normal((nchains, NIN)).astype(np.float32), device=device)
+        lnp = torch.empty(nchains, dtype=torch.float32, device=device)
+        g = torch.empty(nchains, NIN, dtype=torch.float32, device=device)
+        us = _events_us(lambda: lp.evaluate_with_grad(z, out=lnp, grad=g), 300)
+        assert torch.isfinite(g).all() and torch.isfinite(lnp).all()
+        flop = nchains * 2.0 * (2.0 * model.macs_per_eval())
+        h = sampler.BatchedHMC(lp, 0.05 * np.random.RandomState(1).standard_normal((nchains, NIN)).astype(np.float32))
+        us_s = _events_us(lambda: h.step(nleap, 2e-2), 60)
+        out[key] = {"us_per_gradient_eval": us, "gradient_evals_per_s": nchains / (us * 1e-6), "achieved": flop / (us * 1e-6) / 1e12,
+                    "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                    "flop_per_gradient_eval": flop / nchains, "us_per_hmc_sample": us_s,
+                    "leapfrog_steps_per_s": nleap * nchains / (us_s * 1e-6), "hmc_iterations_per_s": 1.0 / (us_s * 1e-6),
+                    "acceptance": float(h.naccept.float().mean()) / max(1, int(h.step_dev.item()))}
+    return out
+
+
+def slice_rate(lp, sizes=(4096, 128), iters=(60, 400)):
+    """The reference's DEFAULT sampler (main.py:22 method="zeus"; sampler.py:699-737): ensemble slice sampling iterations
+    per second on the headline problem, at the bench's 4096 walkers and at the reference's own ensemble size (cosmolike:
+    128 walkers), with the evaluations one iteration costs (stepping out + shrinking, per walker)."""
+    import torch
+    from linna_amd import sampler
+    out = {}
+    for nw, n in zip(sizes, iters):
+        ens = sampler.SliceEnsembleSampler(nw, NIN, lp, seed=1)
+        ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nw, NIN)))
+        ens.run(max(30, n // 4), store=False)                # tunes mu (zeus' first iterations), ramps the clocks
+        torch.cuda.synchronize()
+        e0, it0 = ens.neval, ens.iteration
+        t0 = time.perf_counter()
+        ens.run(n, store=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["walkers_%d" % nw] = {"iterations_per_s": n / dt, "us_per_iteration": 1e6 * dt / n,
+                                  "evals_per_walker_per_iteration": (ens.neval - e0) / max(1, ens.iteration - it0) / nw,
+                                  "walker_updates_per_s": n * nw / dt, "mu": float(ens.mu)}
+    return out
+
+
 def time_dominant_kernel(lp, z, out, iters):
     """HIP-event timing (events recorded on the launch stream) of the dominant kernel: the
     whole-network serving kernel net_stream_kernel<6, 0, false, 0, 16> -- ONE launch per step evaluates prior map,
@@ -390,7 +505,7 @@ def main():
     ap.add_argument("--no-training", action="store_true", help="skip the secondary training-throughput measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the chto_v2 / dense_1000 serving objects (they run the "
                     "same kernel instantiation as the headline: profile the headline without them)")
-    ap.add_argument("--no-driver", action="store_true", help="skip mcmc.driver_steps_per_s (an 11 GB chain file in the temporary directory)")
+    ap.add_argument("--no-driver", action="store_true", help="skip mcmc.driver_steps_per_s (a 2.3 GB chain file in the temporary directory)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank path on a box with fewer GPUs)")
     ap.add_argument("--launch-check", action="store_true", help="ranks only rendezvous (linna_amd.dist.init), sum their ranks over "
@@ -567,6 +682,7 @@ def main():
                        "parallelism": "walkers sharded, %d rank(s), no data-path collective" % world},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this kernel, not measured in this run)" % TRAFFIC_FILE,
                          "kernel": "net_stream_kernel<6, 0, false, 0, 16> (whole network per launch: 16 walkers/workgroup, activations in LDS, fragment-order weight stream loaded straight into the MFMA operand registers, v_mfma_f32_16x16x4_f32)",
                          "avg_launch_ms": ms_kernel, "launch_ms_p10_p50_p90": ms_q, "flop_per_launch": flop_launch},
             "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
@@ -588,6 +704,11 @@ def main():
             for key, spec in (("chto_v2", ("ChtoModelv2", 33, 33, False)), ("dense_1000", ("ChtoModelv2", 40, 1000, True))):
                 try:
                     res[key] = secondary_serving(device, *spec)
+                except Exception as e:                              # noqa: BLE001
+                    res[key] = {"error": repr(e)[:300]}
+            for key, fn in (("hmc", lambda: hmc_rate(device)), ("slice", lambda: slice_rate(lp))):   # configs[4]; the default sampler
+                try:
+                    res[key] = fn()
                 except Exception as e:                              # noqa: BLE001
                     res[key] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 6   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update */
+#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -247,6 +247,12 @@ int linna_logprob_destroy(linna_logprob_t* lp);
  * afterwards -- the reference has no counterpart because `model.load_state_dict`
  * (predictor_gpu.py:439-445) rebinds the tensors the forward pass reads. */
 int linna_weights_changed(linna_ctx_t* ctx);
+/* Rows per workgroup of the whole-network kernel: 0 (default) = chosen per launch from the batch size -- the fewest
+ * of 4 / 8 / 16 that still fit the batch into one workgroup per CU; 4, 8 or 16 = that engine for every launch of the
+ * process (tests and measurements; results differ between engines in the last bits: another summation order over k).
+ * Returns the previous setting, or LINNA_ERR_INVALID.  Process-wide, not a per-launch argument: the launch path reads
+ * one atomic instead of the environment. */
+int linna_engine_rows(int rows);
 size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad);
 /* lnP[B]; THETA[B][ldt] optional (physical parameters, for chain_transformed). */
 int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblinna_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
@@ -106,6 +106,7 @@ _SIGNATURES = {
     "linna_logprob_create": (_I, [_V, _V, C.POINTER(LogprobDesc), _PV]),
     "linna_logprob_destroy": (_I, [_V]),
     "linna_weights_changed": (_I, [_V]),
+    "linna_engine_rows": (_I, [_I]),
     "linna_logprob_ws_bytes": (_SZ, [_V, _I, _I]),
     "linna_logprob_eval": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),
     "linna_logprob_grad": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),
@@ -219,3 +220,12 @@ def iptr(t):
 
 def ld4(w):
     return (int(w) + 3) & ~3
+
+
+def engine_rows(rows=0):
+    """Force one engine of the whole-network kernel (4, 8 or 16 rows per workgroup) for every later launch of this
+    process; 0 = chosen per launch from the batch size.  Returns the previous setting (tests and measurements)."""
+    prev = load().linna_engine_rows(int(rows))
+    if prev < 0:
+        check(prev)
+    return prev

@@ -380,7 +380,7 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
         (void)hipStreamIsCapturing(S(stream), &cap);
         net_ensure_fwd(n, cap == hipStreamCaptureStatusNone);
         if (n->stream_fwd == 1 && n->packed.ready()) {
-            const int rows = net_stream_rows(B);
+            const int rows = std::min(net_stream_rows(B), 8);          // (no 16-row instantiation of this launch: net_stream.hip, ns_launch_kernel)
             const float* packed = nullptr;
             TRY(stream_copy_refresh(n->packed, n, rows, stream, &packed));
             std::vector<float*> y(nl), t(nl);
@@ -923,6 +923,11 @@ int linna_logprob_destroy(linna_logprob_t* lp) {
     return LINNA_OK;
 }
 int linna_weights_changed(linna_ctx_t*) { g_weights_epoch.fetch_add(1); return LINNA_OK; }
+int linna_engine_rows(int rows) {
+    const int prev = net_stream_force_rows(rows);
+    if (prev < 0) { set_error("linna_engine_rows: %d (0, 4, 8 or 16)", rows); return LINNA_ERR_INVALID; }
+    return prev;
+}
 size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad) {
     return (lp_layout(lp, B, with_grad).total + 16) * sizeof(float);
 }

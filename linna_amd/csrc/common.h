@@ -119,6 +119,7 @@ size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size
 // rows per workgroup for a batch of B rows: 16 (v_mfma_f32_16x16x4_f32), or 8 / 4 (v_mfma_f32_4x4x1_16b_f32) when 16-row
 // workgroups would leave CUs idle.  The 16-row engine and the small ones read different orders of the weight stream.
 int net_stream_rows(int B);
+int net_stream_force_rows(int rows);   // 0 automatic, 4 / 8 / 16 forced; returns the previous setting, -1 for an invalid value
 int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog,
                            const NsDense* dn, hipStream_t s);      // prog 0 + dn: the forward program with the dense segment
 bool net_stream_dense_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn);

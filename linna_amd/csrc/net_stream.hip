@@ -53,6 +53,7 @@
 #include <vector>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -504,13 +505,15 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ap) : "memory");
         ap += 64;
     };
+    // (kernel-argument arrays are indexed through readfirstlane: one instantiation -- STORE == 1 on the 16-row engine --
+    // could not prove the segment index uniform and copied the whole 2 KB argument block to scratch)
     auto load_seg = [&]() {
-        const NsSeg S = a.seg[si];
+        const NsSeg S = a.seg[__builtin_amdgcn_readfirstlane(si)];
         s_type = S.type; kleft = s_steps = S.steps; s_passes = S.passes; s_bias = S.bias_off;
         s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2; s_x0col = S.x0_col; s_x0n = S.x0_n;
         if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
-        if constexpr (STORE) { s_gout = a.gout[si]; s_gld = a.gld[si]; s_gn = a.gn[si]; }
-        if constexpr (STORE == 2) { s_gmask = a.gmask[si]; s_gmld = a.gmld[si]; }
+        if constexpr (STORE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gout = a.gout[j]; s_gld = a.gld[j]; s_gn = a.gn[j]; }
+        if constexpr (STORE == 2) { const int j = __builtin_amdgcn_readfirstlane(si); s_gmask = a.gmask[j]; s_gmld = a.gmld[j]; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         const int arow = SM ? sm_arow : li, ak = SM ? 4 * sm_achunk : 4 * kq;
@@ -581,11 +584,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         if (--kleft == 0) {
             // ---- end of run (si, pass).  The next segment's descriptor is requested first: the scalar
             // load's latency then hides under the epilogue stores and the barrier.
-            const NsSeg NX = a.seg[min(si + 1, nseg - 1)];
+            const int nxi = __builtin_amdgcn_readfirstlane(min(si + 1, nseg - 1));
+            const NsSeg NX = a.seg[nxi];
             float* nx_gout = nullptr; int nx_gld = 0, nx_gn = 0;
             const float* nx_gmask = nullptr; int nx_gmld = 0;
-            if constexpr (STORE) { const int j = min(si + 1, nseg - 1); nx_gout = a.gout[j]; nx_gld = a.gld[j]; nx_gn = a.gn[j]; }
-            if constexpr (STORE == 2) { const int j = min(si + 1, nseg - 1); nx_gmask = a.gmask[j]; nx_gmld = a.gmld[j]; }
+            if constexpr (STORE) { nx_gout = a.gout[nxi]; nx_gld = a.gld[nxi]; nx_gn = a.gn[nxi]; }
+            if constexpr (STORE == 2) { nx_gmask = a.gmask[nxi]; nx_gmld = a.gmld[nxi]; }
             const int cur_steps = s_steps;
             auto take_next = [&]() {
                 s_type = NX.type; s_steps = NX.steps; s_passes = NX.passes; s_bias = NX.bias_off;
@@ -1245,11 +1249,26 @@ size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size
     return ns_build_prog(layers, nl, in_size, 0, nullptr).packed_floats;
 }
 
-// Engine for a batch of B rows: the fewest rows per workgroup that still fit the batch into one workgroup per CU.
+// Engine for a batch of B rows: the fewest rows per workgroup that still fit the batch into one workgroup per CU
+// (linna_engine_rows forces one for tests and measurements; LINNA_NS_ROWS in the environment sets the initial value,
+// read ONCE -- the launch path reads an atomic, not the environment).
+static std::atomic<int> g_forced_rows{-1};
+int net_stream_force_rows(int rows) {
+    if (rows != 0 && rows != 4 && rows != 8 && rows != 16) return -1;
+    const int prev = g_forced_rows.exchange(rows);
+    return prev < 0 ? 0 : prev;
+}
 int net_stream_rows(int B) {
-    const char* const env = getenv("LINNA_NS_ROWS");         // tests and measurements: force an engine
-    const int forced = env ? atoi(env) : 0;
-    if (forced == 4 || forced == 8 || forced == 16) return forced;
+    int forced = g_forced_rows.load(std::memory_order_relaxed);
+    if (forced < 0) {
+        const char* const env = getenv("LINNA_NS_ROWS");
+        const int v = env ? atoi(env) : 0;
+        forced = (v == 4 || v == 8 || v == 16) ? v : 0;
+        int expect = -1;
+        g_forced_rows.compare_exchange_strong(expect, forced);
+        forced = g_forced_rows.load(std::memory_order_relaxed);
+    }
+    if (forced) return forced;
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
@@ -1349,7 +1368,13 @@ static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int row
 #endif
     if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s, extra);
     if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s, extra);
-    if (rows == 16) return ns_launch_rows<MOVE, GRAD, STORE, 16>(a, B, lds, s, extra);
+    if constexpr (STORE == 1 && !GRAD) {
+        // no 16-row instantiation of the training / validation forward: it is the one kernel hipcc (ROCm 7.2) copies the
+        // 2 KB argument block to scratch for (234 VGPRs + 2096 bytes of private memory per lane, every argument then read
+        // back through scratch); linna_net_forward runs batches of more than 2048 rows on the 8-row engine
+    } else {
+        if (rows == 16) return ns_launch_rows<MOVE, GRAD, STORE, 16>(a, B, lds, s, extra);
+    }
     set_error("net_stream: %d rows per workgroup", rows);
     return LINNA_ERR_INVALID;
 }

@@ -861,7 +861,12 @@ class Appender(object):
         self._insert(st, level + 1, key, new["addr"], final)
 
     def append(self, blocks):
+        """Order on disk: chunk DATA first (buffered small writes flushed, bulk pieces by parallel ``pwrite``), then the
+        B-tree entries that point at it, then the datasets' new lengths -- a reader (or a run killed) in between sees the
+        state before the append and never an index entry over partly written data; space allocated for data that was
+        never indexed lies past the recorded end of file (offset 40 is rewritten last) and is reused on resume."""
         n = None
+        pending = []                                                # (dataset state, first row of the chunk, its address, key boundary)
         for name, a in blocks.items():
             st = self.ds[name]
             a = np.ascontiguousarray(a, dtype=st["dtype"])
@@ -885,13 +890,16 @@ class Appender(object):
                     self.fh.seek(addr + part.nbytes); self.fh.write(b"\x00" * (st["chunk_bytes"] - part.nbytes))
                 row = st["nrows"]
                 st["nrows"] += len(part)
-                final = (row // st["chunk_rows"] + 1) * st["chunk_rows"]
-                if not st["path"]:                                  # first chunk: the root leaf
-                    node = dict(addr=self._alloc(self._node_bytes(st)), level=0, keys=[], children=[], final=final, left=UNDEF, right=UNDEF)
-                    st["path"].append(node)
-                    self.fh.seek(st["btree_off"]); self.fh.write(struct.pack("<Q", node["addr"]))
-                self._insert(st, 0, (st["chunk_bytes"], row), addr, final)
+                pending.append((st, row, addr, (row // st["chunk_rows"] + 1) * st["chunk_rows"]))
+        self.fh.flush()
         self._run_bulk()                                            # chunk data is in the file before anything points at it
+        for st, row, addr, final in pending:
+            if not st["path"]:                                      # first chunk: the root leaf
+                node = dict(addr=self._alloc(self._node_bytes(st)), level=0, keys=[], children=[], final=final, left=UNDEF, right=UNDEF)
+                st["path"].append(node)
+                self.fh.seek(st["btree_off"]); self.fh.write(struct.pack("<Q", node["addr"]))
+            self._insert(st, 0, (st["chunk_bytes"], row), addr, final)
+        self.fh.flush()
         for name in blocks:                                         # the new length becomes visible last
             st = self.ds[name]
             self.fh.seek(st["dims_off"]); self.fh.write(struct.pack("<Q", st["nrows"]))

@@ -41,10 +41,76 @@ def _numpy_scalar_globals():
     return out
 
 
+def _numpy_module_names():
+    """(name in files of the OTHER numpy generation, name this numpy resolves): numpy 2 moved ``numpy.core`` to
+    ``numpy._core``; a checkpoint written under numpy 1.x names ``numpy.core.multiarray.scalar`` and torch matches
+    allowed globals by that text."""
+    import numpy as np
+    return (b"numpy.core.", b"numpy._core.") if getattr(np, "_core", None) is not None else (b"numpy._core.", b"numpy.core.")
+
+
+def _rename_numpy_globals(pkl):
+    """One pickle stream with the module text of its numpy globals renamed (GLOBAL opcodes and the string pushes a
+    STACK_GLOBAL consumes); everything else byte for byte.  Nothing is unpickled: ``pickletools.genops`` only walks the
+    opcodes.  Returns (new bytes, number of bytes of ``pkl`` the stream occupied)."""
+    import io
+    import pickletools
+    import struct
+    old, new = _numpy_module_names()
+    ops = list(pickletools.genops(io.BytesIO(pkl)))
+    end = ops[-1][2] + 1                                    # STOP is one byte
+    out, last = [], 0
+    for k, (op, arg, pos) in enumerate(ops):
+        nxt = ops[k + 1][2] if k + 1 < len(ops) else end
+        if op.name == "GLOBAL" and arg.encode().startswith(old):
+            mod, name = arg.split(" ", 1)
+            repl = b"c" + new + mod.encode()[len(old):] + b"\n" + name.encode() + b"\n"
+        elif op.name in ("SHORT_BINUNICODE", "BINUNICODE") and isinstance(arg, str) and arg.encode().startswith(old):
+            txt = new + arg.encode()[len(old):]
+            repl = (b"\x8c" + bytes([len(txt)])) if (op.name == "SHORT_BINUNICODE" and len(txt) < 256) else (b"X" + struct.pack("<I", len(txt)))
+            repl += txt
+        else:
+            continue
+        out.append(pkl[last:pos]); out.append(repl)
+        last = nxt
+    out.append(pkl[last:end])
+    return b"".join(out), end
+
+
+def _renamed_copy(path):
+    """The checkpoint file as an in-memory copy whose pickled numpy globals carry this numpy's module names: the
+    ``data.pkl`` record of a zip checkpoint, or the leading pickles of a legacy stream."""
+    import io
+    import zipfile
+    if zipfile.is_zipfile(path):
+        buf = io.BytesIO()
+        with zipfile.ZipFile(path) as zin, zipfile.ZipFile(buf, "w", zipfile.ZIP_STORED) as zout:
+            for info in zin.infolist():
+                raw = zin.read(info.filename)
+                if info.filename.endswith("/data.pkl") or info.filename == "data.pkl":
+                    raw = _rename_numpy_globals(raw)[0]
+                zout.writestr(info.filename, raw)
+        buf.seek(0)
+        return buf
+    with open(path, "rb") as f:
+        raw = f.read()
+    out, pos = [], 0
+    for _ in range(5):                  # magic number, protocol version, sys info, the object, the storage keys
+        if pos >= len(raw):
+            break
+        new, used = _rename_numpy_globals(raw[pos:])
+        out.append(new)
+        pos += used
+    out.append(raw[pos:])
+    return io.BytesIO(b"".join(out))
+
+
 def read_checkpoint(path, device=None):
     """A checkpoint file is only ever read with ``weights_only=True`` (tensors, containers, plain numbers --
-    nothing in the file is executed); files whose ``optim_dict`` holds numpy scalars get exactly those
-    reconstructors allowed, and a file that still does not load is refused."""
+    nothing in the file is executed); files whose ``optim_dict`` holds numpy scalars (the reference's ``lr`` comes from
+    ``np.load(lr.npy) * size``) get exactly those reconstructors allowed -- under the module name this numpy
+    uses AND, for files written under the other numpy generation (``numpy.core`` vs ``numpy._core``), after renaming the
+    module text in the pickle stream of an in-memory copy; a file that still does not load is refused."""
     if not os.path.exists(path):
         raise FileNotFoundError("File doesn't exist {}".format(path))
     where = device if device is not None else "cpu"
@@ -52,7 +118,10 @@ def read_checkpoint(path, device=None):
         return torch.load(path, map_location=where, weights_only=True)
     except Exception:
         with torch.serialization.safe_globals(_numpy_scalar_globals()):
-            return torch.load(path, map_location=where, weights_only=True)
+            try:
+                return torch.load(path, map_location=where, weights_only=True)
+            except Exception:
+                return torch.load(_renamed_copy(path), map_location=where, weights_only=True)
 
 
 def load_checkpoint(checkpoint, model, optimizer=None, device=None, ismpi=False):

@@ -208,6 +208,8 @@ class ChainStore(object):
     the same way, so a run directory started there resumes here."""
 
     GZIP_LIMIT = 64 << 20           # zeus layout: gzip chunks like the reference below this many bytes per dataset
+    MAX_QUEUED = 8                  # device blocks waiting for the writer: a disk slower than the sampler stalls the sampler
+                                    # (put blocks) instead of piling chain blocks up in HBM (108 MB each at 4096 walkers)
 
     def __init__(self, filename, transform=None, write_txt=False):
         self.base = filename[:-3] if filename.endswith(".h5") else filename
@@ -231,7 +233,7 @@ class ChainStore(object):
     def _enqueue(self, path, arrays):
         import queue, threading
         if self._writer is None:
-            self._queue, self._wqueue = queue.Queue(), queue.Queue(maxsize=8)
+            self._queue, self._wqueue = queue.Queue(maxsize=self.MAX_QUEUED), queue.Queue(maxsize=8)
 
             def fetch():
                 while True:

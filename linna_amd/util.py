@@ -169,6 +169,10 @@ class X_transform_class(_Picklable):
     """x -> (x - mean)/std, log10 first on ``dolog10index`` columns (util.py:466-497)."""
 
     def __init__(self, X_mean, X_std, device="cpu", dolog10index=None):
+        # the reference documents dolog10index as an "int array": kept as a plain list of ints, so that X_transform.pkl
+        # holds nothing but builtins, tensors and this class (what CPU_Unpickler reads back; the reference iterates it)
+        if dolog10index is not None:
+            dolog10index = [int(i) for i in np.asarray(dolog10index).reshape(-1)]
         self.X_mean, self.X_std, self.dev, self.dolog10index = X_mean, X_std, device, dolog10index
 
     def __call__(self, X):
@@ -235,6 +239,13 @@ class CPU_Unpickler(pickle.Unpickler):
             return OrderedDict
         if module in ("linna.util", "linna_amd.util") and name in _REFERENCE_CLASSES:
             return globals()[name]
+        # data-only numpy reconstructors (a transform pickle the REFERENCE wrote keeps dolog10index / sigma as the numpy
+        # arrays it was given), under either numpy generation's module name -- the same four ArgsUnpickler allows
+        core = getattr(np, "_core", None) or np.core
+        if module in ("numpy.core.multiarray", "numpy._core.multiarray") and name in ("_reconstruct", "scalar"):
+            return getattr(core.multiarray, name)
+        if module == "numpy" and name in ("ndarray", "dtype"):
+            return getattr(np, name)
         raise pickle.UnpicklingError("refusing to load global %s.%s from a transform pickle" % (module, name))
 
 
@@ -769,17 +780,33 @@ class NN_samplerv1(object):
                            tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
 
 
-def chi2_rows(d, invcov, device=None, chunk=32768):
+def chi2_rows(d, invcov, device=None, chunk=8192):
+    """``d_i^T invcov d_i`` for every row of ``d[n, nout]`` in FLOAT64 on the host, as the reference computes the two
+    quantities this feeds (``logp_theory_data``, util.py:1506-1517: the importance weights of main.py:297-334;
+    ``chisqcut_all``, util.py:1260-1270).  Real inverse covariances are ill-conditioned and the fp32 error of a
+    quadratic form grows with the condition number, which would bias ``w = exp(logp - lp)`` directly; these are one-off
+    post steps of n x nout^2 work, so nothing is gained by the GPU here (``chi2_rows_gpu`` is the fp32 device form)."""
+    d = np.ascontiguousarray(np.atleast_2d(np.asarray(d, np.float64)))
+    S = np.asarray(invcov, np.float64)
+    out = np.empty(len(d))
+    for lo in range(0, len(d), chunk):
+        blk = d[lo:lo + chunk]
+        out[lo:lo + len(blk)] = np.einsum("bi,bi->b", blk @ S, blk)
+    return out
+
+
+def chi2_rows_gpu(d, invcov, device=None, chunk=32768):
     """``d_i^T invcov d_i`` for every row of ``d[n, nout]`` on the GPU: the dense log-likelihood entry
     (``linna_gauss_loglike_dense``: MFMA GEMM d.S fused with the row-dot) with T = 1 and no prior term returns
-    -chi2/2.  fp32 arithmetic on rows handed over in float32; returns float64 [n]."""
+    -chi2/2.  fp32 arithmetic on rows handed over in float32; returns float64 [n].  Well-conditioned problems only
+    (relative error ~ 1e-6 x the condition number): the walker loop's own quantity, not the importance weights'."""
     d = np.ascontiguousarray(np.atleast_2d(np.asarray(d, np.float64)))
     n, nout = d.shape
     if n == 0:
         return np.zeros(0)
     dev = torch.device(device if device is not None else "cuda")
     if dev.type != "cuda" or not torch.cuda.is_available():
-        raise _lib.LinnaHipError("chi2_rows runs on the GPU (no CPU fallback)")
+        raise _lib.LinnaHipError("chi2_rows_gpu runs on the GPU (no CPU fallback)")
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
     ld = _lib.ld4(nout)
@@ -801,7 +828,7 @@ def chi2_rows(d, invcov, device=None, chunk=32768):
 
 def chisqcut_all(data, invcov, chisqcut, fnamey, fnamex):
     """util.py:1260-1270: drop the training rows whose ``y^T invcov y`` reaches ``chisqcut`` (the reference measures
-    the theory vector itself here, not its distance to ``data``; kept as is).  The quadratic forms run on the GPU."""
+    the theory vector itself here, not its distance to ``data``; kept as is).  Float64 on the host, as the reference."""
     y, x = np.load(fnamey), np.loadtxt(fnamex)
     chisq = chi2_rows(y, invcov)
     np.save(fnamey, y[chisq < chisqcut])
@@ -857,7 +884,7 @@ class LogPrior(object):
 
 def logp_theory_data(samples, theory, data, invcov, logprior):
     """util.py:1506-1517: ``-chi2/2 + logprior`` of the importance-sampling post step (main.py:297-334), the
-    ``(t - data)^T invcov (t - data)`` of all rows in one pass of the dense log-likelihood kernel."""
+    ``(t - data)^T invcov (t - data)`` of all rows in float64 (``chi2_rows``)."""
     theory = np.asarray(theory, np.float64)
     data = np.asarray(data, np.float64)
     d = theory[:, :len(data)] - data[None, :]

@@ -150,7 +150,7 @@ def test_pool_gauss_priors_importance_step_and_chisqcut(tmp_path):
     np.testing.assert_array_equal(chain, chain2)
 
 
-def test_chisqcut_cuts_rows_on_the_device(tmp_path):
+def test_chisqcut_cuts_rows(tmp_path):
     from linna_amd import util
     rs = np.random.RandomState(2)
     for nout in (3, 33, 457):
@@ -159,7 +159,8 @@ def test_chisqcut_cuts_rows_on_the_device(tmp_path):
         y = rs.standard_normal((700, nout)) * rs.uniform(0.2, 3.0, size=(700, 1))
         x = rs.standard_normal((700, 4))
         ref = np.einsum("bi,ij,bj->b", y, S, y)
-        np.testing.assert_allclose(util.chi2_rows(y, S), ref, rtol=5e-5)
+        np.testing.assert_allclose(util.chi2_rows_gpu(y, S), ref, rtol=5e-5)        # fp32 on the dense log-likelihood kernel
+        np.testing.assert_allclose(util.chi2_rows(y, S), ref, rtol=1e-12)          # what the post steps use: float64, host
         fy, fx = str(tmp_path / "y.npy"), str(tmp_path / "x.txt")
         np.save(fy, y); np.savetxt(fx, x)
         cut = float(np.median(ref))
@@ -169,12 +170,12 @@ def test_chisqcut_cuts_rows_on_the_device(tmp_path):
         got = np.load(fy)
         assert abs(len(got) - keep.sum()) <= (~margin).sum()
         assert np.loadtxt(fx).shape[0] == len(got)
-    assert util.chi2_rows(np.zeros((0, 5)), np.eye(5)).shape == (0,)
+    assert util.chi2_rows(np.zeros((0, 5)), np.eye(5)).shape == (0,) and util.chi2_rows_gpu(np.zeros((0, 5)), np.eye(5)).shape == (0,)
 
 
 def test_importance_helpers_match_the_live_reference(tmp_path):
-    """``logp_theory_data`` (util.py:1506-1517) and ``chisqcut_all`` (:1260-1270), whose quadratic forms run on the dense
-    log-likelihood kernel here, against the LIVE reference's numbers on the same inputs
+    """``logp_theory_data`` (util.py:1506-1517) and ``chisqcut_all`` (:1260-1270) (float64 quadratic forms on the host, as
+    the reference's) against the LIVE reference's numbers on the same inputs
     (tests/golden/importance_helpers.npz): -chi2/2 + log prior of every sample (theory rows longer than the data vector
     cut as the reference cuts them; -inf outside a flat prior), and the rows a chi^2 cut keeps."""
     import cases

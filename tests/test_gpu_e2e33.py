@@ -27,8 +27,8 @@ pytestmark = pytest.mark.gpu
 
 # Tolerances of the inference-level checks (fp32 emulator trained for 600 epochs per iteration, 4096 walkers):
 CORR_TOL = 0.05           # max |corr - I|: Monte-Carlo error of a correlation at ~16 k independent samples is 0.008, x 4 for the largest of 528
-LNP_MEDIAN_TOL = 0.5      # |median(stored lnP - exact lnP)| at the returned samples (chi^2 of 33 terms: emulator error of a few 0.01 sigma per output)
-LNP_P99_TOL = 2.0         # 99th percentile of |stored lnP - exact lnP|
+LNP_MEDIAN_TOL = 0.1      # |median(stored lnP - exact lnP)| at the returned samples (chi^2 of 33 terms: emulator error of a few 0.01 sigma per output)
+LNP_P99_TOL = 0.6         # 99th percentile of |stored lnP - exact lnP| (measured: median -0.004, p99 0.16)
 
 
 def _write_iteration0(tmp):

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import cases
+from linna_amd import _lib
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -364,15 +365,15 @@ def test_whole_network_kernels_against_oracle(nin, nout, width, depth, which, mo
         monkeypatch.delenv("LINNA_DISABLE_FUSED_GRAD")
         for rows in (None, 4, 8, 16):
             if rows is None:
-                monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+                _lib.engine_rows(0)
             else:
-                monkeypatch.setenv("LINNA_NS_ROWS", str(rows))
+                _lib.engine_rows(int(rows))
             theta = torch.empty_like(zd)
             got = lp.evaluate(zd, theta=theta).cpu().numpy()
             np.testing.assert_allclose(got, ref, rtol=5e-4, atol=1e-3, err_msg="rows %s B %d" % (rows, B))
             np.testing.assert_allclose(got, layered, rtol=2e-4, atol=1e-3, err_msg="rows %s B %d" % (rows, B))
             np.testing.assert_allclose(theta.cpu().numpy(), likelihood.prior_map(z, prob["priors"]), rtol=1e-5, atol=1e-5)
-        monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+        _lib.engine_rows(0)
 
 
 def test_stream_kernel_follows_weight_updates():
@@ -434,9 +435,9 @@ def test_fused_gradient_against_layered_path_and_oracle(nin, nout, width, depth,
     emu = cases.oracle_emulator(prob)
     for B, rows in ((1, None), (17, None), (1000, None), (1000, 8), (300, 16), (4100, 4)):
         if rows is None:
-            monkeypatch.delenv("LINNA_NS_ROWS", raising=False)     # the engine the batch size selects
+            _lib.engine_rows(0)     # the engine the batch size selects
         else:
-            monkeypatch.setenv("LINNA_NS_ROWS", str(rows))
+            _lib.engine_rows(int(rows))
         z = (0.6 * np.random.RandomState(B).standard_normal((B, nin))).astype(np.float32)
         zd = torch.as_tensor(z, device="cuda")
         lf, gf = fused.evaluate_with_grad(zd)
@@ -448,7 +449,7 @@ def test_fused_gradient_against_layered_path_and_oracle(nin, nout, width, depth,
         _, gref = likelihood.grad_log_prob(z.astype(np.float64), emu, prob["priors"], prob["data"], prob["invcov"], 2.0,
                                            dtype=np.float64)
         np.testing.assert_allclose(gf, gref, rtol=5e-3, atol=5e-4 * scale)
-    monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+    _lib.engine_rows(0)
     # the two objects really took different routes (meaningful on the big shape only; best of several
     # short runs: a stray hipFree from garbage collection in the middle of a run costs milliseconds)
     if width == 512 and depth == 4:
@@ -566,15 +567,15 @@ def test_dense_covariance_as_last_segment(nin, nout, width, depth, monkeypatch):
         np.testing.assert_allclose(base, ref, rtol=6e-4)
         for rows in (None, 4, 8, 16):
             if rows is None:
-                monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+                _lib.engine_rows(0)
             else:
-                monkeypatch.setenv("LINNA_NS_ROWS", str(rows))
+                _lib.engine_rows(int(rows))
             theta = torch.empty_like(zd)
             got = fused.evaluate(zd, theta=theta).cpu().numpy()
             np.testing.assert_allclose(got, ref, rtol=6e-4, err_msg="rows %s B %d" % (rows, B))
             np.testing.assert_allclose(got, base, rtol=3e-4, err_msg="rows %s B %d" % (rows, B))
             np.testing.assert_allclose(theta.cpu().numpy(), likelihood.prior_map(z, prob["priors"]), rtol=1e-5, atol=1e-5)
-    monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+    _lib.engine_rows(0)
     # one-launch half step on the dense problem, bit-identical to propose / evaluate / accept
     nw = 70
     x0 = (0.3 * np.random.RandomState(5).standard_normal((nw, nin))).astype(np.float32)

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import cases
+from linna_amd import _lib
 import synth
 
 pytestmark = pytest.mark.gpu
@@ -379,9 +380,9 @@ def test_one_launch_dx_chain_equals_gemm_chain(kind, nin, nout, kw, monkeypatch)
     monkeypatch.delenv("LINNA_BWD_STREAM")
     for rows in (None, "4", "8", "16"):
         if rows is None:
-            monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+            _lib.engine_rows(0)
         else:
-            monkeypatch.setenv("LINNA_NS_ROWS", rows)
+            _lib.engine_rows(int(rows))
         for need_dx in (True, False):
             fused.flat_grads().zero_()
             fused.forward(x)
@@ -393,6 +394,6 @@ def test_one_launch_dx_chain_equals_gemm_chain(kind, nin, nout, kw, monkeypatch)
                 ref = g_ref[k].cpu().numpy()
                 np.testing.assert_allclose(gk.cpu().numpy(), ref, rtol=2e-3, atol=2e-5 * np.abs(ref).max() + 1e-9,
                                            err_msg="%s rows %s" % (k, rows))
-    monkeypatch.delenv("LINNA_NS_ROWS", raising=False)
+    _lib.engine_rows(0)
     # the two objects took different routes: the fused one holds a weight stream for the dX chain
     assert fused.uses_dx_stream() and not chain.uses_dx_stream()

@@ -244,6 +244,84 @@ def test_artefact_readers_execute_nothing(tmp_path):
     with open(bad, "rb") as f:
         back = util.CPU_Unpickler(f).load()
     assert back.dolog10index == [0, 2] and torch.equal(back.X_std, torch.ones(3))
+    # the reference documents dolog10index as an "int array" (train_NN forwards it as given): a numpy array round-trips too
+    xt = util.X_transform_class(torch.zeros(3), torch.ones(3), "cpu", np.array([0, 2]))
+    xt.pickle(bad)
+    with open(bad, "rb") as f:
+        back = util.CPU_Unpickler(f).load()
+    assert back.dolog10index == [0, 2] and all(type(i) is int for i in back.dolog10index)
+    # ... and a transform pickle that does hold numpy arrays (one the reference wrote from such arguments) is data, not code
+    xt.dolog10index = np.array([0, 2])
+    xt.pickle(bad)
+    with open(bad, "rb") as f:
+        back = util.CPU_Unpickler(f).load()
+    np.testing.assert_array_equal(back.dolog10index, [0, 2])
+    x = torch.tensor([[10.0, 1.0, 100.0]])
+    np.testing.assert_allclose(back(x).numpy(), [[1.0, 1.0, 2.0]])
+
+
+def test_checkpoint_written_under_the_other_numpy_generation_loads(tmp_path):
+    """The reference's ``optim_dict`` holds ``lr`` as a numpy scalar (``np.load(lr.npy) * size``); a file written under
+    numpy 1.x names ``numpy.core.multiarray.scalar``, one written under numpy 2 ``numpy._core...`` -- torch matches
+    allowed globals by that text.  Both load (weights_only=True throughout), zip and legacy stream formats."""
+    import io
+    import zipfile
+    from linna_amd import nnutils
+    old, new = nnutils._numpy_module_names()
+    state = {"epoch": 3, "state_dict": {"w": torch.arange(6.0).reshape(2, 3)},
+             "optim_dict": {"param_groups": [{"lr": np.float64(1e-3) * 2, "weight_decay": np.float32(1e-4)}]}}
+    for legacy in (False, True):
+        p = os.path.join(str(tmp_path), "ck%d.pth.tar" % legacy)
+        torch.save(state, p, _use_new_zipfile_serialization=not legacy)
+        if legacy:
+            raw = open(p, "rb").read()
+            assert new + b"multiarray" in raw
+            open(p, "wb").write(raw.replace(new, old))
+        else:
+            buf = io.BytesIO()
+            with zipfile.ZipFile(p) as zin, zipfile.ZipFile(buf, "w") as zout:
+                for info in zin.infolist():
+                    raw = zin.read(info.filename)
+                    if info.filename.endswith("data.pkl"):
+                        assert new + b"multiarray" in raw
+                        raw = raw.replace(new, old)
+                    zout.writestr(info.filename, raw)
+            open(p, "wb").write(buf.getvalue())
+        with torch.serialization.safe_globals(nnutils._numpy_scalar_globals()), pytest.raises(Exception):
+            torch.load(p, weights_only=True)                          # (the other generation's name is not on torch's list)
+        ck = nnutils.read_checkpoint(p)
+        assert float(ck["optim_dict"]["param_groups"][0]["lr"]) == 2e-3 and torch.equal(ck["state_dict"]["w"], state["state_dict"]["w"])
+    # a pickle that names anything else is still refused after the rename
+    class Evil(object):
+        def __reduce__(self):
+            return (os.system, ("true",))
+    p = os.path.join(str(tmp_path), "evil.pth.tar")
+    torch.save({"epoch": 1, "state_dict": {}, "optim_dict": Evil()}, p)
+    with pytest.raises(Exception):
+        nnutils.read_checkpoint(p)
+
+
+def test_quadratic_forms_of_the_post_steps_are_float64():
+    """``logp_theory_data`` / ``chisqcut_all`` (util.py:1506-1517, 1260-1270) feed the importance weights
+    ``w = exp(logp - lp)``: float64 on the host as in the reference.  With an inverse covariance of condition number
+    1e10 the fp32 error of d^T S d would be percent-level; the float64 value is reproduced to 1e-10."""
+    from linna_amd import util
+    rs = np.random.RandomState(4)
+    nout, n = 120, 500
+    q, _ = np.linalg.qr(rs.standard_normal((nout, nout)))
+    S = (q * np.logspace(0, 10, nout)[None, :]) @ q.T
+    S = 0.5 * (S + S.T)
+    assert np.linalg.cond(S) > 1e8
+    th = rs.standard_normal((n, nout + 3))                            # theory rows longer than the data vector are cut
+    data = rs.standard_normal(nout)
+    d = th[:, :nout] - data
+    ref = np.array([di @ S @ di for di in d])
+    np.testing.assert_allclose(util.chi2_rows(d, S), ref, rtol=1e-10)
+    lp = util.logp_theory_data(np.zeros((n, 2)), th, data, S, lambda s: 0.0)
+    np.testing.assert_allclose(lp, -0.5 * ref, rtol=1e-10)
+    d32 = d.astype(np.float32)
+    fp32 = np.einsum("bi,ij,bj->b", d32, S.astype(np.float32), d32)
+    assert np.max(np.abs(fp32 - ref) / ref) > 1e-6                    # (what the fp32 form would have cost)
 
 
 def _npy(tmp_path, v):

@@ -10,7 +10,7 @@ import numpy as np, torch
 import cases
 from test_gpu_serving import build_logprob, _custom_problem
 from oracle import likelihood
-from linna_amd import nn
+from linna_amd import nn, _lib
 
 def run(ncfg, seed0):
     """Returns the number of failing configurations."""
@@ -29,9 +29,9 @@ def run(ncfg, seed0):
             nout = int(rs.choice([1, 2, 3, 5, 8, 10, 16, 25, 30, 31, 33, 64, 100, 457]))
         tag = "cfg %d: %s nin %d nout %d width %d depth %d dense %d B %d rows %s" % (seed0 + it, kind, nin, nout, width, depth, dense, B, rows or "auto")
         if rows:
-            os.environ["LINNA_NS_ROWS"] = rows
+            _lib.engine_rows(int(rows))
         else:
-            os.environ.pop("LINNA_NS_ROWS", None)
+            _lib.engine_rows(0)
         try:
             prob = _custom_problem(nin, nout, 7000 + seed0 + it, width, depth, dense=dense)
             if kind != "MLP":

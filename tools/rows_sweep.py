@@ -8,6 +8,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 from bench_paths import problem, timeit
+from linna_amd import _lib
 
 out = {}
 for kind, kw in (("MLP", dict(width=512, depth=4)), ("ChtoModelv2", {})):
@@ -18,9 +19,9 @@ for kind, kw in (("MLP", dict(width=512, depth=4)), ("ChtoModelv2", {})):
         row = {}
         for rows in ("16", "8", "4", ""):
             if rows:
-                os.environ["LINNA_NS_ROWS"] = rows
+                _lib.engine_rows(int(rows))
             else:
-                os.environ.pop("LINNA_NS_ROWS", None)
+                _lib.engine_rows(0)
             row["eval_" + (rows or "auto")] = round(timeit(lambda: lp.evaluate(z, out=o), 300) * 1e6, 1)
             if kind == "MLP":
                 row["grad_" + (rows or "auto")] = round(timeit(lambda: lp.evaluate_with_grad(z, out=o, grad=g), 200) * 1e6, 1)
@@ -32,9 +33,9 @@ for kind, kw in (("MLP", dict(width=512, depth=4)), ("ChtoModelv2", {})):
         row = {}
         for rows in ("16", "8", "4", ""):
             if rows:
-                os.environ["LINNA_NS_ROWS"] = rows
+                _lib.engine_rows(int(rows))
             else:
-                os.environ.pop("LINNA_NS_ROWS", None)
+                _lib.engine_rows(0)
             row["fwd500_" + (rows or "auto")] = round(timeit(lambda: m.forward(x), 300) * 1e6, 1)
         out["ChtoModelv2 training forward B=500"] = row
         print("train fwd", row, flush=True)
