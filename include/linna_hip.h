@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows */
+#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -431,6 +431,24 @@ int linna_slice_shrink(linna_ctx_t* ctx, const float* Z0, const float* Ztrial, f
                        void* stream);
 int linna_slice_commit(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                        const float* DIR, int ldd, const float* Wacc, const float* Zacc, void* stream);
+/* One half step of the ensemble slice sampler in ONE call (replaces the round-by-round use of the six entries above for
+ * log-probabilities the whole-network kernel serves; LINNA_ERR_UNSUPPORTED otherwise): directions + slice heights
+ * (linna_slice_init's arithmetic and Philox counters: stream `half`), `nexp_rounds` stepping-out rounds that each evaluate
+ * the `m` bracket ends per side the sequential loop `while lnP(L) > Z0: L -= 1` would visit next, `nshr_rounds` shrinking
+ * rounds of `ntrial` trials each placed as if its predecessors were rejected (linna_slice_draw's rule, stream 2 + half,
+ * sub-counter round * ntrial + j + 1), and the commit: 2 + 2 (nexp_rounds + nshr_rounds) launches on `stream`, no host
+ * synchronisation.  The accepted points are those of the one-point-per-round procedure; rounds behind the one that
+ * finished the last walker leave at once on a device-side count.
+ *   state[5 ns]  : Z0 | L | R | Wacc | Zacc;  flags[3 ns];  W[2 m ns], Wd[ntrial ns], Zt[max(2 m, ntrial) ns]: scratch
+ *   counters[4 + nexp_rounds + nshr_rounds]: [0] expansions, [1] contractions (zeroed first when zero_totals),
+ *       [2] walkers the rounds of a call left unfinished -- they keep their position; the caller treats a non-zero
+ *       count as zeus treats its `maxsteps` (an error) -- [3] evaluated points (both cumulative), [4 + r] scratch.
+ * zeus' EnsembleSampler behind sampler.py:728-735. */
+int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
+                          const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
+                          const int* step_dev, int half, int m, int nexp_rounds, int ntrial, int nshr_rounds, float* DIR,
+                          int ldd, float* state, int* flags, float* W, float* Wd, float* Zt, int* counters, int zero_totals,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -972,6 +972,47 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
                              d.outmap.cexp ? d.outmap.cshift2 : nullptr);
 }
 
+// One half step of the ensemble slice sampler (zeus behind sampler.py:728-735) in ONE call: the differential-move directions
+// and slice heights, `nexp_rounds` speculative stepping-out rounds of `m` bracket ends per side, `nshr_rounds` shrinking
+// rounds of `ntrial` trials, the commit -- 2 + 2 (nexp_rounds + nshr_rounds) launches, none of which the host waits for.
+// Every evaluation is the whole-network kernel with the trial points formed in its prologue (never written to memory);
+// rounds behind the one that finished the last walker are gated off on the device.
+int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
+                          const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
+                          const int* step_dev, int half, int m, int nexp_rounds, int ntrial, int nshr_rounds, float* DIR, int ldd,
+                          float* state, int* flags, float* W, float* Wd, float* Zt, int* counters, int zero_totals, void* stream) {
+    if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !mu || !step_dev || !DIR || !state || !flags || !W || !Wd ||
+        !Zt || !counters || ns < 1 || nc < 2 || m < 1 || ntrial < 1 || nexp_rounds < 1 || nshr_rounds < 1 || (half != 0 && half != 1)) {
+        set_error("slice_half_step: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    const linna_logprob_desc_t& d = lp->d;
+    if (ndim != d.nin) { set_error("slice_half_step: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
+    if (!fused_enabled() || !lp->packed.ready() || (d.outmap.cexp && (!d.w || !d.outmap.cpost || !d.outmap.cshift2)) ||
+        (!d.w && !lp->dense_fused) || d.nin > 64) {
+        set_error("slice_half_step: this log-probability does not run the whole-network kernel");
+        return LINNA_ERR_UNSUPPORTED;          // the caller falls back to the round-by-round entries
+    }
+    float* const Z0 = state; float* const L = state + ns; float* const R = state + 2 * ns;
+    float* const Wacc = state + 3 * ns; float* const Zacc = state + 4 * ns;
+    hipStream_t st = S(stream);
+    TRY(launch_slice_begin(logp, S_idx, ns, ccoords, ldcc, C_idx, nc, ndim, mu, seed, step_dev, half, DIR, ldd, Z0, L, R, flags, W, m,
+                           counters, nexp_rounds + nshr_rounds, zero_totals, st));
+    int slot = 4;
+    for (int r = 0; r < nexp_rounds; ++r, ++slot) {
+        const int* gate = r > 0 ? counters + slot - 1 : nullptr;
+        TRY(linna_logprob_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, W, 2 * m, Zt, gate, stream));
+        TRY(launch_slice_expand_multi(Z0, Zt, L, R, S_idx, flags, ns, m, counters, slot, r > 0 ? slot - 1 : -1, W, Wd, seed, step_dev,
+                                      2 + half, ntrial, st));
+    }
+    for (int r = 0; r < nshr_rounds; ++r, ++slot) {
+        const int* gate = r > 0 ? counters + slot - 1 : nullptr;
+        TRY(linna_logprob_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, ntrial, Zt, gate, stream));
+        TRY(launch_slice_shrink_multi(Z0, Zt, L, R, S_idx, Wd, flags, Wacc, Zacc, ns, counters, slot, r > 0 ? slot - 1 : -1, ntrial, r,
+                                      seed, step_dev, 2 + half, st));
+    }
+    return launch_slice_commit_checked(coords, ldc, ndim, logp, S_idx, ns, DIR, ldd, Wacc, Zacc, flags, counters, st);
+}
+
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                             const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
                             int step_offset, int stream_id, float a, int* naccept, void* stream) {

@@ -565,6 +565,139 @@ __global__ void slice_commit_kernel(float* __restrict__ coords, int ldc, int ndi
     }
 }
 
+// ---- one-call half step (linna_slice_half_step): the same procedure with SPECULATIVE rounds, so that a half step is a
+// fixed sequence of launches the host enqueues in one call and never waits for.  Stepping out: a round evaluates the
+// bracket ends the sequential loop would visit next, L, L-1, ..., L-(m-1) and R, R+1, ..., R+(m-1), in ONE launch, and
+// the logic below walks them in the loop's order; shrinking: `ntrial` trials per round, each placed as if its
+// predecessors were rejected (slice_draw_kernel's rule).  Same Philox counters, same comparisons, same accepted point
+// as the one-point-per-round procedure -- only the count of evaluated-and-discarded points differs.  Rounds after the
+// one that finishes the last walker are gated off on the device (the evaluation leaves at once on a zero count, the logic
+// kernels return per walker on its flags).
+// counters: [0] expansions, [1] contractions, [2] walkers left unfinished by the rounds of a call (sticky),
+//           [3] evaluated points, [4 + r] walkers still active after round r (expand rounds first, then shrink rounds)
+__device__ __forceinline__ void slice_draw_dev(int k, int wk, float l, float r, float* __restrict__ W, int ns, uint64_t seed,
+                                               uint32_t step, int stream_id, int round, int ntrial) {
+    for (int j = 0; j < ntrial; ++j) {
+        const U4 b = walker_bits(seed, (uint32_t)wk, step, (uint32_t)stream_id, (uint32_t)(round + j + 1));
+        const float w = l + u01(b.x) * (r - l);
+        W[(size_t)j * ns + k] = w;
+        if (w < 0.f) l = w; else r = w;
+    }
+}
+
+__global__ void slice_begin_kernel(const float* __restrict__ logp, const int* __restrict__ S, int ns,
+                                   const float* __restrict__ cc, int ldcc, const int* __restrict__ C, int nc, int ndim,
+                                   const float* __restrict__ mu, uint64_t seed, const int* __restrict__ step_dev,
+                                   int stream_id, float* __restrict__ DIR, int ldd, float* __restrict__ Z0,
+                                   float* __restrict__ L, float* __restrict__ R, int* __restrict__ flags,
+                                   float* __restrict__ W, int m, int* __restrict__ counters, int nslots, int zero_totals) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx == 0) {
+        for (int i = 0; i < nslots; ++i) counters[4 + i] = 0;
+        if (zero_totals) { counters[0] = 0; counters[1] = 0; }
+    }
+    if (idx >= (size_t)ns * ldd) return;
+    const int k = (int)(idx / ldd), d = (int)(idx % ldd);
+    const int wk = S[k];
+    const U4 r = walker_bits(seed, (uint32_t)wk, (uint32_t)step_dev[0], (uint32_t)stream_id, 0u);
+    const int ia = (int)(((uint64_t)r.x * (uint64_t)nc) >> 32);
+    int ib = (int)(((uint64_t)r.y * (uint64_t)(nc - 1)) >> 32);
+    ib += (ib >= ia);
+    if (d < ndim) DIR[idx] = mu[0] * (cc[(size_t)C[ia] * ldcc + d] - cc[(size_t)C[ib] * ldcc + d]);
+    else DIR[idx] = 0.f;
+    if (d == 0) {
+        Z0[k] = logp[wk] + logf(u01(r.z));
+        const float l = -u01(r.w);
+        L[k] = l; R[k] = l + 1.f;
+        flags[3 * k] = 1; flags[3 * k + 1] = 1; flags[3 * k + 2] = 1;
+        for (int j = 0; j < m; ++j) { W[(size_t)j * ns + k] = l - (float)j; W[(size_t)(m + j) * ns + k] = l + 1.f + (float)j; }
+    }
+}
+
+// Zt[j*ns + k]: lnP at L - j (j < m) and at R + (j - m) (m <= j < 2m) of the bracket this round started from
+__global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
+                                          float* __restrict__ R, const int* __restrict__ S, int* __restrict__ flags, int ns,
+                                          int m, int* __restrict__ counters, int slot, int prev_slot, float* __restrict__ W,
+                                          float* __restrict__ Wd, uint64_t seed, const int* __restrict__ step_dev,
+                                          int stream_id_shrink, int ntrial) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && (prev_slot < 0 || counters[prev_slot] > 0)) atomicAdd(counters + 3, 2 * m * ns);   // this round's evaluation ran
+    if (k >= ns || !(flags[3 * k] | flags[3 * k + 1])) return;
+    if (prev_slot >= 0 && counters[prev_slot] == 0) return;       // (never: a walker with a flag set was counted)
+    const float z0 = Z0[k];
+    int n = 0;
+    float l = L[k], r = R[k];
+    if (flags[3 * k]) {
+        int j = 0;
+        for (; j < m; ++j) { if (Zt[(size_t)j * ns + k] > z0) { l -= 1.f; ++n; } else break; }
+        if (j < m) flags[3 * k] = 0;
+    }
+    if (flags[3 * k + 1]) {
+        int j = 0;
+        for (; j < m; ++j) { if (Zt[(size_t)(m + j) * ns + k] > z0) { r += 1.f; ++n; } else break; }
+        if (j < m) flags[3 * k + 1] = 0;
+    }
+    L[k] = l; R[k] = r;
+    if (n) atomicAdd(counters + 0, n);
+    if (flags[3 * k] | flags[3 * k + 1]) {
+        atomicAdd(counters + slot, 1);
+        for (int j = 0; j < m; ++j) { W[(size_t)j * ns + k] = l - (float)j; W[(size_t)(m + j) * ns + k] = r + (float)j; }
+    } else {
+        slice_draw_dev(k, S[k], l, r, Wd, ns, seed, (uint32_t)step_dev[0], stream_id_shrink, 0, ntrial);   // first shrink round's trials
+    }
+}
+
+__global__ void slice_shrink_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
+                                          float* __restrict__ R, const int* __restrict__ S, float* __restrict__ W,
+                                          int* __restrict__ flags, float* __restrict__ Wacc, float* __restrict__ Zacc, int ns,
+                                          int* __restrict__ counters, int slot, int prev_slot, int ntrial, int round,
+                                          uint64_t seed, const int* __restrict__ step_dev, int stream_id) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0 && (prev_slot < 0 || counters[prev_slot] > 0)) atomicAdd(counters + 3, ntrial * ns);
+    if (k >= ns || !flags[3 * k + 2] || (flags[3 * k] | flags[3 * k + 1])) return;   // done, or its bracket never closed
+    if (prev_slot >= 0 && counters[prev_slot] == 0) return;
+    int ncon = 0;
+    bool active = true;
+    float l = L[k], r = R[k];
+    for (int j = 0; j < ntrial && active; ++j) {
+        const float zt = Zt[(size_t)j * ns + k], w = W[(size_t)j * ns + k];
+        if (zt < Z0[k] || isnan(zt)) {
+            if (w < 0.f) l = w; else r = w;
+            ++ncon;
+            if (r - l < 1e-30f) { active = false; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
+        } else {
+            active = false; Wacc[k] = w; Zacc[k] = zt;
+        }
+    }
+    L[k] = l; R[k] = r;
+    if (ncon) atomicAdd(counters + 1, ncon);
+    if (active) {
+        atomicAdd(counters + slot, 1);
+        slice_draw_dev(k, S[k], l, r, W, ns, seed, (uint32_t)step_dev[0], stream_id, (round + 1) * ntrial, ntrial);
+    } else {
+        flags[3 * k + 2] = 0;
+    }
+}
+
+// the move of every finished walker; a walker the rounds of the call left unfinished stays where it is and is counted
+__global__ void slice_commit_checked_kernel(float* __restrict__ coords, int ldc, int ndim, float* __restrict__ logp,
+                                            const int* __restrict__ S, int ns, const float* __restrict__ DIR, int ldd,
+                                            const float* __restrict__ Wacc, const float* __restrict__ Zacc,
+                                            const int* __restrict__ flags, int* __restrict__ counters) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)ns * ndim) return;
+    const int k = (int)(idx / ndim), d = (int)(idx % ndim);
+    if (flags[3 * k] | flags[3 * k + 1] | flags[3 * k + 2]) {
+        if (d == 0) atomicAdd(counters + 2, 1);
+        return;
+    }
+    const int wk = S[k];
+    if (Wacc[k] != 0.f) {
+        coords[(size_t)wk * ldc + d] += Wacc[k] * DIR[(size_t)k * ldd + d];
+        if (d == 0) logp[wk] = Zacc[k];
+    }
+}
+
 // ------------------------------------------------------------------ host-side launchers (namespace-internal)
 #define LAUNCH_CHECK(name) return check_hip(hipGetLastError(), name)
 
@@ -735,6 +868,33 @@ int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, co
     hipLaunchKernelGGL(slice_shrink_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, W, flags, Wacc, Zacc, ns,
                        counters, slot, ntrial);
     LAUNCH_CHECK("slice_shrink");
+}
+int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc, int ldcc, const int* C, int nc, int ndim,
+                       const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0, float* L,
+                       float* R, int* flags, float* W, int m, int* counters, int nslots, int zero_totals, hipStream_t s) {
+    hipLaunchKernelGGL(slice_begin_kernel, grid1d((size_t)ns * ldd, 256), dim3(256), 0, s, logp, S, ns, cc, ldcc, C, nc, ndim, mu,
+                       seed, step_dev, stream_id, DIR, ldd, Z0, L, R, flags, W, m, counters, nslots, zero_totals);
+    LAUNCH_CHECK("slice_begin");
+}
+int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,
+                              int* counters, int slot, int prev_slot, float* W, float* Wd, uint64_t seed, const int* step_dev,
+                              int stream_id_shrink, int ntrial, hipStream_t s) {
+    hipLaunchKernelGGL(slice_expand_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, flags, ns, m, counters, slot,
+                       prev_slot, W, Wd, seed, step_dev, stream_id_shrink, ntrial);
+    LAUNCH_CHECK("slice_expand_multi");
+}
+int launch_slice_shrink_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, float* W, int* flags, float* Wacc,
+                              float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int round, uint64_t seed,
+                              const int* step_dev, int stream_id, hipStream_t s) {
+    hipLaunchKernelGGL(slice_shrink_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, W, flags, Wacc, Zacc, ns,
+                       counters, slot, prev_slot, ntrial, round, seed, step_dev, stream_id);
+    LAUNCH_CHECK("slice_shrink_multi");
+}
+int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
+                                const float* Wacc, const float* Zacc, const int* flags, int* counters, hipStream_t s) {
+    hipLaunchKernelGGL(slice_commit_checked_kernel, grid1d((size_t)ns * ndim, 256), dim3(256), 0, s, coords, ldc, ndim, logp, S, ns,
+                       DIR, ldd, Wacc, Zacc, flags, counters);
+    LAUNCH_CHECK("slice_commit_checked");
 }
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
                         const float* Wacc, const float* Zacc, hipStream_t s) {

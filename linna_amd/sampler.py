@@ -774,8 +774,11 @@ class SliceEnsembleSampler(EnsembleSampler):
     checked statistically.
     """
 
+    FAST_EXPANSIONS = 12            # per side and half step on the one-call path (a tuned mu needs about one)
+    FAST_TRIALS = 32                # shrinking trials per walker and half step on the one-call path (each halves the bracket)
+
     def __init__(self, nwalkers, ndim, log_prob, mu=1.0, seed=0, tune=True, tolerance=0.05, patience=5, maxsteps=10000,
-                 maxiter=100000, dist_group=None, exchange="none"):
+                 maxiter=100000, dist_group=None, exchange="none", fast=None):
         EnsembleSampler.__init__(self, nwalkers, ndim, log_prob, seed=seed, dist_group=dist_group, exchange=exchange)
         z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=self.dev)
         ns = self.half
@@ -793,8 +796,22 @@ class SliceEnsembleSampler(EnsembleSampler):
         self.Z2 = z(2 * ns)
         self.flags = torch.zeros(3 * ns, dtype=torch.int32, device=self.dev)
         self.counters = torch.zeros(4, dtype=torch.int32, device=self.dev)   # expansions, contractions, active (ping-pong)
-        self.neval = 0
+        self._neval_host = 0
         self._cs, self._pin = None, None
+        # One C call per half step (linna_slice_half_step) once mu is tuned: speculative rounds -- `m` bracket ends per side
+        # per stepping-out round, `ntrial` trials per shrinking round, sized so that one evaluation launch carries about
+        # 4096 points whatever the ensemble size -- and a fixed number of rounds, gated off on the device behind the one
+        # that finished the last walker.  The host then never waits inside an iteration (with 4-128 walkers the
+        # round-by-round loop below was bound by its own launches and count read-backs, not by the GPU).  The rounds allow
+        # FAST_EXPANSIONS stepping-out steps per side and FAST_TRIALS shrinking trials per walker and half step; a walker
+        # that needs more stays put and is counted, and `run` raises as zeus does past its `maxsteps`.
+        self.fast = fast
+        self._fast_ok = None                              # None: try the entry on the first tuned iteration
+        self.m = int(min(8, max(1, 4096 // (2 * ns))))
+        self.nt_fast = int(min(16, max(2, 4096 // ns)))
+        self.nexp_rounds = max(3, -(-self.FAST_EXPANSIONS // self.m))
+        self.nshr_rounds = max(3, -(-self.FAST_TRIALS // self.nt_fast))
+        self._fast_bufs = None
 
     # -- data-dependent rounds with one round of lookahead ------------------------------------------
     # A round = a few small kernels + one evaluation + a kernel that counts the walkers still active.
@@ -857,10 +874,67 @@ class SliceEnsembleSampler(EnsembleSampler):
                   P(w), P(self.Q2), self.ld, nrep, st)
         self._eval_if(self.Q2[:nrep * ns], self.Z2[:nrep * ns], gate)
 
+    @property
+    def neval(self):
+        """Log-probability evaluations so far (points, both paths; reads a device counter)."""
+        dev = int(self._fast_bufs["counters"][3].item()) if self._fast_bufs is not None else 0
+        return self._neval_host + dev
+
+    def _use_fast(self):
+        if self.fast is False or self.host_lp or self.tune or self._fast_ok is False:
+            return False
+        return self.fast is True or self.half <= 1024 or self._fast_ok is True
+
+    def _step_fast(self, halves, seed):
+        """Both half steps through linna_slice_half_step; False when the entry does not serve this log-probability."""
+        ns, P, I = self.half, _lib.ptr, _lib.iptr
+        if self._fast_bufs is None:
+            z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=self.dev)
+            nrep = max(2 * self.m, self.nt_fast)
+            self._fast_bufs = dict(state=z(5 * ns), W=z(2 * self.m * ns), Wd=z(self.nt_fast * ns), Zt=z(nrep * ns),
+                                   counters=torch.zeros(4 + self.nexp_rounds + self.nshr_rounds, dtype=torch.int32, device=self.dev))
+        b, st = self._fast_bufs, _lib.stream()
+        for h in (0, 1):
+            S, Cc = halves[h], halves[1 - h]
+            comp, ldc, cidx, nc = self.coords, self.ld, Cc, self.half
+            if self.exchange == "allgather" and self.world > 1:
+                comp, cidx, nc = self._allgather_complement(Cc)
+            rc = _lib.load().linna_slice_half_step(
+                self.lp._ensure()["handle"], P(self.coords), self.ld, self.ndim, P(self.logp), I(S), ns, P(comp), ldc, I(cidx), nc,
+                P(self.mu_dev), seed, I(self.step_dev), h, self.m, self.nexp_rounds, self.nt_fast, self.nshr_rounds, P(self.DIR), self.ld,
+                P(b["state"]), I(self.flags), P(b["W"]), P(b["Wd"]), P(b["Zt"]), I(b["counters"]), 1 if h == 0 else 0, st)
+            if rc != 0:
+                if rc == _lib.ERR_UNSUPPORTED and h == 0 and self._fast_ok is None:
+                    self._fast_ok = False
+                    return False
+                _lib.check(rc)
+        self._fast_ok = True
+        _lib.call("linna_step_increment", self.ctx, I(self.step_dev), st)
+        self.iteration += 1
+        self._fast_steps = getattr(self, "_fast_steps", 0) + 1
+        return True
+
+    def check_overflow(self):
+        """Raise, as zeus does past ``maxsteps``, when a walker needed more stepping-out steps or shrinking trials than
+        the one-call path's rounds hold (it kept its position in that half step).  One device read: called by ``run``."""
+        if self._fast_bufs is not None and getattr(self, "_fast_steps", 0):
+            n = int(self._fast_bufs["counters"][2].item())
+            if n:
+                raise RuntimeError("ensemble slice sampler: %d walker half steps needed more than %d expansions per side or %d "
+                                   "contractions (zeus: 'Number of expansions exceeded maximum limit'); construct the sampler "
+                                   "with fast=False for the unbounded round loop" % (n, self.nexp_rounds * self.m, self.nshr_rounds * self.nt_fast))
+
+    def run(self, nsteps, store=True):
+        out = EnsembleSampler.run(self, nsteps, store)
+        self.check_overflow()
+        return out
+
     def step(self):
         st, ns, ndim = _lib.stream(), self.half, self.ndim
         halves = self._splits()
         seed = C.c_uint64((self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF)
+        if self._use_fast() and self._step_fast(halves, seed):
+            return
         self.counters.zero_()
         P = _lib.ptr
         nt = self.ntrial
@@ -875,7 +949,7 @@ class SliceEnsembleSampler(EnsembleSampler):
 
             def expand_round(r, slot, gate):            # stepping out, both ends per round
                 self._eval_points(S, self.LR, 2, gate)
-                self.neval += 2 * ns
+                self._neval_host += 2 * ns
                 _lib.call("linna_slice_expand", self.ctx, P(self.Z0), P(self.Z2), C.c_void_p(self.Z2.data_ptr() + 4 * ns),
                           P(self.L), P(self.R), _lib.iptr(self.flags), ns, _lib.iptr(self.counters), slot, st)
 
@@ -887,7 +961,7 @@ class SliceEnsembleSampler(EnsembleSampler):
                 _lib.call("linna_slice_draw", self.ctx, P(self.L), P(self.R), _lib.iptr(S), P(self.W), _lib.iptr(self.flags),
                           ns, seed, _lib.iptr(self.step_dev), 2 + h, r * nt, nt, st)
                 self._eval_points(S, self.W, nt, gate)
-                self.neval += nt * ns
+                self._neval_host += nt * ns
                 _lib.call("linna_slice_shrink", self.ctx, P(self.Z0), P(self.Z2), P(self.L), P(self.R), P(self.W),
                           _lib.iptr(self.flags), P(self.Wacc), P(self.Zacc), ns, _lib.iptr(self.counters), slot, nt, st)
 

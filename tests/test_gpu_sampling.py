@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import cases
+from linna_amd import _lib
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -305,7 +306,8 @@ def test_slice_ensemble_posterior_33d_gaussian():
     z_last = c[-1]
     np.testing.assert_allclose(lp.evaluate(torch.nn.functional.pad(z_last, (0, ens.ld - ndim))).cpu().numpy(),
                                l[-1].cpu().numpy(), rtol=1e-4, atol=1e-4)
-    assert ens.neval / (ens.iteration * nw) < 25            # batched rounds, inactive lanes included
+    assert ens._fast_ok is True                             # the tuned iterations ran through linna_slice_half_step
+    assert ens.neval / (ens.iteration * nw) < 40            # speculative rounds (8 bracket ends per side, 16 trials), inactive lanes included
 
 
 def test_zeus_driver_smoke(tmp_path):
@@ -436,3 +438,42 @@ def test_slice_sampler_fused_trial_points_are_bit_identical():
     assert a.fused_points is True and b.fused_points is False
     assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp)
     assert a.mu == b.mu and a.neval == b.neval
+
+
+@pytest.mark.parametrize("name,nw", [("mlp_33_33", 96), ("v2_33_33", 16), ("mlp_33_33", 1024)])
+def test_one_call_slice_half_step_equals_the_round_loop(name, nw):
+    """linna_slice_half_step (speculative rounds: several bracket ends / trials per evaluation launch, a fixed launch
+    sequence gated on the device, no host wait) against the round-by-round loop over linna_slice_init / _expand / _draw /
+    _shrink / _commit: same Philox counters, same comparisons -> the chains must be EQUAL, as must the expansion and
+    contraction counts that tune mu.  Ensembles of 16, 96 and 1024 walkers (8 / 8 / 4 ends per side, 16 / 16 / 8 trials)."""
+    from linna_amd import sampler
+    lp, pred, yinv, prob = build_logprob(name, 2.0)
+    nd = 33
+    x0 = (0.3 * np.random.RandomState(8).standard_normal((nw, nd))).astype(np.float32)
+    _lib.engine_rows(4)                                     # one engine for every batch size: bit-equal evaluations
+    try:
+        a = sampler.SliceEnsembleSampler(nw, nd, lp, seed=4, tune=False, mu=0.7, fast=True)
+        b = sampler.SliceEnsembleSampler(nw, nd, lp, seed=4, tune=False, mu=0.7, fast=False)
+        a.set_state(x0); b.set_state(x0)
+        for it in range(12):
+            a.step(); b.step()
+            torch.cuda.synchronize()
+            assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp), it
+            ca = a._fast_bufs["counters"].cpu().numpy()
+            cb = b.counters.cpu().numpy()
+            assert ca[0] == cb[0] and ca[1] == cb[1] and ca[2] == 0, (it, ca[:4], cb)      # expansions, contractions, none unfinished
+    finally:
+        _lib.engine_rows(0)
+    assert a._fast_ok is True and a.iteration == b.iteration == 12
+    assert a.neval >= b.neval                               # speculation evaluates points the round loop never visits
+    # a walker that cannot finish within the rounds is reported, not moved: one expansion round of one end per side
+    c = sampler.SliceEnsembleSampler(nw, nd, lp, seed=4, tune=False, mu=1e-4, fast=True)
+    c.m, c.nexp_rounds = 1, 1
+    c.set_state(x0)
+    before = c.coords.clone()
+    with pytest.raises(RuntimeError, match="expansions"):
+        c.run(1, store=False)
+    assert int(c._fast_bufs["counters"][2].item()) > 0
+    assert torch.isfinite(c.coords).all() and torch.isfinite(c.logp).all()
+    stuck = (c.coords == before).all(dim=1)                  # walkers whose bracket never closed kept their position
+    assert int(stuck.sum()) > 0

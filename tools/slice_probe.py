@@ -1,17 +1,22 @@
-"""Timing/profile target: zeus-style ensemble slice sampler iterations on the bench problem."""
+"""Timing target: zeus-style ensemble slice sampler iterations on the bench problem, round-by-round loop against the
+one-call half step (linna_slice_half_step), over ensemble sizes.  usage: slice_probe.py [nw ...]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from linna_amd import sampler
-nw = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+sizes = [int(a) for a in sys.argv[1:]] or [16, 128, 512, 1024, 4096]
 lp, model, consts = bench.build_problem(torch.device("cuda", 0))
-ens = sampler.SliceEnsembleSampler(nw, 33, lp, seed=1)
-ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nw, 33)))
-ens.run(40, store=False)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-n = 40
-ens.run(n, store=False)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print("slice sampler: %d walkers, %.1f us/iteration, %.0f it/s, mu %.3f, evals/iter/walker %.2f" % (nw, dt / n * 1e6, n / dt, ens.mu, getattr(ens, "neval", 0) / max(1, ens.iteration) / nw))
+for nw in sizes:
+    for fast in (False, True):
+        ens = sampler.SliceEnsembleSampler(nw, 33, lp, seed=1, fast=fast)
+        ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nw, 33)))
+        ens.run(60, store=False)
+        torch.cuda.synchronize()
+        n = 400 if nw <= 1024 else 60
+        e0 = ens.neval
+        t0 = time.perf_counter()
+        ens.run(n, store=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("%5d walkers  %-9s %8.1f us/iteration  %7.0f it/s  mu %.3f  evals/walker/iteration %.1f  tuned %s" % (
+            nw, "one-call" if fast else "rounds", dt / n * 1e6, n / dt, ens.mu, (ens.neval - e0) / n / nw, not ens.tune), flush=True)
