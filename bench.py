@@ -407,7 +407,7 @@ def hmc_rate(device, nchains=4096, nleap=5):
     return out
 
 
-def slice_rate(lp, sizes=(4096, 128), iters=(60, 400)):
+def slice_rate(lp, sizes=(4096, 128), iters=(100, 600)):
     """The reference's DEFAULT sampler (main.py:22 method="zeus"; sampler.py:699-737): ensemble slice sampling iterations
     per second on the headline problem, at the bench's 4096 walkers and at the reference's own ensemble size (cosmolike:
     128 walkers), with the evaluations one iteration costs (stepping out + shrinking, per walker)."""
@@ -424,7 +424,8 @@ def slice_rate(lp, sizes=(4096, 128), iters=(60, 400)):
         ens.run(n, store=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        out["walkers_%d" % nw] = {"iterations_per_s": n / dt, "us_per_iteration": 1e6 * dt / n,
+        out["walkers_%d" % nw] = {"path": "one C call per half step (linna_slice_half_step)" if ens._fast_ok else "round loop",
+                                  "iterations_per_s": n / dt, "us_per_iteration": 1e6 * dt / n,
                                   "evals_per_walker_per_iteration": (ens.neval - e0) / max(1, ens.iteration - it0) / nw,
                                   "walker_updates_per_s": n * nw / dt, "mu": float(ens.mu)}
     return out
