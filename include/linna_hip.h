@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step */
+#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -253,6 +253,13 @@ int linna_weights_changed(linna_ctx_t* ctx);
  * Returns the previous setting, or LINNA_ERR_INVALID.  Process-wide, not a per-launch argument: the launch path reads
  * one atomic instead of the environment. */
 int linna_engine_rows(int rows);
+/* The serving program the whole-network kernel would run for this op list on the engine of `rows` rows per workgroup
+ * (dense_nout > 0: with a dense inverse covariance of that size as its last segment), as text: a header line, then one
+ * line per segment ("WIDE|SPLIT|SIDE steps passes ncg kc dst zext N").  Host-side planning only -- nothing is launched,
+ * no pointer is read -- for tests and diagnostics.  Returns the number of segments, 0 when the network is outside the
+ * kernel's reach. */
+int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size, int rows, int dense_nout, char* buf,
+                           size_t n);
 size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad);
 /* lnP[B]; THETA[B][ldt] optional (physical parameters, for chain_transformed). */
 int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,

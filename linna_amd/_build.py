@@ -38,5 +38,26 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_stamps(extra=("-DNS_STAMPS",), name="liblinna_hip_stamps.so", verbose=True):
+    """Diagnostic variant next to the product library: net_stream.hip compiled with phase stamps (every launch of the
+    whole-network kernel then needs LINNA_FUSED_STAMPS), the other objects shared.  Load it with LINNA_LIB_PATH."""
+    build(verbose=verbose)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    o = os.path.join(CSRC, "net_stream_stamps.o")
+    src = os.path.join(CSRC, "net_stream.hip")
+    if _stale(o, [src, os.path.join(CSRC, "common.h")]) or True:
+        cmd = [hipcc] + FLAGS + list(extra) + ["-c", src, "-o", o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES if s != "net_stream.hip"] + [o]
+    lib = os.path.join(HERE, name)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--stamps" in sys.argv:
+        build_stamps(tuple(a for a in sys.argv[1:] if a.startswith("-D")) or ("-DNS_STAMPS",))
+    else:
+        build(force="--force" in sys.argv)

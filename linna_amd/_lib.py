@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblinna_hip.so")
+LIB_PATH = os.environ.get("LINNA_LIB_PATH") or os.path.join(_HERE, "liblinna_hip.so")   # (LINNA_LIB_PATH: a diagnostic build, tools/ns_stamps.py)
 ABI_VERSION = 7
 
 c_float_p = C.c_void_p   # device pointers travel as void*
@@ -107,6 +107,7 @@ _SIGNATURES = {
     "linna_logprob_destroy": (_I, [_V]),
     "linna_weights_changed": (_I, [_V]),
     "linna_engine_rows": (_I, [_I]),
+    "linna_program_describe": (_I, [_V, _I, _I, _I, _I, _V, C.c_size_t]),
     "linna_logprob_ws_bytes": (_SZ, [_V, _I, _I]),
     "linna_logprob_eval": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),
     "linna_logprob_grad": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),

@@ -115,7 +115,7 @@ struct linna_net {
 };
 
 static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog = 0,
-                               const NsDense* dn = nullptr);
+                               const NsDense* dn = nullptr, int serve = 0);
 
 struct FwdLayout {
     std::vector<size_t> t_off, y_off;   // float offsets, per op (y_off of the last op unused)
@@ -819,7 +819,7 @@ static bool fused_enabled() {
     return on;
 }
 static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, void* stream, const float** out, int prog,
-                               const NsDense* dn) {
+                               const NsDense* dn, int serve) {
     const int k = rows < 16 ? 1 : 0;
     const unsigned long long epoch = g_weights_epoch.load();
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -828,10 +828,10 @@ static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, voi
     if (cap != hipStreamCaptureStatusNone) {
         // a captured launch carries its own re-layout, so that every replay sees the weights of that
         // moment; the copy is not valid for direct launches until they redo it
-        TRY(launch_net_stream_pack(LL.data(), (int)LL.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
+        TRY(launch_net_stream_pack(LL.data(), (int)LL.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream), serve));
         sc.epoch[k] = 0;
     } else if (sc.epoch[k] != epoch) {
-        TRY(launch_net_stream_pack(LL.data(), (int)LL.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream)));
+        TRY(launch_net_stream_pack(LL.data(), (int)LL.size(), n->in_size, sc.buf[k], rows, prog, dn, S(stream), serve));
         sc.epoch[k] = epoch;
     }
     *out = sc.buf[k];
@@ -841,7 +841,7 @@ static int stream_copy_refresh(StreamCopy& sc, const linna_net* n, int rows, voi
 static int lp_refresh_stream(linna_logprob* lp, int B, void* stream, const float** packed, int* rows) {
     *rows = net_stream_rows(B);
     const NsDense dn = lp->dense();
-    return stream_copy_refresh(lp->packed, lp->net, *rows, stream, packed, 0, lp->dense_fused ? &dn : nullptr);
+    return stream_copy_refresh(lp->packed, lp->net, *rows, stream, packed, 0, lp->dense_fused ? &dn : nullptr, 1);   // serve: SIDE segments on the 16-row engine
 }
 
 static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* w, const LpLayout& L, float* lnP,
@@ -923,6 +923,13 @@ int linna_logprob_destroy(linna_logprob_t* lp) {
     return LINNA_OK;
 }
 int linna_weights_changed(linna_ctx_t*) { g_weights_epoch.fetch_add(1); return LINNA_OK; }
+int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size, int rows, int dense_nout, char* buf, size_t n) {
+    if (!layers || nlayers < 1 || !buf || !n) { set_error("program_describe: bad arguments"); return LINNA_ERR_INVALID; }
+    // (pointers are only compared, never read: a placeholder stands for the dense inverse covariance)
+    static float dummy;
+    NsDense dn{&dummy, (dense_nout + 3) & ~3, nullptr, nullptr};
+    return net_stream_describe(layers, nlayers, in_size, 0, dense_nout > 0 ? &dn : nullptr, rows, 1, buf, n);
+}
 int linna_engine_rows(int rows) {
     const int prev = net_stream_force_rows(rows);
     if (prev < 0) { set_error("linna_engine_rows: %d (0, 4, 8 or 16)", rows); return LINNA_ERR_INVALID; }

@@ -132,8 +132,10 @@ size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size
 int net_stream_rows(int B);
 int net_stream_force_rows(int rows);   // 0 automatic, 4 / 8 / 16 forced; returns the previous setting, -1 for an invalid value
 int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog,
-                           const NsDense* dn, hipStream_t s);      // prog 0 + dn: the forward program with the dense segment
+                           const NsDense* dn, hipStream_t s, int serve = 0);      // prog 0 + dn: the forward program with the dense segment
 bool net_stream_dense_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn);
+int net_stream_describe(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn, int rows, int serve, char* buf,
+                        size_t n);
 size_t net_stream_dense_packed_floats(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn);
 // the dX chain of a training step as a program of the same kernel (prog 1: ops nl-1..1, prog 2: down to op 0)
 bool net_stream_dx_eligible(const linna_layer_t* layers, int nl, int in_size, int with_input);

@@ -74,7 +74,7 @@ constexpr int NS_LDS_BYTES = 160 * 1024;
 #ifndef NS_PRE
 #define NS_PRE 2
 #endif
-enum { NS_WIDE = 0, NS_SPLIT = 1 };
+enum { NS_WIDE = 0, NS_SPLIT = 1, NS_SIDE = 2 };
 
 struct NsSeg {            // kernel-side view of a segment
     int type, steps, passes, bias_off;
@@ -84,6 +84,7 @@ struct NsSeg {            // kernel-side view of a segment
     int x0_n;                          // ... that many columns of them (a multiple of 16)
     int x0_col;                        // > 0: the network INPUT rows (kept aside in LDS) are copied to this column of the segment's
                                        // input buffer before it runs (ChtoModelv2_linear's input skip, nn.py:160-163,195)
+    int kcl, side_off;                 // SIDE: log2 of the k chunks per wave and step; float offset of its weights from `packed`
 };
 
 struct NsArgs {
@@ -139,7 +140,16 @@ struct NsPackSeg {
     int transA;                                   // Wa is read transposed: value(n, k) = Wa[k][n] (backward segments)
     int transB;                                   // the same for Wb
     const float* rscale; const float* rshift;     // per output column: weights and bias * rscale, bias + rshift (folded output map)
+    int kc, side_off;                             // SIDE segments: k chunks per wave and step (2 or 4), float offset of their block
 };
+// SIDE segments (serving programs of the 16-row engine): a SPLIT segment of <= 32 output columns -- the hidden
+// h = relu(W1 x + b1) of a residual block, 1000 -> 16 and 500 -> 32 in ChtoModelv2 -- costs the step loop 8 + 4 steps of
+// which three quarters / half multiply zero weights (a wave's four 16-column tiles need 64 columns).  As a SIDE segment it
+// leaves the weight stream: its weights sit in a block of their own behind the biases, laid out so that a wave's four tiles
+// are (column tile, k chunk) pairs -- kc = 4 chunks of 16 columns, or 2 chunks of 32 -- and the whole segment is at most
+// two steps per wave, run inside the run-end code of the segment before it (loads issued before that segment's epilogue,
+// by inline asm: the compiler's counted waits for the ring never see them).  The step loop itself is untouched.
+//   side[w][s][t][lane][e]:  n = 16 (t % (4 / kc)) + li,  k = 16 (kc (w steps + s) + t / (4 / kc)) + 4 kq + e
 struct NsPackArgs {
     NsPackSeg seg[NS_MAXSEG];
     int run_seg[NS_MAXRUN], run_pass[NS_MAXRUN], run_first[NS_MAXRUN + 1];
@@ -202,6 +212,35 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
     p.out[nw4 * 4 + j] = bv;
 }
 
+__global__ void ns_pack_side_kernel(NsPackArgs p) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // one f32x4 of one SIDE segment's block
+    size_t base = 0;
+    for (int si = 0; si < p.nseg; ++si) {
+        const NsPackSeg& S = p.seg[si];
+        if (S.type != NS_SIDE) continue;
+        const size_t n4 = (size_t)NS_NW * S.steps * NS_NT * 64;
+        if (idx >= base + n4) { base += n4; continue; }
+        size_t q = idx - base;
+        const int lane = (int)(q & 63); q >>= 6;
+        const int t = (int)(q % NS_NT); q /= NS_NT;
+        const int st = (int)(q % S.steps);
+        const int w = (int)(q / S.steps);
+        const int tpc = NS_NT / S.kc;
+        const int n = 16 * (t % tpc) + (lane & 15);
+        const int k0 = 16 * (S.kc * (w * S.steps + st) + t / tpc) + 4 * (lane >> 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < S.N) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = k0 + e;
+                if (k < S.Ka) v[e] = S.Wa[(size_t)n * S.lda + k];
+            }
+        }
+        reinterpret_cast<f32x4*>(p.out + S.side_off)[idx - base] = v;
+        return;
+    }
+}
+
 __device__ __forceinline__ float ns_prior_theta(float z, int flat, float a1, float a2) {
     float u = 0.5f * (1.f + erff(z / 1.41421356237309515f));
     asm volatile("" : "+v"(u));                    // computed unconditionally: no branch on the loaded flag
@@ -232,6 +271,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int RS = SM ? ROWS / 4 : 1;
     constexpr int NQ = SM ? RS : NT;               // result quads per lane: (row set) or (column tile)
     constexpr int NACC = SM ? 4 * RS : NT;
+    constexpr bool K4 = !SM && STORE == 0;         // serving instantiations of the 16-row engine: programs may hold SIDE segments
     static_assert(ROWS == 16 || ROWS == 8 || ROWS == 4, "rows per workgroup");
     static_assert(R % 2 == 0, "the A double buffer alternates with the ring slot parity");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -494,7 +534,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // 4x4x1 engine: block b = lane >> 2 of the A read holds row set b & 3 (rows wrap below ROWS: never selected), k chunk b >> 2
     const int sm_arow = (4 * ((lane >> 2) & 3) + (lane & 3)) % ROWS, sm_achunk = lane >> 4;
     int si = 0, pass = 0, P = 0, kleft;
-    int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl, s_mstore = 0, s_mapply = 0, s_x0col = 0, s_x0n = 0;
+    int s_type, s_steps, s_passes, s_bias, s_dst, s_relu, s_kslice, s_zext, s_ncgl, s_mstore = 0, s_mapply = 0, s_x0col = 0, s_x0n = 0, s_kcl = 0;
     unsigned* const lmask = reinterpret_cast<unsigned*>(lbias + ((a.bias_total + 3) & ~3));   // GRAD: [slot][512 lanes]
     float lnp_grad = 0.f;                          // GRAD: lnP, stored at the very end (no store next to the weight loads)
     float* s_gout = nullptr; int s_gld = 0, s_gn = 0;   // STORE: global destination of the current segment's output
@@ -591,14 +631,40 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             if constexpr (STORE) { nx_gout = a.gout[nxi]; nx_gld = a.gld[nxi]; nx_gn = a.gn[nxi]; }
             if constexpr (STORE == 2) { nx_gmask = a.gmask[nxi]; nx_gmld = a.gmld[nxi]; }
             const int cur_steps = s_steps;
+            auto take_seg = [&](const NsSeg& X) {
+                s_type = X.type; s_steps = X.steps; s_passes = X.passes; s_bias = X.bias_off;
+                s_dst = X.dst_col; s_relu = X.relu; s_kslice = X.kslice; s_zext = X.zext; s_ncgl = X.ncg_log2; s_x0col = X.x0_col; s_x0n = X.x0_n;
+                if constexpr (K4) s_kcl = X.kcl;
+                if constexpr (GRAD) { s_mstore = X.mask_store; s_mapply = X.mask_apply; }
+                kleft = X.steps;
+            };
             auto take_next = [&]() {
-                s_type = NX.type; s_steps = NX.steps; s_passes = NX.passes; s_bias = NX.bias_off;
-                s_dst = NX.dst_col; s_relu = NX.relu; s_kslice = NX.kslice; s_zext = NX.zext; s_ncgl = NX.ncg_log2; s_x0col = NX.x0_col; s_x0n = NX.x0_n;
-                if constexpr (GRAD) { s_mstore = NX.mask_store; s_mapply = NX.mask_apply; }
+                take_seg(NX);
                 if constexpr (STORE) { s_gout = nx_gout; s_gld = nx_gld; s_gn = nx_gn; }
                 if constexpr (STORE == 2) { s_gmask = nx_gmask; s_gmld = nx_gmld; }
-                kleft = NX.steps;
             };
+            // SIDE segment next (and this run is its predecessor's last): its weights are requested NOW, by loads the compiler
+            // does not see, so that they fly under this segment's epilogue and barrier
+            f32x4 sdw[2][NT];
+            bool side_next = false;
+            if constexpr (K4) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) sdw[s2][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (NX.type == NS_SIDE && si + 1 < nseg && (s_type != NS_WIDE || pass + 1 == s_passes)) {
+                    side_next = true;
+                    const char* const sb = reinterpret_cast<const char*>(a.packed + NX.side_off) + (size_t)wave * NX.steps * NS_STEP_B + voff;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sdw[0][t]) : "v"(sb + t * 1024) : "memory");
+                    if (NX.steps > 1) {
+#pragma unroll
+                        for (int t = 0; t < NT; ++t)
+                            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sdw[1][t]) : "v"(sb + NS_STEP_B + t * 1024) : "memory");
+                    }
+                }
+            }
             bool seg_done = true;
 #ifdef NS_STAMPS_FINE
             const bool fine = si >= NS_STAMPS_FINE && si < NS_STAMPS_FINE + 4;
@@ -837,6 +903,82 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 }
                 lds_barrier();
             }
+            if constexpr (K4) {
+                if (side_next && seg_done) {
+                    // ---- SIDE run: the segment now in s_* (taken above), whole, right here.  Wave w owns the k range
+                    // [w kslice, (w + 1) kslice) (ncg = 1); a step covers kc chunks of 16 k: tile t of the weights is
+                    // (column tile t % (4 / kc), chunk t / (4 / kc)).
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const bool kc4 = s_kcl == 2;
+                    const uint32_t abase = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq + wave * s_kslice);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        if (s2 < s_steps) {
+                            const uint32_t as = abase + (uint32_t)s2 * (64u << s_kcl);
+                            f32x4 af0, af1, af2 = f32x4{0.f, 0.f, 0.f, 0.f}, af3 = f32x4{0.f, 0.f, 0.f, 0.f};
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(af0) : "v"(as) : "memory");
+                            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(af1) : "v"(as) : "memory");
+                            if (kc4) {
+                                asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(af2) : "v"(as) : "memory");
+                                asm volatile("ds_read_b128 %0, %1 offset:192" : "=v"(af3) : "v"(as) : "memory");
+                            }
+                            if (s2 == 0)
+                                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                                             : "+v"(af0), "+v"(af1), "+v"(af2), "+v"(af3), "+v"(sdw[0][0]), "+v"(sdw[0][1]), "+v"(sdw[0][2]),
+                                               "+v"(sdw[0][3]), "+v"(sdw[1][0]), "+v"(sdw[1][1]), "+v"(sdw[1][2]), "+v"(sdw[1][3]) :: "memory");
+                            else
+                                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af0), "+v"(af1), "+v"(af2), "+v"(af3) :: "memory");
+                            const f32x4 f1 = kc4 ? af1 : af0, f2 = kc4 ? af2 : af1, f3 = kc4 ? af3 : af1;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[e], sdw[s2][0][e], acc[0], 0, 0, 0);
+                                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[e], sdw[s2][1][e], acc[1], 0, 0, 0);
+                            }
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(f2[e], sdw[s2][2][e], acc[2], 0, 0, 0);
+                                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(f3[e], sdw[s2][3][e], acc[3], 0, 0, 0);
+                            }
+                        }
+                    }
+                    int treal;
+                    if (kc4) { acc[0] = (acc[0] + acc[1]) + (acc[2] + acc[3]); treal = 1; }
+                    else { acc[0] = acc[0] + acc[2]; acc[1] = acc[1] + acc[3]; treal = 2; }
+                    float* const part = act + (P ^ 1) * ABUF;       // [8 waves][16 rows][64]: the SPLIT layout and swizzle
+                    constexpr int PW = ROWS * 64;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        if (t < treal) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) part[wave * PW + (4 * kq + e) * 64 + ((16 * t + li) ^ (16 * kq))] = acc[t][e];
+                        }
+                    lds_barrier();
+                    {
+                        float* const cur = act + P * ABUF + pr * LD + s_dst;
+                        const int ncol = 16 * treal, sw = 16 * (pr >> 2);
+                        for (int c = pc0; c < s_zext; c += RG) {
+                            float v = 0.f;
+                            if (c < ncol) {
+                                const float* src = part + pr * 64 + (c ^ sw);
+                                float x[NW];
+#pragma unroll
+                                for (int kp = 0; kp < NW; ++kp) x[kp] = src[kp * PW];
+#pragma unroll
+                                for (int kp = 0; kp < NW; ++kp) v += x[kp];
+                                v += lbias[s_bias + c];
+                                if (s_relu) v = fmaxf(v, 0.f);
+                            }
+                            cur[c] = v;
+                        }
+                    }
+                    lds_barrier();
+                    NS_STAMP();
+                    ++si;
+                    const NsSeg N2 = a.seg[__builtin_amdgcn_readfirstlane(min(si, nseg - 1))];
+                    take_seg(N2);
+                }
+            }
             if (si < nseg) {
                 begin_run();
                 a_read(Aq[(U + 1) & 1]);           // replaces the speculative fragment
@@ -988,6 +1130,7 @@ struct NsProgram {
     size_t lds_bytes = 0, lds_bytes_grad = 0, packed_floats = 0;   // LDS of the 16-row engine (lds_for: any engine)
     int dense = 0, u_col = 0, u_same = 0;                   // dense inverse covariance appended as the last segment
     int x0_keep = 0;                                        // an input-skip segment copies the network input later
+    size_t side_f4 = 0;                                     // 16-byte vectors of all SIDE blocks
     size_t lds_for(int rows, bool grad) const {
         size_t b = (size_t)(2 * rows * LD + ((bias_total + 3) & ~3)) * sizeof(float) + 128 + (x0_keep ? 4096 : 0);   // + [16] set rows, [16] den (STORE == 3), kept input rows
 #ifdef NS_STAMPS
@@ -1005,10 +1148,10 @@ static int ceil16(int k) { return (k + 15) & ~15; }
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
 enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4, NS_PROG_FWD_DXI = 5 };
-static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn = nullptr);
-static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
-    NsProgram p = ns_build_one(layers, nl, in_size, NS_PROG_FWD);
-    if (!p.ok) p = ns_build_one(layers, nl, in_size, NS_PROG_FWD_NOGRAD);      // the backward half may be what did not fit
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn = nullptr, bool k4 = false);
+static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size, bool k4 = false) {
+    NsProgram p = ns_build_one(layers, nl, in_size, NS_PROG_FWD, nullptr, k4);
+    if (!p.ok) p = ns_build_one(layers, nl, in_size, NS_PROG_FWD_NOGRAD, nullptr, k4);      // the backward half may be what did not fit
     return p;
 }
 // mode NS_PROG_DX: the dX chain of a training step as a program of its own (linna_net_backward's order): the rows are
@@ -1019,7 +1162,9 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size) {
 // mode NS_PROG_FWD_DENSE: the forward program with the output map (d = raw * cscale + cshift) folded into the last
 // layer's weights and bias, and the dense inverse covariance appended as one more bias-free segment U = d S -- the
 // Gaussian log-likelihood (util.py:953-955) with a dense covariance then needs no GEMM launch of its own.
-static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn) {
+// k4: SPLIT segments of <= 32 columns become SIDE segments where they fit (see NsPackArgs): the kernel's K4 path, i.e. the
+// serving instantiations of the 16-row engine only.
+static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn, bool k4) {
     NsProgram p;
     const bool allow_grad = mode == NS_PROG_FWD, dx_prog = mode == NS_PROG_DX || mode == NS_PROG_DX_INPUT;
     if (mode == NS_PROG_FWD_DENSE && (!dn || !dn->S)) return p;
@@ -1145,7 +1290,18 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         const int split_steps = ncg ? (ksteps + NS_NW / ncg - 1) / (NS_NW / ncg) : 0;
         const bool split = ncg && !L.force_wide && (L.same_buf || split_steps + 3 <= ksteps * passes);
         if (L.same_buf && !ncg) return p;
-        if (split) {
+        const int kc = L.N <= 16 ? 4 : L.N <= 32 ? 2 : 1;
+        const int side_steps = (ksteps + NS_NW * kc - 1) / (NS_NW * kc);
+        // (never the first segment nor the last forward one: the kernel runs a SIDE segment between two runs of the step loop)
+        const bool side = k4 && split && kc > 1 && side_steps <= 2 && i > 0 && (int)i < nfwd - 1 && p.seg.back().type != NS_SIDE &&
+                          !L.Wb && !L.transA && L.Wa && !L.rscale && !L.rshift && !L.b2 && !L.x0_col;
+        if (side) {
+            s.type = NS_SIDE; s.steps = side_steps; s.passes = 1; s.kslice = 16 * kc * s.steps;
+            s.ncg_log2 = 0; s.kcl = kc == 4 ? 2 : 1;
+            s.zext = 64;
+            in_ext[i] = NS_NW * s.kslice;
+            q.bias_pad = 64; q.ncg = 1;
+        } else if (split) {
             s.type = NS_SPLIT; s.steps = split_steps; s.passes = 1; s.kslice = 16 * s.steps;
             s.ncg_log2 = ncg == 1 ? 0 : ncg == 2 ? 1 : 2;
             s.zext = 64 * ncg;
@@ -1159,6 +1315,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         q.Wa = L.Wa; q.lda = L.lda; q.Ka = L.Ka; q.Kapad = L.Kapad; q.Wb = L.Wb; q.ldb = L.ldb; q.Kb = L.Kb; q.alpha = L.alpha;
         q.b = L.b; q.bscale = L.bscale; q.N = L.N; q.type = s.type; q.steps = s.steps; q.passes = s.passes; q.bias_off = bias_off;
         q.transA = L.transA; q.transB = L.transB; q.rscale = L.rscale; q.rshift = L.rshift; q.b2 = L.b2; q.b2scale = L.b2scale;
+        q.kc = side ? kc : 1; q.side_off = 0;
         s.x0_col = L.x0_col; s.x0_n = L.x0_col ? ceil16(L.Kb) : 0;
         if (L.transA && !dx_prog) {                                     // backward segments have no bias: ONE shared block of zeros
             if (zero_off < 0) { zero_off = bias_off; zero_pad = 0; }
@@ -1167,7 +1324,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
             zero_pad += grow; q.bias_pad = grow;            // (the first backward segment's record carries the block; later ones extend it)
         }
         bias_off += q.bias_pad;
-        G += s.steps * s.passes;
+        if (!side) G += s.steps * s.passes;        // (a SIDE segment is not part of the weight stream)
         p.seg.push_back(s); p.pack.push_back(q);
     }
     if (want_grad) {
@@ -1192,7 +1349,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         }
     }
     int Gf = 0;
-    for (int i = 0; i < nfwd; ++i) Gf += p.seg[i].steps * p.seg[i].passes;
+    for (int i = 0; i < nfwd; ++i) if (p.seg[i].type != NS_SIDE) Gf += p.seg[i].steps * p.seg[i].passes;
 
     // 3. every column a segment reads must have been WRITTEN (finite; zero where the weights are zero):
     //    track the defined prefix [0, def) of the current buffer and widen the zero fill of the last
@@ -1219,7 +1376,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
             writer = (int)i;
         }
     }
-    for (const NsSeg& s : p.seg) if (s.type == NS_SPLIT) maxext = std::max(maxext, s.dst_col + s.zext);
+    for (const NsSeg& s : p.seg) if (s.type != NS_WIDE) maxext = std::max(maxext, s.dst_col + s.zext);
     if (p.kpad0 > (dx_prog ? 1024 : 256)) return p;
     p.nout = lins[nfwd - 1].N;
     p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
@@ -1239,11 +1396,17 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     for (const NsSeg& s : p.seg) nrun += s.passes;
     if (nrun > NS_MAXRUN) return p;
     p.packed_floats = (size_t)NS_NW * G * NS_NT * 256 + (size_t)((bias_off + 3) & ~3);
+    for (size_t i = 0; i < p.seg.size(); ++i)
+        if (p.seg[i].type == NS_SIDE) {            // blocks of their own behind the biases
+            p.seg[i].side_off = p.pack[i].side_off = (int)p.packed_floats;
+            p.packed_floats += (size_t)NS_NW * p.seg[i].steps * NS_NT * 256;
+            p.side_f4 += (size_t)NS_NW * p.seg[i].steps * NS_NT * 64;
+        }
     p.ok = true;
     return p;
 }
 
-static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn);
+static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn = nullptr, bool k4 = false);
 bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 0, nullptr).ok; }
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size) {
     return ns_build_prog(layers, nl, in_size, 0, nullptr).packed_floats;
@@ -1278,7 +1441,17 @@ int net_stream_rows(int B) {
     return B <= 4 * ncu ? 4 : B <= 8 * ncu ? 8 : 16;
 }
 
-static NsProgram ns_build_prog_uncached(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn) {
+// SIDE segments: serving launches (linna_logprob_*, the fused sampler moves) on the 16-row engine; LINNA_NS_K4=0 turns them off
+bool net_stream_k4(int rows, int serve) {
+    static const bool on = !(getenv("LINNA_NS_K4") && getenv("LINNA_NS_K4")[0] == '0');
+    return on && serve && rows == 16;
+}
+
+static NsProgram ns_build_prog_uncached(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn, bool k4) {
+    if (k4 && prog == 0) {                     // the serving programs of the 16-row engine; the plain program where this one does not fit
+        NsProgram p = dn ? ns_build_one(layers, nl, in_size, NS_PROG_FWD_DENSE, dn, true) : ns_build(layers, nl, in_size, true);
+        if (p.ok) return p;
+    }
     if (prog == 0 && dn) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DENSE, dn);
     if (prog == 3) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DXI);
     return prog == 0 ? ns_build(layers, nl, in_size) : ns_build_one(layers, nl, in_size, prog == 2 ? NS_PROG_DX_INPUT : NS_PROG_DX);
@@ -1287,13 +1460,13 @@ static NsProgram ns_build_prog_uncached(const linna_layer_t* layers, int nl, int
 // the pack descriptors carry them), the program kind and the dense descriptor, so it is built once and looked up by
 // those bytes on every later launch -- no segment planning, no vector allocation on the launch path.  Entries live for
 // the life of the library (a handful per network; the table is cleared if it ever reaches 256 entries).
-static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn = nullptr) {
+static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn, bool k4) {
     static std::mutex mu;
     static std::unordered_map<std::string, std::unique_ptr<NsProgram>> cache;
     std::string key;
     key.reserve((size_t)nl * sizeof(linna_layer_t) + 64);
     key.append(reinterpret_cast<const char*>(layers), (size_t)nl * sizeof(linna_layer_t));
-    const int hdr[3] = {nl, in_size, prog};
+    const int hdr[4] = {nl, in_size, prog, k4 ? 1 : 0};
     key.append(reinterpret_cast<const char*>(hdr), sizeof(hdr));
     if (dn) {                                               // field by field: the struct has padding bytes
         const void* const ptrs[3] = {dn->S, dn->cscale, dn->cshift};
@@ -1304,8 +1477,27 @@ static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int i
     auto it = cache.find(key);
     if (it != cache.end()) return *it->second;
     if (cache.size() >= 256) cache.clear();
-    auto ins = cache.emplace(std::move(key), std::unique_ptr<NsProgram>(new NsProgram(ns_build_prog_uncached(layers, nl, in_size, prog, dn))));
+    auto ins = cache.emplace(std::move(key), std::unique_ptr<NsProgram>(new NsProgram(ns_build_prog_uncached(layers, nl, in_size, prog, dn, k4))));
     return *ins.first->second;
+}
+// Text form of a program (tests, diagnostics): one line per segment, "type steps passes ncg kc dst_col zext".
+int net_stream_describe(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn, int rows, int serve, char* buf,
+                        size_t n) {
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn, prog == 0 && net_stream_k4(rows, serve));
+    std::string out = p.ok ? "ok" : "not eligible";
+    char line[160];
+    snprintf(line, sizeof line, " G %d Gstride %d nseg_f %d LD %d kpad0 %d packed_floats %zu grad %d\n", p.G, p.Gstride, p.nseg_f, p.LD,
+             p.kpad0, p.packed_floats, (int)p.grad_ok);
+    out += line;
+    for (size_t i = 0; p.ok && i < p.seg.size(); ++i) {
+        const NsSeg& g = p.seg[i];
+        snprintf(line, sizeof line, "%s steps %d passes %d ncg %d kc %d dst %d zext %d N %d\n",
+                 g.type == NS_WIDE ? "WIDE" : g.type == NS_SPLIT ? "SPLIT" : "SIDE", g.steps, g.passes, 1 << g.ncg_log2, 1 << g.kcl, g.dst_col,
+                 g.zext, p.pack[i].N);
+        out += line;
+    }
+    if (buf && n) { snprintf(buf, n, "%s", out.c_str()); }
+    return p.ok ? (int)p.seg.size() : 0;
 }
 bool net_stream_dense_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn) {
     return ns_build_prog(layers, nl, in_size, 0, &dn).ok;
@@ -1322,8 +1514,8 @@ size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_s
 
 // prog: 0 the forward program (+ the fused gradient's backward half), 1 / 2 the dX chain without / with op 0
 int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog,
-                           const NsDense* dn, hipStream_t s) {
-    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn);
+                           const NsDense* dn, hipStream_t s, int serve) {
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn, prog == 0 && net_stream_k4(rows, serve));
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsPackArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -1332,6 +1524,7 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     int nrun = 0, first = 0;
     for (int i = 0; i < a.nseg; ++i) {
         a.seg[i] = p.pack[i];
+        if (p.seg[i].type == NS_SIDE) continue;                 // not in the stream: ns_pack_side_kernel below
         for (int ps = 0; ps < p.seg[i].passes; ++ps) {
             a.run_seg[nrun] = i; a.run_pass[nrun] = ps; a.run_first[nrun] = first;
             first += p.seg[i].steps; ++nrun;
@@ -1340,6 +1533,7 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     a.run_first[nrun] = first; a.nrun = nrun;
     const size_t total = (size_t)NS_NW * p.Gstride * NS_NT * 64 + (size_t)p.bias_total;
     hipLaunchKernelGGL(ns_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    if (p.side_f4) hipLaunchKernelGGL(ns_pack_side_kernel, dim3((unsigned)((p.side_f4 + 255) / 256)), dim3(256), 0, s, a);
     return check_hip(hipGetLastError(), "net_stream pack launch");
 }
 
@@ -1570,7 +1764,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
                       const NsDense* dn, hipStream_t s, const float* cpost, const float* cshift2) {
-    const NsProgram& p = ns_build_prog(layers, nl, in_size, 0, dn);
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 0, dn, net_stream_k4(rows, 1));
     if ((cpost != nullptr) != (cshift2 != nullptr) || (cpost && (dn || gr))) {
         set_error("net_stream: the exp output map needs cpost and cshift2, and has no dense / gradient program"); return LINNA_ERR_INVALID;
     }

@@ -417,3 +417,29 @@ class ResBlock_batchnorm(object):
     def __init__(self, in_size, channel, out_size):
         self.in_size, self.channel, self.out_size = in_size, channel, out_size
         self.op = _Op(_lib.OP_RESBLOCK, "block", in_size, out_size, C=channel)
+
+
+def describe_program(model, rows=16, dense_nout=0):
+    """The serving program the whole-network kernel would run for ``model`` on the engine of ``rows`` rows per workgroup, as
+    text (``linna_program_describe``: host-side planning, no GPU needed; parameter pointers are placeholders)."""
+    arr = (_lib.Layer * len(model.ops))()
+    nxt = [4096]
+
+    def fake(n):                                            # distinct, 16-byte aligned, never read
+        p = nxt[0]
+        nxt[0] += 16 * ((int(n) + 3) // 4 + 1)
+        return C.c_void_p(p)
+    for i, op in enumerate(model.ops):
+        L = arr[i]
+        L.op, L.K, L.C, L.N, L.relu, L.alpha = op.op, op.K, op.C, op.N, op.relu, op.alpha
+        if op.op == _lib.OP_RESBLOCK:
+            L.W1, L.b1, L.W2, L.b2 = fake(op.C * op.K), fake(op.C), fake(op.N * op.C), fake(op.N)
+            if op.K != op.N:
+                L.Ws = fake(op.N * op.K)
+        else:
+            L.W, L.b = fake(op.N * op.K), fake(op.N)
+    buf = C.create_string_buffer(8192)
+    n = _lib.load().linna_program_describe(arr, len(model.ops), model.in_size, int(rows), int(dense_nout), buf, len(buf))
+    if n < 0:
+        _lib.check(n)
+    return n, buf.value.decode()

@@ -761,6 +761,10 @@ class EnsembleSampler(object):
 
 
 # ------------------------------------------------------------------ ensemble slice sampling (zeus)
+class _FastOverflow(Exception):
+    """A walker of the one-call slice half step needed more rounds than the call holds (SliceEnsembleSampler._guard)."""
+
+
 class SliceEnsembleSampler(EnsembleSampler):
     """zeus' ensemble slice sampler (Karamanis & Beutler 2021; driven by sampler.py:728-735) with
     every trial point of a half ensemble evaluated in one batched GPU call.
@@ -804,7 +808,8 @@ class SliceEnsembleSampler(EnsembleSampler):
         # that finished the last walker.  The host then never waits inside an iteration (with 4-128 walkers the
         # round-by-round loop below was bound by its own launches and count read-backs, not by the GPU).  The rounds allow
         # FAST_EXPANSIONS stepping-out steps per side and FAST_TRIALS shrinking trials per walker and half step; a walker
-        # that needs more stays put and is counted, and `run` raises as zeus does past its `maxsteps`.
+        # that needs more is counted (and kept in place), and `run` / `step` then take the sampler back to the state they
+        # started from and redo their iterations on the unbounded round loop: the chain is always the round loop's.
         self.fast = fast
         self._fast_ok = None                              # None: try the entry on the first tuned iteration
         self.m = int(min(8, max(1, 4096 // (2 * ns))))
@@ -813,6 +818,9 @@ class SliceEnsembleSampler(EnsembleSampler):
         self.nshr_rounds = max(3, -(-self.FAST_TRIALS // self.nt_fast))
         self._fast_bufs = None
         self._last_nexp = None                            # expansions of the last tuning iteration (whole ensemble)
+        self._fast_after = 0                              # no one-call steps before this iteration (set after an overflow)
+        self._guarded = False
+        self.noverflow = 0                                # runs redone on the round loop
 
     # -- data-dependent rounds with one round of lookahead ------------------------------------------
     # A round = a few small kernels + one evaluation + a kernel that counts the walkers still active.
@@ -886,7 +894,7 @@ class SliceEnsembleSampler(EnsembleSampler):
         While mu is still being tuned it is used only once an iteration has needed few expansions: the walkers of a run
         start in a 1e-3 ball (util.py:937) and the first iterations step out hundreds of times per side, which the
         unbounded round loop handles and the fixed rounds of the one-call path would not."""
-        if self.fast is False or self.host_lp or self._fast_ok is False:
+        if self.fast is False or self.host_lp or self._fast_ok is False or self.iteration < self._fast_after:
             return False
         if self.tune and not (self._last_nexp is not None and self._last_nexp < 2.0 * self.nw):
             return False
@@ -922,7 +930,7 @@ class SliceEnsembleSampler(EnsembleSampler):
         if self.tune:
             c = b["counters"][:3].cpu().numpy()          # one read per iteration while mu is tuned, as the round loop
             if c[2]:
-                self.check_overflow()
+                raise _FastOverflow()
             self._tune_mu(int(c[0]), int(c[1]))
         return True
 
@@ -937,22 +945,68 @@ class SliceEnsembleSampler(EnsembleSampler):
         if self._tune_count > self.patience:
             self.tune = False
 
-    def check_overflow(self):
-        """Raise, as zeus does past ``maxsteps``, when a walker needed more stepping-out steps or shrinking trials than
-        the one-call path's rounds hold (it kept its position in that half step).  One device read: called by ``run``."""
-        if self._fast_bufs is not None and getattr(self, "_fast_steps", 0):
-            n = int(self._fast_bufs["counters"][2].item())
-            if n:
-                raise RuntimeError("ensemble slice sampler: %d walker half steps needed more than %d expansions per side or %d "
-                                   "contractions (zeus: 'Number of expansions exceeded maximum limit'); construct the sampler "
-                                   "with fast=False for the unbounded round loop" % (n, self.nexp_rounds * self.m, self.nshr_rounds * self.nt_fast))
+    def _overflowed(self):
+        """A walker needed more stepping-out steps or shrinking trials than the one-call path's rounds hold (one device read)."""
+        return (self._fast_bufs is not None and getattr(self, "_fast_steps", 0)
+                and int(self._fast_bufs["counters"][2].item()) > 0)
+
+    def _snapshot(self):
+        slot = None
+        if self._split_dev is not None:
+            slot = [t.clone() for t in self._split_dev]
+        return dict(coords=self.coords.clone(), logp=self.logp.clone(), naccept=self.naccept.clone(), step_dev=self.step_dev.clone(),
+                    mu=self.mu, tune=self.tune, tune_count=self._tune_count, last_nexp=self._last_nexp, iteration=self.iteration,
+                    dev_steps=self._dev_steps, rs=self._rs.get_state(), split_pos=self._split_pos, split_dev=slot,
+                    neval=self._neval_host)
+
+    def _restore(self, k):
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.coords.copy_(k["coords"]); self.logp.copy_(k["logp"]); self.naccept.copy_(k["naccept"]); self.step_dev.copy_(k["step_dev"])
+        self.mu, self.tune, self._tune_count, self._last_nexp = k["mu"], k["tune"], k["tune_count"], k["last_nexp"]
+        self.mu_dev.fill_(self.mu)
+        self.iteration, self._dev_steps, self._neval_host = k["iteration"], k["dev_steps"], k["neval"]
+        self._rs.set_state(k["rs"]); self._split_pos = k["split_pos"]
+        if k["split_dev"] is not None:
+            for dst, src in zip(self._split_dev, k["split_dev"]):
+                dst.copy_(src)
+        if self._fast_bufs is not None:
+            self._fast_bufs["counters"][2:3].zero_()
+
+    def _guard(self, body):
+        """Run ``body`` (iterations that may take the one-call path); if a walker overflowed its rounds, go back to the state
+        at entry and run ``body`` again on the round loop -- what comes out is the round loop's chain either way."""
+        if self._guarded or not self._use_fast_possible():
+            return body()
+        snap = self._snapshot()
+        self._guarded = True
+        try:
+            try:
+                out = body()
+                redo = self._overflowed()
+            except _FastOverflow:
+                redo = True
+            if redo:
+                self._restore(snap)
+                self.noverflow += 1
+                self._fast_after = snap["iteration"] + 1 << 30       # (this attempt: round loop only)
+                out = body()
+                self._fast_after = self.iteration + 200                # the one-call path again after 200 quiet iterations
+            return out
+        finally:
+            self._guarded = False
+
+    def _use_fast_possible(self):
+        return not (self.fast is False or self.host_lp or self._fast_ok is False)
 
     def run(self, nsteps, store=True):
-        out = EnsembleSampler.run(self, nsteps, store)
-        self.check_overflow()
-        return out
+        return self._guard(lambda: EnsembleSampler.run(self, nsteps, store))
 
     def step(self):
+        if not self._guarded:
+            return self._guard(self._step)
+        return self._step()
+
+    def _step(self):
         st, ns, ndim = _lib.stream(), self.half, self.ndim
         halves = self._splits()
         seed = C.c_uint64((self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1)) & 0xFFFFFFFFFFFFFFFF)
