@@ -817,11 +817,24 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     float v = 0.f;
                     if (c < ncol) {
                         const float* src = part + (c >> 6) * PW + sr * 64 + ((c & 63) ^ sw);
-                        float x[NW];
+                        // the partials of this column's K parts, all reads in flight (8, 4 or 2 of them: the same sums in the
+                        // same order as one loop over kp < nkp)
+                        if (nkp == NW) {
+                            float x[NW];
 #pragma unroll
-                        for (int kp = 0; kp < NW; ++kp) x[kp] = src[((kp & (nkp - 1)) << s_ncgl) * PW];   // 8 reads in flight
+                            for (int kp = 0; kp < NW; ++kp) x[kp] = src[(kp << s_ncgl) * PW];
 #pragma unroll
-                        for (int kp = 0; kp < NW; ++kp) v += kp < nkp ? x[kp] : 0.f;
+                            for (int kp = 0; kp < NW; ++kp) v += x[kp];
+                        } else if (nkp == NW / 2) {
+                            float x[NW / 2];
+#pragma unroll
+                            for (int kp = 0; kp < NW / 2; ++kp) x[kp] = src[(kp << s_ncgl) * PW];
+#pragma unroll
+                            for (int kp = 0; kp < NW / 2; ++kp) v += x[kp];
+                        } else {
+                            const float x0 = src[0], x1 = src[(1 << s_ncgl) * PW];
+                            v += x0; v += x1;
+                        }
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
                         if constexpr (STORE == 2) {
@@ -910,7 +923,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     // (column tile t % (4 / kc), chunk t / (4 / kc)).
 #pragma unroll
                     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const bool kc4 = s_kcl == 2;
+                    const bool kc4 = s_kcl == 2, kc1 = s_kcl == 0;
                     const uint32_t abase = act_lds + 4u * (uint32_t)(P * ABUF + li * LD + 4 * kq + wave * s_kslice);
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
@@ -918,7 +931,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             const uint32_t as = abase + (uint32_t)s2 * (64u << s_kcl);
                             f32x4 af0, af1, af2 = f32x4{0.f, 0.f, 0.f, 0.f}, af3 = f32x4{0.f, 0.f, 0.f, 0.f};
                             asm volatile("ds_read_b128 %0, %1" : "=v"(af0) : "v"(as) : "memory");
-                            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(af1) : "v"(as) : "memory");
+                            af1 = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (!kc1) asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(af1) : "v"(as) : "memory");
                             if (kc4) {
                                 asm volatile("ds_read_b128 %0, %1 offset:128" : "=v"(af2) : "v"(as) : "memory");
                                 asm volatile("ds_read_b128 %0, %1 offset:192" : "=v"(af3) : "v"(as) : "memory");
@@ -929,7 +943,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                                                "+v"(sdw[0][3]), "+v"(sdw[1][0]), "+v"(sdw[1][1]), "+v"(sdw[1][2]), "+v"(sdw[1][3]) :: "memory");
                             else
                                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af0), "+v"(af1), "+v"(af2), "+v"(af3) :: "memory");
-                            const f32x4 f1 = kc4 ? af1 : af0, f2 = kc4 ? af2 : af1, f3 = kc4 ? af3 : af1;
+                            // tile t multiplies chunk t (kc = 4), t >> 1 (kc = 2) or the one chunk (kc = 1)
+                            const f32x4 f1 = kc4 ? af1 : af0, f2 = kc4 ? af2 : kc1 ? af0 : af1, f3 = kc4 ? af3 : kc1 ? af0 : af1;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af0[e], sdw[s2][0][e], acc[0], 0, 0, 0);
@@ -942,13 +957,13 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             }
                         }
                     }
-                    int treal;
+                    int treal = NT;
                     if (kc4) { acc[0] = (acc[0] + acc[1]) + (acc[2] + acc[3]); treal = 1; }
-                    else { acc[0] = acc[0] + acc[2]; acc[1] = acc[1] + acc[3]; treal = 2; }
+                    else if (!kc1) { acc[0] = acc[0] + acc[2]; acc[1] = acc[1] + acc[3]; treal = 2; }
                     float* const part = act + (P ^ 1) * ABUF;       // [8 waves][16 rows][64]: the SPLIT layout and swizzle
                     constexpr int PW = ROWS * 64;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < NT; ++t)
                         if (t < treal) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) part[wave * PW + (4 * kq + e) * 64 + ((16 * t + li) ^ (16 * kq))] = acc[t][e];
@@ -1292,12 +1307,13 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         if (L.same_buf && !ncg) return p;
         const int kc = L.N <= 16 ? 4 : L.N <= 32 ? 2 : 1;
         const int side_steps = (ksteps + NS_NW * kc - 1) / (NS_NW * kc);
-        // (never the first segment nor the last forward one: the kernel runs a SIDE segment between two runs of the step loop)
-        const bool side = k4 && split && kc > 1 && side_steps <= 2 && i > 0 && (int)i < nfwd - 1 && p.seg.back().type != NS_SIDE &&
+        // (never the first segment nor the last forward one: the kernel runs a SIDE segment between two runs of the step loop;
+        // kc = 1, <= 64 columns: the SPLIT mapping itself, run out of the stream -- 250 -> 64 is two steps per wave)
+        const bool side = k4 && split && ncg == 1 && side_steps <= 2 && i > 0 && (int)i < nfwd - 1 && p.seg.back().type != NS_SIDE &&
                           !L.Wb && !L.transA && L.Wa && !L.rscale && !L.rshift && !L.b2 && !L.x0_col;
         if (side) {
             s.type = NS_SIDE; s.steps = side_steps; s.passes = 1; s.kslice = 16 * kc * s.steps;
-            s.ncg_log2 = 0; s.kcl = kc == 4 ? 2 : 1;
+            s.ncg_log2 = 0; s.kcl = kc == 4 ? 2 : kc == 2 ? 1 : 0;
             s.zext = 64;
             in_ext[i] = NS_NW * s.kslice;
             q.bias_pad = 64; q.ncg = 1;

@@ -68,3 +68,25 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(_lib.LinnaHipError):
         _lib.ctx()
+
+
+def test_serving_programs_are_planned_on_the_host_without_a_gpu():
+    """linna_program_describe: the segment program of the whole-network kernel for the reference's network class
+    (nn.py:59-133) -- on the 16-row serving engine the hidden h of the three residual blocks (1000 -> 16, 500 -> 32,
+    250 -> 64) are SIDE segments of 4 / 2 / 1 k chunks and two steps, outside the weight stream (107 steps instead of 121);
+    the small-batch engines keep them as SPLIT segments; a plain MLP has none."""
+    import torch  # noqa: F401
+    from linna_amd import nn
+    m = nn.ChtoModelv2(33, 33, None)
+    n16, t16 = nn.describe_program(m, 16)
+    n4, t4 = nn.describe_program(m, 4)
+    assert n16 == n4 == 10 and t16.startswith("ok G 107 ") and t4.startswith("ok G 121 ")
+    seg16, seg4 = t16.splitlines()[1:], t4.splitlines()[1:]
+    assert seg16[1].startswith("SIDE steps 2 passes 1 ncg 1 kc 4") and seg16[3].startswith("SIDE steps 2 passes 1 ncg 1 kc 2")
+    assert seg4[1].startswith("SPLIT steps 8") and seg4[3].startswith("SPLIT steps 4")
+    assert seg16[5].startswith("SIDE steps 2 passes 1 ncg 1 kc 1")
+    assert [ln.split()[0] for ln in seg16] == ["WIDE", "SIDE", "WIDE", "SIDE", "SPLIT", "SIDE", "SPLIT", "WIDE", "SPLIT", "WIDE"]
+    nd, td = nn.describe_program(nn.ChtoModelv2(40, 1000, None), 16, dense_nout=1000)
+    assert nd == 11 and td.count("SIDE") == 3 and td.splitlines()[-1].startswith("WIDE steps 63 passes 2")    # the inverse covariance: last segment
+    nm, tm = nn.describe_program(nn.MLP(33, 33, None), 16)
+    assert nm == 10 and "SIDE" not in tm and " grad 1" in tm.splitlines()[0]                       # forward + backward half
