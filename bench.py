@@ -194,6 +194,12 @@ def _fs_type(path):
     return "%s on %s" % (best[1], best[0] or "?")
 
 
+def _lib_launches(model, B):
+    from linna_amd import _lib
+    n = _lib.load().linna_net_train_launches(model.net_handle(with_grads=True), int(B))
+    return n if n > 0 else None
+
+
 def training_rate(device, world, rank, backend, nsteps=150):
     """BASELINE configs[2] shape: ChtoModelv2(26, 457) (3x2pt-like stand-in), dense covariance, batch 500 PER RANK,
     one all-reduce of the flat gradient per step when N > 1 (RCCL over xGMI), lr * N (predictor_gpu.py:246).
@@ -260,9 +266,9 @@ def training_rate(device, world, rank, backend, nsteps=150):
            "resident_rows": n,
            "samples_per_s": world * B * nsteps / dt, "ms_per_step": 1e3 * dt / nsteps, "global_batch": world * B, "steps": nsteps,
            "loss_finite": bool(np.isfinite(loss)),
-           # one rank: one C call, three launches (forward + loss, dX chain, parameter gradients with AdamW in the epilogue);
+           # one rank: one C call, two launches (forward + loss + dX chain; parameter gradients with AdamW in the epilogue);
            # data parallel: the all-reduce sits between backward and update, AdamW is a launch of its own
-           "launches_per_step": 3 if (world == 1 and getattr(eng, "one_update", None) is True) else None}
+           "launches_per_step": (_lib_launches(model, B) if (world == 1 and getattr(eng, "one_update", None) is True) else None)}
     # algorithmic work of one step on one rank: 3 x forward MLP FLOP per sample + the loss's 3 x 2 nout^2
     flop = B * (3 * 2.0 * model.macs_per_eval() + 6.0 * nout * nout)
     res["roofline"] = {"bound": "mfma", "flop_per_step": flop, "achieved": flop / (dt / nsteps) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,

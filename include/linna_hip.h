@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe */
+#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -188,6 +188,11 @@ int linna_net_backward(linna_net_t* net, const float* X, int ldx, int B, void* f
  * whole-network kernel instead of one GEMM per op.  Each flag is -1 (not decided yet: decided at the first
  * call of that kind), 0 or 1.  fwd: linna_net_forward; dx: the dX chain of linna_net_backward with dX == NULL
  * (training); dx_input: with dX != NULL (gradient with respect to the network input).  Any pointer may be NULL. */
+/* Launches of one optimiser step through linna_net_train_step_update for a batch of B rows, once linna_net_prepare_loss
+ * has seen the loss: 2 = forward + loss + dX chain in ONE launch of the whole-network kernel (the 4-row engine:
+ * B <= 1024) and the grouped parameter-gradient launch with the optimiser in its epilogue; 3 = forward + loss and dX chain
+ * as two launches; 0 = the network or its loss trains layer by layer. */
+int linna_net_train_launches(const linna_net_t* net, int B);
 int linna_net_stream_state(const linna_net_t* net, int* fwd, int* dx, int* dx_input);
 
 /* ------------------------------------------------------------------ prior map + input transform

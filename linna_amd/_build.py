@@ -38,12 +38,13 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def build_stamps(extra=("-DNS_STAMPS",), name="liblinna_hip_stamps.so", verbose=True):
+def build_stamps(extra=("-DNS_STAMPS",), name="liblinna_hip_stamps.so", verbose=True, base=True):
     """Diagnostic variant next to the product library: net_stream.hip compiled with phase stamps (every launch of the
     whole-network kernel then needs LINNA_FUSED_STAMPS), the other objects shared.  Load it with LINNA_LIB_PATH."""
-    build(verbose=verbose)
+    if base:
+        build(verbose=verbose)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    o = os.path.join(CSRC, "net_stream_stamps.o")
+    o = os.path.join(CSRC, "net_stream_%s.o" % os.path.splitext(name)[0].replace("liblinna_hip_", ""))
     src = os.path.join(CSRC, "net_stream.hip")
     if _stale(o, [src, os.path.join(CSRC, "common.h")]) or True:
         cmd = [hipcc] + FLAGS + list(extra) + ["-c", src, "-o", o]

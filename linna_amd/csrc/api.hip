@@ -102,6 +102,9 @@ struct linna_net {
     NsDense loss_dn{nullptr, 0, nullptr, nullptr};   // the inverse covariance that stream ends in
     int stream_loss = -1;                    // -1 unknown, 0 no (not eligible / LINNA_LOSS_STREAM=0), 1 yes
     StreamCopy packed_dx[2];                 // ... for the one-launch dX chain of the backward ([1]: down to the network input)
+    StreamCopy packed_tb;                    // ... for forward + loss + dX chain in ONE launch (linna_net_train_step on the small-batch engines)
+    int stream_tb = -1;                      // -1 unknown, 0 no (not eligible / LINNA_TRAIN_MERGED=0), 1 yes
+    int as_merged = -1;                      // which streams as_args describes: 1 = packed_tb, 0 = packed_loss + packed_dx[0]
     AsArgs as_args;                          // linna_net_adamw_step's descriptor table, valid for (as_params, as_n, as_k)
     const float* as_params = nullptr; size_t as_n = 0; int as_k = -1; int as_state = -1;   // as_state: -1 unknown, 0 unsupported, 1 ready
     int upd_state = -1; int upd_B = 0;       // linna_net_train_step_update: -1 unknown, 0 unsupported, 1 every parameter gradient of the step is in the grouped launch
@@ -307,6 +310,7 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
 int linna_net_destroy(linna_net_t* net) {
     if (net) {
         net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release(); net->packed_loss.release();
+        net->packed_tb.release();
     }
     delete net;
     return LINNA_OK;
@@ -435,6 +439,19 @@ static void net_ensure_loss(linna_net* n, const NsDense& dn) {
     n->packed_loss.release();
     n->stream_loss = 0; n->loss_dn = dn;
     if (ok && n->packed_loss.alloc(net_stream_dense_packed_floats(n->L.data(), nl, n->in_size, dn)) == LINNA_OK) n->stream_loss = 1;
+    // the same loss behind the one-launch training step (forward + loss + dX chain in one weight stream)
+    const char* m = getenv("LINNA_TRAIN_MERGED");
+    const char* b = getenv("LINNA_BWD_STREAM");
+    const bool okm = ok && n->stream_loss == 1 && !(m && m[0] == '0') && !(b && b[0] == '0') && nl >= 2 &&
+                     net_stream_tb_eligible(n->L.data(), nl, n->in_size, dn);
+    n->packed_tb.release();
+    n->stream_tb = 0; n->as_merged = -1; n->as_state = -1;
+    if (okm && n->packed_tb.alloc(net_stream_tb_packed_floats(n->L.data(), nl, n->in_size, dn)) == LINNA_OK) n->stream_tb = 1;
+}
+// The one-launch training step serves this batch size (the 4-row engine only) -- decided the same way by every entry
+// that touches the training streams of a step (train_step, train_step_update, adamw_step)
+static bool net_tb_usable(const linna_net* n, int B) {
+    return n->stream_tb == 1 && n->packed_tb.ready() && net_stream_rows(B) == 4;     // (batches of up to 1024 rows)
 }
 int linna_loss_targets(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* YN, int ldyn, void* stream) {
     if (!d || !Y || !YN || nrows < 1 || ldyn < d->nout) { set_error("loss_targets: bad arguments"); return LINNA_ERR_INVALID; }
@@ -454,7 +471,8 @@ int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
 // runs that sequence).  The batch mean is a second, tiny launch (fixed summation order).
 struct NetUpdate { float* params; float* m; float* v; size_t n; float* hyper; float b1, b2, eps; };
 static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
-                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post, const NetUpdate* upd = nullptr);
+                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post, const NetUpdate* upd = nullptr,
+                             bool dx_done = false, const GemmPost* gpost = nullptr);
 static int net_forward_loss_impl(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                                  const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
                                  int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
@@ -472,12 +490,74 @@ int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const flo
 // on the rows it gathered, with the step's two single-thread jobs (batch mean of the loss, AdamW step counter and bias
 // corrections) riding in the backward's dX-chain launch as one extra workgroup instead of a launch of their own between
 // the two whole-network launches.  LINNA_ERR_UNSUPPORTED exactly when linna_net_forward_loss is.
+// Forward + loss + dX chain of a training step in ONE launch (net_stream.hip TRB); the caller has checked net_tb_usable.
+static int net_train_merged_impl(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
+                                 const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* fwd_ws, float* PRED,
+                                 int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
+                                 float* dPRED, int lddp, void* bwd_ws, float* hyper, int* step_dev, float b1, float b2, void* stream) {
+    if (!n || !d || !X || !xmean || !xstd || !XB || !PRED || !YN || !den || !loss_rows || !dPRED || !fwd_ws || !bwd_ws || B < 1) {
+        set_error("net_train_step: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    if (d->nout != n->out_size) { set_error("net_train_step: loss for %d outputs, network has %d", d->nout, n->out_size); return LINNA_ERR_INVALID; }
+    const int nl = (int)n->L.size();
+    const FwdLayout f = fwd_layout(n, B);
+    float* w = static_cast<float*>(fwd_ws);
+    float* bw = static_cast<float*>(bwd_ws);
+    const int rows = net_stream_rows(B);
+    const float* packed = nullptr;
+    TRY(stream_copy_refresh(n->packed_tb, n, rows, stream, &packed, 4, &n->loss_dn));
+    std::vector<float*> y(nl), t(nl), dprev(nl, nullptr), dt(nl, nullptr);
+    std::vector<const float*> hinp(nl, nullptr);
+    std::vector<int> ldy_(nl), ldt(nl), ldpv(nl, 0), ldhv(nl, 0), lddt(nl, 0);
+    for (int i = 0; i < nl; ++i) {
+        const bool last = i == nl - 1;
+        y[i] = last ? PRED : w + f.y_off[i]; ldy_[i] = last ? ldp : ld4(n->L[i].N);
+        t[i] = n->L[i].op == LINNA_OP_RESBLOCK ? w + f.t_off[i] : nullptr; ldt[i] = ld4(n->L[i].C);
+    }
+    float* cur = bw;
+    for (int i = nl - 1; i >= 1; --i) {                            // net_backward_impl's workspace walk (no input gradient)
+        const linna_layer_t& l = n->L[i];
+        dprev[i] = cur; ldpv[i] = ld4(l.K);
+        cur += (size_t)B * ld4(l.K);
+        const bool hin_relu = n->L[i - 1].op == LINNA_OP_RESBLOCK || n->L[i - 1].relu;
+        hinp[i] = hin_relu ? w + f.y_off[i - 1] : nullptr; ldhv[i] = ld4(n->L[i - 1].N);
+        if (l.op == LINNA_OP_RESBLOCK) { dt[i] = cur; lddt[i] = ld4(l.C); cur += (size_t)B * ld4(l.C); }
+    }
+    const NsTrainLoss L{YN, ldyn, den, inv_batch, loss_rows, dPRED, lddp};
+    const bool prep = hyper && step_dev;
+    const NsPost post{nullptr, 0, 0.f, nullptr, prep ? step_dev : nullptr, prep ? hyper : nullptr, b1, b2};
+    return launch_net_stream_train_bwd(n->L.data(), nl, n->in_size, packed, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, y.data(),
+                                       ldy_.data(), t.data(), ldt.data(), L, n->loss_dn, dprev.data(), ldpv.data(), hinp.data(),
+                                       ldhv.data(), dt.data(), lddt.data(), rows, S(stream), prep ? &post : nullptr);
+}
+// (the loss descriptor's stream state, as net_forward_loss_impl establishes it)
+static int net_train_ensure_loss(linna_net_t* n, const linna_loss_desc_t* d, void* stream) {
+    if (!n || !d) { set_error("net_train_step: null argument"); return LINNA_ERR_INVALID; }
+    const NsDense dn{d->Cinv, d->ldc, nullptr, nullptr};
+    if (n->stream_loss < 0 || n->loss_dn.S != dn.S || n->loss_dn.lds != dn.lds) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(S(stream), &cap);
+        if (cap != hipStreamCaptureStatusNone) {
+            set_error("net_train_step: first use inside a stream capture (call linna_net_prepare_loss before)"); return LINNA_ERR_UNSUPPORTED;
+        }
+        net_ensure_loss(n, dn);
+    }
+    return LINNA_OK;
+}
 int linna_net_train_step(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                          const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* fwd_ws, float* PRED,
                          int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
                          float* loss_mean, float* dPRED, int lddp, void* bwd_ws, float* hyper, int* step_dev, float b1, float b2,
                          void* stream) {
     if (!bwd_ws) { set_error("net_train_step: backward workspace required"); return LINNA_ERR_INVALID; }
+    TRY(net_train_ensure_loss(n, d, stream));
+    if (net_tb_usable(n, B)) {
+        // two launches: forward + loss + dX chain, then every parameter gradient (the batch mean of the loss riding in it)
+        TRY(net_train_merged_impl(n, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, fwd_ws, PRED, ldp, YN, ldyn, den, inv_batch,
+                                  loss_rows, dPRED, lddp, bwd_ws, hyper, step_dev, b1, b2, stream));
+        const GemmPost gp{loss_rows, loss_mean ? B : 0, inv_batch, loss_mean};
+        return net_backward_impl(n, XB, ldxb, B, fwd_ws, bwd_ws, dPRED, lddp, nullptr, 0, 1, stream, nullptr, nullptr, true, &gp);
+    }
     TRY(net_forward_loss_impl(n, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, fwd_ws, PRED, ldp, YN, ldyn, den, inv_batch,
                               loss_rows, loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, true));
     const bool prep = hyper && step_dev;
@@ -529,6 +609,12 @@ static int net_forward_loss_impl(linna_net_t* n, const linna_loss_desc_t* d, con
     return LINNA_OK;
 }
 
+int linna_net_train_launches(const linna_net_t* n, int B) {
+    if (!n || B < 1) { set_error("net_train_launches: bad arguments"); return LINNA_ERR_INVALID; }
+    if (n->stream_loss != 1) return 0;
+    if (net_tb_usable(n, B)) return 2;
+    return n->stream_bwd[0] == 1 ? 3 : 0;
+}
 int linna_net_stream_state(const linna_net_t* n, int* fwd, int* dx, int* dx_input) {
     if (!n) { set_error("net_stream_state: null network"); return LINNA_ERR_INVALID; }
     if (fwd) *fwd = n->stream_fwd;
@@ -545,8 +631,11 @@ int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd
 // as an extra workgroup, or run as the launch of their own they otherwise are, in front of the GEMM chain
 // `upd`: the optimiser rides in the grouped parameter-gradient launch (linna_net_train_step_update; the caller has checked
 // net_update_supported: every parameter gradient of the step goes into that launch)
+// `dx_done`: the dX chain already ran (inside the one-launch training step): only the parameter gradients are left;
+// `gpost`: the batch mean of the loss rows rides in the grouped parameter-gradient launch as one extra workgroup
 static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
-                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post, const NetUpdate* upd) {
+                             int lddo, float* dX, int lddx, int pg, void* stream, const NsPost* post, const NetUpdate* upd,
+                             bool dx_done, const GemmPost* gpost) {
     if (!n || !X || !dOUT || !bwd_ws || B < 1) { set_error("net_backward: bad arguments"); return LINNA_ERR_INVALID; }
     const FwdLayout f = fwd_layout(n, B);
     const float* w = static_cast<const float*>(fwd_ws);
@@ -647,9 +736,9 @@ static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, voi
     // The dX chain -- one GEMM per op, each waiting for the one before (140 us of 300 at batch 500) -- as ONE launch of
     // the whole-network kernel over the transposed weights (net_stream.hip, STORE == 2), when the network has such a
     // program.  The loop below then only collects the parameter gradients.
-    bool fused_dx = false;
+    bool fused_dx = dx_done;
     const int wi = dX ? 1 : 0;
-    if (!n->has_inskip && (nl >= 2 || dX)) {
+    if (!dx_done && !n->has_inskip && (nl >= 2 || dX)) {
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
         net_ensure_dx(n, wi, cap == hipStreamCaptureStatusNone);
@@ -741,8 +830,9 @@ static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, voi
         }
         dcur = dprev; ldd = ldp;
     }
-    if (grp.nprob) TRY(gemm_launch_group(grp, grp_blocks, st));     // every dY is on `st` by now: one grid over all the dW tiles
-    if (grpu.nprob) TRY(gemm_launch_group_update(grpu, gu, grp_blocks, st));
+    if (grp.nprob) { TRY(gemm_launch_group(grp, grp_blocks, st, gpost)); gpost = nullptr; }     // every dY is on `st` by now: one grid over all the dW tiles
+    if (grpu.nprob) { TRY(gemm_launch_group_update(grpu, gu, grp_blocks, st, gpost)); gpost = nullptr; }
+    if (gpost && gpost->n > 0) TRY(launch_sum_scale(gpost->rows, gpost->n, gpost->scale, gpost->out, st));   // (no grouped launch to ride in)
     if (overlap && aux_used) {       // join: the caller's stream continues only after every gradient is written
         hipEvent_t e = ctx->events[next_event++];
         TRY(check_hip(hipEventRecord(e, ctx->aux), "hipEventRecord"));
@@ -1183,14 +1273,17 @@ int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v,
 // The placement tables of the flat parameter buffer `p[n]` in the two training streams (net_stream_adamw_args), cached.
 static int net_ensure_as_args(linna_net_t* net, int B, const float* p, size_t n) {
     static const bool off = getenv("LINNA_ADAMW_STREAMS") && getenv("LINNA_ADAMW_STREAMS")[0] == '0';
-    if (off || net->stream_loss != 1 || net->stream_bwd[0] != 1 || !net->packed_loss.ready() || !net->packed_dx[0].ready()) {
+    const int merged = net_tb_usable(net, B) ? 1 : 0;
+    if (off || net->stream_loss != 1 || (!merged && (net->stream_bwd[0] != 1 || !net->packed_loss.ready() || !net->packed_dx[0].ready()))) {
         set_error("the network does not train through the whole-network streams"); return LINNA_ERR_UNSUPPORTED;
     }
     const int rows = net_stream_rows(B), k = rows < 16 ? 1 : 0;
-    if (net->as_state < 0 || net->as_params != p || net->as_n != n || net->as_k != k) {
-        net->as_params = p; net->as_n = n; net->as_k = k;
-        net->as_state = net_stream_adamw_args(net->L.data(), (int)net->L.size(), net->in_size, rows, p, n, net->packed_loss.buf[k],
-                                              &net->loss_dn, net->packed_dx[0].buf[k], &net->as_args) == LINNA_OK ? 1 : 0;
+    if (net->as_state < 0 || net->as_params != p || net->as_n != n || net->as_k != k || net->as_merged != merged) {
+        net->as_params = p; net->as_n = n; net->as_k = k; net->as_merged = merged;
+        net->as_state = (merged ? net_stream_adamw_args(net->L.data(), (int)net->L.size(), net->in_size, rows, p, n, net->packed_tb.buf[k],
+                                                        &net->loss_dn, nullptr, &net->as_args, 1)
+                                : net_stream_adamw_args(net->L.data(), (int)net->L.size(), net->in_size, rows, p, n, net->packed_loss.buf[k],
+                                                        &net->loss_dn, net->packed_dx[0].buf[k], &net->as_args)) == LINNA_OK ? 1 : 0;
         net->upd_state = -1;
     }
     return net->as_state == 1 ? LINNA_OK : LINNA_ERR_UNSUPPORTED;   // (the error text is net_stream_adamw_args')
@@ -1203,14 +1296,22 @@ int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, floa
     const int rows = net_stream_rows(B), k = rows < 16 ? 1 : 0;
     // both streams must hold the CURRENT weights and their constant parts before they are patched in place
     const float* dummy = nullptr;
-    TRY(stream_copy_refresh(net->packed_loss, net, rows, stream, &dummy, 0, &net->loss_dn));
-    TRY(stream_copy_refresh(net->packed_dx[0], net, rows, stream, &dummy, 1, nullptr));
+    const bool merged = net->as_merged == 1;
+    if (merged) {
+        TRY(stream_copy_refresh(net->packed_tb, net, rows, stream, &dummy, 4, &net->loss_dn));
+    } else {
+        TRY(stream_copy_refresh(net->packed_loss, net, rows, stream, &dummy, 0, &net->loss_dn));
+        TRY(stream_copy_refresh(net->packed_dx[0], net, rows, stream, &dummy, 1, nullptr));
+    }
     if (!prepared) TRY(launch_adamw_prepare(hyper, step_dev, b1, b2, S(stream)));
     TRY(launch_adamw_streams(net->as_args, p, g, m, v, hyper, b1, b2, eps, S(stream)));
     const unsigned long long epoch = g_weights_epoch.fetch_add(1) + 1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(S(stream), &cap);
-    if (cap == hipStreamCaptureStatusNone) { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
+    if (cap == hipStreamCaptureStatusNone) {
+        if (merged) net->packed_tb.epoch[k] = epoch;
+        else { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
+    }
     return LINNA_OK;
 }
 
@@ -1228,6 +1329,7 @@ int linna_net_train_step_update(linna_net_t* net, const linna_loss_desc_t* d, co
     if (!net || !params || !m || !v || !hyper || !step_dev || !bwd_ws || B < 1) { set_error("net_train_step_update: bad arguments"); return LINNA_ERR_INVALID; }
     static const bool off = getenv("LINNA_ADAMW_IN_GEMM") && getenv("LINNA_ADAMW_IN_GEMM")[0] == '0';
     if (off || net->has_inskip) { set_error("net_train_step_update: switched off / input-skip network"); return LINNA_ERR_UNSUPPORTED; }
+    TRY(net_train_ensure_loss(net, d, stream));
     TRY(net_ensure_as_args(net, B, params, n));
     if (net->upd_state < 0 || net->upd_B != B) {
         // every parameter gradient of the step must be a problem of the grouped launch, and the gradient pointers of the layer
@@ -1255,16 +1357,29 @@ int linna_net_train_step_update(linna_net_t* net, const linna_loss_desc_t* d, co
         net->upd_B = B;
     }
     if (net->upd_state != 1) { set_error("net_train_step_update: a parameter gradient of this network falls outside the grouped launch"); return LINNA_ERR_UNSUPPORTED; }
-    TRY(net_forward_loss_impl(net, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, fwd_ws, PRED, ldp, YN, ldyn, den, inv_batch,
-                              loss_rows, loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, true));
-    const NsPost post{loss_rows, B, inv_batch, loss_mean, step_dev, hyper, b1, b2};
     const NetUpdate upd{params, m, v, n, hyper, b1, b2, eps};
-    TRY(net_backward_impl(net, XB, ldxb, B, fwd_ws, bwd_ws, dPRED, lddp, nullptr, 0, 1, stream, &post, &upd));
+    const bool merged = net->as_merged == 1;
+    if (merged) {
+        // TWO launches: forward + loss + dX chain (AdamW's step constants riding in it), then every parameter gradient with the
+        // optimiser in the tiles' epilogue (the batch mean of the loss riding in it)
+        TRY(net_train_merged_impl(net, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, fwd_ws, PRED, ldp, YN, ldyn, den, inv_batch,
+                                  loss_rows, dPRED, lddp, bwd_ws, hyper, step_dev, b1, b2, stream));
+        const GemmPost gp{loss_rows, loss_mean ? B : 0, inv_batch, loss_mean};
+        TRY(net_backward_impl(net, XB, ldxb, B, fwd_ws, bwd_ws, dPRED, lddp, nullptr, 0, 1, stream, nullptr, &upd, true, &gp));
+    } else {
+        TRY(net_forward_loss_impl(net, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, fwd_ws, PRED, ldp, YN, ldyn, den, inv_batch,
+                                  loss_rows, loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, true));
+        const NsPost post{loss_rows, B, inv_batch, loss_mean, step_dev, hyper, b1, b2};
+        TRY(net_backward_impl(net, XB, ldxb, B, fwd_ws, bwd_ws, dPRED, lddp, nullptr, 0, 1, stream, &post, &upd));
+    }
     const int k = net_stream_rows(B) < 16 ? 1 : 0;
     const unsigned long long epoch = g_weights_epoch.fetch_add(1) + 1;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(S(stream), &cap);
-    if (cap == hipStreamCaptureStatusNone) { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
+    if (cap == hipStreamCaptureStatusNone) {
+        if (merged) net->packed_tb.epoch[k] = epoch;
+        else { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
+    }
     return LINNA_OK;
 }
 

@@ -143,6 +143,9 @@ size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_s
 // A small job that rides in the dX-chain launch as one extra workgroup (linna_net_train_step): the batch mean of the loss
 // rows (out = scale * sum rows[n], sum_scale_prepare_kernel's order) and AdamW's step counter / bias corrections
 struct NsPost { const float* rows; int n; float scale; float* out; int* step; float* hyper; float b1, b2; };
+struct NsTrainLoss;
+bool net_stream_tb_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn);
+size_t net_stream_tb_packed_floats(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn);
 int launch_net_stream_dx(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* dOUT, int lddo,
                          int B, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
                          float* const* dt, const int* lddt, const float* const* t, const int* ldt, int with_input, int rows,
@@ -168,6 +171,12 @@ int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, co
                             const int* ROWS, int B, const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb,
                             float* const* y, const int* ldy, float* const* t, const int* ldt, const NsTrainLoss& L,
                             const NsDense& dn, int rows, hipStream_t s);
+// the same followed by the dX chain down to op 1 in the SAME launch (GRAD + STORE == 3; prog 4)
+int launch_net_stream_train_bwd(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
+                                const int* ROWS, int B, const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb,
+                                float* const* y, const int* ldy, float* const* t, const int* ldt, const NsTrainLoss& L,
+                                const NsDense& dn, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
+                                float* const* dt, const int* lddt, int rows, hipStream_t s, const NsPost* post);
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
 struct NsGrad { const float* gscale; float* G; int ldg; };
 // AdamW that also writes the two weight streams of a training step (net_stream.hip: adamw_streams_kernel; gemm.hip: the
@@ -198,7 +207,7 @@ __device__ __forceinline__ void adamw_one(float& pi, float gi, float& mi, float&
     pi = pi - (lr / bc1) * (mi / denom);
 }
 int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int rows, const float* params, size_t nflat,
-                          float* s_fwd, const NsDense* dn, float* s_dx, AsArgs* out);
+                          float* s_fwd, const NsDense* dn, float* s_dx, AsArgs* out, int merged = 0);
 int launch_adamw_streams(const AsArgs& a, float* p, const float* g, float* m, float* v, const float* hyper, float b1, float b2,
                          float eps, hipStream_t s);
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size);
@@ -232,9 +241,10 @@ struct GemmUpdate { long long pdiff, mdiff, vdiff;           // parameter / mome
                     const float* hyper; float beta1, beta2, eps; int small;
                     AsPlace pl[GEMM_UPD_MAX][2]; AsBias bias[GEMM_UPD_MAX]; };
 struct GemmUpd1 { long long pdiff, mdiff, vdiff; const float* hyper; float beta1, beta2, eps; int small; AsPlace pl[2]; AsBias bias; };
-int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream);
+struct GemmPost { const float* rows; int n; float scale; float* out; };   // batch mean of the loss rows riding as one extra workgroup
+int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream, const GemmPost* post = nullptr);
 bool gemm_group_ok(const GemmArgs& a);
 int gemm_group_blocks(const GemmArgs& a);
-int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream);
+int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream, const GemmPost* post = nullptr);
 
 }  // namespace linna

@@ -483,8 +483,34 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a, KSp
 // (column sums of dY) taken inside the tiles of the first tile column.  The descriptors travel BY VALUE as
 // kernel arguments (56 bytes per problem): no device table, nothing to upload, capturable as it is; the
 // search for a block's problem runs on the scalar unit over the kernarg segment.
+// The batch mean of a training step's loss rows as one extra workgroup of the grouped parameter-gradient launch (the
+// one-launch forward + loss + dX chain cannot hold it: the rows are complete only when every workgroup has passed its
+// turnaround).  sum_scale_prepare_kernel's arithmetic in its order: 1024 strided partial sums (four per thread here),
+// sixteen wave sums, added in wave order.
+__device__ __forceinline__ void gemm_post_mean(const GemmPost& q) {
+    __shared__ float post_part[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        for (int i = tid + 256 * j; i < q.n; i += 1024) acc[j] += q.rows[i];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+        if (lane == 0) post_part[wave + 4 * j] = acc[j];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += post_part[w];
+        q.out[0] = t * q.scale;
+    }
+}
+
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const GemmGroupArgs g) {
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const GemmGroupArgs g, const GemmPost post) {
+    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean(post); return; }
     int p = 0;
     while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
     const GemmGroupProb q = g.p[p];
@@ -499,7 +525,8 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const Gem
 }
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
-__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_update_kernel(const GemmGroupArgsS g, const GemmUpdate u) {
+__global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_update_kernel(const GemmGroupArgsS g, const GemmUpdate u, const GemmPost post) {
+    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean(post); return; }
     int p = 0;
     while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
     const GemmGroupProb q = g.p[p];
@@ -619,15 +646,17 @@ bool gemm_group_ok(const GemmArgs& a) {
            ((a.p[0].lda | a.p[0].ldb) & 3) == 0;
 }
 int gemm_group_blocks(const GemmArgs& a) { return ((a.M + 63) / 64) * ((a.N + 63) / 64); }
-int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream) {
+int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream, const GemmPost* post) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
-    hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks), dim3(256), lds, stream, g);
+    const GemmPost q = post ? *post : GemmPost{nullptr, 0, 0.f, nullptr};
+    hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(256), lds, stream, g, q);
     return check_hip(hipGetLastError(), "gemm group launch");
 }
 
-int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream) {
+int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream, const GemmPost* post) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
-    hipLaunchKernelGGL((gemm_group_update_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks), dim3(256), lds, stream, g, u);
+    const GemmPost q = post ? *post : GemmPost{nullptr, 0, 0.f, nullptr};
+    hipLaunchKernelGGL((gemm_group_update_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(256), lds, stream, g, u, q);
     return check_hip(hipGetLastError(), "gemm group update launch");
 }
 

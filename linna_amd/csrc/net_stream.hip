@@ -272,6 +272,13 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NQ = SM ? RS : NT;               // result quads per lane: (row set) or (column tile)
     constexpr int NACC = SM ? 4 * RS : NT;
     constexpr bool K4 = !SM && STORE == 0;         // serving instantiations of the 16-row engine: programs may hold SIDE segments
+    // TRB: a whole training step's network work in ONE launch (linna_net_train_step): gather + transform + forward with the
+    // activations kept + chi^2-ratio loss (STORE == 3) as the forward half, the loss finish as the TURNAROUND (loss rows,
+    // d loss / d pred to memory AND into LDS as the input of the first backward segment), then the dX chain (STORE == 2's
+    // epilogues: gates from the activations this very launch stored, read through the L2) -- one prologue and one launch
+    // boundary less than forward + loss and dX chain as two launches, the weight ring never drained in between.
+    constexpr bool TRB = GRAD && STORE == 3;
+    constexpr bool DXE = STORE == 2 || TRB;        // epilogues of dX segments: gate by the stored activation, store
     static_assert(ROWS == 16 || ROWS == 8 || ROWS == 4, "rows per workgroup");
     static_assert(R % 2 == 0, "the A double buffer alternates with the ring slot parity");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -283,8 +290,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const int li = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.x * ROWS;
     if (a.gate && a.gate[0] == 0) return;
-    if constexpr (STORE == 2 && !GRAD) {
-        if (a.p_n > 0 && blockIdx.x == gridDim.x - 1) {
+    if constexpr ((STORE == 2 && !GRAD) || TRB) {
+        if ((a.p_n > 0 || a.p_step) && blockIdx.x == gridDim.x - 1) {
             // sum_scale_prepare_kernel's arithmetic in its order: 1024 strided partial sums (two per thread here),
             // sixteen wave sums, added in wave order
             float* const part = smem;
@@ -332,6 +339,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         zden = a.t_den[zsrc];
     }
     const int kpad0 = a.kpad0, nin = a.nin, nout = a.nout, nseg = a.nseg;
+    const int nlast = (TRB ? a.nseg_f : nseg) - 2;  // STORE == 3: the network's last layer (the loss segment follows it)
     constexpr int ZPRE = 2;
     float zr[ZPRE], za1[ZPRE], za2[ZPRE], zxm[ZPRE], zxs[ZPRE]; int zfl[ZPRE], zlg[ZPRE];
     const int* const lgp = a.lg ? a.lg : a.is_flat;
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
     for (int i = 0; i < FIN; ++i) {
         const int cc = min(pc0 + i * RG, nout - 1);
-        if constexpr (GRAD) fgs[i] = a.gscale[cc]; else fgs[i] = 0.f;
+        if constexpr (GRAD && !TRB) fgs[i] = a.gscale[cc]; else fgs[i] = 0.f;
         const int c1 = a.cscale ? cc : 0, c2 = a.cshift ? cc : 0, c3 = a.w ? cc : 0;
         const float cs = csp[c1], ct = ctp[c2], ww = wtp[c3];
         fcs[i] = a.cscale ? cs : 1.f; fct[i] = a.cshift ? ct : 0.f; fw[i] = a.w ? ww : 0.f;
@@ -525,6 +533,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // raw: __syncthreads() would drain the weight stream
     asm volatile("" ::: "memory");
+#ifdef NS_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(NS_PRIO);          // experiment: static priority for the second-dispatched half
+#endif
+#ifdef NS_STAGGER
+    if (wave >= 4) __builtin_amdgcn_s_sleep(NS_STAGGER);
+#endif
     NS_STAMP();
 
     // ---- 4. the step loop
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2; s_x0col = S.x0_col; s_x0n = S.x0_n;
         if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
         if constexpr (STORE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gout = a.gout[j]; s_gld = a.gld[j]; s_gn = a.gn[j]; }
-        if constexpr (STORE == 2) { const int j = __builtin_amdgcn_readfirstlane(si); s_gmask = a.gmask[j]; s_gmld = a.gmld[j]; }
+        if constexpr (DXE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gmask = a.gmask[j]; s_gmld = a.gmld[j]; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         const int arow = SM ? sm_arow : li, ak = SM ? 4 * sm_achunk : 4 * kq;
@@ -580,6 +594,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#ifdef NS_STAGGER
+        if (wave >= 4) __builtin_amdgcn_s_sleep(NS_STAGGER);     // experiment: SIMD partners half a step apart (-DNS_STAGGER=n x 64 cycles)
+#endif
     };
     load_seg();
     begin_run();
@@ -629,7 +646,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             float* nx_gout = nullptr; int nx_gld = 0, nx_gn = 0;
             const float* nx_gmask = nullptr; int nx_gmld = 0;
             if constexpr (STORE) { nx_gout = a.gout[nxi]; nx_gld = a.gld[nxi]; nx_gn = a.gn[nxi]; }
-            if constexpr (STORE == 2) { nx_gmask = a.gmask[nxi]; nx_gmld = a.gmld[nxi]; }
+            if constexpr (DXE) { nx_gmask = a.gmask[nxi]; nx_gmld = a.gmld[nxi]; }
             const int cur_steps = s_steps;
             auto take_seg = [&](const NsSeg& X) {
                 s_type = X.type; s_steps = X.steps; s_passes = X.passes; s_bias = X.bias_off;
@@ -641,7 +658,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             auto take_next = [&]() {
                 take_seg(NX);
                 if constexpr (STORE) { s_gout = nx_gout; s_gld = nx_gld; s_gn = nx_gn; }
-                if constexpr (STORE == 2) { s_gmask = nx_gmask; s_gmld = nx_gmld; }
+                if constexpr (DXE) { s_gmask = nx_gmask; s_gmld = nx_gmld; }
             };
             // SIDE segment next (and this run is its predecessor's last): its weights are requested NOW, by loads the compiler
             // does not see, so that they fly under this segment's epilogue and barrier
@@ -685,7 +702,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 // for the weight ring into vmcnt(0) in EVERY step); one explicit wait for all of them
                 float ty[NQ][4];                        // STORE == 3: normalised targets; STORE == 2: gates
                 if constexpr (STORE == 3) {
-                    if (si == nseg - 2) {
+                    if (si == nlast) {
 #pragma unroll
                         for (int t = 0; t < NQ; ++t) {
                             const int dc = min(512 * pass + 64 * wave + q_col(t), nout - 1);
@@ -700,7 +717,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ty[t][0]), "+v"(ty[t][1]), "+v"(ty[t][2]), "+v"(ty[t][3]) :: "memory");
                     }
                 }
-                if constexpr (STORE == 2) {
+                if constexpr (DXE) {
                     // the gates (stored forward activations), by loads the compiler does not count -- a visible load in this
                     // loop body makes every step's wait for the weight ring a vmcnt(0) -- with one explicit wait
                     if (s_gmask) {
@@ -740,12 +757,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         float v = fin[t][e];
                         if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
                         v = s_relu ? fmaxf(v, 0.f) : v;
-                        if constexpr (STORE == 2) {
+                        if constexpr (DXE) {
                             if (s_gmask && !(ty[t][e] > 0.f)) v = 0.f;
                         }
                         float v_lds = v;
                         if constexpr (STORE == 3) {
-                            if (si == nseg - 2) {              // the network's last layer: delta replaces pred in LDS
+                            if (si == nlast) {                 // the network's last layer: delta replaces pred in LDS
                                 const int dc = 512 * pass + 64 * wave + q_col(t);
                                 const float yn = ty[t][e];
                                 v_lds = dc < nout ? (isnan(yn) ? -0.f : (yn - v) + 0.f) : 0.f;   // -0: "masked", read back by the finish
@@ -798,7 +815,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 const int sw = SM ? 32 * (sr & 1) : 16 * (sr >> 2);
                 constexpr int NGJ = 256 / RGS;          // (SPLIT outputs are <= 256 columns: 8 / 4 / 2 per thread)
                 float sg[NGJ];
-                if constexpr (STORE == 2) {
+                if constexpr (DXE) {
                     if (s_gmask) {
 #pragma unroll
                         for (int j = 0; j < NGJ; ++j) {
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         }
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
-                        if constexpr (STORE == 2) {
+                        if constexpr (DXE) {
                             float gv = 1.f;             // (dynamic register-array index: a select chain)
 #pragma unroll
                             for (int j = 0; j < NGJ; ++j) gv = gj == j ? sg[j] : gv;
@@ -855,7 +872,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     cur[c] = v;
                 }
                 if constexpr (STORE == 3) {
-                    if (si == nseg - 2) {
+                    if (si == nlast) {
                         // the network's last layer (nout <= 256): thread (row sr, lane sc0) turns its own columns
                         // sc0 + RGS j of pred into delta, in place (asm loads: see the WIDE epilogue)
                         constexpr int NJ = NGJ;
@@ -882,8 +899,46 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
             if constexpr (GRAD) {
                 if (seg_done && si == a.nseg_f) {   // (seg_done: not again after a pass of the first backward segment)
-                    if constexpr (STORE == 2)       // the forward activations every wave stored are in memory before any gate load
+                    if constexpr (DXE)              // the forward activations every wave stored are in memory before any gate load
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if constexpr (TRB) {
+                        // ---- turnaround of a training step = the loss finish: delta and U = delta Cinv sit in LDS (U at column
+                        // u_col of buffer P, or at column 0 with delta in the other buffer).  loss_b = delta . U / den
+                        // (util.py:1086-1088); d loss / d pred = -2 U inv_batch / den, zero where delta was masked, goes to
+                        // memory (the last layer's parameter gradient reads it) AND over delta / U in LDS: the input rows of the
+                        // first backward segment (their padding columns hold the zeros the forward left there).
+                        {
+                            const float* const F = act + P * ABUF + pr * LD;
+                            const bool rok = prow && row0 + pr < a.B;
+                            const float* const Dv = a.u_same ? F : act + (P ^ 1) * ABUF + pr * LD;
+                            const float* const Uv = a.u_same ? F + a.u_col : F;
+                            float chi = 0.f;
+                            for (int c = pc0; c < nout; c += RG) chi += Dv[c] * Uv[c];
+#pragma unroll
+                            for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
+                            if (rok && pc0 == 0) gstore(a.t_loss_rows + row0 + pr, chi / lden[pr]);
+                        }
+                        lds_barrier();                  // every row's chi is taken before delta is overwritten (u_same)
+                        {
+                            constexpr int TPR = 64 * NW / ROWS;
+                            const int fr = tid / TPR, fc = tid % TPR;
+                            float* const Fr = act + P * ABUF + fr * LD;
+                            const float* const Dr = a.u_same ? Fr : act + (P ^ 1) * ABUF + fr * LD;
+                            const float* const Ur = a.u_same ? Fr + a.u_col : Fr;
+                            const float dr = lden[fr];
+                            const bool rowok = row0 + fr < a.B;
+                            for (int c = fc; c < a.t_lddp; c += TPR) {
+                                float g = 0.f;
+                                if (c < nout && rowok) {
+                                    const bool masked = __float_as_uint(Dr[c]) == 0x80000000u;
+                                    g = masked ? 0.f : (-2.f * Ur[c]) * a.t_inv_batch / dr;
+                                }
+                                if (rowok) gstore(a.t_dP + (size_t)(row0 + fr) * a.t_lddp + c, g);
+                                if (c < nout) Fr[c] = g;
+                            }
+                        }
+                        lds_barrier();
+                    } else {
                     // ---- turnaround: the output rows (bias added) sit in buffer P.  lnP as in the finish, and
                     // d lnP / d out = -(d w) gscale / T written over them: the input of the first backward segment
                     float* const F = act + P * ABUF + pr * LD;
@@ -901,6 +956,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
                     lnp_grad = (-0.5f * chi) / a.T + (-0.5f * zz);
                     lds_barrier();
+                    }
                 }
             }
 #undef fin
@@ -1020,7 +1076,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[0]), "+v"(Aq[1]) :: "memory");
     NS_STAMP();
 
-    if constexpr ((STORE == 1 || STORE == 2) && !GRAD) { NS_STAMPS_FLUSH(); return; }   // every output is in global memory already
+    if constexpr (((STORE == 1 || STORE == 2) && !GRAD) || TRB) { NS_STAMPS_FLUSH(); return; }   // every output is in global memory already
     if constexpr (STORE == 3) {
         // ---- 5 (loss).  delta and U = delta Cinv sit in LDS (as d and U of the dense serving program): chi2 = delta . U,
         // loss_b = chi2 / den (util.py:1086-1088), d loss / d pred = -2 U inv_batch / den, zero where delta was masked
@@ -1155,6 +1211,7 @@ struct NsProgram {
     }
     bool ok = false, grad_ok = false;                       // grad_ok: backward segments appended (ReLU MLPs)
     bool dxi_ok = false;                                    // the dX chain down to the input appended (NS_PROG_FWD_DXI)
+    bool train_ok = false;                                  // forward + loss + dX chain (NS_PROG_TRAIN)
     std::vector<int> seg_op, seg_hidden;                    // forward segments: op index; 1 = the hidden h of a residual block
                                                             // (dX-chain program: 1 = d/dh of a residual block, else d/d(input) of the op)
 };
@@ -1162,7 +1219,8 @@ struct NsProgram {
 static int ceil16(int k) { return (k + 15) & ~15; }
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
-enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4, NS_PROG_FWD_DXI = 5 };
+enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4, NS_PROG_FWD_DXI = 5,
+       NS_PROG_TRAIN = 6 };   // TRAIN: forward + loss segment (FWD_DENSE with the loss's inverse covariance) followed by the dX chain down to op 1
 static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn = nullptr, bool k4 = false);
 static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size, bool k4 = false) {
     NsProgram p = ns_build_one(layers, nl, in_size, NS_PROG_FWD, nullptr, k4);
@@ -1182,7 +1240,8 @@ static NsProgram ns_build(const linna_layer_t* layers, int nl, int in_size, bool
 static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, int mode, const NsDense* dn, bool k4) {
     NsProgram p;
     const bool allow_grad = mode == NS_PROG_FWD, dx_prog = mode == NS_PROG_DX || mode == NS_PROG_DX_INPUT;
-    if (mode == NS_PROG_FWD_DENSE && (!dn || !dn->S)) return p;
+    const bool train = mode == NS_PROG_TRAIN;
+    if ((mode == NS_PROG_FWD_DENSE || train) && (!dn || !dn->S)) return p;
     if (nl < 1 || in_size < 1 || in_size > 256) return p;
     // 1. linear maps: [Wa | alpha Wb] over K = [Kapad ; Kb], N outputs, written to dst_col (same_buf: into the input's buffer)
     struct Lin { const float* Wa; int lda, Ka, Kapad; const float* Wb; int ldb, Kb; float alpha; const float* b; float bscale;
@@ -1195,7 +1254,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     // d lnP / d z in one launch for ANY network (residual blocks, SPLIT segments): the forward segments store their
     // activations, the backward segments gate on them (the kernel's GRAD + STORE == 2 instantiation)
     const bool fwd_dxi = mode == NS_PROG_FWD_DXI;
-    for (int i = 0; i < nl && (dx_prog || fwd_dxi); ++i) {      // shape checks as in the forward program
+    for (int i = 0; i < nl && (dx_prog || fwd_dxi || train); ++i) {      // shape checks as in the forward program
         const linna_layer_t& l = layers[i];
         if (l.K != width || l.N < 1 || l.N > 1024 || l.K > 1024) return p;
         if (l.op == LINNA_OP_LINEAR) { if (l.alpha != 1.f) return p; }
@@ -1254,7 +1313,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     }
     if (dx_prog) in_size = layers[nl - 1].N;                   // the rows of this program are d loss / d output
     if (lins.empty() || lins.back().relu || (int)lins.size() > NS_MAXSEG) return p;
-    if (mode == NS_PROG_FWD_DENSE) {
+    if (mode == NS_PROG_FWD_DENSE || train) {
         Lin& last = lins.back();
         if (last.Wb || last.same_buf || last.dst_col) return p;               // the last op must be a plain linear layer
         last.rscale = dn->cscale; last.rshift = dn->cshift;
@@ -1270,6 +1329,11 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     if (fwd_dxi) {
         if (in_size > 64 || lins.back().N > 64) return p;      // (prologue / turnaround constants are held for <= 64 columns)
         push_dx(0);
+        if ((int)lins.size() > NS_MAXSEG) return p;
+    }
+    if (train) {                                               // the turnaround works on the rows in LDS: any width
+        if (nl < 2) return p;
+        push_dx(1);
         if ((int)lins.size() > NS_MAXSEG) return p;
     }
     // Backward (d lnP / d z) for plain ReLU MLPs whose hidden layers come out as WIDE segments: the backward
@@ -1398,6 +1462,7 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
     p.G = Gf; p.Gstride = G; p.nseg_f = nfwd; p.grad_ok = want_grad;
     for (size_t i = 0; i < lins.size(); ++i) { p.seg_op.push_back(lins[i].op); p.seg_hidden.push_back(lins[i].same_buf ? 1 : 0); }
     p.dxi_ok = fwd_dxi;
+    p.train_ok = train;
     p.bias_total = bias_off;
     p.LD = std::max(((maxext + 63) & ~63) + 4, 516);        // >= 516: SPLIT partials need [8][rows][64] floats in one buffer
     if (bias_off > 3 * 64 * NS_NW * 4) return p;            // BMAX rounds of float4 per thread
@@ -1470,6 +1535,7 @@ static NsProgram ns_build_prog_uncached(const linna_layer_t* layers, int nl, int
     }
     if (prog == 0 && dn) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DENSE, dn);
     if (prog == 3) return ns_build_one(layers, nl, in_size, NS_PROG_FWD_DXI);
+    if (prog == 4) return ns_build_one(layers, nl, in_size, NS_PROG_TRAIN, dn);
     return prog == 0 ? ns_build(layers, nl, in_size) : ns_build_one(layers, nl, in_size, prog == 2 ? NS_PROG_DX_INPUT : NS_PROG_DX);
 }
 // Kernel-configuration cache: a program is a pure function of the op list (shapes AND parameter pointers:
@@ -1520,6 +1586,13 @@ bool net_stream_dense_eligible(const linna_layer_t* layers, int nl, int in_size,
 }
 size_t net_stream_dense_packed_floats(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn) {
     return ns_build_prog(layers, nl, in_size, 0, &dn).packed_floats;
+}
+bool net_stream_tb_eligible(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn) {
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 4, &dn);
+    return p.ok && p.train_ok;
+}
+size_t net_stream_tb_packed_floats(const linna_layer_t* layers, int nl, int in_size, const NsDense& dn) {
+    return ns_build_prog(layers, nl, in_size, 4, &dn).packed_floats;
 }
 bool net_stream_dx_eligible(const linna_layer_t* layers, int nl, int in_size, int with_input) {
     return nl >= (with_input ? 1 : 2) && ns_build_prog(layers, nl, in_size, with_input ? 2 : 1).ok;
@@ -1577,8 +1650,14 @@ static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int row
     const NsArgs& a = a0;
 #endif
     if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s, extra);
-    if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s, extra);
-    if constexpr (STORE == 1 && !GRAD) {
+    if constexpr (STORE == 3 && GRAD) {
+        // the one-launch training step exists for the 4-row engine only (batches up to 1024 rows; the caller checks): its
+        // 8-row instantiation needs 256 VGPRs and spills
+    } else {
+        if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s, extra);
+    }
+    if constexpr (STORE == 3 && GRAD) {
+    } else if constexpr (STORE == 1 && !GRAD) {
         // no 16-row instantiation of the training / validation forward: it is the one kernel hipcc (ROCm 7.2) copies the
         // 2 KB argument block to scratch for (234 VGPRs + 2096 bytes of private memory per lane, every argument then read
         // back through scratch); linna_net_forward runs batches of more than 2048 rows on the 8-row engine
@@ -1685,10 +1764,14 @@ __global__ __launch_bounds__(AS_BLOCK) void adamw_streams_kernel(AsArgs a, float
 // when the buffer is not exactly the layers' tensors back to back, or a stream folds something into the weights that
 // an element-wise scatter cannot reproduce (output maps, a second bias).
 int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int rows, const float* params, size_t nflat,
-                          float* s_fwd, const NsDense* dn, float* s_dx, AsArgs* out) {
-    const NsProgram& pf = ns_build_prog(layers, nl, in_size, 0, dn);
-    const NsProgram& pd = ns_build_prog(layers, nl, in_size, 1);
-    if (!pf.ok || !pd.ok || !s_fwd || !s_dx) { set_error("adamw_streams: no forward / dX-chain program"); return LINNA_ERR_UNSUPPORTED; }
+                          float* s_fwd, const NsDense* dn, float* s_dx, AsArgs* out, int merged) {
+    // merged: ONE stream holds the forward + loss segments [0, nseg_f) and the dX chain [nseg_f, nseg) (NS_PROG_TRAIN)
+    const NsProgram& pf = merged ? ns_build_prog(layers, nl, in_size, 4, dn) : ns_build_prog(layers, nl, in_size, 0, dn);
+    const NsProgram& pd = merged ? pf : ns_build_prog(layers, nl, in_size, 1);
+    if (merged) s_dx = s_fwd;
+    if (!pf.ok || !pd.ok || !s_fwd || !s_dx || (merged && !pf.train_ok)) { set_error("adamw_streams: no forward / dX-chain program"); return LINNA_ERR_UNSUPPORTED; }
+    const size_t f_lo = 0, f_hi = merged ? (size_t)pf.nseg_f : pf.pack.size();
+    const size_t d_lo = merged ? (size_t)pf.nseg_f : 0, d_hi = pd.pack.size();
     ::memset(static_cast<void*>(out), 0, sizeof(*out));
     out->small = rows < 16;
     struct T { const float* ptr; int N, K, bias; };
@@ -1709,8 +1792,8 @@ int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int 
         for (int i = 0; i < seg; ++i) first += p.seg[i].steps * p.seg[i].passes;
         return first + pass * p.seg[seg].steps;
     };
-    auto place = [&](const NsProgram& p, float* base, const float* W, AsPlace* q) -> int {
-        for (size_t i = 0; i < p.pack.size(); ++i) {
+    auto place = [&](const NsProgram& p, float* base, const float* W, AsPlace* q, size_t lo, size_t hi) -> int {
+        for (size_t i = lo; i < hi; ++i) {
             const NsPackSeg& S = p.pack[i];
             const bool isA = S.Wa == W, isB = S.Wb == W;
             if (!isA && !isB) continue;
@@ -1740,20 +1823,20 @@ int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int 
             R.idx = (short)nb;
             AsBias& B = out->b[nb++];
             B.N = t.N;
-            for (size_t j = 0; j < pf.pack.size(); ++j) {
+            for (size_t j = f_lo; j < f_hi; ++j) {
                 const NsPackSeg& S = pf.pack[j];
                 if (S.b != t.ptr) continue;
                 if (B.out || S.rscale || S.rshift || S.b2) { set_error("adamw_streams: bias folded or used twice"); return LINNA_ERR_UNSUPPORTED; }
                 B.out = s_fwd + (size_t)NS_NW * pf.Gstride * NS_NT * 256 + S.bias_off; B.scale = S.bscale;
             }
-            for (const NsPackSeg& S : pd.pack) if (S.b == t.ptr) { set_error("adamw_streams: bias in the dX program"); return LINNA_ERR_UNSUPPORTED; }
+            for (size_t j = d_lo; j < d_hi; ++j) if (pd.pack[j].b == t.ptr) { set_error("adamw_streams: bias in the dX program"); return LINNA_ERR_UNSUPPORTED; }
         } else {
             if (nw >= AS_MAXW) { set_error("adamw_streams: weight matrices"); return LINNA_ERR_UNSUPPORTED; }
             R.idx = (short)nw;
             AsMat& W = out->w[nw++];
             W.N = t.N; W.ld = ld;
-            int rc = place(pf, s_fwd, t.ptr, &W.pl[0]);
-            if (rc == LINNA_OK) rc = place(pd, s_dx, t.ptr, &W.pl[1]);
+            int rc = place(pf, s_fwd, t.ptr, &W.pl[0], f_lo, f_hi);
+            if (rc == LINNA_OK) rc = place(pd, s_dx, t.ptr, &W.pl[1], d_lo, d_hi);
             if (rc != LINNA_OK) return rc;
             if (!W.pl[0].out) { set_error("adamw_streams: a weight matrix outside the forward stream"); return LINNA_ERR_UNSUPPORTED; }
         }
@@ -1910,6 +1993,49 @@ int launch_net_stream_train(const linna_layer_t* layers, int nl, int in_size, co
     a.t_Y = L.YN; a.t_ldy = L.ldyn;
     a.t_den = L.den; a.t_inv_batch = L.inv_batch; a.t_loss_rows = L.loss_rows; a.t_dP = L.dP; a.t_lddp = L.lddp;
     return ns_launch_kernel<0, false, 3>(a, B, p, rows, s);
+}
+
+// A training step's network work in ONE launch (TRB: GRAD + STORE == 3): launch_net_stream_train's forward + loss, its
+// finish as the turnaround, then launch_net_stream_dx's chain down to op 1 -- same arguments as the two of them.  `post`:
+// only the AdamW step constants ride here (the loss rows are not complete before every workgroup's turnaround: the batch
+// mean rides in the parameter-gradient launch instead).
+int launch_net_stream_train_bwd(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
+                                const int* ROWS, int B, const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb,
+                                float* const* y, const int* ldy, float* const* t, const int* ldt, const NsTrainLoss& L,
+                                const NsDense& dn, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
+                                float* const* dt, const int* lddt, int rows, hipStream_t s, const NsPost* post) {
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 4, &dn);
+    if (!p.ok || !p.train_ok || !p.dense) { set_error("net_stream: network + loss have no one-launch training program"); return LINNA_ERR_UNSUPPORTED; }
+    if (rows != 4) { set_error("net_stream: the one-launch training step runs on the 4-row engine"); return LINNA_ERR_UNSUPPORTED; }
+    NsArgs a;
+    ::memset(static_cast<void*>(&a), 0, sizeof(a));
+    a.Z = X; a.ldz = ldx; a.B = B; a.nin = in_size;
+    a.is_flat = reinterpret_cast<const int*>(xmean); a.a1 = xmean; a.a2 = xmean;     // loaded and ignored
+    a.lg = lg; a.xmean = xmean; a.xstd = xstd;
+    a.packed = packed;
+    a.Gstride = p.Gstride; a.nseg_f = p.nseg_f; a.G = p.Gstride; a.nseg = (int)p.seg.size();
+    a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
+    a.T = 1.f;
+    a.dense = p.dense; a.u_col = p.u_col; a.u_same = p.u_same;
+    for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
+    for (int i = 0; i < (int)p.seg.size(); ++i) {
+        const int op = p.seg_op[i];
+        if (i < p.nseg_f) {
+            if (op >= nl) continue;                               // the loss segment stores nothing
+            if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
+            else { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
+        } else if (p.seg_hidden[i]) {                             // d/dh of residual block op, gated by its stored h
+            a.gout[i] = dt[op]; a.gld[i] = lddt[op]; a.gn[i] = layers[op].C; a.gmask[i] = t[op]; a.gmld[i] = ldt[op];
+        } else {                                                  // d/d(input of op), gated by the producing op's output
+            a.gout[i] = dprev[op]; a.gld[i] = ldp[op]; a.gn[i] = layers[op].K; a.gmask[i] = hin[op]; a.gmld[i] = ldh[op];
+        }
+    }
+    a.t_rows = ROWS; a.t_xb = XB; a.t_ldxb = ldxb;
+    a.t_Y = L.YN; a.t_ldy = L.ldyn;
+    a.t_den = L.den; a.t_inv_batch = L.inv_batch; a.t_loss_rows = L.loss_rows; a.t_dP = L.dP; a.t_lddp = L.lddp;
+    int extra = 0;
+    if (post && post->step) { a.p_step = post->step; a.p_hyper = post->hyper; a.p_b1 = post->b1; a.p_b2 = post->b2; extra = 1; }
+    return ns_launch_kernel<0, true, 3>(a, B, p, rows, s, extra);
 }
 }  // namespace linna
 

@@ -91,7 +91,8 @@ class TrainEngine(object):
             # whole-network kernel (seven launches otherwise)
             # (linna_net_train_step: that launch AND the backward in one call, the batch mean of the loss and AdamW's step
             # constants riding in the backward's dX-chain launch; `update`: AdamW too, in the epilogue of the grouped
-            # parameter-gradient launch -- the whole optimiser step in one call and three launches)
+            # parameter-gradient launch -- the whole optimiser step in one call; since round 3 forward + loss + dX chain are ONE
+            # launch on the small-batch engines: two launches per step)
             m = self.model
             self._updated = False
             if update and opt is not None and self.one_update is not False:

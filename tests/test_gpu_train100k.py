@@ -74,7 +74,7 @@ def test_full_epoch_over_a_100k_row_resident_set():
     for s in range(nsteps):
         eng.step(frozen, perm[s], hist[s:s + 1])
     torch.cuda.synchronize()
-    assert eng.one_update is True                              # the one-call, three-launch step is what ran
+    assert eng.one_update is True                              # the one-call step (two launches: forward + loss + dX chain, parameter gradients + AdamW) is what ran
     assert eng.YN.shape[0] == NROWS                            # linna_loss_targets over the whole resident set
     for k, v in model.state_dict().items():
         np.testing.assert_array_equal(v.cpu().numpy(), w0[k])

@@ -115,6 +115,8 @@ def test_adamw_writing_the_weight_streams_equals_update_plus_relayout(name):
     if name in ("train_v2_33_33", "train_v2_26_457"):
         assert res[0][5] is True                    # the reference's network trains through the one-launch update
         assert res[2][6] is True                    # ... and through the update in the gradient launch
+        # ... with forward + loss + dX chain as ONE launch of the whole-network kernel (two launches per optimiser step)
+        assert _lib.load().linna_net_train_launches(model.net_handle(with_grads=True), B) == 2
 
 
 @pytest.mark.parametrize("name", ["train_v2_33_33", "train_v2_26_457"])
