@@ -240,3 +240,31 @@ def test_emcee_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
     assert np.max(np.abs(res[0][1] - means) / sig) < 0.3 and res[0][3] > 0     # 400 steps x 256 walkers, tau ~ 100: a plumbing check
     np.testing.assert_allclose(res[0][2], sig, rtol=0.3)
     assert sorted(os.listdir(tmp_path)) == ["chemcee_256.h5"]
+
+
+def _ml_sampler_job(rank, world):
+    import contextlib
+    import io
+    from test_gpu_callbacks import _problem2d, _core
+    means, cov, priors = _problem2d(gauss=False)
+    out = os.environ["LINNA_TEST_SHARED_DIR"] + "/run/"
+    with contextlib.redirect_stdout(io.StringIO()) as log:
+        chain, lp = _core(out, priors, means, cov, nwalkers=16, params={"nimp": 100})
+    files = sorted(os.listdir(out + "iter_1"))
+    return chain, np.asarray(lp), files, log.getvalue().count("rank %d of %d" % (rank, world))
+
+
+def test_ml_sampler_core_under_two_ranks(tmp_path, monkeypatch):
+    """``ml_sampler_core`` called on every rank of a two-rank run (what `torchrun script.py` gives): `dist.init()` brings
+    the ranks up, rank 0 designs the points / calls the theory / owns every file, both ranks train (data parallel, one
+    gradient all-reduce per step) and sample their shard of the 16 walkers, and both return the same chain -- the
+    importance subsample rank 0 drew -- read from the one run directory."""
+    monkeypatch.setenv("LINNA_TEST_SHARED_DIR", str(tmp_path))
+    res = _run(_ml_sampler_job)
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][0].shape == (100, 2) and np.all(np.isfinite(res[0][0]))
+    assert res[0][2] == res[1][2] and "chemcee_256.h5" in res[0][2] and "best.pth.tar" in res[0][2] and "finish.pkl" in res[0][2]
+    assert res[0][3] == 1 and res[1][3] == 1                       # each rank announced its transport once
+    d = np.load(str(tmp_path) + "/run/weight_im.npy")
+    assert d.shape == (3, 100) and abs(d[2].sum() - 1.0) < 1e-9
