@@ -246,6 +246,17 @@ def agree(flag, group=None):
     return bool(box[0])
 
 
+def any_rank(flag, group=None):
+    """True on every rank when ``flag`` is true on at least one (a decision every rank must take the same way because
+    collectives follow it)."""
+    if world_size(group) == 1 or not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(int(t.item()))
+
+
 def rank_batches(batches, rank, size):
     """Step s of rank r uses global batch s*size + r: disjoint batches, ``len(batches)//size`` steps."""
     nsteps = len(batches) // size

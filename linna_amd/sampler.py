@@ -158,8 +158,23 @@ class DeviceChain(object):
             except Exception:                            # a warm-up only: the checks create what is missing
                 pass
         t = threading.Thread(target=work, name="linna-fft-prewarm", daemon=True)
+        # A process that exits while this thread is still inside rocFFT dies in the runtime's teardown ("terminate called
+        # without an active exception" / a segmentation fault at exit: seen when a short run finished before its plans
+        # did): the thread is joined at interpreter exit, and by the drivers when they return.
+        if not cls._pending:
+            import atexit
+            atexit.register(cls.join_prewarm)
+        cls._pending.append(t)
         t.start()
         return t
+
+    _pending = []
+
+    @classmethod
+    def join_prewarm(cls, timeout=60.0):
+        """Wait for every plan-creating thread started so far."""
+        while cls._pending:
+            cls._pending.pop().join(timeout)
 
     def checkmeanstd(self, nlast, meanshift, stdshift):
         """sampler.py:370-387 on the last ``nlast`` steps: first-half / second-half drift."""
@@ -930,7 +945,10 @@ class SliceEnsembleSampler(EnsembleSampler):
         if self.tune:
             c = b["counters"][:3].cpu().numpy()          # one read per iteration while mu is tuned, as the round loop
             if c[2]:
-                raise _FastOverflow()
+                if self._shared():
+                    self._overflow_seen = True       # (ranks exchange walkers every half step: no rank may leave the loop alone)
+                else:
+                    raise _FastOverflow()
             self._tune_mu(int(c[0]), int(c[1]))
         return True
 
@@ -945,10 +963,19 @@ class SliceEnsembleSampler(EnsembleSampler):
         if self._tune_count > self.patience:
             self.tune = False
 
+    def _shared(self):
+        return self.world > 1 and self.exchange == "allgather"
+
     def _overflowed(self):
-        """A walker needed more stepping-out steps or shrinking trials than the one-call path's rounds hold (one device read)."""
-        return (self._fast_bufs is not None and getattr(self, "_fast_steps", 0)
-                and int(self._fast_bufs["counters"][2].item()) > 0)
+        """A walker needed more stepping-out steps or shrinking trials than the one-call path's rounds hold (one device
+        read); with walkers exchanged between ranks: on ANY rank -- every rank then redoes the run."""
+        mine = bool(self._fast_bufs is not None and getattr(self, "_fast_steps", 0)
+                    and int(self._fast_bufs["counters"][2].item()) > 0) or getattr(self, "_overflow_seen", False)
+        self._overflow_seen = False
+        if self._shared():
+            from . import dist as ldist
+            return ldist.any_rank(mine, self.group)
+        return mine
 
     def _snapshot(self):
         slot = None
@@ -1266,6 +1293,7 @@ class HMCSampler(object):
                 break
         if rk.rank == 0:
             store.flush()
+            DeviceChain.join_prewarm()
         rk.barrier()                                                          # the file is complete before any rank reads it
         self.sampler = None
         return store
@@ -1346,5 +1374,6 @@ class ZeusSampler(object):
                 break
         if rk.rank == 0:
             store.flush()
+            DeviceChain.join_prewarm()
         rk.barrier()
         return store

@@ -268,3 +268,41 @@ def test_ml_sampler_core_under_two_ranks(tmp_path, monkeypatch):
     assert res[0][3] == 1 and res[1][3] == 1                       # each rank announced its transport once
     d = np.load(str(tmp_path) + "/run/weight_im.npy")
     assert d.shape == (3, 100) and abs(d[2].sum() - 1.0) < 1e-9
+
+
+def _zeus_driver_job(rank, world):
+    import contextlib
+    import io
+    from linna_amd import sampler, util
+    from test_gpu_sampling import identity_emulator_logprob, _gaussian_33
+    ndim, means, cov, priors = _gaussian_33()
+    lp = identity_emulator_logprob(ndim, means, cov, priors)
+    out = os.environ["LINNA_TEST_SHARED_DIR"]
+    nw = 136                                                          # 68 per rank (> 2 ndim in total)
+    x0 = util.invTransform(priors)(means)[None, :] + 0.001 * np.random.RandomState(3 + rank).standard_normal((nw, ndim))
+    drv = sampler.ZeusSampler(lp, ndim, nw, x0=x0, transform=util.Transform(priors), seed=2)
+    with contextlib.redirect_stdout(io.StringIO()):
+        drv.sample(None, 400, outdir=out, ntimes=1e9, tautol=1e-9)
+    d = sampler.ChainStore.load(os.path.join(out, "zeus_256.h5"))
+    ens = drv.sampler
+    th = np.asarray(d["chain_transformed"])[200:]
+    return d["chain"].shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), bool(ens._fast_ok), ens.noverflow, ens.tune
+
+
+def test_zeus_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
+    """The reference's default sampler on two ranks: one ensemble of 136 walkers, 68 per rank, slice directions from both
+    ranks' complementary halves; the walkers start in a 1e-3 ball (util.py:937), so the first iterations overflow the
+    one-call half step's rounds and BOTH ranks fall back to the round loop together (a decision taken over the ranks:
+    collectives follow it), later iterations run the one-call path; rank 0 writes zeus_256.h5."""
+    from test_gpu_sampling import _gaussian_33
+    monkeypatch.setenv("LINNA_TEST_SHARED_DIR", str(tmp_path))
+    ndim, means, cov, priors = _gaussian_33()
+    res = _run(_zeus_driver_job)
+    sig = np.sqrt(np.diag(cov))
+    assert res[0][0] == res[1][0] == (400, 136, ndim)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert np.max(np.abs(res[0][1] - means) / sig) < 0.3
+    np.testing.assert_allclose(res[0][2], sig, rtol=0.3)
+    assert res[0][3] and res[1][3]                                   # the one-call half step ran on both ranks
+    assert res[0][4] == res[1][4]                                    # ... and they redid the same runs on the round loop
+    assert sorted(os.listdir(tmp_path)) == ["zeus_256.h5"]
