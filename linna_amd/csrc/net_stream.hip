@@ -605,6 +605,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     auto step = [&](auto Uc, auto Refill) {
         constexpr int U = decltype(Uc)::value;
         constexpr bool refill = decltype(Refill)::value;
+#ifdef NS_ALTPRIO
+        // experiment: the two waves of a SIMD take turns at the higher issue priority every R / 2 steps, so that neither runs
+        // ahead of the other by thousands of cycles inside a segment (-DNS_ALTPRIO)
+        if constexpr (U == 0) { if (wave < 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+        if constexpr (U == R / 2) { if (wave < 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
+#endif
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[U & 1]) :: "memory");
         a_read(Aq[(U + 1) & 1]);                   // next step's A (speculative at a run end)
         const f32x4 av = Aq[U & 1];
