@@ -433,7 +433,8 @@ def slice_rate(lp, sizes=(4096, 128), iters=(100, 600)):
         out["walkers_%d" % nw] = {"path": "one C call per half step (linna_slice_half_step)" if ens._fast_ok else "round loop",
                                   "iterations_per_s": n / dt, "us_per_iteration": 1e6 * dt / n,
                                   "evals_per_walker_per_iteration": (ens.neval - e0) / max(1, ens.iteration - it0) / nw,
-                                  "walker_updates_per_s": n * nw / dt, "mu": float(ens.mu)}
+                                  "walker_updates_per_s": n * nw / dt, "mu": float(ens.mu),
+                                  "ends_per_side_by_round": ens.m_sched, "trials_by_round": ens.nt_sched}
     return out
 
 

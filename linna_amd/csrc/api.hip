@@ -1043,9 +1043,11 @@ int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, v
     return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false, gate);
 }
 
-int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
-                                    const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
-                                    void* stream) {
+// `list` / `count` / `mul`: only the trial points list[0 .. count[0] * mul) are evaluated (device-side count; the launch is
+// sized for all nrep * ns); `b_engine`: the batch size the engine is chosen for (the expected number of live rows)
+static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
+                                const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
+                                const int* list, const int* count, int mul, int b_engine, void* stream) {
     if (!lp || !coords || !S_idx || !DIR || !w || !lnP || ns < 1 || nrep < 1) {
         set_error("logprob_eval_slice_points: bad arguments"); return LINNA_ERR_INVALID;
     }
@@ -1057,9 +1059,9 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
         return LINNA_ERR_UNSUPPORTED;          // the caller falls back to linna_slice_points + linna_logprob_eval_if
     }
     const float* packed = nullptr; int rows = 16;
-    TRY(lp_refresh_stream(lp, nrep * ns, stream, &packed, &rows));
+    TRY(lp_refresh_stream(lp, b_engine > 0 ? b_engine : nrep * ns, stream, &packed, &rows));
     const linna_net* n = lp->net;
-    NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, nullptr, ns, 0ull, nullptr, 0, 0, 0.f, nullptr, 1};
+    NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, list, ns, 0ull, count, mul, 0, 0.f, nullptr, 1};
     const NsDense dn = lp->dense();
     const bool df = lp->dense_fused;
     return launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
@@ -1068,20 +1070,28 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
                              df ? &dn : nullptr, S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr,
                              d.outmap.cexp ? d.outmap.cshift2 : nullptr);
 }
+int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
+                                    const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
+                                    void* stream) {
+    return lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, w, nrep, lnP, gate, nullptr, nullptr, 0, 0, stream);
+}
 
 // One half step of the ensemble slice sampler (zeus behind sampler.py:728-735) in ONE call: the differential-move directions
-// and slice heights, `nexp_rounds` speculative stepping-out rounds of `m` bracket ends per side, `nshr_rounds` shrinking
-// rounds of `ntrial` trials, the commit -- 2 + 2 (nexp_rounds + nshr_rounds) launches, none of which the host waits for.
+// and slice heights, `nexp_rounds` speculative stepping-out rounds of `m_sched[r]` bracket ends per side, `nshr_rounds`
+// shrinking rounds of `nt_sched[r]` trials, the commit -- 2 + 2 (nexp_rounds + nshr_rounds) launches, none of which the host waits for.
 // Every evaluation is the whole-network kernel with the trial points formed in its prologue (never written to memory);
 // rounds behind the one that finished the last walker are gated off on the device.
 int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
-                          const int* step_dev, int half, int m, int nexp_rounds, int ntrial, int nshr_rounds, float* DIR, int ldd,
-                          float* state, int* flags, float* W, float* Wd, float* Zt, int* counters, int zero_totals, void* stream) {
+                          const int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched, int nshr_rounds,
+                          float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt, int* list, int* counters,
+                          int zero_totals, void* stream) {
     if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !mu || !step_dev || !DIR || !state || !flags || !W || !Wd ||
-        !Zt || !counters || ns < 1 || nc < 2 || m < 1 || ntrial < 1 || nexp_rounds < 1 || nshr_rounds < 1 || (half != 0 && half != 1)) {
+        !Zt || !list || !counters || ns < 1 || nc < 2 || !m_sched || !nt_sched || nexp_rounds < 1 || nshr_rounds < 1 || (half != 0 && half != 1)) {
         set_error("slice_half_step: bad arguments"); return LINNA_ERR_INVALID;
     }
+    for (int r = 0; r < nexp_rounds; ++r) if (m_sched[r] < 1) { set_error("slice_half_step: m_sched[%d] = %d", r, m_sched[r]); return LINNA_ERR_INVALID; }
+    for (int r = 0; r < nshr_rounds; ++r) if (nt_sched[r] < 1) { set_error("slice_half_step: nt_sched[%d] = %d", r, nt_sched[r]); return LINNA_ERR_INVALID; }
     const linna_logprob_desc_t& d = lp->d;
     if (ndim != d.nin) { set_error("slice_half_step: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
     if (!fused_enabled() || !lp->packed.ready() || (d.outmap.cexp && (!d.w || !d.outmap.cpost || !d.outmap.cshift2)) ||
@@ -1092,20 +1102,29 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
     float* const Z0 = state; float* const L = state + ns; float* const R = state + 2 * ns;
     float* const Wacc = state + 3 * ns; float* const Zacc = state + 4 * ns;
     hipStream_t st = S(stream);
-    TRY(launch_slice_begin(logp, S_idx, ns, ccoords, ldcc, C_idx, nc, ndim, mu, seed, step_dev, half, DIR, ldd, Z0, L, R, flags, W, m,
+    TRY(launch_slice_begin(logp, S_idx, ns, ccoords, ldcc, C_idx, nc, ndim, mu, seed, step_dev, half, DIR, ldd, Z0, L, R, flags, W, m_sched[0],
                            counters, nexp_rounds + nshr_rounds, zero_totals, st));
     int slot = 4;
+    // rounds after the first evaluate only the walkers still active: the logic kernel of round r lists their trial points
+    // (list[pos * nrep + j] = j ns + k, pos = the walker's rank among the active ones) and counts them in counters[slot];
+    // round r + 1's launch is sized for all of them, runs the engine chosen for the expected number (a quarter of the
+    // walkers per round) and leaves at the counted one.  Because only those walkers are evaluated, the later rounds can look
+    // further ahead for nothing (m_sched / nt_sched grow) and the call needs few rounds.
     for (int r = 0; r < nexp_rounds; ++r, ++slot) {
-        const int* gate = r > 0 ? counters + slot - 1 : nullptr;
-        TRY(linna_logprob_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, W, 2 * m, Zt, gate, stream));
-        TRY(launch_slice_expand_multi(Z0, Zt, L, R, S_idx, flags, ns, m, counters, slot, r > 0 ? slot - 1 : -1, W, Wd, seed, step_dev,
-                                      2 + half, ntrial, st));
+        const int m = m_sched[r], m_next = r + 1 < nexp_rounds ? m_sched[r + 1] : 0;
+        TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, W, 2 * m, Zt, nullptr, r > 0 ? list : nullptr,
+                                 r > 0 ? counters + slot - 1 : nullptr, 2 * m, std::max(1, (2 * m * ns) >> (2 * r)), stream));
+        TRY(launch_slice_expand_multi(Z0, Zt, L, R, S_idx, flags, ns, m, m_next, counters, slot, r > 0 ? slot - 1 : -1, W, Wd, list, seed,
+                                      step_dev, 2 + half, nt_sched[0], st));
     }
+    int trials = 0;
     for (int r = 0; r < nshr_rounds; ++r, ++slot) {
-        const int* gate = r > 0 ? counters + slot - 1 : nullptr;
-        TRY(linna_logprob_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, ntrial, Zt, gate, stream));
-        TRY(launch_slice_shrink_multi(Z0, Zt, L, R, S_idx, Wd, flags, Wacc, Zacc, ns, counters, slot, r > 0 ? slot - 1 : -1, ntrial, r,
-                                      seed, step_dev, 2 + half, st));
+        const int nt = nt_sched[r], nt_next = r + 1 < nshr_rounds ? nt_sched[r + 1] : 0;
+        trials += nt;
+        TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, nt, Zt, nullptr, r > 0 ? list : nullptr,
+                                 r > 0 ? counters + slot - 1 : nullptr, nt, std::max(1, (nt * ns) >> (2 * r)), stream));
+        TRY(launch_slice_shrink_multi(Z0, Zt, L, R, S_idx, Wd, flags, Wacc, Zacc, ns, counters, slot, r > 0 ? slot - 1 : -1, nt, nt_next,
+                                      trials, list, seed, step_dev, 2 + half, st));
     }
     return launch_slice_commit_checked(coords, ldc, ndim, logp, S_idx, ns, DIR, ldd, Wacc, Zacc, flags, counters, st);
 }

@@ -110,11 +110,11 @@ int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc,
                        const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0, float* L,
                        float* R, int* flags, float* W, int m, int* counters, int nslots, int zero_totals, hipStream_t s);
 int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,
-                              int* counters, int slot, int prev_slot, float* W, float* Wd, uint64_t seed, const int* step_dev,
-                              int stream_id_shrink, int ntrial, hipStream_t s);
+                              int m_next, int* counters, int slot, int prev_slot, float* W, float* Wd, int* list, uint64_t seed,
+                              const int* step_dev, int stream_id_shrink, int ntrial, hipStream_t s);
 int launch_slice_shrink_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, float* W, int* flags, float* Wacc,
-                              float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int round, uint64_t seed,
-                              const int* step_dev, int stream_id, hipStream_t s);
+                              float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int nt_next,
+                              int trials_so_far, int* list, uint64_t seed, const int* step_dev, int stream_id, hipStream_t s);
 int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
                                 const float* Wacc, const float* Zacc, const int* flags, int* counters, hipStream_t s);
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,

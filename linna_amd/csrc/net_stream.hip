@@ -290,6 +290,16 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const int li = lane & 15, kq = lane >> 4;
     const int row0 = blockIdx.x * ROWS;
     if (a.gate && a.gate[0] == 0) return;
+    // MOVE == 2 with a row list (the later rounds of linna_slice_half_step): only the trial points of the walkers still
+    // active are evaluated -- row r of the launch is trial point mv_C[r] (= j ns + k), mv_step[0] * mv_step_off rows in
+    // all, counted on the device; the workgroups behind them leave at once
+    int mv_rows = a.B;
+    if constexpr (MOVE == 2) {
+        if (a.mv_C) {
+            mv_rows = a.mv_step[0] * a.mv_step_off;
+            if (row0 >= mv_rows) return;
+        }
+    }
     if constexpr ((STORE == 2 && !GRAD) || TRB) {
         if ((a.p_n > 0 || a.p_step) && blockIdx.x == gridDim.x - 1) {
             // sum_scale_prepare_kernel's arithmetic in its order: 1024 strided partial sums (two per thread here),
@@ -331,7 +341,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     const int prt = tid / RG, pc0 = tid % RG;
     const bool prow = prt < ROWS;                   // (ROWS < 16: the thread rows past ROWS only keep the barriers company)
     const int pr = SM ? min(prt, ROWS - 1) : prt;
-    const int grow = min(row0 + pr, a.B - 1);
+    int grow = min(row0 + pr, a.B - 1);
+    if constexpr (MOVE == 2) {
+        if (a.mv_C) grow = a.mv_C[min(row0 + pr, mv_rows - 1)];     // the trial point this row evaluates
+    }
     int zsrc = grow;                                // STORE == 3: the row of the resident set this batch row is
     float zden = 1.f;
     if constexpr (STORE == 3) {
@@ -1171,7 +1184,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         for (int o = RG / 2; o >= 1; o >>= 1) chi += __shfl_xor(chi, o, 64);
         float lnp_new = (-0.5f * chi) / a.T + (-0.5f * zz);
         lnp_new = isnan(lnp_new) ? -INFINITY : lnp_new;
-        if (a.lnP && (a.w || a.dense) && pc0 == 0 && rok) a.lnP[row0 + pr] = lnp_new;
+        if constexpr (MOVE == 2) {
+            if (a.lnP && pc0 == 0 && prow && row0 + pr < mv_rows) a.lnP[a.mv_C ? grow : row0 + pr] = lnp_new;
+        } else {
+            if (a.lnP && (a.w || a.dense) && pc0 == 0 && rok) a.lnP[row0 + pr] = lnp_new;
+        }
         if constexpr (MOVE == 1) {
             // Metropolis test of the stretch move (linna_stretch_accept); every lane of the row agrees
             if (rok && mv_factor + lnp_new - mv_lnp_old > mv_logu) {

@@ -614,14 +614,15 @@ __global__ void slice_begin_kernel(const float* __restrict__ logp, const int* __
     }
 }
 
-// Zt[j*ns + k]: lnP at L - j (j < m) and at R + (j - m) (m <= j < 2m) of the bracket this round started from
+// Zt[j*ns + k]: lnP at L - j (j < m) and at R + (j - m) (m <= j < 2m) of the bracket this round started from; the next
+// round looks at m_next ends per side (0: this is the last stepping-out round)
 __global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
                                           float* __restrict__ R, const int* __restrict__ S, int* __restrict__ flags, int ns,
-                                          int m, int* __restrict__ counters, int slot, int prev_slot, float* __restrict__ W,
-                                          float* __restrict__ Wd, uint64_t seed, const int* __restrict__ step_dev,
-                                          int stream_id_shrink, int ntrial) {
+                                          int m, int m_next, int* __restrict__ counters, int slot, int prev_slot, float* __restrict__ W,
+                                          float* __restrict__ Wd, int* __restrict__ list, uint64_t seed,
+                                          const int* __restrict__ step_dev, int stream_id_shrink, int ntrial) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0 && (prev_slot < 0 || counters[prev_slot] > 0)) atomicAdd(counters + 3, 2 * m * ns);   // this round's evaluation ran
+    if (k == 0) atomicAdd(counters + 3, 2 * m * (prev_slot < 0 ? ns : counters[prev_slot]));   // the points this round evaluated
     if (k >= ns || !(flags[3 * k] | flags[3 * k + 1])) return;
     if (prev_slot >= 0 && counters[prev_slot] == 0) return;       // (never: a walker with a flag set was counted)
     const float z0 = Z0[k];
@@ -640,8 +641,9 @@ __global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const fl
     L[k] = l; R[k] = r;
     if (n) atomicAdd(counters + 0, n);
     if (flags[3 * k] | flags[3 * k + 1]) {
-        atomicAdd(counters + slot, 1);
-        for (int j = 0; j < m; ++j) { W[(size_t)j * ns + k] = l - (float)j; W[(size_t)(m + j) * ns + k] = r + (float)j; }
+        const int pos = atomicAdd(counters + slot, 1);           // rank among the walkers still stepping out: its rows of the next launch
+        for (int j = 0; j < m_next; ++j) { W[(size_t)j * ns + k] = l - (float)j; W[(size_t)(m_next + j) * ns + k] = r + (float)j; }
+        for (int j = 0; j < 2 * m_next; ++j) list[(size_t)pos * 2 * m_next + j] = j * ns + k;
     } else {
         slice_draw_dev(k, S[k], l, r, Wd, ns, seed, (uint32_t)step_dev[0], stream_id_shrink, 0, ntrial);   // first shrink round's trials
     }
@@ -650,10 +652,11 @@ __global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const fl
 __global__ void slice_shrink_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
                                           float* __restrict__ R, const int* __restrict__ S, float* __restrict__ W,
                                           int* __restrict__ flags, float* __restrict__ Wacc, float* __restrict__ Zacc, int ns,
-                                          int* __restrict__ counters, int slot, int prev_slot, int ntrial, int round,
-                                          uint64_t seed, const int* __restrict__ step_dev, int stream_id) {
+                                          int* __restrict__ counters, int slot, int prev_slot, int ntrial, int nt_next,
+                                          int trials_so_far, int* __restrict__ list, uint64_t seed,
+                                          const int* __restrict__ step_dev, int stream_id) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0 && (prev_slot < 0 || counters[prev_slot] > 0)) atomicAdd(counters + 3, ntrial * ns);
+    if (k == 0) atomicAdd(counters + 3, ntrial * (prev_slot < 0 ? ns : counters[prev_slot]));
     if (k >= ns || !flags[3 * k + 2] || (flags[3 * k] | flags[3 * k + 1])) return;   // done, or its bracket never closed
     if (prev_slot >= 0 && counters[prev_slot] == 0) return;
     int ncon = 0;
@@ -672,8 +675,9 @@ __global__ void slice_shrink_multi_kernel(const float* __restrict__ Z0, const fl
     L[k] = l; R[k] = r;
     if (ncon) atomicAdd(counters + 1, ncon);
     if (active) {
-        atomicAdd(counters + slot, 1);
-        slice_draw_dev(k, S[k], l, r, W, ns, seed, (uint32_t)step_dev[0], stream_id, (round + 1) * ntrial, ntrial);
+        const int pos = atomicAdd(counters + slot, 1);
+        slice_draw_dev(k, S[k], l, r, W, ns, seed, (uint32_t)step_dev[0], stream_id, trials_so_far, nt_next);   // the next round's trials
+        for (int j = 0; j < nt_next; ++j) list[(size_t)pos * nt_next + j] = j * ns + k;
     } else {
         flags[3 * k + 2] = 0;
     }
@@ -877,17 +881,17 @@ int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc,
     LAUNCH_CHECK("slice_begin");
 }
 int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,
-                              int* counters, int slot, int prev_slot, float* W, float* Wd, uint64_t seed, const int* step_dev,
-                              int stream_id_shrink, int ntrial, hipStream_t s) {
-    hipLaunchKernelGGL(slice_expand_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, flags, ns, m, counters, slot,
-                       prev_slot, W, Wd, seed, step_dev, stream_id_shrink, ntrial);
+                              int m_next, int* counters, int slot, int prev_slot, float* W, float* Wd, int* list, uint64_t seed,
+                              const int* step_dev, int stream_id_shrink, int ntrial, hipStream_t s) {
+    hipLaunchKernelGGL(slice_expand_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, flags, ns, m, m_next, counters, slot,
+                       prev_slot, W, Wd, list, seed, step_dev, stream_id_shrink, ntrial);
     LAUNCH_CHECK("slice_expand_multi");
 }
 int launch_slice_shrink_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, float* W, int* flags, float* Wacc,
-                              float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int round, uint64_t seed,
-                              const int* step_dev, int stream_id, hipStream_t s) {
+                              float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int nt_next,
+                              int trials_so_far, int* list, uint64_t seed, const int* step_dev, int stream_id, hipStream_t s) {
     hipLaunchKernelGGL(slice_shrink_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, W, flags, Wacc, Zacc, ns,
-                       counters, slot, prev_slot, ntrial, round, seed, step_dev, stream_id);
+                       counters, slot, prev_slot, ntrial, nt_next, trials_so_far, list, seed, step_dev, stream_id);
     LAUNCH_CHECK("slice_shrink_multi");
 }
 int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,

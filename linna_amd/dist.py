@@ -103,7 +103,7 @@ def comm_forget(device_index=None):
 
 
 def comm_selftest(device_index=None, timeout=60.0):
-    """One ``linna_allreduce_sum_f32`` of 1024 floats on a side stream, waited for at most ``timeout`` seconds and
+    """One ``linna_allreduce_sum_f32`` of 1024 floats and one ``linna_allgather_f32`` on a side stream, waited for at most ``timeout`` seconds and
     checked against the closed form: True when this rank's communicator works.  (A launcher calls this before it
     commits the data path to the communicator; every rank must then agree, e.g. by a MIN all-reduce of the answers.)"""
     import time
@@ -118,13 +118,18 @@ def comm_selftest(device_index=None, timeout=60.0):
     with torch.cuda.stream(side):
         t = torch.full((1024,), float(r + 1), dtype=torch.float32, device=dev)
         _lib.call("linna_allreduce_sum_f32", _lib.ctx(device_index), _f32(t), t.numel(), C.c_void_p(side.cuda_stream))
+        # ... and one all-gather (the walker exchange of a half step, the chain gather of a flush)
+        g_in = torch.full((256,), float(r + 1), dtype=torch.float32, device=dev)
+        g_out = torch.zeros((w * 256,), dtype=torch.float32, device=dev)
+        _lib.call("linna_allgather_f32", _lib.ctx(device_index), _f32(g_in), _f32(g_out), g_in.numel(), C.c_void_p(side.cuda_stream))
         done.record(side)
     t0 = time.perf_counter()
     while not done.query():
         if time.perf_counter() - t0 > timeout:
             return False
         time.sleep(0.005)
-    return bool((t == float(w * (w + 1) // 2)).all().item())
+    want = torch.arange(1, w + 1, dtype=torch.float32, device=dev).repeat_interleave(256)
+    return bool((t == float(w * (w + 1) // 2)).all().item()) and bool((g_out == want).all().item())
 
 
 def _f32(t):

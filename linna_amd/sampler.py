@@ -793,8 +793,10 @@ class SliceEnsembleSampler(EnsembleSampler):
     checked statistically.
     """
 
-    FAST_EXPANSIONS = 12            # per side and half step on the one-call path (a tuned mu needs about one)
-    FAST_TRIALS = 32                # shrinking trials per walker and half step on the one-call path (each halves the bracket)
+    FAST_EXPANSIONS = 12            # at least so many per side and half step on the one-call path (a tuned mu needs about one)
+    FAST_TRIALS = 32                # at least so many shrinking trials per walker and half step (each halves the bracket)
+    FAST_FIRST = None               # bracket ends per side in the first stepping-out round (None: by ensemble size, below)
+    FAST_CAP = (8, 32)              # most ends per side / trials a later round looks ahead
 
     def __init__(self, nwalkers, ndim, log_prob, mu=1.0, seed=0, tune=True, tolerance=0.05, patience=5, maxsteps=10000,
                  maxiter=100000, dist_group=None, exchange="none", fast=None):
@@ -818,24 +820,41 @@ class SliceEnsembleSampler(EnsembleSampler):
         self._neval_host = 0
         self._cs, self._pin = None, None
         # One C call per half step (linna_slice_half_step) once mu is tuned: speculative rounds -- `m` bracket ends per side
-        # per stepping-out round, `ntrial` trials per shrinking round, sized so that one evaluation launch carries about
-        # 4096 points whatever the ensemble size -- and a fixed number of rounds, gated off on the device behind the one
-        # that finished the last walker.  The host then never waits inside an iteration (with 4-128 walkers the
-        # round-by-round loop below was bound by its own launches and count read-backs, not by the GPU).  The rounds allow
-        # FAST_EXPANSIONS stepping-out steps per side and FAST_TRIALS shrinking trials per walker and half step; a walker
-        # that needs more is counted (and kept in place), and `run` / `step` then take the sampler back to the state they
-        # started from and redo their iterations on the unbounded round loop: the chain is always the round loop's.
+        # per stepping-out round, `nt` trials per shrinking round -- and a fixed number of rounds, gated off on the device
+        # behind the one that finished the last walker.  The host then never waits inside an iteration (with 4-128 walkers
+        # the round-by-round loop below was bound by its own launches and count read-backs, not by the GPU).  The first
+        # round of each kind evaluates every walker and is sized by the ensemble (a launch of up to ~2000 points costs what
+        # one point costs; beyond ~4000 the evaluation is compute bound at 14 ns a point); the later rounds evaluate only
+        # the walkers still active, so they look twice as far ahead each time for next to nothing and few rounds cover
+        # FAST_EXPANSIONS stepping-out steps per side and FAST_TRIALS shrinking trials.  A walker that needs more is
+        # counted (and kept in place), and `run` / `step` then take the sampler back to the state they started from and
+        # redo their iterations on the unbounded round loop: the chain is always the round loop's.
         self.fast = fast
         self._fast_ok = None                              # None: try the entry on the first tuned iteration
-        self.m = int(min(8, max(1, 4096 // (2 * ns))))
-        self.nt_fast = int(min(16, max(2, 4096 // ns)))
-        self.nexp_rounds = max(3, -(-self.FAST_EXPANSIONS // self.m))
-        self.nshr_rounds = max(3, -(-self.FAST_TRIALS // self.nt_fast))
-        self._fast_bufs = None
+        first = self.FAST_FIRST or (8 if ns <= 64 else 4 if ns <= 256 else 2 if ns <= 2048 else 1)   # measured: tools/slice_probe.py
+        self.set_schedule(self._schedule(first, self.FAST_EXPANSIONS, self.FAST_CAP[0]),
+                          self._schedule(2 * first, self.FAST_TRIALS, self.FAST_CAP[1]))
         self._last_nexp = None                            # expansions of the last tuning iteration (whole ensemble)
         self._fast_after = 0                              # no one-call steps before this iteration (set after an overflow)
         self._guarded = False
         self.noverflow = 0                                # runs redone on the round loop
+
+    def set_schedule(self, m_sched, nt_sched):
+        """Bracket ends per side of each stepping-out round and trials of each shrinking round of the one-call path."""
+        self.m_sched, self.nt_sched = [int(v) for v in m_sched], [int(v) for v in nt_sched]
+        self.m, self.nt_fast = max(self.m_sched), max(self.nt_sched)         # (scratch sizes)
+        self.nexp_rounds, self.nshr_rounds = len(self.m_sched), len(self.nt_sched)
+        self._m_arr = (C.c_int * self.nexp_rounds)(*self.m_sched)
+        self._nt_arr = (C.c_int * self.nshr_rounds)(*self.nt_sched)
+        self._fast_bufs = None
+
+    @staticmethod
+    def _schedule(first, total, cap):
+        """first, 2 first, 4 first ... (at most `cap` each) until at least `total` are covered; two rounds at least."""
+        out = [min(first, cap)]
+        while sum(out) < total or len(out) < 2:
+            out.append(min(2 * out[-1], cap))
+        return out
 
     # -- data-dependent rounds with one round of lookahead ------------------------------------------
     # A round = a few small kernels + one evaluation + a kernel that counts the walkers still active.
@@ -922,6 +941,7 @@ class SliceEnsembleSampler(EnsembleSampler):
             z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=self.dev)
             nrep = max(2 * self.m, self.nt_fast)
             self._fast_bufs = dict(state=z(5 * ns), W=z(2 * self.m * ns), Wd=z(self.nt_fast * ns), Zt=z(nrep * ns),
+                                   list=torch.zeros(nrep * ns, dtype=torch.int32, device=self.dev),
                                    counters=torch.zeros(4 + self.nexp_rounds + self.nshr_rounds, dtype=torch.int32, device=self.dev))
         b, st = self._fast_bufs, _lib.stream()
         for h in (0, 1):
@@ -931,8 +951,8 @@ class SliceEnsembleSampler(EnsembleSampler):
                 comp, cidx, nc = self._allgather_complement(Cc)
             rc = _lib.load().linna_slice_half_step(
                 self.lp._ensure()["handle"], P(self.coords), self.ld, self.ndim, P(self.logp), I(S), ns, P(comp), ldc, I(cidx), nc,
-                P(self.mu_dev), seed, I(self.step_dev), h, self.m, self.nexp_rounds, self.nt_fast, self.nshr_rounds, P(self.DIR), self.ld,
-                P(b["state"]), I(self.flags), P(b["W"]), P(b["Wd"]), P(b["Zt"]), I(b["counters"]), 1 if h == 0 else 0, st)
+                P(self.mu_dev), seed, I(self.step_dev), h, self._m_arr, self.nexp_rounds, self._nt_arr, self.nshr_rounds, P(self.DIR), self.ld,
+                P(b["state"]), I(self.flags), P(b["W"]), P(b["Wd"]), P(b["Zt"]), I(b["list"]), I(b["counters"]), 1 if h == 0 else 0, st)
             if rc != 0:
                 if rc == _lib.ERR_UNSUPPORTED and h == 0 and self._fast_ok is None:
                     self._fast_ok = False

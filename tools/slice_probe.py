@@ -1,13 +1,17 @@
 """Timing target: zeus-style ensemble slice sampler iterations on the bench problem, round-by-round loop against the
-one-call half step (linna_slice_half_step), over ensemble sizes.  usage: slice_probe.py [nw ...]"""
+one-call half step (linna_slice_half_step), over ensemble sizes.  usage: slice_probe.py [nw ...]
+SLICE_FIRST=a,b,...: the one-call path with that many bracket ends per side in its first round (SliceEnsembleSampler.FAST_FIRST; 0: by ensemble size)
+SLICE_ONLY_FAST=1: skip the round loop"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from linna_amd import sampler
 sizes = [int(a) for a in sys.argv[1:]] or [16, 128, 512, 1024, 4096]
+points = [int(a) for a in os.environ.get("SLICE_FIRST", "0").split(",")]
 lp, model, consts = bench.build_problem(torch.device("cuda", 0))
 for nw in sizes:
-    for fast in (False, True):
+    for fast, pts in ([] if os.environ.get("SLICE_ONLY_FAST") else [(False, 0)]) + [(True, p) for p in points]:
+        sampler.SliceEnsembleSampler.FAST_FIRST = pts or None
         ens = sampler.SliceEnsembleSampler(nw, 33, lp, seed=1, fast=fast)
         ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nw, 33)))
         ens.run(60, store=False)
@@ -18,5 +22,5 @@ for nw in sizes:
         ens.run(n, store=False)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print("%5d walkers  %-9s %8.1f us/iteration  %7.0f it/s  mu %.3f  evals/walker/iteration %.1f  tuned %s" % (
-            nw, "one-call" if fast else "rounds", dt / n * 1e6, n / dt, ens.mu, (ens.neval - e0) / n / nw, not ens.tune), flush=True)
+        print("%5d walkers  %-44s %8.1f us/iteration  %7.0f it/s  mu %.3f  evals/walker/iteration %.1f  tuned %s" % (
+            nw, ("one-call m %s nt %s" % (ens.m_sched, ens.nt_sched)) if fast else "rounds", dt / n * 1e6, n / dt, ens.mu, (ens.neval - e0) / n / nw, not ens.tune), flush=True)
