@@ -38,20 +38,21 @@ def build(force=False, verbose=True):
     return LIB
 
 
-def build_stamps(extra=("-DNS_STAMPS",), name="liblinna_hip_stamps.so", verbose=True, base=True):
-    """Diagnostic variant next to the product library: net_stream.hip compiled with phase stamps (every launch of the
-    whole-network kernel then needs LINNA_FUSED_STAMPS), the other objects shared.  Load it with LINNA_LIB_PATH."""
+def build_stamps(extra=("-DNS_STAMPS",), name="liblinna_hip_stamps.so", verbose=True, base=True, source="net_stream.hip"):
+    """Diagnostic variant next to the product library: ONE source (net_stream.hip by default) compiled with extra
+    definitions -- phase stamps (every launch of the whole-network kernel then needs LINNA_FUSED_STAMPS), experiment
+    switches -- the other objects shared.  Load it with LINNA_LIB_PATH."""
     if base:
         build(verbose=verbose)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    o = os.path.join(CSRC, "net_stream_%s.o" % os.path.splitext(name)[0].replace("liblinna_hip_", ""))
-    src = os.path.join(CSRC, "net_stream.hip")
+    o = os.path.join(CSRC, "%s_%s.o" % (os.path.splitext(source)[0], os.path.splitext(name)[0].replace("liblinna_hip_", "")))
+    src = os.path.join(CSRC, source)
     if _stale(o, [src, os.path.join(CSRC, "common.h")]) or True:
         cmd = [hipcc] + FLAGS + list(extra) + ["-c", src, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES if s != "net_stream.hip"] + [o]
+    objs = [os.path.join(CSRC, s.replace(".hip", ".o")) for s in SOURCES if s != source] + [o]
     lib = os.path.join(HERE, name)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs + ["-ldl"])
     return lib
@@ -59,6 +60,7 @@ def build_stamps(extra=("-DNS_STAMPS",), name="liblinna_hip_stamps.so", verbose=
 
 if __name__ == "__main__":
     if "--stamps" in sys.argv:
-        build_stamps(tuple(a for a in sys.argv[1:] if a.startswith("-D")) or ("-DNS_STAMPS",))
+        src = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--source=")]
+        build_stamps(tuple(a for a in sys.argv[1:] if a.startswith("-D")) or ("-DNS_STAMPS",), source=src[0] if src else "net_stream.hip")
     else:
         build(force="--force" in sys.argv)

@@ -54,8 +54,10 @@ struct Tile {
 
     // Issue this wave's share of the tile as LDS-DMA.  `row0`/`nrows`: first row of the tile and
     // the operand's extent along the tiled dimension; `ld` multiple of 4 and base 16-B aligned.
+    // `klast` (k-major operands): k rows past it read row klast again -- the partial last K tile rides the ring too, and
+    // the consumer zeroes those rows of ONE operand in LDS before it multiplies.
     __device__ static __forceinline__ void dma(const float* __restrict__ g, int ld, int row0, int nrows, int k0,
-                                               float* stage, int wave, int lane) {
+                                               float* stage, int wave, int lane, int klast = 0x7fffffff) {
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             const int ins = wave * NI + j;
@@ -68,7 +70,7 @@ struct Tile {
                 constexpr int CH = ROWS / 4, KR = 64 / CH;          // chunks per k-row, k-rows per instruction
                 const int k = ins * KR + lane / CH;
                 const int col = min(row0 + 4 * (lane % CH), ld - 4);  // stays inside the (padded) row
-                src = g + (size_t)(k0 + k) * ld + col;
+                src = g + (size_t)min(k0 + k, klast) * ld + col;
             }
             __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(stage + ins * 256), 16, 0, 0);
         }
@@ -134,6 +136,16 @@ struct Tile {
 // as one serial MFMA chain per tile on 8-64 of the 256 CUs.
 struct KSplit { int kz; float* scratch; int* counters; };
 
+#ifdef GEMM_STAMPS
+// diagnostic build (python linna_amd/_build.py --stamps --source=gemm.hip -DGEMM_STAMPS; tools/gemm_stamps.py): cycle
+// counter at four points of every workgroup of the LAST gemm_body launch -- entry, first K tile requested, K loop done,
+// epilogue stores drained -- plus the hardware id (which CU the workgroup ran on)
+__device__ unsigned long long g_gemm_stamps[8 * 1024];
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GEMM_STAMP(i) do {} while (0)
+#endif
+
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS, bool UPD = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all, const KSplit ks, float* const db = nullptr,
                                           const GemmUpd1* const up = nullptr) {
@@ -145,6 +157,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
     extern __shared__ __attribute__((aligned(16))) float smem[];  // NS x KS x (A tile | B tile)
     constexpr int STAGE = TA::SIZE + TB::SIZE;
 
+    GEMM_STAMP(0);
+#ifdef GEMM_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_gemm_stamps[blockIdx.x * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int kg = wave_all / NW, wave = wave_all % NW;       // K group, wave within the group
@@ -231,34 +253,81 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
         asm volatile("" : "+v"(e_b[j]), "+v"(e_cs[j]), "+v"(e_ct[j]), "+v"(e_cp[j]), "+v"(e_ct2[j]));
     }
 
+    // UPD: the parameters and moments of this tile's elements are requested HERE, before the first K tile -- they do not
+    // depend on the product, and behind the K loop their latency was a third of the epilogue (tools/gemm_stamps.py).  They
+    // are older than every LDS-DMA, so the ring's counted waits are untouched.
+    float pv[16], mv[16], vv[16];
+    if constexpr (UPD) {
+        const int col = n0 + wn * 32 + (lane & 31);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+            const float* const gp = a.C + (size_t)min(row, a.M - 1) * a.ldc + min(col, a.N - 1);
+            pv[e] = gp[up->pdiff]; mv[e] = gp[up->mdiff]; vv[e] = gp[up->vdiff];
+        }
+    }
+
     for (int pi = 0; pi < a.npairs; ++pi) {
         const GemmPair p = a.p[pi];
         const bool dma_ok = ((p.lda & 3) == 0) && ((p.ldb & 3) == 0) &&
                             (((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) == 0);
-        const int nfast = dma_ok ? p.K / BK : 0;               // full K tiles streamed by LDS-DMA
+        const int nfull = dma_ok ? p.K / BK : 0;                // full K tiles streamed by LDS-DMA
         const int nall = (p.K + BK - 1) / BK;
+        // ... and the partial last one with them where both operands are k-major (the parameter-gradient products: K = the
+        // batch, 500 = 15 x 32 + 20): its rows past K are re-reads of row K - 1, zeroed in A's LDS image before the MFMAs
+        // (through registers it cost 7-11 k of a workgroup's 65 k cycles)
+        const bool tail_dma = dma_ok && ALAY == LAY_MN && BLAY == LAY_MN && KS == 1 && ks.kz <= 1 && nall > nfull;
+        const int nfast = nfull + (tail_dma ? 1 : 0);
         const int nmine = nfast > gid ? (nfast - gid + ngrp - 1) / ngrp : 0;   // ... of which this group takes gid, gid+ngrp, ...
         const int niter = (nfast + ngrp - 1) / ngrp;            // ring turns (same for every group of the workgroup: barriers)
         auto stage_of = [&](int i) { return smem + ((i % NS) * KS + kg) * STAGE; };
         auto issue = [&](int i) {
             float* st = stage_of(i);
             const int t = gid + i * ngrp;
-            TA::dma(p.A, p.lda, m0, a.M, t * BK, st, wave, lane);
-            TB::dma(p.B, p.ldb, n0, a.N, t * BK, st + TA::SIZE, wave, lane);
+            TA::dma(p.A, p.lda, m0, a.M, t * BK, st, wave, lane, p.K - 1);
+            TB::dma(p.B, p.ldb, n0, a.N, t * BK, st + TA::SIZE, wave, lane, p.K - 1);
         };
         if (nfast > 0) {
 #pragma unroll
             for (int i = 0; i < NS - 1; ++i)
                 if (i < nmine) issue(i);
+            GEMM_STAMP(1);
+#ifdef GEMM_STAMPS
+            unsigned long long tw = 0, tb = 0, tc = 0;
+#endif
             for (int it = 0; it < niter; ++it) {
+#ifdef GEMM_STAMPS
+                const unsigned long long s0 = __builtin_readcyclecounter();
+#endif
                 // tile `it` of this group must have landed; up to NS-2 younger ones stay in flight
                 if (it < nmine) wait_younger<NS - 2, LPT>(min(NS - 2, nmine - 1 - it));
+#ifdef GEMM_STAMPS
+                const unsigned long long s1 = __builtin_readcyclecounter();
+#endif
                 __builtin_amdgcn_s_barrier();      // all waves' DMA for this turn landed; stage (it-1)%NS is free
                 asm volatile("" ::: "memory");
+#ifdef GEMM_STAMPS
+                const unsigned long long s2 = __builtin_readcyclecounter();
+#endif
                 if (it + NS - 1 < nmine) issue(it + NS - 1);
+                if (tail_dma && it == nfull) {     // (block-uniform) the partial tile: A's k rows past K to zero
+                    float* const za = stage_of(it) + (p.K - nfull * BK) * BM;
+                    const int nz = (nall * BK - p.K) * BM / 4;
+                    for (int f = tid; f < nz; f += NT) reinterpret_cast<f32x4*>(za)[f] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    __syncthreads();
+                }
                 if (it < nmine) compute(stage_of(it));
+#ifdef GEMM_STAMPS
+                const unsigned long long s3 = __builtin_readcyclecounter();
+                tw += s1 - s0; tb += s2 - s1; tc += s3 - s2;
+#endif
             }
             __builtin_amdgcn_s_barrier();          // last tile fully read before anything restages
+#ifdef GEMM_STAMPS
+            if (threadIdx.x == 0 && blockIdx.x < 1024) {
+                g_gemm_stamps[blockIdx.x * 8 + 5] = tw; g_gemm_stamps[blockIdx.x * 8 + 6] = tb; g_gemm_stamps[blockIdx.x * 8 + 7] = tc;
+            }
+#endif
         }
         if (kzi == 0) {
             for (int kt = nfast; kt < nall; ++kt) {    // partial tile / unaligned operand: register path, group 0 of split 0
@@ -284,6 +353,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
         }
     }
 
+    GEMM_STAMP(2);
     if (db != nullptr && ALAY == LAY_MN && KS == 1 && TM == 1 && BM == 64 && ks.kz <= 1) {   // (block-uniform)
         if (do_colsum) {
             __syncthreads();
@@ -379,18 +449,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
         const int col = n0 + wn * 32 + (lane & 31);
         const bool cok = col < a.N;
         const float lr = up->hyper[0], wd = up->hyper[1], bc1 = up->hyper[2], sbc2 = up->hyper[3];
-        // three phases -- every load, then the arithmetic, then every store: parameters and moments are reached through one
-        // pointer plus offsets, so a store of element e and a load of element e + 1 may alias as far as the compiler knows, and
-        // an element-by-element loop turns into sixteen dependent memory round trips per lane
-        float pv[16], mv[16], vv[16];
+        // the loads were requested before the K loop; here the arithmetic, then every store (parameters and moments are
+        // reached through one pointer plus offsets, so a store of element e and a load of element e + 1 may alias as far as
+        // the compiler knows: an element-by-element loop would be sixteen dependent memory round trips per lane)
         bool okv[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            okv[e] = cok && row < a.M;
-            const float* const gp = a.C + (size_t)min(row, a.M - 1) * a.ldc + min(col, a.N - 1);
-            pv[e] = gp[up->pdiff]; mv[e] = gp[up->mdiff]; vv[e] = gp[up->vdiff];
-        }
+        for (int e = 0; e < 16; ++e) okv[e] = cok && m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h < a.M;
         float gv[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -424,6 +488,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
                 }
             }
         }
+#ifdef GEMM_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GEMM_STAMP(3);
+#endif
         return;
     }
     float dot[TM][16];
@@ -683,3 +751,9 @@ int gemm_launch(const GemmArgs& a, hipStream_t stream) {
 }
 
 }  // namespace linna
+
+#ifdef GEMM_STAMPS
+extern "C" int linna_debug_gemm_stamps(unsigned long long* out, int nwords) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(linna::g_gemm_stamps), sizeof(unsigned long long) * (size_t)nwords, 0, hipMemcpyDeviceToHost);
+}
+#endif
