@@ -440,6 +440,42 @@ def test_slice_sampler_fused_trial_points_are_bit_identical():
     assert a.mu == b.mu and a.neval == b.neval
 
 
+@pytest.mark.parametrize("nw,m_sched,nt_sched", [(34, [1, 1, 2, 3, 8], [1, 3, 7, 21]), (250, [3, 5, 5], [5, 2, 9, 16]),
+                                                 (2050, [1, 2, 4, 8], [2, 4, 8, 16, 32]), (6, [2, 16], [33])])
+def test_one_call_slice_schedules_and_ragged_ensembles(nw, m_sched, nt_sched):
+    """The rounds after the first evaluate only the trial points of the walkers still active (a device-side list and count,
+    read by the evaluation's prologue): whatever the schedule of bracket ends / trials per round and the ensemble size
+    (half ensembles of 17, 125, 1025 and 3 walkers; schedules that shrink, grow, are odd), the chain is the round loop's,
+    bit for bit, and so are the expansion / contraction counts."""
+    from linna_amd import sampler
+    lp, pred, yinv, prob = build_logprob("mlp_33_33", 2.0)
+    nd = 33
+    x0 = (0.3 * np.random.RandomState(nw).standard_normal((nw, nd))).astype(np.float32)
+    _lib.engine_rows(4)
+    try:
+        a = sampler.SliceEnsembleSampler(nw, nd, lp, seed=9, tune=False, mu=0.9, fast=True)
+        b = sampler.SliceEnsembleSampler(nw, nd, lp, seed=9, tune=False, mu=0.9, fast=False)
+        a.set_schedule(m_sched, nt_sched)
+        a.set_state(x0); b.set_state(x0)
+        for it in range(6):
+            a.step(); b.step()
+            torch.cuda.synchronize()
+            ca = a._fast_bufs["counters"].cpu().numpy()
+            if ca[2]:                                    # (a short schedule can leave a walker unfinished: redone below)
+                break
+            assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp), it
+            cb = b.counters.cpu().numpy()
+            assert ca[0] == cb[0] and ca[1] == cb[1], (it, ca[:4], cb)
+        assert a._fast_ok is True
+        # evaluated points: every walker of a half ensemble in the first round of each kind, then only the listed ones
+        ns = nw // 2
+        per_it = 2 * (2 * m_sched[0] + nt_sched[0]) * ns
+        assert a.neval >= (it + 1) * per_it - 1 or ca[2]
+        assert a.neval < (it + 1) * 2 * (2 * sum(m_sched) + sum(nt_sched)) * ns
+    finally:
+        _lib.engine_rows(0)
+
+
 @pytest.mark.parametrize("name,nw", [("mlp_33_33", 96), ("v2_33_33", 16), ("mlp_33_33", 1024)])
 def test_one_call_slice_half_step_equals_the_round_loop(name, nw):
     """linna_slice_half_step (speculative rounds: several bracket ends / trials per evaluation launch, a fixed launch
