@@ -389,7 +389,8 @@ def _events_us(fn, iters, warm_s=0.3):
 def hmc_rate(device, nchains=4096, nleap=5):
     """BASELINE configs[4] (HMCSampler.py:19-68 batched over walkers; one process per GPU, chains are independent: no
     collective): lnP + d lnP / d z per launch (linna_logprob_grad), and whole HMC transitions of `nleap` leapfrog steps
-    (momentum draw, half kick, nleap x (drift, gradient, kick), Metropolis test).  For the reference's network class
+    (momentum draw, half kick, nleap x (drift, gradient, kick), Metropolis test: 3 + nleap launches, every kick and drift
+    after the first riding in the finish of a gradient launch).  For the reference's network class
     ChtoModelv2(33,33) and the 4 x 512 MLP.  One gradient evaluation = forward + dX-only backward = 2 x the forward FLOP
     (SURVEY 8d)."""
     import torch
@@ -407,7 +408,7 @@ def hmc_rate(device, nchains=4096, nleap=5):
         us_s = _events_us(lambda: h.step(nleap, 2e-2), 60)
         out[key] = {"us_per_gradient_eval": us, "gradient_evals_per_s": nchains / (us * 1e-6), "achieved": flop / (us * 1e-6) / 1e12,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                    "flop_per_gradient_eval": flop / nchains, "us_per_hmc_sample": us_s,
+                    "flop_per_gradient_eval": flop / nchains, "us_per_hmc_sample": us_s, "launches_per_hmc_sample": 3 + nleap,
                     "leapfrog_steps_per_s": nleap * nchains / (us_s * 1e-6), "hmc_iterations_per_s": 1.0 / (us_s * 1e-6),
                     "acceptance": float(h.naccept.float().mean()) / max(1, int(h.step_dev.item()))}
     return out

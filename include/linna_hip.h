@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches */
+#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -285,6 +285,11 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
 /* lnP[B] and d lnP / d z [B][ldg]  (intended semantics of util.py:1023-1035; HMCSampler.py:32). */
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP,
                        float* G, int ldg, void* stream);
+/* One leapfrog step's gradient, kick and drift (HMCSampler.py:35-49: p += eps dlnp(q); q += eps p / m): lnP and G at Q, then
+ * P += eps_kick * G and Q += eps_drift * P / mass (= linna_logprob_grad + linna_hmc_kick_drift, same arithmetic).  ONE launch
+ * where linna_logprob_grad is one: the kick and the drift ride in the finish of the whole-network kernel. */
+int linna_logprob_grad_leapfrog(linna_logprob_t* lp, float* Q, int ldq, int B, void* ws, float* lnP, float* G, int ldg,
+                                float* P, int ldp, const float* mass, float eps_kick, float eps_drift, void* stream);
 
 /* ------------------------------------------------------------------ training
  * chi^2-ratio loss of util.py:1070-1088,1114-1116 on the raw network output PRED:
@@ -407,6 +412,11 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
 int linna_hmc_init(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint64_t seed,
                    const int* step_dev, const float* lnp, const float* P0, int ldp0, float* P, int ldp,
                    float* H0, void* stream);
+/* linna_hmc_init, the first half kick and the first drift in one launch (HMCSampler.py:26-37): P ~ N(0, m),
+ * H0 = P^2 / 2m - lnp, P += eps_kick * G, Q = X + eps_drift * P / m. */
+int linna_hmc_start(linna_ctx_t* ctx, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev,
+                    const float* lnp, const float* P0, int ldp0, const float* G, int ldg, float eps_kick, float eps_drift,
+                    const float* X, int ldx, float* P, int ldp, float* Q, int ldq, float* H0, void* stream);
 int linna_hmc_kick_drift(linna_ctx_t* ctx, int B, int ndim, const float* mass, float eps_kick,
                          float eps_drift, const float* G, int ldg, float* P, int ldp, float* Q, int ldq,
                          void* stream);

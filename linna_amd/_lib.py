@@ -112,6 +112,7 @@ _SIGNATURES = {
     "linna_logprob_ws_bytes": (_SZ, [_V, _I, _I]),
     "linna_logprob_eval": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),
     "linna_logprob_grad": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V]),
+    "linna_logprob_grad_leapfrog": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V, _I, _V, _F, _F, _V]),
     "linna_loss_scratch_bytes": (_SZ, [_I, _I]),
     "linna_chi2_md": (_I, [_V, C.POINTER(LossDesc), _V, _I, _I, _V, _V, _V]),
     "linna_chi2_ratio_loss_fwd_bwd": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _V, _I, _V, _V, _V, _V, _I, _F, _V]),
@@ -133,6 +134,7 @@ _SIGNATURES = {
     "linna_logprob_eval_slice_points": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V]),
     "linna_stretch_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _I, _F, _V, _V]),
     "linna_hmc_init": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V]),
+    "linna_hmc_start": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _F, _F, _V, _I, _V, _I, _V, _I, _V, _V]),
     "linna_hmc_kick_drift": (_I, [_V, _I, _I, _V, _F, _F, _V, _I, _V, _I, _V, _I, _V]),
     "linna_hmc_accept": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V]),
     "linna_step_increment": (_I, [_V, _V, _V]),

@@ -1155,8 +1155,12 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
                              d.outmap.cexp ? d.outmap.cshift2 : nullptr);
 }
 
-int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
-                       void* stream) {
+}  // extern "C"
+
+// lnP and its gradient at Z; `leap` (hm_* of an NsGrad, the rest unset): the leapfrog's kick and drift behind it -- in the
+// finish of the one-launch forms, as a launch of its own behind the others
+static int logprob_grad_impl(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
+                             const NsGrad* leap, void* stream) {
     if (!lp || !Z || !ws || !lnP || !G || B < 1) { set_error("logprob_grad: bad arguments"); return LINNA_ERR_INVALID; }
     const linna_logprob_desc_t& d = lp->d;
     if (d.outmap.cexp) { set_error("logprob_grad: ypositive (exp) output map has no gradient path"); return LINNA_ERR_UNSUPPORTED; }
@@ -1166,7 +1170,8 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
         const float* packed = nullptr; int rows = 16;
         TRY(lp_refresh_stream(lp, B, stream, &packed, &rows));
         const linna_net* n = lp->net;
-        NsGrad gr{d.gscale, G, ldg};
+        NsGrad gr{d.gscale, G, ldg, nullptr, 0, nullptr, nullptr, 0.f, 0.f};
+        if (leap) { gr.hm_p = leap->hm_p; gr.hm_ldp = leap->hm_ldp; gr.hm_q = leap->hm_q; gr.hm_mass = leap->hm_mass; gr.hm_ek = leap->hm_ek; gr.hm_ed = leap->hm_ed; }
         return launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2,
                                  d.log10_flag, d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP,
                                  nullptr, 0, nullptr, 0, nullptr, &gr, nullptr, rows, nullptr, S(stream));
@@ -1190,7 +1195,8 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
             if (i < nl - 1) { y[i] = base + f.y_off[i]; ldy[i] = ld4(n->L[i].N); }
             if (n->L[i].op == LINNA_OP_RESBLOCK) { t[i] = base + f.t_off[i]; ldt[i] = ld4(n->L[i].C); }
         }
-        const NsGrad gr{d.gscale, G, ldg};
+        NsGrad gr{d.gscale, G, ldg, nullptr, 0, nullptr, nullptr, 0.f, 0.f};
+        if (leap) { gr.hm_p = leap->hm_p; gr.hm_ldp = leap->hm_ldp; gr.hm_q = leap->hm_q; gr.hm_mass = leap->hm_mass; gr.hm_ek = leap->hm_ek; gr.hm_ed = leap->hm_ed; }
         return launch_net_stream_grad2(n->L.data(), nl, n->in_size, packed, Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag,
                                        d.xmean, d.xstd, d.outmap.cscale, d.outmap.cshift, d.w, d.temperature, lnP, gr, y.data(),
                                        ldy.data(), t.data(), ldt.data(), rows, S(stream));
@@ -1205,7 +1211,25 @@ int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void
         TRY(gemm_launch(a, S(stream)));
     }
     TRY(linna_net_backward(lp->net, w + L.x0, ldx, B, w + L.fwd, w + L.bwd, w + L.dh, ldd, w + L.dx, ldx, 0, stream));
-    return launch_prior_map_bwd(Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag, d.xstd, w + L.dx, ldx, G, ldg, S(stream));
+    TRY(launch_prior_map_bwd(Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag, d.xstd, w + L.dx, ldx, G, ldg, S(stream)));
+    if (leap) return launch_hmc_kick_drift(B, d.nin, leap->hm_mass, leap->hm_ek, leap->hm_ed, G, ldg, leap->hm_p, leap->hm_ldp, leap->hm_q, ldz, S(stream));
+    return LINNA_OK;
+}
+
+extern "C" {
+
+int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
+                       void* stream) {
+    return logprob_grad_impl(lp, Z, ldz, B, ws, lnP, G, ldg, nullptr, stream);
+}
+
+// One leapfrog step's gradient, kick and drift (HMCSampler.py:35-49): lnP and G = d lnP / d z at Q, then P += eps_kick G and
+// Q += eps_drift P / mass.  ONE launch where linna_logprob_grad is one (the kick and the drift ride in its finish).
+int linna_logprob_grad_leapfrog(linna_logprob_t* lp, float* Q, int ldq, int B, void* ws, float* lnP, float* G, int ldg, float* P,
+                                int ldp, const float* mass, float eps_kick, float eps_drift, void* stream) {
+    if (!P || !mass || !Q) { set_error("logprob_grad_leapfrog: bad arguments"); return LINNA_ERR_INVALID; }
+    NsGrad leap{nullptr, nullptr, 0, P, ldp, Q, mass, eps_kick, eps_drift};
+    return logprob_grad_impl(lp, Q, ldq, B, ws, lnP, G, ldg, &leap, stream);
 }
 
 // ------------------------------------------------------------------ training
@@ -1418,6 +1442,12 @@ int linna_stretch_accept(linna_ctx_t*, float* coords, int ldc, int ndim, float* 
 int linna_hmc_init(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
                    const float* P0, int ldp0, float* P, int ldp, float* H0, void* stream) {
     return launch_hmc_init(B, ndim, mass, seed, step_dev, lnp, P0, ldp0, P, ldp, H0, S(stream));
+}
+int linna_hmc_start(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
+                    const float* P0, int ldp0, const float* G, int ldg, float eps_kick, float eps_drift, const float* X, int ldx,
+                    float* P, int ldp, float* Q, int ldq, float* H0, void* stream) {
+    if (B < 1 || ndim < 1 || !mass || !step_dev || !lnp || !G || !X || !P || !Q || !H0) { set_error("hmc_start: bad arguments"); return LINNA_ERR_INVALID; }
+    return launch_hmc_start(B, ndim, mass, seed, step_dev, lnp, P0, ldp0, G, ldg, eps_kick, eps_drift, X, ldx, P, ldp, Q, ldq, H0, S(stream));
 }
 int linna_hmc_kick_drift(linna_ctx_t*, int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg,
                          float* P, int ldp, float* Q, int ldq, void* stream) {

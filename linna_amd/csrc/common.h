@@ -90,6 +90,9 @@ int launch_stretch_accept(float* coords, int ldc, int ndim, float* logp, const i
                           int* naccept, hipStream_t s);
 int launch_hmc_init(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
                     const float* P0, int ldp0, float* P, int ldp, float* H0, hipStream_t s);
+int launch_hmc_start(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp, const float* P0,
+                     int ldp0, const float* G, int ldg, float ek, float ed, const float* X, int ldx, float* P, int ldp, float* Q,
+                     int ldq, float* H0, hipStream_t s);
 int launch_hmc_kick_drift(int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg, float* P,
                           int ldp, float* Q, int ldq, hipStream_t s);
 int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
@@ -178,7 +181,9 @@ int launch_net_stream_train_bwd(const linna_layer_t* layers, int nl, int in_size
                                 const NsDense& dn, float* const* dprev, const int* ldp, const float* const* hin, const int* ldh,
                                 float* const* dt, const int* lddt, int rows, hipStream_t s, const NsPost* post);
 // gradient fused behind the evaluation (plain ReLU MLPs, diagonal covariance): G = d lnP / d z
-struct NsGrad { const float* gscale; float* G; int ldg; };
+// hm_*: a leapfrog kick and drift riding in the gradient's finish (HMCSampler.py:35-49): P += ek G; Q += ed P / mass, Q the
+// launch's own input rows (hm_p == nullptr: none)
+struct NsGrad { const float* gscale; float* G; int ldg; float* hm_p; int hm_ldp; float* hm_q; const float* hm_mass; float hm_ek, hm_ed; };
 // AdamW that also writes the two weight streams of a training step (net_stream.hip: adamw_streams_kernel; gemm.hip: the
 // update epilogue of the grouped parameter-gradient launch).  An AsPlace says where the elements of a weight matrix sit
 // in one fragment-order stream (segment type 0 = WIDE, 1 = SPLIT; see net_stream.hip).

@@ -95,6 +95,7 @@ struct NsArgs {
     int G, nseg, LD, kpad0, nout, bias_total;
     int Gstride, nseg_f;                // steps per wave in the packed stream; forward segments (GRAD: the rest is the backward)
     const float* gscale; float* Gout; int ldg;   // GRAD: d(d)/d(raw output); d lnP / d z
+    float* hm_p; int hm_ldp; float* hm_q; const float* hm_mass; float hm_ek, hm_ed;   // GRAD: leapfrog kick + drift in the finish
     const float* cscale; const float* cshift; const float* w; float T;
     const float* cpost; const float* cshift2;   // ypositive output map (util.py:540): d = exp(raw cscale + cshift) cpost + cshift2
     float* lnP; float* D; int ldd; float* TH; int ldt;
@@ -1146,7 +1147,16 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     if (a.lg && zlg[j]) g = g / (theta[j] * 2.30258509299404568f);
                     const float z = zr[j];
                     const float dth = zfl[j] ? za2[j] * (expf(-0.5f * z * z) * 0.398942280401432678f) : za2[j];
-                    a.Gout[(size_t)(row0 + pr) * a.ldg + c] = g * dth - z;
+                    const float gz = g * dth - z;
+                    a.Gout[(size_t)(row0 + pr) * a.ldg + c] = gz;
+                    if (a.hm_p) {
+                        // the leapfrog's kick with this gradient and the drift to the next position (hmc_kick_drift_kernel's
+                        // arithmetic: the launch between two gradient evaluations it replaces was 4.5 us of nothing)
+                        float* const pp = a.hm_p + (size_t)(row0 + pr) * a.hm_ldp + c;
+                        float pm = *pp;
+                        if (a.hm_ek != 0.f) { pm += a.hm_ek * gz; *pp = pm; }
+                        if (a.hm_ed != 0.f) a.hm_q[(size_t)(row0 + pr) * a.ldz + c] = z + a.hm_ed * (pm / a.hm_mass[c]);
+                    }
                 }
             }
             if (pc0 == 0) a.lnP[row0 + pr] = isnan(lnp_grad) ? -INFINITY : lnp_grad;
@@ -1918,6 +1928,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     }
     if (gr) {
         a.gscale = gr->gscale; a.Gout = gr->G; a.ldg = gr->ldg;
+        a.hm_p = gr->hm_p; a.hm_ldp = gr->hm_ldp; a.hm_q = gr->hm_q; a.hm_mass = gr->hm_mass; a.hm_ek = gr->hm_ek; a.hm_ed = gr->hm_ed;
         return ns_launch_kernel<0, true>(a, B, p, rows, s);
     }
     return ns_launch_kernel<0, false>(a, B, p, rows, s);
@@ -1971,6 +1982,7 @@ int launch_net_stream_grad2(const linna_layer_t* layers, int nl, int in_size, co
     a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T; a.lnP = lnP;
     a.gscale = gr.gscale; a.Gout = gr.G; a.ldg = gr.ldg;
+    a.hm_p = gr.hm_p; a.hm_ldp = gr.hm_ldp; a.hm_q = gr.hm_q; a.hm_mass = gr.hm_mass; a.hm_ek = gr.hm_ek; a.hm_ed = gr.hm_ed;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
     for (int i = 0; i < (int)p.seg.size(); ++i) {
         const int op = p.seg_op[i];

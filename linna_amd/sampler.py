@@ -1105,7 +1105,8 @@ class BatchedHMC(object):
     """``linna/HMCSampler.py:19-68`` for B independent chains: p ~ N(0, m); half kick; ``num_steps``
     x (drift, gradient, kick); final half kick; Metropolis test on H = p^2/2m - lnP."""
 
-    def __init__(self, log_prob, x0, mass=None, seed=0):
+    def __init__(self, log_prob, x0, mass=None, seed=0, fused=True):
+        self.fused = fused                      # kick + drift in the gradient launch's finish (False: the separate entries)
         if not getattr(log_prob, "device_only", True):
             raise NotImplementedError("HMC needs the gradient of the log-probability: a user loglikelihoodfunc / "
                                       "externalloglike is host code without one")
@@ -1135,6 +1136,20 @@ class BatchedHMC(object):
         args = (self.ctx, self.B, self.ndim, _lib.ptr(self.mass))
         p0d = None if p0 is None else torch.as_tensor(np.ascontiguousarray(p0, np.float32), device=self.dev)
         ud = None if u is None else torch.as_tensor(np.ascontiguousarray(u, np.float32), device=self.dev)
+        if self.fused and num_steps >= 1:
+            # 3 + num_steps launches: momentum draw + first half kick + first drift; per leapfrog step the gradient with the
+            # next kick (a half one behind the last step, :51) and drift in its finish; Metropolis test; counter
+            _lib.call("linna_hmc_start", *args, seed, _lib.iptr(self.step_dev), _lib.ptr(self.lnp),
+                      _lib.ptr(p0d) if p0d is not None else None, self.ndim, _lib.ptr(self.g), self.ld, 0.5 * eps, eps,
+                      _lib.ptr(self.x), self.ld, _lib.ptr(self.p), self.ld, _lib.ptr(self.q), self.ld, _lib.ptr(self.H0), st)
+            h, ws = self.lp._ensure()["handle"], _lib.ptr(self.lp._workspace(self.B, True))
+            for i in range(num_steps):
+                last = i == num_steps - 1
+                _lib.call("linna_logprob_grad_leapfrog", h, _lib.ptr(self.q), self.ld, self.B, ws, _lib.ptr(self.lnp_new),
+                          _lib.ptr(self.g_new), self.ld, _lib.ptr(self.p), self.ld, _lib.ptr(self.mass),
+                          0.5 * eps if last else eps, 0.0 if last else eps, st)
+            self._accept(args, seed, ud, st)
+            return
         _lib.call("linna_hmc_init", *args, seed, _lib.iptr(self.step_dev), _lib.ptr(self.lnp),
                   _lib.ptr(p0d) if p0d is not None else None, self.ndim, _lib.ptr(self.p), self.ld, _lib.ptr(self.H0), st)
         self.q.copy_(self.x)
@@ -1147,6 +1162,9 @@ class BatchedHMC(object):
             g = self.g_new
         _lib.call("linna_hmc_kick_drift", *args, 0.5 * eps, 0.0, _lib.ptr(g), self.ld, _lib.ptr(self.p), self.ld,
                   _lib.ptr(self.q), self.ld, st)                                             # :51
+        self._accept(args, seed, ud, st)
+
+    def _accept(self, args, seed, ud, st):
         _lib.call("linna_hmc_accept", *args, seed, _lib.iptr(self.step_dev), _lib.ptr(self.H0), _lib.ptr(self.p), self.ld,
                   _lib.ptr(self.q), self.ld, _lib.ptr(self.lnp_new), _lib.ptr(self.g_new), self.ld,
                   _lib.ptr(ud) if ud is not None else None, _lib.ptr(self.x), self.ld, _lib.ptr(self.lnp), _lib.ptr(self.g),

@@ -107,6 +107,30 @@ def test_batched_hmc_step_matches_oracle():
     np.testing.assert_allclose(h.lnp.cpu().numpy()[ok], ln[ok], rtol=2e-3)
 
 
+@pytest.mark.parametrize("name,B", [("mlp_33_33", 70), ("v2_33_33", 5), ("mlp_33_33_dense", 33), ("mlp_33_33", 2100)])
+def test_leapfrog_in_the_gradient_launch_equals_the_separate_entries(name, B):
+    """linna_hmc_start + linna_logprob_grad_leapfrog (momentum draw, first half kick and drift in one launch; every later kick
+    and drift in the FINISH of the gradient launch) against linna_hmc_init / _kick_drift / linna_logprob_grad: the same
+    arithmetic in the same order -> equal chains.  Plain MLP (GRAD program), ChtoModelv2 (forward + dX chain program), a dense
+    covariance (no one-launch gradient: the kick follows as a launch of its own), and a batch the 16-row engine serves."""
+    from linna_amd import sampler
+    lp = build_logprob(name, 2.0)[0]
+    nd = 33
+    x0 = (0.2 * np.random.RandomState(B).standard_normal((B, nd))).astype(np.float32)
+    mass = np.linspace(0.5, 2.0, nd).astype(np.float32)
+    a = sampler.BatchedHMC(lp, x0, mass=mass, seed=3, fused=True)
+    b = sampler.BatchedHMC(lp, x0, mass=mass, seed=3, fused=False)
+    for it, (nleap, eps) in enumerate([(1, 1e-2), (5, 2e-2), (3, 5e-2), (4, 1e-2)]):
+        a.step(nleap, eps); b.step(nleap, eps)
+        torch.cuda.synchronize()
+        for nm in ("x", "lnp", "g", "p", "q", "H0", "lnp_new", "g_new"):
+            ta, tb = getattr(a, nm), getattr(b, nm)
+            ta, tb = (ta[:, :nd], tb[:, :nd]) if ta.dim() == 2 else (ta, tb)
+            assert torch.equal(ta, tb), (it, nm, float((ta - tb).abs().max()))
+        assert torch.equal(a.naccept, b.naccept)
+    assert 0 < int(a.naccept.sum()) <= 4 * B
+
+
 def test_batched_hmc_proposals_match_the_references_integrator():
     """The per-walker HMC move of the reference (sampler.py:59-98 ``_hmc_wrapper``, :141-143 the Metropolis test; code it
     never reaches through emcee, called directly for tests/golden/hmc_move.npz with the autograd gradient of its own
