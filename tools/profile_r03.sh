@@ -1,7 +1,8 @@
 #!/bin/bash
 # GPU box: the round-3 profile set.  Summaries land in gpurun_out/prof_r03/ (copy what is to be judged into profiles/).
 #  1. bench.py un-profiled (the bench line), kernel trace of the headline, FETCH_SIZE / WRITE_SIZE passes (tools/profile_bench.sh)
-#  2. ONE workload per rocprofv3 run: ChtoModelv2(33,33) serving, ChtoModelv2(40,1000) dense serving, the training step at (26,457)
+#  2. ONE workload per rocprofv3 run: ChtoModelv2(33,33) serving, ChtoModelv2(40,1000) dense serving, the training step at (26,457),
+#     the one-call slice sampler at 4096 and 128 walkers, HMC transitions (MLP, ChtoModelv2)
 #  3. matrix-pipe counters (separate --pmc passes): the headline kernel, ChtoModelv2(33,33) serving, the training step
 set -e
 root=$(pwd)
@@ -12,6 +13,10 @@ echo "bench done"; tail -c 300 $out/bench.json; echo
 tools/profile_cmd.sh r03_chto_v2 python tools/serve_probe.py ChtoModelv2 33 33 0 4096 2000 > $out/chto_v2.log 2>&1; tail -4 $out/chto_v2.log
 tools/profile_cmd.sh r03_dense_1000 python tools/serve_probe.py ChtoModelv2 40 1000 1 4096 1000 > $out/dense_1000.log 2>&1; tail -4 $out/dense_1000.log
 tools/profile_cmd.sh r03_training_26_457 python tools/train_probe.py 26 457 500 > $out/training.log 2>&1; tail -9 $out/training.log
+SLICE_ONLY_FAST=1 tools/profile_cmd.sh r03_slice_4096 python tools/slice_probe.py 4096 > $out/slice_4096.log 2>&1; tail -9 $out/slice_4096.log
+SLICE_ONLY_FAST=1 tools/profile_cmd.sh r03_slice_128 python tools/slice_probe.py 128 > $out/slice_128.log 2>&1; tail -9 $out/slice_128.log
+tools/profile_cmd.sh r03_hmc_mlp python tools/hmc_probe.py MLP > $out/hmc_mlp.log 2>&1; tail -9 $out/hmc_mlp.log
+tools/profile_cmd.sh r03_hmc_chto_v2 python tools/hmc_probe.py ChtoModelv2 > $out/hmc_v2.log 2>&1; tail -9 $out/hmc_v2.log
 export TMPDIR=/tmp
 PMC="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32"
 cd /tmp
