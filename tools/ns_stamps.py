@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Diagnostic: per-segment cycle stamps of net_stream_kernel (library built with
-LINNA_HIPCC_EXTRA=-DNS_STAMPS).  Usage: python tools/ns_stamps.py [mlp|v2] [B]
+"""Diagnostic: per-segment cycle stamps of net_stream_kernel (the diagnostic build: python linna_amd/_build.py --stamps).  Usage: python tools/ns_stamps.py [mlp|v2] [B]
 Stamp order: start, after prologue barrier, after every segment's last barrier, after the loop, end."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+os.environ.setdefault("LINNA_LIB_PATH", os.path.join(ROOT, "linna_amd", "liblinna_hip_stamps.so"))   # python linna_amd/_build.py --stamps
 which = sys.argv[1] if len(sys.argv) > 1 else "v2"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 nb = (B + 3) // 4                       # room for the smallest engine's grid (4 rows per workgroup); unused blocks stay zero
