@@ -46,6 +46,62 @@ def _stage(msg):
         print("[bench rank %s] %.1f %s" % (os.environ.get("RANK", "0"), time.perf_counter(), msg), file=sys.stderr, flush=True)
 
 
+class _Watchdog(object):
+    """N > 1 only.  The headline is timed without any data-path collective, but the sections behind it (strong scaling,
+    training with its gradient all-reduce, the ensemble iterations with their walker exchange, the shutdown barrier) call
+    collectives, and a collective that never completes would take the whole line with it: nothing is printed before the
+    end.  Armed once the headline is known; if the remaining sections have not finished after `seconds`, rank 0 prints the
+    line with what it has (and says so in "watchdog"), and every rank leaves with os._exit -- no exec, no retry."""
+
+    def __init__(self, seconds, rank):
+        import threading
+        self.rank, self.line, self.stage, self.done = rank, None, "armed", False
+        self.lock = threading.Lock()
+        self.timer = threading.Timer(seconds + (0.0 if rank == 0 else 20.0), self._fire)   # rank 0 first: its line must get out
+        self.timer.daemon = True
+        self.seconds = seconds
+
+    def arm(self, line):
+        self.line = line
+        self.timer.start()
+
+    def emit(self, line):
+        """The one place the JSON line is printed; False if the watchdog already printed it."""
+        with self.lock:
+            if self.done:
+                return False
+            self.done = True
+        self.timer.cancel()
+        print(json.dumps(line), flush=True)
+        return True
+
+    def failed(self, exc):
+        """An exception behind the headline (a collective that broke, a peer that left): the headline line still goes out
+        from rank 0, the other ranks leave quietly -- nothing they could still do would change the line."""
+        import traceback
+        traceback.print_exc()
+        with self.lock:
+            if self.done:
+                os._exit(0)
+            self.done = True
+        if self.rank == 0 and self.line is not None:
+            self.line["watchdog"] = "a section after the headline raised %s at stage '%s'; the remaining sections are missing from this line" % (repr(exc)[:200], self.stage)
+            print(json.dumps(self.line), flush=True)
+        os._exit(0)
+
+    def _fire(self):
+        with self.lock:
+            if self.done:
+                os._exit(0)
+            self.done = True
+        if self.rank == 0 and self.line is not None:
+            self.line["watchdog"] = "sections after the headline did not finish within %.0f s (last stage: %s); they are missing from this line" % (self.seconds, self.stage)
+            print(json.dumps(self.line), flush=True)
+        sys.stderr.write("[bench rank %d] watchdog: leaving at stage '%s'\n" % (self.rank, self.stage))
+        sys.stderr.flush()
+        os._exit(0)
+
+
 def build_problem(device):
     """README.rst:69-83 shaped problem with a random-init emulator (seed 1234, Xavier-uniform
     weights, bias 0.01 -- nn.py:97-99); synthetic: there is no trained checkpoint offline."""
@@ -625,6 +681,42 @@ def main():
     # sanity: the timed path produced finite numbers
     assert torch.isfinite(out).all(), "non-finite log-probabilities in the timed path"
 
+    def headline_line():
+        ms_kernel, flop_launch, ms_q = time_dominant_kernel(lp, z, out, max(500, args.steps))
+        achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
+        return {
+            "metric": "emulator log-likelihood evals/sec",
+            "value": world * NWALKERS * args.steps / elapsed,
+            "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "33-D Gaussian, 4x512 MLP emulator (33->512x4->33), nwalkers=4096 batched "
+                                   "log-likelihood per GPU (BASELINE configs[1])",
+                       "nwalkers_per_gpu": NWALKERS, "flop_per_eval": 2 * MACS_PER_EVAL + 3 * NOUT,
+                       "launch": "hipGraph replay" if graph is not None else "direct launches",
+                       "parallelism": "walkers sharded, %d rank(s), no data-path collective" % world},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
+                         "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this kernel, not measured in this run)" % TRAFFIC_FILE,
+                         "kernel": "net_stream_kernel<6, 0, false, 0, 16> (whole network per launch: 16 walkers/workgroup, activations in LDS, fragment-order weight stream loaded straight into the MFMA operand registers, v_mfma_f32_16x16x4_f32)",
+                         "avg_launch_ms": ms_kernel, "launch_ms_p10_p50_p90": ms_q, "flop_per_launch": flop_launch},
+            "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
+        }
+
+    # N > 1: from here on the sections call collectives; the headline line is put together first and a watchdog holds it
+    dog = None
+    res = headline_line() if rank == 0 else None
+    if world > 1:
+        global _DOG
+        dog = _DOG = _Watchdog(float(os.environ.get("LINNA_BENCH_WATCHDOG_S", "420")), rank)
+        dog.arm(res)
+    def _at(stage):
+        _stage(stage)
+        if dog is not None:
+            dog.stage = stage
+
     # N > 1: also the strong-scaling figure (the SAME 4096 walkers split over the ranks, BASELINE's "nwalkers=4096
     # ... at 8xMI355X"): each rank evaluates 4096 / N walkers per step on the small-batch engine of the kernel
     strong = None
@@ -648,7 +740,7 @@ def main():
 
     # secondary figure, every rank takes part (collective inside): training throughput on the configs[2] shape.
     # Guarded: a failure here must not cost the headline line.
-    _stage("strong scaling done")
+    _at("strong scaling done")
     training = None
     if not args.no_training:
         try:
@@ -656,7 +748,7 @@ def main():
         except Exception as e:                                      # noqa: BLE001
             training = {"error": repr(e)[:300]}
 
-    _stage("training done: %s" % (training,))
+    _at("training done: %s" % (training,))
     # ensemble iterations: every rank takes part (cross-rank partner exchange for N > 1)
     mcmc = None
     try:
@@ -672,30 +764,8 @@ def main():
     except Exception as e:                                          # noqa: BLE001
         mcmc = {"error": repr(e)[:300]}
 
-    _stage("mcmc done: %s" % (mcmc,))
+    _at("mcmc done: %s" % (mcmc,))
     if rank == 0:
-        ms_kernel, flop_launch, ms_q = time_dominant_kernel(lp, z, out, max(500, args.steps))
-        achieved = flop_launch / (ms_kernel * 1e-3) / 1e12
-        res = {
-            "metric": "emulator log-likelihood evals/sec",
-            "value": world * NWALKERS * args.steps / elapsed,
-            "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "33-D Gaussian, 4x512 MLP emulator (33->512x4->33), nwalkers=4096 batched "
-                                   "log-likelihood per GPU (BASELINE configs[1])",
-                       "nwalkers_per_gpu": NWALKERS, "flop_per_eval": 2 * MACS_PER_EVAL + 3 * NOUT,
-                       "launch": "hipGraph replay" if graph is not None else "direct launches",
-                       "parallelism": "walkers sharded, %d rank(s), no data-path collective" % world},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic(),
-                         "traffic_source": "profiles/%s (rocprofv3 --pmc passes of this kernel, not measured in this run)" % TRAFFIC_FILE,
-                         "kernel": "net_stream_kernel<6, 0, false, 0, 16> (whole network per launch: 16 walkers/workgroup, activations in LDS, fragment-order weight stream loaded straight into the MFMA operand registers, v_mfma_f32_16x16x4_f32)",
-                         "avg_launch_ms": ms_kernel, "launch_ms_p10_p50_p90": ms_q, "flop_per_launch": flop_launch},
-            "step_tflops": world * NWALKERS * args.steps * (2 * MACS_PER_EVAL) / elapsed / 1e12,
-        }
         if strong is not None:
             res["strong_scaling"] = strong
         if training is not None:
@@ -722,11 +792,26 @@ def main():
                     res[key] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
             res["cpu_baseline"] = cpu_baseline(consts, z_host)
-        print(json.dumps(res), flush=True)
+        if dog is None:
+            print(json.dumps(res), flush=True)
+        else:
+            dog.emit(res)                            # (cancels the watchdog's own print; the shutdown below is still covered)
     if world > 1:
         from linna_amd import dist as ldist
+        _at("shutdown")
+        if rank == 0:
+            threading_guard = __import__("threading").Timer(120.0, lambda: os._exit(0))   # the line is out: a stuck teardown must not hold the launcher
+            threading_guard.daemon = True
+            threading_guard.start()
         ldist.shutdown()
 
 
+_DOG = None
+
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:                                   # noqa: BLE001
+        if _DOG is None:
+            raise
+        _DOG.failed(e)                                       # N > 1, behind the headline: the line is not lost to it

@@ -306,3 +306,37 @@ def test_zeus_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
     assert res[0][3] and res[1][3]                                   # the one-call half step ran on both ranks
     assert res[0][4] == res[1][4]                                    # ... and they redid the same runs on the round loop
     assert sorted(os.listdir(tmp_path)) == ["zeus_256.h5"]
+
+
+def _bench2(extra_env, *argv):
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "30", "--no-secondary",
+                           "--no-cpu-baseline"] + list(argv), capture_output=True, text=True, env=e, timeout=600)
+
+
+def test_two_rank_bench_line_and_its_watchdog():
+    """`python bench.py --gpus 2` from a bare shell on the GPU box (two ranks share the device, gloo carries the collectives):
+    ONE JSON line with the whole-job value, the strong-scaling, training and ensemble sections.  With the watchdog's budget
+    set to nothing, the sections behind the headline are cut off: the line still comes out -- headline and roofline intact,
+    the reason under "watchdog" -- and the launcher exits 0 (a collective that hangs on a node this code has never seen must
+    not cost the driver its scaling point)."""
+    import json
+    r = _bench2({})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 1e7 and d["scaling"] == "weak" and "watchdog" not in d
+    assert d["strong_scaling"]["nwalkers_per_gpu"] == 2048 and "error" not in d["training"] and "error" not in d["mcmc"]
+    assert abs(d["value"] - 2 * 4096 * 30 / (d["ms_per_step"] * 1e-3 * 30)) < 1e-6 * d["value"]
+    w = _bench2({"LINNA_BENCH_WATCHDOG_S": "0.5"})
+    assert w.returncode == 0, w.stderr[-3000:]
+    lines = [ln for ln in w.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    dw = json.loads(lines[0])
+    assert "watchdog" in dw and dw["n_gpus"] == 2 and dw["value"] > 1e7 and dw["roofline"]["frac"] > 0.5
