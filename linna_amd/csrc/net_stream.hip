@@ -280,6 +280,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // boundary less than forward + loss and dX chain as two launches, the weight ring never drained in between.
     constexpr bool TRB = GRAD && STORE == 3;
     constexpr bool DXE = STORE == 2 || TRB;        // epilogues of dX segments: gate by the stored activation, store
+#ifdef NS_EARLY_REFILL
+    constexpr bool LATE_REFILL = false;
+#else
+    constexpr bool LATE_REFILL = !TRB;             // see `step`
+#endif
     static_assert(ROWS == 16 || ROWS == 8 || ROWS == 4, "rows per workgroup");
     static_assert(R % 2 == 0, "the A double buffer alternates with the ring slot parity");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #ifdef NS_STAMPS_FINE
     NS_STAMP();                                    // the rest of the input in LDS
 #endif
-    NS_PF_ALL(PRE, R)
+    NS_PF_ALL(PRE, (LATE_REFILL ? R - 1 : R))
 #undef NS_PF_ALL
 #undef NS_PF
 #pragma unroll
@@ -619,6 +624,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     auto step = [&](auto Uc, auto Refill) {
         constexpr int U = decltype(Uc)::value;
         constexpr bool refill = decltype(Refill)::value;
+        // the refill of this step goes to the slot the PREVIOUS step consumed: a load whose target the MFMAs just issued
+        // still read waits for them at issue (measured: the same loads one slot back, 1.2-1.4 % off every launch; R - 1
+        // steps are in flight instead of R).  Not in the merged training launch: its register allocation does not survive
+        // the longer slot lifetimes (2.3 KB of scratch per lane, +40 % on the step).
+        constexpr int RU = LATE_REFILL ? (U + R - 1) % R : U;
 #ifdef NS_ALTPRIO
         // experiment: the two waves of a SIMD take turns at the higher issue priority every R / 2 steps, so that neither runs
         // ahead of the other by thousands of cycles inside a segment (-DNS_ALTPRIO)
@@ -641,7 +651,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #undef NS_M4
             if constexpr (refill) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) Bq[U][t] = wload(t);
+                for (int t = 0; t < NT; ++t) Bq[RU][t] = wload(t);
             }
         } else {
 #pragma unroll
@@ -652,8 +662,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     acc[h + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][h + 1][s], acc[h + 1], 0, 0, 0);
                 }
                 if constexpr (refill) {
-                    Bq[U][h] = wload(h);
-                    Bq[U][h + 1] = wload(h + 1);
+                    Bq[RU][h] = wload(h);
+                    Bq[RU][h + 1] = wload(h + 1);
                 }
             }
         }
