@@ -384,7 +384,7 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
         (void)hipStreamIsCapturing(S(stream), &cap);
         net_ensure_fwd(n, cap == hipStreamCaptureStatusNone);
         if (n->stream_fwd == 1 && n->packed.ready()) {
-            const int rows = std::min(net_stream_rows(B), 8);          // (no 16-row instantiation of this launch: net_stream.hip, ns_launch_kernel)
+            const int rows = net_stream_rows(B);
             const float* packed = nullptr;
             TRY(stream_copy_refresh(n->packed, n, rows, stream, &packed));
             std::vector<float*> y(nl), t(nl);

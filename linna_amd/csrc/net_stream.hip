@@ -283,12 +283,19 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #ifdef NS_EARLY_REFILL
     constexpr bool LATE_REFILL = false;
 #else
-    constexpr bool LATE_REFILL = !TRB;             // see `step`
+    constexpr bool LATE_REFILL = true;             // see `step`
 #endif
     static_assert(ROWS == 16 || ROWS == 8 || ROWS == 4, "rows per workgroup");
     static_assert(R % 2 == 0, "the A double buffer alternates with the ring slot parity");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int LD = a.LD, ABUF = ROWS * LD;
+    // The per-segment tables are indexed at run time.  Through `a` (a by-value argument) such an index makes the compiler
+    // keep a private copy of the whole 2.3 KB block whenever it cannot split it -- scratch traffic at every run end, and which
+    // instantiation is hit changes with unrelated edits (STORE == 1 on the 16-row engine in round 2, the merged training
+    // launch with the refill one slot back in round 3).  Through the kernel-argument segment itself they are scalar loads.
+    // (Only in the training instantiations, where that copy appeared: the serving ones lose 0.3-0.7 % to the explicit pointer.)
+    constexpr bool KA = STORE == 3 || STORE == 1;
+    const NsArgs* const ka = KA ? reinterpret_cast<const NsArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) : &a;
     float* const act = smem;                       // [2][ROWS][LD]
     float* const lbias = smem + 2 * ABUF;          // packed biases of every segment
     const int tid = threadIdx.x, lane = tid & 63;
@@ -581,12 +588,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // (kernel-argument arrays are indexed through readfirstlane: one instantiation -- STORE == 1 on the 16-row engine --
     // could not prove the segment index uniform and copied the whole 2 KB argument block to scratch)
     auto load_seg = [&]() {
-        const NsSeg S = a.seg[__builtin_amdgcn_readfirstlane(si)];
+        const NsSeg S = ka->seg[__builtin_amdgcn_readfirstlane(si)];
         s_type = S.type; kleft = s_steps = S.steps; s_passes = S.passes; s_bias = S.bias_off;
         s_dst = S.dst_col; s_relu = S.relu; s_kslice = S.kslice; s_zext = S.zext; s_ncgl = S.ncg_log2; s_x0col = S.x0_col; s_x0n = S.x0_n;
         if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
-        if constexpr (STORE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gout = a.gout[j]; s_gld = a.gld[j]; s_gn = a.gn[j]; }
-        if constexpr (DXE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gmask = a.gmask[j]; s_gmld = a.gmld[j]; }
+        if constexpr (STORE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gout = ka->gout[j]; s_gld = ka->gld[j]; s_gn = ka->gn[j]; }
+        if constexpr (DXE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gmask = ka->gmask[j]; s_gmld = ka->gmld[j]; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         const int arow = SM ? sm_arow : li, ak = SM ? 4 * sm_achunk : 4 * kq;
@@ -672,11 +679,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             // ---- end of run (si, pass).  The next segment's descriptor is requested first: the scalar
             // load's latency then hides under the epilogue stores and the barrier.
             const int nxi = __builtin_amdgcn_readfirstlane(min(si + 1, nseg - 1));
-            const NsSeg NX = a.seg[nxi];
+            const NsSeg NX = ka->seg[nxi];
             float* nx_gout = nullptr; int nx_gld = 0, nx_gn = 0;
             const float* nx_gmask = nullptr; int nx_gmld = 0;
-            if constexpr (STORE) { nx_gout = a.gout[nxi]; nx_gld = a.gld[nxi]; nx_gn = a.gn[nxi]; }
-            if constexpr (DXE) { nx_gmask = a.gmask[nxi]; nx_gmld = a.gmld[nxi]; }
+            if constexpr (STORE) { nx_gout = ka->gout[nxi]; nx_gld = ka->gld[nxi]; nx_gn = ka->gn[nxi]; }
+            if constexpr (DXE) { nx_gmask = ka->gmask[nxi]; nx_gmld = ka->gmld[nxi]; }
             const int cur_steps = s_steps;
             auto take_seg = [&](const NsSeg& X) {
                 s_type = X.type; s_steps = X.steps; s_passes = X.passes; s_bias = X.bias_off;
@@ -1076,7 +1083,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     lds_barrier();
                     NS_STAMP();
                     ++si;
-                    const NsSeg N2 = a.seg[__builtin_amdgcn_readfirstlane(min(si, nseg - 1))];
+                    const NsSeg N2 = ka->seg[__builtin_amdgcn_readfirstlane(min(si, nseg - 1))];
                     take_seg(N2);
                 }
             }
@@ -1694,17 +1701,10 @@ static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int row
 #endif
     if (rows == 4) return ns_launch_rows<MOVE, GRAD, STORE, 4>(a, B, lds, s, extra);
     if constexpr (STORE == 3 && GRAD) {
-        // the one-launch training step exists for the 4-row engine only (batches up to 1024 rows; the caller checks): its
-        // 8-row instantiation needs 256 VGPRs and spills
+        // the one-launch training step exists for the 4-row engine only (batches up to 1024 rows; the caller checks): on the
+        // 8-row engine it was measured SLOWER than its two halves (batch 1500 at (26,457): 218.5 against 210.9 us per step)
     } else {
         if (rows == 8) return ns_launch_rows<MOVE, GRAD, STORE, 8>(a, B, lds, s, extra);
-    }
-    if constexpr (STORE == 3 && GRAD) {
-    } else if constexpr (STORE == 1 && !GRAD) {
-        // no 16-row instantiation of the training / validation forward: it is the one kernel hipcc (ROCm 7.2) copies the
-        // 2 KB argument block to scratch for (234 VGPRs + 2096 bytes of private memory per lane, every argument then read
-        // back through scratch); linna_net_forward runs batches of more than 2048 rows on the 8-row engine
-    } else {
         if (rows == 16) return ns_launch_rows<MOVE, GRAD, STORE, 16>(a, B, lds, s, extra);
     }
     set_error("net_stream: %d rows per workgroup", rows);

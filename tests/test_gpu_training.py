@@ -119,15 +119,18 @@ def test_adamw_writing_the_weight_streams_equals_update_plus_relayout(name):
         assert _lib.load().linna_net_train_launches(model.net_handle(with_grads=True), B) == 2
 
 
-@pytest.mark.parametrize("name", ["train_v2_33_33", "train_v2_26_457"])
-def test_train_step_entry_equals_forward_loss_plus_backward(name):
+@pytest.mark.parametrize("name,engine", [("train_v2_33_33", 0), ("train_v2_26_457", 0), ("train_v2_26_457", 8), ("train_v2_33_33", 16)])
+def test_train_step_entry_equals_forward_loss_plus_backward(name, engine):
     """``linna_net_train_step`` (forward + loss + backward in one call, the batch mean and AdamW's step constants riding
     in the dX-chain launch) against ``linna_net_forward_loss`` + ``linna_net_backward``: loss rows, batch mean, every
-    parameter gradient, the step counter and the bias corrections, bit for bit."""
+    parameter gradient, the step counter and the bias corrections, bit for bit.  On the engine the batch size picks (4 rows
+    per workgroup: forward + loss + dX chain in ONE launch) and on the 8- and 16-row engines of larger batches (the entry
+    runs forward + loss and the dX chain as two launches there)."""
     import ctypes as C
     from linna_amd import _lib
     from linna_amd.predictor_gpu import _AdamWState
     got = []
+    _lib.engine_rows(engine)
     for one_call in (True, False):
         p, model, pred, eng, B = make_engine(name)
         opt = _AdamWState(model, 1e-3)
@@ -137,6 +140,7 @@ def test_train_step_entry_equals_forward_loss_plus_backward(name):
             if one_call:
                 eng._forward_loss_backward(rows, out, opt)
                 assert eng.one_launch is True
+                assert _lib.load().linna_net_train_launches(model.net_handle(with_grads=True), B) == (3 if engine else 2)
             else:
                 k, m = eng.k, model
                 _lib.call("linna_net_forward_loss", m.net_handle(with_grads=True), C.byref(eng.desc), _lib.ptr(eng.X), eng.X.stride(0),
@@ -150,6 +154,7 @@ def test_train_step_entry_equals_forward_loss_plus_backward(name):
         torch.cuda.synchronize()
         got.append([eng.loss_rows.cpu().numpy().copy(), out.cpu().numpy().copy(), model.flat_grads().cpu().numpy().copy(),
                     opt.step_dev.cpu().numpy().copy(), opt.hyper.cpu().numpy().copy()])
+    _lib.engine_rows(0)
     assert int(got[0][3][0]) == 2 and np.isfinite(got[0][1]).all() and np.abs(got[0][2]).max() > 0
     for a, b in zip(*got):
         np.testing.assert_array_equal(a, b)
