@@ -107,6 +107,11 @@ struct NsArgs {
     // STORE == 2 (the dX chain of a training step): a segment's output is zeroed where gmask (the stored forward
     // activation whose gradient it is) is not positive, before it is stored and handed to the next segment
     const float* gmask[NS_MAXSEG]; int gmld[NS_MAXSEG];
+    // GRAD + STORE == 2 (lnP and its gradient in one launch, any network): the backward needs the SIGN of the forward
+    // activations only, and it needs it in this very workgroup -- one bit per (row, column) in LDS ([ROWS][nbw] words at
+    // float offset bits_off) instead of the activations in global memory: gout / gmask are flags there, gld / gmld the first
+    // bit column (a multiple of 64) of the tensor a segment writes / is gated by
+    int nbw, bits_off;
     // STORE == 3 (one launch = gather + input transform + training forward + chi^2-ratio loss and its gradient,
     // predictor_gpu.py:274-285 with util.py:1070-1116): Z is the RESIDENT training set X[n][ldz], row `t_rows[b]` is
     // transformed in the prologue (and stored to t_xb for the first layer's parameter gradient); the last network layer's
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int NQ = SM ? RS : NT;               // result quads per lane: (row set) or (column tile)
     constexpr int NACC = SM ? 4 * RS : NT;
     constexpr bool K4 = !SM && STORE == 0;         // serving instantiations of the 16-row engine: programs may hold SIDE segments
+    // (the one-launch gradient with SIDE segments in its forward half was measured SLOWER: 156.4 against 154.2 us at ChtoModelv2(33,33))
     // TRB: a whole training step's network work in ONE launch (linna_net_train_step): gather + transform + forward with the
     // activations kept + chi^2-ratio loss (STORE == 3) as the forward half, the loss finish as the TURNAROUND (loss rows,
     // d loss / d pred to memory AND into LDS as the input of the first backward segment), then the dX chain (STORE == 2's
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // boundary less than forward + loss and dX chain as two launches, the weight ring never drained in between.
     constexpr bool TRB = GRAD && STORE == 3;
     constexpr bool DXE = STORE == 2 || TRB;        // epilogues of dX segments: gate by the stored activation, store
+    constexpr bool G2 = GRAD && STORE == 2;        // the gates are sign bits in LDS (NsArgs::nbw)
 #ifdef NS_EARLY_REFILL
     constexpr bool LATE_REFILL = false;
 #else
@@ -293,11 +300,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // keep a private copy of the whole 2.3 KB block whenever it cannot split it -- scratch traffic at every run end, and which
     // instantiation is hit changes with unrelated edits (STORE == 1 on the 16-row engine in round 2, the merged training
     // launch with the refill one slot back in round 3).  Through the kernel-argument segment itself they are scalar loads.
-    // (Only in the training instantiations, where that copy appeared: the serving ones lose 0.3-0.7 % to the explicit pointer.)
-    constexpr bool KA = STORE == 3 || STORE == 1;
+    // (Only in the instantiations where that copy has appeared -- training, the one-launch gradient with SIDE segments: the
+    // serving ones lose 0.3-0.7 % to the explicit pointer.)
+    constexpr bool KA = STORE == 3 || STORE == 1 || (GRAD && STORE == 2);
     const NsArgs* const ka = KA ? reinterpret_cast<const NsArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) : &a;
     float* const act = smem;                       // [2][ROWS][LD]
     float* const lbias = smem + 2 * ABUF;          // packed biases of every segment
+    unsigned* const lbits = reinterpret_cast<unsigned*>(smem + a.bits_off);   // G2: sign bits [ROWS][nbw]
+    const int nbw = a.nbw;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
@@ -754,7 +764,19 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ty[t][0]), "+v"(ty[t][1]), "+v"(ty[t][2]), "+v"(ty[t][3]) :: "memory");
                     }
                 }
-                if constexpr (DXE) {
+                unsigned long long gw[SM ? NQ : 1][4];      // G2: the 64 sign bits of this wave's columns, per result row
+                if constexpr (G2) {
+                    if (s_gmask) {
+                        const int cw = 512 * pass + 64 * wave, w0 = (s_gmld + cw) >> 5;
+                        const bool mine = cw < ((s_gn + 63) & ~63);             // (past the tensor: padding columns, their gradients are zero)
+#pragma unroll
+                        for (int t = 0; t < (SM ? NQ : 1); ++t)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                gw[t][e] = mine ? *reinterpret_cast<const unsigned long long*>(lbits + (SM ? 4 * t + e : 4 * kq + e) * nbw + w0) : 0ull;
+                    }
+                }
+                if constexpr (DXE && !G2) {
                     // the gates (stored forward activations), by loads the compiler does not count -- a visible load in this
                     // loop body makes every step's wait for the weight ring a vmcnt(0) -- with one explicit wait
                     if (s_gmask) {
@@ -794,7 +816,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         float v = fin[t][e];
                         if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
                         v = s_relu ? fmaxf(v, 0.f) : v;
-                        if constexpr (DXE) {
+                        if constexpr (G2) {
+                            if (s_gmask && !((gw[SM ? t : 0][e] >> (SM ? lane : 16 * t + li)) & 1ull)) v = 0.f;
+                        } else if constexpr (DXE) {
                             if (s_gmask && !(ty[t][e] > 0.f)) v = 0.f;
                         }
                         float v_lds = v;
@@ -806,7 +830,19 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             }
                         }
                         nxt[q_row(t, e) * LD + q_col(t)] = v_lds;
-                        if constexpr (STORE) {
+                        if constexpr (G2) {
+                            if (s_gout) {                      // the sign of this activation, for the gate of its gradient
+                                const unsigned long long bb = __ballot(v > 0.f);
+                                const int cw = 512 * pass + 64 * wave;          // (a wave whose 64 columns lie past the tensor's
+                                const bool mine = cw < ((s_gn + 63) & ~63);     //  bit range writes nothing: the next row's bits, or the
+                                const int c0 = s_gld + cw;                      //  neighbouring workgroup's LDS, sit there)
+                                if constexpr (SM) {            // lane = column: 64 columns of row 4 t + e
+                                    if (lane == 0 && mine) *reinterpret_cast<unsigned long long*>(lbits + (4 * t + e) * nbw + (c0 >> 5)) = bb;
+                                } else {                       // 16 columns of tile t for each of the rows 4 kq + e
+                                    if (li == 0 && mine) reinterpret_cast<unsigned short*>(lbits + (4 * kq + e) * nbw)[(c0 + 16 * t) >> 4] = (unsigned short)(bb >> (16 * kq));
+                                }
+                            }
+                        } else if constexpr (STORE) {
                             const int grow_ = row0 + q_row(t, e), gcol = 512 * pass + 64 * wave + q_col(t);
                             if (s_gout && grow_ < a.B && gcol < s_gn) {
                                 float vs = v;                      // the network's last output carries the column affine
@@ -852,7 +888,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 const int sw = SM ? 32 * (sr & 1) : 16 * (sr >> 2);
                 constexpr int NGJ = 256 / RGS;          // (SPLIT outputs are <= 256 columns: 8 / 4 / 2 per thread)
                 float sg[NGJ];
-                if constexpr (DXE) {
+                if constexpr (DXE && !G2) {
                     if (s_gmask) {
 #pragma unroll
                         for (int j = 0; j < NGJ; ++j) {
@@ -891,13 +927,15 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         }
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
-                        if constexpr (DXE) {
+                        if constexpr (G2) {
+                            if (s_gmask && !(c < ((s_gn + 63) & ~63) && ((lbits[sr * nbw + ((s_gmld + c) >> 5)] >> (c & 31)) & 1u))) v = 0.f;
+                        } else if constexpr (DXE) {
                             float gv = 1.f;             // (dynamic register-array index: a select chain)
 #pragma unroll
                             for (int j = 0; j < NGJ; ++j) gv = gj == j ? sg[j] : gv;
                             if (s_gmask && !(gv > 0.f)) v = 0.f;
                         }
-                        if constexpr (STORE) {
+                        if constexpr (STORE && !G2) {
                             if (s_gout && row0 + sr < a.B && c < s_gn) {
                                 float vs = v;
                                 if constexpr (STORE == 1)
@@ -907,6 +945,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         }
                     }
                     cur[c] = v;
+                    if constexpr (G2) {
+                        if (s_gout) {                       // (every lane of a wave runs the same trips of this loop)
+                            const unsigned long long bb = __ballot(v > 0.f);
+                            const bool mine = c < ((s_gn + 63) & ~63);
+                            if constexpr (SM) { if (lane == 0 && mine) *reinterpret_cast<unsigned long long*>(lbits + sr * nbw + ((s_gld + c) >> 5)) = bb; }
+                            else { if ((lane & 31) == 0 && mine) lbits[sr * nbw + ((s_gld + c) >> 5)] = (unsigned)(bb >> (lane & 32)); }
+                        }
+                    }
                 }
                 if constexpr (STORE == 3) {
                     if (si == nlast) {
@@ -936,7 +982,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
             if constexpr (GRAD) {
                 if (seg_done && si == a.nseg_f) {   // (seg_done: not again after a pass of the first backward segment)
-                    if constexpr (DXE)              // the forward activations every wave stored are in memory before any gate load
+                    if constexpr (DXE && !G2)       // the forward activations every wave stored are in memory before any gate load
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if constexpr (TRB) {
                         // ---- turnaround of a training step = the loss finish: delta and U = delta Cinv sit in LDS (U at column
@@ -1178,6 +1224,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
             if (pc0 == 0) a.lnP[row0 + pr] = isnan(lnp_grad) ? -INFINITY : lnp_grad;
         }
+        if constexpr (STORE == 2) { NS_STAMP(); NS_STAMPS_FLUSH(); }     // (diagnostic build; the MLP-only GRAD keeps its masks where the stamps would sit)
         return;
     }
     // ---- 5. output rows are in buffer P (bias added, no ReLU): output transform, d, log-likelihood
@@ -1689,8 +1736,8 @@ static int ns_launch_rows(const NsArgs& a, int B, size_t lds_bytes, hipStream_t 
     return check_hip(hipGetLastError(), "net_stream launch");
 }
 template <int MOVE, bool GRAD, int STORE = 0>
-static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int rows, hipStream_t s, int extra = 0) {
-    const size_t lds = p.lds_for(rows, GRAD);
+static int ns_launch_kernel(const NsArgs& a0, int B, const NsProgram& p, int rows, hipStream_t s, int extra = 0, size_t lds_extra = 0) {
+    const size_t lds = p.lds_for(rows, GRAD) + lds_extra;
 #ifdef NS_STAMPS
     // diagnostic build: every launch writes its phase stamps to the buffer LINNA_FUSED_STAMPS names (tools/ns_stamps*.py)
     NsArgs a = a0;
@@ -1898,7 +1945,21 @@ int launch_adamw_streams(const AsArgs& a, float* p, const float* g, float* m, fl
 }
 
 bool net_stream_has_grad(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 0).grad_ok; }
-bool net_stream_dxi_eligible(const linna_layer_t* layers, int nl, int in_size) { const NsProgram& p = ns_build_prog(layers, nl, in_size, 3); return p.ok && p.dxi_ok; }
+// bit columns of the one-launch gradient's sign matrix: every tensor a gate asks for, each rounded up to 64 columns
+static int ns_g2_cols(const NsProgram& p, const linna_layer_t* layers, int nl) {
+    int n = 0;
+    for (int i = 0; i < p.nseg_f; ++i) {
+        const int op = p.seg_op[i];
+        if (p.seg_hidden[i]) n += (layers[op].C + 63) & ~63;
+        else if (op < nl - 1) n += (layers[op].N + 63) & ~63;
+    }
+    return n;
+}
+bool net_stream_dxi_eligible(const linna_layer_t* layers, int nl, int in_size) {
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 3);
+    if (!p.ok || !p.dxi_ok) return false;
+    return ((p.lds_for(NS_ROWS, true) + 7) & ~(size_t)7) + (size_t)NS_ROWS * (ns_g2_cols(p, layers, nl) / 32) * sizeof(unsigned) <= (size_t)NS_LDS_BYTES;
+}
 size_t net_stream_dxi_packed_floats(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 3).packed_floats; }
 
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
@@ -1994,19 +2055,38 @@ int launch_net_stream_grad2(const linna_layer_t* layers, int nl, int in_size, co
     a.gscale = gr.gscale; a.Gout = gr.G; a.ldg = gr.ldg;
     a.hm_p = gr.hm_p; a.hm_ldp = gr.hm_ldp; a.hm_q = gr.hm_q; a.hm_mass = gr.hm_mass; a.hm_ek = gr.hm_ek; a.hm_ed = gr.hm_ed;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
-    for (int i = 0; i < (int)p.seg.size(); ++i) {
+    // What the backward gates on is the SIGN of a forward activation, and the workgroup that needs it is the one that
+    // computed it: one bit per (row, column) in LDS (NsArgs::nbw).  Round 2 kept the activations themselves in the caller's
+    // workspace (y / t: 40 MB written and read back per 4096-chain launch of ChtoModelv2(33,33), in bursts at the run ends of
+    // 256 workgroups in step, each read an exposed L2 round trip behind a drained weight ring); gout / gmask are flags now.
+    (void)y; (void)ldy; (void)t; (void)ldt;
+    std::vector<int> base_y(nl, -1), base_t(nl, -1);
+    int ncolbits = 0;
+    for (int i = 0; i < p.nseg_f; ++i) {                      // forward: keep the signs a gate will ask for
         const int op = p.seg_op[i];
-        if (i < p.nseg_f) {                                   // forward: keep what a gate will ask for
-            if (p.seg_hidden[i]) { a.gout[i] = t[op]; a.gld[i] = ldt[op]; a.gn[i] = layers[op].C; }
-            else if (op < nl - 1) { a.gout[i] = y[op]; a.gld[i] = ldy[op]; a.gn[i] = layers[op].N; }
-        } else if (p.seg_hidden[i]) {                         // d/dh of residual block op: gated by its stored h
-            a.gmask[i] = t[op]; a.gmld[i] = ldt[op]; a.gn[i] = layers[op].C;
+        if (p.seg_hidden[i]) { base_t[op] = ncolbits; a.gn[i] = layers[op].C; }
+        else if (op < nl - 1) { base_y[op] = ncolbits; a.gn[i] = layers[op].N; }
+        else continue;
+        a.gout[i] = const_cast<float*>(packed);               // (a flag)
+        a.gld[i] = ncolbits;
+        ncolbits += (a.gn[i] + 63) & ~63;
+    }
+    for (int i = p.nseg_f; i < (int)p.seg.size(); ++i) {
+        const int op = p.seg_op[i];
+        if (p.seg_hidden[i]) {                                // d/dh of residual block op: gated by its h
+            a.gmask[i] = packed; a.gmld[i] = base_t[op]; a.gn[i] = layers[op].C;
         } else {                                              // d/d(input of op): gated by the producing op's output, if it went through a ReLU
             const bool relu_in = op > 0 && (layers[op - 1].op == LINNA_OP_RESBLOCK || layers[op - 1].relu);
-            a.gmask[i] = relu_in ? y[op - 1] : nullptr; a.gmld[i] = relu_in ? ldy[op - 1] : 0; a.gn[i] = layers[op].K;
+            a.gmask[i] = relu_in ? packed : nullptr; a.gmld[i] = relu_in ? base_y[op - 1] : 0; a.gn[i] = layers[op].K;
         }
+        if (a.gmask[i] && a.gmld[i] < 0) { set_error("net_stream: a gate of the one-launch gradient has no producer"); return LINNA_ERR_UNSUPPORTED; }
     }
-    return ns_launch_kernel<0, true, 2>(a, B, p, rows, s);
+    a.nbw = ncolbits / 32;
+    const size_t lds0 = (p.lds_for(rows, true) + 7) & ~(size_t)7;
+    a.bits_off = (int)(lds0 / sizeof(float));
+    const size_t lds_bits = (size_t)rows * a.nbw * sizeof(unsigned);
+    if (lds0 + lds_bits > (size_t)NS_LDS_BYTES) { set_error("net_stream: the one-launch gradient's sign bits do not fit the LDS"); return LINNA_ERR_UNSUPPORTED; }
+    return ns_launch_kernel<0, true, 2>(a, B, p, rows, s, 0, lds0 + lds_bits - p.lds_for(rows, true));
 }
 
 // Training forward + loss in one launch (STORE == 3): X[n][ldx] the resident set, ROWS the batch (null: rows 0..B-1);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Diagnostic: per-segment cycle stamps of net_stream_kernel (the diagnostic build: python linna_amd/_build.py --stamps).  Usage: python tools/ns_stamps.py [mlp|v2] [B]
+"""Diagnostic: per-segment cycle stamps of net_stream_kernel (the diagnostic build: python linna_amd/_build.py --stamps).  Usage: python tools/ns_stamps.py [mlp|v2] [B]   (NS_STAMPS_GRAD=1: lnP + gradient in one launch)
 Stamp order: start, after prologue barrier, after every segment's last barrier, after the loop, end."""
 import os, sys
 import numpy as np, torch
@@ -22,7 +22,11 @@ else:
     p = bench_paths.problem("ChtoModelv2", nin, nout, which != "v2")
     lp = p["lp"]
 z = torch.randn(B, nin, device="cuda"); out = torch.empty(B, device="cuda")
-for _ in range(5): lp.evaluate(z, out=out)
+if os.environ.get("NS_STAMPS_GRAD"):                 # the one-launch gradient (HMC) instead of the evaluation
+    g = torch.empty(B, nin, device="cuda")
+    for _ in range(5): lp.evaluate_with_grad(z, out=out, grad=g)
+else:
+    for _ in range(5): lp.evaluate(z, out=out)
 torch.cuda.synchronize()
 t = buf.cpu().numpy().reshape(nb, 8, 32).astype(np.float64)
 t = t[t[:, 0, 0] > 0]                      # the workgroups that ran
