@@ -109,9 +109,11 @@ struct NsArgs {
     const float* gmask[NS_MAXSEG]; int gmld[NS_MAXSEG];
     // GRAD + STORE == 2 (lnP and its gradient in one launch, any network): the backward needs the SIGN of the forward
     // activations only, and it needs it in this very workgroup -- one bit per (row, column) in LDS ([ROWS][nbw] words at
-    // float offset bits_off) instead of the activations in global memory: gout / gmask are flags there, gld / gmld the first
-    // bit column (a multiple of 64) of the tensor a segment writes / is gated by
+    // float offset bits_off) instead of the activations in global memory.  gbit / mbit: the first bit column (a multiple of
+    // 64) of the tensor a segment writes / is gated by, -1 = none.  The merged training launch (GRAD + STORE == 3) gates the
+    // same way -- its activations still go to global memory, the parameter gradients need them.
     int nbw, bits_off;
+    int gbit[NS_MAXSEG], mbit[NS_MAXSEG];
     // STORE == 3 (one launch = gather + input transform + training forward + chi^2-ratio loss and its gradient,
     // predictor_gpu.py:274-285 with util.py:1070-1116): Z is the RESIDENT training set X[n][ldz], row `t_rows[b]` is
     // transformed in the prologue (and stored to t_xb for the first layer's parameter gradient); the last network layer's
@@ -286,7 +288,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // boundary less than forward + loss and dX chain as two launches, the weight ring never drained in between.
     constexpr bool TRB = GRAD && STORE == 3;
     constexpr bool DXE = STORE == 2 || TRB;        // epilogues of dX segments: gate by the stored activation, store
-    constexpr bool G2 = GRAD && STORE == 2;        // the gates are sign bits in LDS (NsArgs::nbw)
+    constexpr bool G2 = GRAD && STORE == 2;        // lnP + gradient in one launch: nothing of the forward half goes to global memory
+    // the gates are sign bits in LDS (NsArgs::nbw).  The merged training launch can gate the same way (LB = G2 || TRB: its
+    // launcher fills gbit / mbit), measured SLOWER on its 4-row engine (155.4 against 152.4 us per step at (26,457): the
+    // gate loads are not what its run ends wait for, the ballots and bit writes of every forward epilogue are extra) -- off.
+    constexpr bool LB = G2;
 #ifdef NS_EARLY_REFILL
     constexpr bool LATE_REFILL = false;
 #else
@@ -589,6 +595,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     float lnp_grad = 0.f;                          // GRAD: lnP, stored at the very end (no store next to the weight loads)
     float* s_gout = nullptr; int s_gld = 0, s_gn = 0;   // STORE: global destination of the current segment's output
     const float* s_gmask = nullptr; int s_gmld = 0;     // STORE == 2: forward activation gating it
+    int s_gbit = -1, s_mbit = -1;                       // LB: bit column of the signs this segment writes / is gated by
     auto gstore = [&](float* p, float v) { asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory"); };
     uint32_t ap;
     auto a_read = [&](f32x4& dst) {
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         if constexpr (GRAD) { s_mstore = S.mask_store; s_mapply = S.mask_apply; }
         if constexpr (STORE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gout = ka->gout[j]; s_gld = ka->gld[j]; s_gn = ka->gn[j]; }
         if constexpr (DXE) { const int j = __builtin_amdgcn_readfirstlane(si); s_gmask = ka->gmask[j]; s_gmld = ka->gmld[j]; }
+        if constexpr (LB) { const int j = __builtin_amdgcn_readfirstlane(si); s_gbit = ka->gbit[j]; s_mbit = ka->mbit[j]; }
     };
     auto begin_run = [&]() {                       // accumulators and A pointer of run (si, pass)
         const int arow = SM ? sm_arow : li, ak = SM ? 4 * sm_achunk : 4 * kq;
@@ -694,6 +702,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             const float* nx_gmask = nullptr; int nx_gmld = 0;
             if constexpr (STORE) { nx_gout = ka->gout[nxi]; nx_gld = ka->gld[nxi]; nx_gn = ka->gn[nxi]; }
             if constexpr (DXE) { nx_gmask = ka->gmask[nxi]; nx_gmld = ka->gmld[nxi]; }
+            int nx_gbit = -1, nx_mbit = -1;
+            if constexpr (LB) { nx_gbit = ka->gbit[nxi]; nx_mbit = ka->mbit[nxi]; }
             const int cur_steps = s_steps;
             auto take_seg = [&](const NsSeg& X) {
                 s_type = X.type; s_steps = X.steps; s_passes = X.passes; s_bias = X.bias_off;
@@ -706,6 +716,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 take_seg(NX);
                 if constexpr (STORE) { s_gout = nx_gout; s_gld = nx_gld; s_gn = nx_gn; }
                 if constexpr (DXE) { s_gmask = nx_gmask; s_gmld = nx_gmld; }
+                if constexpr (LB) { s_gbit = nx_gbit; s_mbit = nx_mbit; }
             };
             // SIDE segment next (and this run is its predecessor's last): its weights are requested NOW, by loads the compiler
             // does not see, so that they fly under this segment's epilogue and barrier
@@ -765,9 +776,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     }
                 }
                 unsigned long long gw[SM ? NQ : 1][4];      // G2: the 64 sign bits of this wave's columns, per result row
-                if constexpr (G2) {
-                    if (s_gmask) {
-                        const int cw = 512 * pass + 64 * wave, w0 = (s_gmld + cw) >> 5;
+                if constexpr (LB) {
+                    if (s_mbit >= 0) {
+                        const int cw = 512 * pass + 64 * wave, w0 = (s_mbit + cw) >> 5;
                         const bool mine = cw < ((s_gn + 63) & ~63);             // (past the tensor: padding columns, their gradients are zero)
 #pragma unroll
                         for (int t = 0; t < (SM ? NQ : 1); ++t)
@@ -776,7 +787,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                                 gw[t][e] = mine ? *reinterpret_cast<const unsigned long long*>(lbits + (SM ? 4 * t + e : 4 * kq + e) * nbw + w0) : 0ull;
                     }
                 }
-                if constexpr (DXE && !G2) {
+                if constexpr (DXE && !LB) {
                     // the gates (stored forward activations), by loads the compiler does not count -- a visible load in this
                     // loop body makes every step's wait for the weight ring a vmcnt(0) -- with one explicit wait
                     if (s_gmask) {
@@ -816,8 +827,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         float v = fin[t][e];
                         if constexpr (GRAD) v = ((mbits >> (4 * t + e)) & 1u) ? v : 0.f;
                         v = s_relu ? fmaxf(v, 0.f) : v;
-                        if constexpr (G2) {
-                            if (s_gmask && !((gw[SM ? t : 0][e] >> (SM ? lane : 16 * t + li)) & 1ull)) v = 0.f;
+                        if constexpr (LB) {
+                            if (s_mbit >= 0 && !((gw[SM ? t : 0][e] >> (SM ? lane : 16 * t + li)) & 1ull)) v = 0.f;
                         } else if constexpr (DXE) {
                             if (s_gmask && !(ty[t][e] > 0.f)) v = 0.f;
                         }
@@ -830,19 +841,20 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             }
                         }
                         nxt[q_row(t, e) * LD + q_col(t)] = v_lds;
-                        if constexpr (G2) {
-                            if (s_gout) {                      // the sign of this activation, for the gate of its gradient
+                        if constexpr (LB) {
+                            if (s_gbit >= 0) {                 // the sign of this activation, for the gate of its gradient
                                 const unsigned long long bb = __ballot(v > 0.f);
                                 const int cw = 512 * pass + 64 * wave;          // (a wave whose 64 columns lie past the tensor's
                                 const bool mine = cw < ((s_gn + 63) & ~63);     //  bit range writes nothing: the next row's bits, or the
-                                const int c0 = s_gld + cw;                      //  neighbouring workgroup's LDS, sit there)
+                                const int c0 = s_gbit + cw;                     //  neighbouring workgroup's LDS, sit there)
                                 if constexpr (SM) {            // lane = column: 64 columns of row 4 t + e
                                     if (lane == 0 && mine) *reinterpret_cast<unsigned long long*>(lbits + (4 * t + e) * nbw + (c0 >> 5)) = bb;
                                 } else {                       // 16 columns of tile t for each of the rows 4 kq + e
                                     if (li == 0 && mine) reinterpret_cast<unsigned short*>(lbits + (4 * kq + e) * nbw)[(c0 + 16 * t) >> 4] = (unsigned short)(bb >> (16 * kq));
                                 }
                             }
-                        } else if constexpr (STORE) {
+                        }
+                        if constexpr (STORE && !G2) {
                             const int grow_ = row0 + q_row(t, e), gcol = 512 * pass + 64 * wave + q_col(t);
                             if (s_gout && grow_ < a.B && gcol < s_gn) {
                                 float vs = v;                      // the network's last output carries the column affine
@@ -888,7 +900,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 const int sw = SM ? 32 * (sr & 1) : 16 * (sr >> 2);
                 constexpr int NGJ = 256 / RGS;          // (SPLIT outputs are <= 256 columns: 8 / 4 / 2 per thread)
                 float sg[NGJ];
-                if constexpr (DXE && !G2) {
+                if constexpr (DXE && !LB) {
                     if (s_gmask) {
 #pragma unroll
                         for (int j = 0; j < NGJ; ++j) {
@@ -927,8 +939,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         }
                         v += lbias[s_bias + c];
                         if (s_relu) v = fmaxf(v, 0.f);
-                        if constexpr (G2) {
-                            if (s_gmask && !(c < ((s_gn + 63) & ~63) && ((lbits[sr * nbw + ((s_gmld + c) >> 5)] >> (c & 31)) & 1u))) v = 0.f;
+                        if constexpr (LB) {
+                            if (s_mbit >= 0 && !(c < ((s_gn + 63) & ~63) && ((lbits[sr * nbw + ((s_mbit + c) >> 5)] >> (c & 31)) & 1u))) v = 0.f;
                         } else if constexpr (DXE) {
                             float gv = 1.f;             // (dynamic register-array index: a select chain)
 #pragma unroll
@@ -945,12 +957,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         }
                     }
                     cur[c] = v;
-                    if constexpr (G2) {
-                        if (s_gout) {                       // (every lane of a wave runs the same trips of this loop)
+                    if constexpr (LB) {
+                        if (s_gbit >= 0) {                  // (every lane of a wave runs the same trips of this loop)
                             const unsigned long long bb = __ballot(v > 0.f);
                             const bool mine = c < ((s_gn + 63) & ~63);
-                            if constexpr (SM) { if (lane == 0 && mine) *reinterpret_cast<unsigned long long*>(lbits + sr * nbw + ((s_gld + c) >> 5)) = bb; }
-                            else { if ((lane & 31) == 0 && mine) lbits[sr * nbw + ((s_gld + c) >> 5)] = (unsigned)(bb >> (lane & 32)); }
+                            if constexpr (SM) { if (lane == 0 && mine) *reinterpret_cast<unsigned long long*>(lbits + sr * nbw + ((s_gbit + c) >> 5)) = bb; }
+                            else { if ((lane & 31) == 0 && mine) lbits[sr * nbw + ((s_gbit + c) >> 5)] = (unsigned)(bb >> (lane & 32)); }
                         }
                     }
                 }
@@ -982,7 +994,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
             if constexpr (GRAD) {
                 if (seg_done && si == a.nseg_f) {   // (seg_done: not again after a pass of the first backward segment)
-                    if constexpr (DXE && !G2)       // the forward activations every wave stored are in memory before any gate load
+                    if constexpr (DXE && !LB)       // the forward activations every wave stored are in memory before any gate load
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if constexpr (TRB) {
                         // ---- turnaround of a training step = the loss finish: delta and U = delta Cinv sit in LDS (U at column
@@ -2062,24 +2074,25 @@ int launch_net_stream_grad2(const linna_layer_t* layers, int nl, int in_size, co
     (void)y; (void)ldy; (void)t; (void)ldt;
     std::vector<int> base_y(nl, -1), base_t(nl, -1);
     int ncolbits = 0;
+    for (int i = 0; i < NS_MAXSEG; ++i) a.gbit[i] = a.mbit[i] = -1;
     for (int i = 0; i < p.nseg_f; ++i) {                      // forward: keep the signs a gate will ask for
         const int op = p.seg_op[i];
         if (p.seg_hidden[i]) { base_t[op] = ncolbits; a.gn[i] = layers[op].C; }
         else if (op < nl - 1) { base_y[op] = ncolbits; a.gn[i] = layers[op].N; }
         else continue;
-        a.gout[i] = const_cast<float*>(packed);               // (a flag)
-        a.gld[i] = ncolbits;
+        a.gbit[i] = ncolbits;
         ncolbits += (a.gn[i] + 63) & ~63;
     }
     for (int i = p.nseg_f; i < (int)p.seg.size(); ++i) {
         const int op = p.seg_op[i];
         if (p.seg_hidden[i]) {                                // d/dh of residual block op: gated by its h
-            a.gmask[i] = packed; a.gmld[i] = base_t[op]; a.gn[i] = layers[op].C;
+            a.mbit[i] = base_t[op]; a.gn[i] = layers[op].C;
+            if (a.mbit[i] < 0) { set_error("net_stream: a gate of the one-launch gradient has no producer"); return LINNA_ERR_UNSUPPORTED; }
         } else {                                              // d/d(input of op): gated by the producing op's output, if it went through a ReLU
             const bool relu_in = op > 0 && (layers[op - 1].op == LINNA_OP_RESBLOCK || layers[op - 1].relu);
-            a.gmask[i] = relu_in ? packed : nullptr; a.gmld[i] = relu_in ? base_y[op - 1] : 0; a.gn[i] = layers[op].K;
+            a.mbit[i] = relu_in ? base_y[op - 1] : -1; a.gn[i] = layers[op].K;
+            if (relu_in && a.mbit[i] < 0) { set_error("net_stream: a gate of the one-launch gradient has no producer"); return LINNA_ERR_UNSUPPORTED; }
         }
-        if (a.gmask[i] && a.gmld[i] < 0) { set_error("net_stream: a gate of the one-launch gradient has no producer"); return LINNA_ERR_UNSUPPORTED; }
     }
     a.nbw = ncolbits / 32;
     const size_t lds0 = (p.lds_for(rows, true) + 7) & ~(size_t)7;
@@ -2155,12 +2168,35 @@ int launch_net_stream_train_bwd(const linna_layer_t* layers, int nl, int in_size
             a.gout[i] = dprev[op]; a.gld[i] = ldp[op]; a.gn[i] = layers[op].K; a.gmask[i] = hin[op]; a.gmld[i] = ldh[op];
         }
     }
+    // the gates of the backward half: sign bits in LDS (see launch_net_stream_grad2) -- the activations go to memory all the
+    // same (the parameter gradients read them), but no gate is read back from there
+    std::vector<int> base_y(nl, -1), base_t(nl, -1);
+    int ncolbits = 0;
+    for (int i = 0; i < NS_MAXSEG; ++i) a.gbit[i] = a.mbit[i] = -1;
+    for (int i = 0; i < p.nseg_f; ++i) {
+        const int op = p.seg_op[i];
+        if (op >= nl) continue;
+        if (p.seg_hidden[i]) base_t[op] = ncolbits; else if (op < nl - 1) base_y[op] = ncolbits; else continue;
+        a.gbit[i] = ncolbits;
+        ncolbits += (a.gn[i] + 63) & ~63;
+    }
+    for (int i = p.nseg_f; i < (int)p.seg.size(); ++i) {
+        const int op = p.seg_op[i];
+        if (!a.gmask[i]) continue;
+        a.mbit[i] = p.seg_hidden[i] ? base_t[op] : (op > 0 ? base_y[op - 1] : -1);
+        if (a.mbit[i] < 0) { set_error("net_stream: a gate of the one-launch training step has no producer"); return LINNA_ERR_UNSUPPORTED; }
+    }
+    a.nbw = ncolbits / 32;
+    const size_t lds0 = (p.lds_for(rows, true) + 7) & ~(size_t)7;
+    a.bits_off = (int)(lds0 / sizeof(float));
+    const size_t lds_bits = (size_t)rows * a.nbw * sizeof(unsigned);
+    if (lds0 + lds_bits > (size_t)NS_LDS_BYTES) { set_error("net_stream: the training step's sign bits do not fit the LDS"); return LINNA_ERR_UNSUPPORTED; }
     a.t_rows = ROWS; a.t_xb = XB; a.t_ldxb = ldxb;
     a.t_Y = L.YN; a.t_ldy = L.ldyn;
     a.t_den = L.den; a.t_inv_batch = L.inv_batch; a.t_loss_rows = L.loss_rows; a.t_dP = L.dP; a.t_lddp = L.lddp;
     int extra = 0;
     if (post && post->step) { a.p_step = post->step; a.p_hyper = post->hyper; a.p_b1 = post->b1; a.p_b2 = post->b2; extra = 1; }
-    return ns_launch_kernel<0, true, 3>(a, B, p, rows, s, extra);
+    return ns_launch_kernel<0, true, 3>(a, B, p, rows, s, extra, lds0 + lds_bits - p.lds_for(rows, true));
 }
 }  // namespace linna
 
