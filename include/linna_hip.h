@@ -259,7 +259,8 @@ int linna_weights_changed(linna_ctx_t* ctx);
  * one atomic instead of the environment. */
 int linna_engine_rows(int rows);
 /* The serving program the whole-network kernel would run for this op list on the engine of `rows` rows per workgroup
- * (dense_nout > 0: with a dense inverse covariance of that size as its last segment), as text: a header line, then one
+ * (dense_nout > 0: with a dense inverse covariance of that size as its last segment; dense_nout == -1: the program of
+ * the one-launch gradient instead, forward segments then the dX chain down to the input), as text: a header line, then one
  * line per segment ("WIDE|SPLIT|SIDE steps passes ncg kc dst zext N").  Host-side planning only -- nothing is launched,
  * no pointer is read -- for tests and diagnostics.  Returns the number of segments, 0 when the network is outside the
  * kernel's reach. */

@@ -1018,6 +1018,7 @@ int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size
     // (pointers are only compared, never read: a placeholder stands for the dense inverse covariance)
     static float dummy;
     NsDense dn{&dummy, (dense_nout + 3) & ~3, nullptr, nullptr};
+    if (dense_nout == -1) return net_stream_describe(layers, nlayers, in_size, 3, nullptr, rows, 1, buf, n);   // the one-launch gradient's program
     return net_stream_describe(layers, nlayers, in_size, 0, dense_nout > 0 ? &dn : nullptr, rows, 1, buf, n);
 }
 int linna_engine_rows(int rows) {

@@ -104,3 +104,17 @@ def test_no_kernel_of_the_library_uses_scratch():
     spilling = [(k["name"], k["scratch"]) for k in ks if k["scratch"]]
     assert not spilling, spilling
     assert max(k["vgpr"] for k in ks) <= 256
+
+
+def test_gradient_program_planning_without_a_gpu():
+    """``linna_program_describe(dense_nout = -1)``: the program of the one-launch gradient for ChtoModelv2(33,33) on the 16-row
+    engine -- the forward segments (hidden h of the residual blocks as SPLIT segments: no SIDE segments in this launch,
+    measured slower there), then the dX chain down to the 33 inputs: 121 + 119 steps in one weight stream."""
+    import torch
+    from linna_amd import nn
+    n, txt = nn.describe_program(nn.ChtoModelv2(33, 33, None), 16, -1)
+    lines = txt.strip().splitlines()
+    assert n == 20 and lines[0].startswith("ok G 121 Gstride 240 nseg_f 10")
+    assert not any(ln.startswith("SIDE") for ln in lines)
+    assert lines[-1].startswith("SPLIT steps 8") and lines[-1].endswith("N 33")          # d lnP / d x of the 1000-wide first layer
+    assert sum(int(ln.split()[2]) * int(ln.split()[4]) for ln in lines[1:11]) == 121
