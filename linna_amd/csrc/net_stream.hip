@@ -306,9 +306,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // keep a private copy of the whole 2.3 KB block whenever it cannot split it -- scratch traffic at every run end, and which
     // instantiation is hit changes with unrelated edits (STORE == 1 on the 16-row engine in round 2, the merged training
     // launch with the refill one slot back in round 3).  Through the kernel-argument segment itself they are scalar loads.
-    // (Only in the instantiations where that copy has appeared -- training, the one-launch gradient with SIDE segments: the
-    // serving ones lose 0.3-0.7 % to the explicit pointer.)
-    constexpr bool KA = STORE == 3 || STORE == 1 || (GRAD && STORE == 2);
+    // (Only in the instantiations where that copy has appeared -- the training ones: the serving ones and the one-launch
+    // gradient lose 0.3-0.7 % to the explicit pointer; tests/test_abi.py watches every kernel's scratch size.)
+    constexpr bool KA = STORE == 3 || STORE == 1;
     const NsArgs* const ka = KA ? reinterpret_cast<const NsArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) : &a;
     float* const act = smem;                       // [2][ROWS][LD]
     float* const lbias = smem + 2 * ABUF;          // packed biases of every segment
