@@ -1671,6 +1671,7 @@ static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int i
     auto ins = cache.emplace(std::move(key), std::unique_ptr<NsProgram>(new NsProgram(ns_build_prog_uncached(layers, nl, in_size, prog, dn, k4))));
     return *ins.first->second;
 }
+static int ns_g2_cols(const NsProgram& p, const linna_layer_t* layers, int nl);
 // Text form of a program (tests, diagnostics): one line per segment, "type steps passes ncg kc dst_col zext".
 int net_stream_describe(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn, int rows, int serve, char* buf,
                         size_t n) {
@@ -1685,6 +1686,13 @@ int net_stream_describe(const linna_layer_t* layers, int nl, int in_size, int pr
         snprintf(line, sizeof line, "%s steps %d passes %d ncg %d kc %d dst %d zext %d N %d\n",
                  g.type == NS_WIDE ? "WIDE" : g.type == NS_SPLIT ? "SPLIT" : "SIDE", g.steps, g.passes, 1 << g.ncg_log2, 1 << g.kcl, g.dst_col,
                  g.zext, p.pack[i].N);
+        out += line;
+    }
+    if (p.ok && prog == 3) {                        // the one-launch gradient: its LDS with the sign-bit matrix, on the 16-row engine
+        const int cols = ns_g2_cols(p, layers, nl);
+        const size_t need = ((p.lds_for(NS_ROWS, true) + 7) & ~(size_t)7) + (size_t)NS_ROWS * (cols / 32) * sizeof(unsigned);
+        snprintf(line, sizeof line, "lds %zu of %d bytes with %d sign-bit columns: %s\n", need, NS_LDS_BYTES, cols,
+                 need <= (size_t)NS_LDS_BYTES && p.dxi_ok ? "one launch" : "layered");
         out += line;
     }
     if (buf && n) { snprintf(buf, n, "%s", out.c_str()); }

@@ -116,5 +116,8 @@ def test_gradient_program_planning_without_a_gpu():
     lines = txt.strip().splitlines()
     assert n == 20 and lines[0].startswith("ok G 121 Gstride 240 nseg_f 10")
     assert not any(ln.startswith("SIDE") for ln in lines)
-    assert lines[-1].startswith("SPLIT steps 8") and lines[-1].endswith("N 33")          # d lnP / d x of the 1000-wide first layer
+    assert lines[-2].startswith("SPLIT steps 8") and lines[-2].endswith("N 33")          # d lnP / d x of the 1000-wide first layer
     assert sum(int(ln.split()[2]) * int(ln.split()[4]) for ln in lines[1:11]) == 121
+    # the signs of the forward activations (the backward's gates) are a bit matrix in LDS: 2688 columns x 16 rows fit
+    assert lines[-1].startswith("lds ") and "2688 sign-bit columns" in lines[-1] and lines[-1].endswith("one launch")
+    assert int(lines[-1].split()[1]) <= 160 * 1024
