@@ -51,7 +51,12 @@ class _Watchdog(object):
     training with its gradient all-reduce, the ensemble iterations with their walker exchange, the shutdown barrier) call
     collectives, and a collective that never completes would take the whole line with it: nothing is printed before the
     end.  Armed once the headline is known; if the remaining sections have not finished after `seconds`, rank 0 prints the
-    line with what it has (and says so in "watchdog"), and every rank leaves with os._exit -- no exec, no retry."""
+    line with what it has (and says so in "watchdog"), and every rank leaves with os._exit -- no exec, no retry -- with a
+    NON-ZERO code: EXIT_HANG (3) when a section or the teardown did not finish, EXIT_RAISED (4) when one raised.  The line
+    is out either way (self_launch relays it), and the launcher's exit code tells the driver that a collective hung or
+    broke instead of calling the run clean."""
+    EXIT_HANG, EXIT_RAISED = 3, 4
+
 
     def __init__(self, seconds, rank):
         import threading
@@ -81,25 +86,25 @@ class _Watchdog(object):
         import traceback
         traceback.print_exc()
         with self.lock:
-            if self.done:
-                os._exit(0)
+            if self.done:                            # the line is out already (emitted, or printed by the timer): only the code is left to give
+                os._exit(self.EXIT_RAISED)
             self.done = True
         if self.rank == 0 and self.line is not None:
             self.line["watchdog"] = "a section after the headline raised %s at stage '%s'; the remaining sections are missing from this line" % (repr(exc)[:200], self.stage)
             print(json.dumps(self.line), flush=True)
-        os._exit(0)
+        os._exit(self.EXIT_RAISED)
 
     def _fire(self):
         with self.lock:
-            if self.done:
-                os._exit(0)
+            if self.done:                            # emit() won the race: the run is finishing normally
+                return
             self.done = True
         if self.rank == 0 and self.line is not None:
             self.line["watchdog"] = "sections after the headline did not finish within %.0f s (last stage: %s); they are missing from this line" % (self.seconds, self.stage)
             print(json.dumps(self.line), flush=True)
         sys.stderr.write("[bench rank %d] watchdog: leaving at stage '%s'\n" % (self.rank, self.stage))
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(self.EXIT_HANG)
 
 
 def build_problem(device):
@@ -800,7 +805,9 @@ def main():
         from linna_amd import dist as ldist
         _at("shutdown")
         if rank == 0:
-            threading_guard = __import__("threading").Timer(120.0, lambda: os._exit(0))   # the line is out: a stuck teardown must not hold the launcher
+            # the line is out: a stuck teardown must not hold the launcher -- but it is a hang, and the exit code says so
+            threading_guard = __import__("threading").Timer(float(os.environ.get("LINNA_BENCH_TEARDOWN_S", "120")),
+                                                            lambda: os._exit(_Watchdog.EXIT_HANG))
             threading_guard.daemon = True
             threading_guard.start()
         ldist.shutdown()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 7   /* 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
+#define LINNA_ABI_VERSION 8   /* 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -39,6 +39,18 @@ typedef struct linna_graph linna_graph_t;
 /* ------------------------------------------------------------------ runtime */
 int linna_abi_version(void);
 const char* linna_last_error(void);
+/* Error codes: 0 OK; -1 invalid argument; -2 a HIP / RCCL call failed; -3 unsupported (the caller takes the documented
+ * other route); -4 a C++ exception (std::bad_alloc, std::length_error ... from the host-side planners) was caught at
+ * this boundary -- every entry below is a function-try-block, the text names the exception.  size_t-returning entries
+ * return 0 in that case. */
+#define LINNA_OK 0
+#define LINNA_ERR_INVALID (-1)
+#define LINNA_ERR_HIP (-2)
+#define LINNA_ERR_UNSUPPORTED (-3)
+#define LINNA_ERR_INTERNAL (-4)
+/* diagnostic: throws inside a guarded entry -- 1 std::bad_alloc, 2 std::length_error, 3 a non-std exception,
+ * 4 std::out_of_range, else nothing -- and returns what the barrier made of it (tests/test_abi.py) */
+int linna_debug_raise(int kind);
 int linna_ctx_create(int device, linna_ctx_t** out);
 int linna_ctx_destroy(linna_ctx_t* ctx);
 int linna_stream_sync(void* stream);

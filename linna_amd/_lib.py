@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LINNA_LIB_PATH") or os.path.join(_HERE, "liblinna_hip.so")   # (LINNA_LIB_PATH: a diagnostic build, tools/ns_stamps.py)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
@@ -68,6 +68,7 @@ _PV = C.POINTER(C.c_void_p)
 _SIGNATURES = {
     "linna_abi_version": (_I, []),
     "linna_last_error": (C.c_char_p, []),
+    "linna_debug_raise": (_I, [_I]),
     "linna_ctx_create": (_I, [_I, _PV]),
     "linna_ctx_destroy": (_I, [_V]),
     "linna_stream_sync": (_I, [_V]),
@@ -174,7 +175,8 @@ def load():
     return lib
 
 
-ERR_UNSUPPORTED = -3     # LINNA_ERR_UNSUPPORTED (csrc/common.h)
+ERR_UNSUPPORTED = -3     # LINNA_ERR_UNSUPPORTED (include/linna_hip.h)
+ERR_INTERNAL = -4        # LINNA_ERR_INTERNAL: a C++ exception caught at the C boundary
 
 
 def check(rc):

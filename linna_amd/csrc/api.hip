@@ -26,6 +26,12 @@ void set_error(const char* fmt, ...) {
     g_err = buf;
 }
 
+int caught_exception(const char* what) noexcept {
+    // (the text is built in a fixed buffer; if even the assignment cannot allocate, the previous text stays)
+    try { set_error("C++ exception at the C boundary: %s", what ? what : "unknown type"); } catch (...) {}
+    return LINNA_ERR_INTERNAL;
+}
+
 int check_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return LINNA_OK;
     set_error("%s: %s", what, hipGetErrorString(e));
@@ -145,8 +151,16 @@ extern "C" {
 // ------------------------------------------------------------------ runtime
 int linna_abi_version(void) { return LINNA_ABI_VERSION; }
 const char* linna_last_error(void) { return g_err.c_str(); }
+// diagnostic: raise inside a guarded entry (tests/test_abi.py checks that the barrier turns it into a code and a text)
+int linna_debug_raise(int kind) try {
+    if (kind == 1) throw std::bad_alloc();
+    if (kind == 2) { std::vector<int> v; v.reserve(v.max_size() + 1); }      // std::length_error, as a planner's vector would
+    if (kind == 3) throw 42;                                                  // not derived from std::exception
+    if (kind == 4) { std::string s; (void)s.at(7); }                          // std::out_of_range
+    return LINNA_OK;
+} LINNA_CATCH_INT
 
-int linna_ctx_create(int device, linna_ctx_t** out) {
+int linna_ctx_create(int device, linna_ctx_t** out) try {
     if (!out) { set_error("ctx_create: null out"); return LINNA_ERR_INVALID; }
     int n = 0;
     TRY(check_hip(hipGetDeviceCount(&n), "hipGetDeviceCount"));
@@ -171,8 +185,8 @@ int linna_ctx_create(int device, linna_ctx_t** out) {
     if (rc != LINNA_OK) { (void)linna_ctx_destroy(c); return rc; }
     *out = c;
     return LINNA_OK;
-}
-int linna_ctx_destroy(linna_ctx_t* ctx) {
+} LINNA_CATCH_INT
+int linna_ctx_destroy(linna_ctx_t* ctx) try {
     if (ctx) {
         (void)linna_comm_destroy(ctx);
         for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
@@ -181,13 +195,13 @@ int linna_ctx_destroy(linna_ctx_t* ctx) {
     }
     delete ctx;
     return LINNA_OK;
-}
-int linna_stream_sync(void* stream) { return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize"); }
+} LINNA_CATCH_INT
+int linna_stream_sync(void* stream) try { return check_hip(hipStreamSynchronize(S(stream)), "hipStreamSynchronize"); } LINNA_CATCH_INT
 
-int linna_graph_begin(void* stream) {
+int linna_graph_begin(void* stream) try {
     return check_hip(hipStreamBeginCapture(S(stream), hipStreamCaptureModeThreadLocal), "hipStreamBeginCapture");
-}
-int linna_graph_end(void* stream, linna_graph_t** out) {
+} LINNA_CATCH_INT
+int linna_graph_end(void* stream, linna_graph_t** out) try {
     hipGraph_t g = nullptr;
     TRY(check_hip(hipStreamEndCapture(S(stream), &g), "hipStreamEndCapture"));
     hipGraphExec_t e = nullptr;
@@ -195,51 +209,51 @@ int linna_graph_end(void* stream, linna_graph_t** out) {
     if (rc != LINNA_OK) { (void)hipGraphDestroy(g); return rc; }
     *out = new linna_graph{g, e};
     return LINNA_OK;
-}
-int linna_graph_launch(linna_graph_t* g, void* stream) {
+} LINNA_CATCH_INT
+int linna_graph_launch(linna_graph_t* g, void* stream) try {
     if (!g) { set_error("graph_launch: null graph"); return LINNA_ERR_INVALID; }
     g_weights_epoch.fetch_add(1);            // the graph may hold an AdamW step
     return check_hip(hipGraphLaunch(g->exec, S(stream)), "hipGraphLaunch");
-}
-int linna_graph_destroy(linna_graph_t* g) {
+} LINNA_CATCH_INT
+int linna_graph_destroy(linna_graph_t* g) try {
     if (!g) return LINNA_OK;
     (void)hipGraphExecDestroy(g->exec);
     (void)hipGraphDestroy(g->graph);
     delete g;
     return LINNA_OK;
-}
-int linna_event_create(void** ev) {
+} LINNA_CATCH_INT
+int linna_event_create(void** ev) try {
     hipEvent_t e;
     TRY(check_hip(hipEventCreate(&e), "hipEventCreate"));
     *ev = e;
     return LINNA_OK;
-}
-int linna_event_record(void* ev, void* stream) { return check_hip(hipEventRecord((hipEvent_t)ev, S(stream)), "hipEventRecord"); }
-int linna_event_elapsed_ms(void* a, void* b, float* ms) {
+} LINNA_CATCH_INT
+int linna_event_record(void* ev, void* stream) try { return check_hip(hipEventRecord((hipEvent_t)ev, S(stream)), "hipEventRecord"); } LINNA_CATCH_INT
+int linna_event_elapsed_ms(void* a, void* b, float* ms) try {
     TRY(check_hip(hipEventSynchronize((hipEvent_t)b), "hipEventSynchronize"));
     return check_hip(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b), "hipEventElapsedTime");
-}
-int linna_event_destroy(void* ev) { return check_hip(hipEventDestroy((hipEvent_t)ev), "hipEventDestroy"); }
+} LINNA_CATCH_INT
+int linna_event_destroy(void* ev) try { return check_hip(hipEventDestroy((hipEvent_t)ev), "hipEventDestroy"); } LINNA_CATCH_INT
 
 // ------------------------------------------------------------------ GEMM
-int linna_gemm_f32(linna_ctx_t*, const linna_gemm_t* d, void* stream) {
+int linna_gemm_f32(linna_ctx_t*, const linna_gemm_t* d, void* stream) try {
     if (!d) { set_error("gemm: null descriptor"); return LINNA_ERR_INVALID; }
     return gemm_launch(*d, S(stream));
-}
-int linna_gemm_dot_slots(int M, int N) { return gemm_slots(M, N); }
+} LINNA_CATCH_INT
+int linna_gemm_dot_slots(int M, int N) try { return gemm_slots(M, N); } LINNA_CATCH_INT
 
 // ------------------------------------------------------------------ layers
 int linna_linear_fwd(linna_ctx_t*, const float* X, int ldx, const float* W, int ldw, const float* b, float* Y, int ldy,
-                     int B, int K, int N, int relu, float alpha, const float* R, int ldr, void* stream) {
+                     int B, int K, int N, int relu, float alpha, const float* R, int ldr, void* stream) try {
     GemmArgs a = gemm_zero();
     set_pair(a, 0, X, ldx, LAY_K, W, ldw, LAY_K, K);
     a.M = B; a.N = N; a.C = Y; a.ldc = ldy; a.bias0 = b; a.alpha0 = alpha; a.R = R; a.ldr = ldr; a.relu = relu;
     return gemm_launch(a, S(stream));
-}
+} LINNA_CATCH_INT
 
 int linna_resblock_fwd(linna_ctx_t*, const float* X, int ldx, const float* W1, const float* b1, const float* W2,
                        const float* b2, const float* Ws, float* T, int ldt, float* Y, int ldy, int B, int K, int C,
-                       int N, void* stream) {
+                       int N, void* stream) try {
     if (!Ws && K != N) { set_error("resblock: identity skip needs K == N"); return LINNA_ERR_INVALID; }
     TRY(linna_linear_fwd(nullptr, X, ldx, W1, ld4(K), b1, T, ldt, B, K, C, 1, 1.f, nullptr, 0, stream));
     GemmArgs a = gemm_zero();
@@ -248,11 +262,11 @@ int linna_resblock_fwd(linna_ctx_t*, const float* X, int ldx, const float* W1, c
     if (Ws) { a.npairs = 2; set_pair(a, 1, X, ldx, LAY_K, Ws, ld4(K), LAY_K, K); }
     else { a.R = X; a.ldr = ldx; }
     return gemm_launch(a, S(stream));
-}
+} LINNA_CATCH_INT
 
 int linna_linear_bwd(linna_ctx_t*, const float* dY, int lddy, const float* X, int ldx, const float* W, int ldw,
                      float* dX, int lddx, const float* Xmask, int ldxm, float* dW, int lddw, float* db, int B, int K,
-                     int N, float scale, void* stream) {
+                     int N, float scale, void* stream) try {
     if (dW) {   // dW[n][k] = scale * sum_b dY[b][n] X[b][k]
         GemmArgs a = gemm_zero();
         set_pair(a, 0, dY, lddy, LAY_MN, X, ldx, LAY_MN, B);
@@ -267,10 +281,10 @@ int linna_linear_bwd(linna_ctx_t*, const float* dY, int lddy, const float* X, in
         TRY(gemm_launch(a, S(stream)));
     }
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
 // ------------------------------------------------------------------ network
-int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers, int in_size, linna_net_t** out) {
+int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers, int in_size, linna_net_t** out) try {
     if (!layers || nlayers < 1 || !out) { set_error("net_create: bad arguments"); return LINNA_ERR_INVALID; }
     linna_net* n = new linna_net();
     n->ctx = ctx; n->in_size = in_size; n->has_inskip = false; n->max_w = in_size; n->max_c = 4;
@@ -306,15 +320,15 @@ int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers,
     if (n->has_inskip) n->Lfull.push_back(n->inskip);
     *out = n;
     return LINNA_OK;
-}
-int linna_net_destroy(linna_net_t* net) {
+} LINNA_CATCH_INT
+int linna_net_destroy(linna_net_t* net) try {
     if (net) {
         net->packed.release(); net->packed_dx[0].release(); net->packed_dx[1].release(); net->packed_loss.release();
         net->packed_tb.release();
     }
     delete net;
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
 // Device-side weight copies of the one-launch paths (net_stream.hip): decided once per network, allocated by
 // linna_net_prepare -- or on first use, when the caller did not prepare and the stream is not capturing.
@@ -340,7 +354,7 @@ static void net_ensure_dx(linna_net* n, int wi, bool may_alloc) {
         if (sc.alloc(net_stream_dx_packed_floats(n->L.data(), nl, n->in_size, wi)) != LINNA_OK) n->stream_bwd[wi] = 0;
     }
 }
-int linna_net_prepare(linna_net_t* n, int backward, int input_grad) {
+int linna_net_prepare(linna_net_t* n, int backward, int input_grad) try {
     if (!n) { set_error("net_prepare: null network"); return LINNA_ERR_INVALID; }
     net_ensure_fwd(n, true);
     if (backward) net_ensure_dx(n, input_grad ? 1 : 0, true);
@@ -354,9 +368,9 @@ int linna_net_prepare(linna_net_t* n, int backward, int input_grad) {
         }
     }
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
-size_t linna_net_fwd_ws_bytes(const linna_net_t* n, int B) { return (fwd_layout(n, B).total + 16) * sizeof(float); }
+size_t linna_net_fwd_ws_bytes(const linna_net_t* n, int B) try { return (fwd_layout(n, B).total + 16) * sizeof(float); } LINNA_CATCH_SIZE
 // backward scratch: one buffer per op for the gradient wrt that op's input (no reuse: the
 // parameter-gradient GEMMs of an op may still be reading it on the auxiliary stream while the dX
 // chain moves on) + one dT buffer per residual block
@@ -368,10 +382,10 @@ static size_t bwd_floats(const linna_net* n, int B) {
     }
     return f;
 }
-size_t linna_net_bwd_ws_bytes(const linna_net_t* n, int B) { return (bwd_floats(n, B) + 16) * sizeof(float); }
+size_t linna_net_bwd_ws_bytes(const linna_net_t* n, int B) try { return (bwd_floats(n, B) + 16) * sizeof(float); } LINNA_CATCH_SIZE
 
 int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, float* OUT, int ldo,
-                      const linna_colmap_t* om, void* stream) {
+                      const linna_colmap_t* om, void* stream) try {
     if (!n || !X || !OUT || B < 1) { set_error("net_forward: bad arguments"); return LINNA_ERR_INVALID; }
     const FwdLayout f = fwd_layout(n, B);
     float* w = static_cast<float*>(ws);
@@ -430,7 +444,7 @@ int linna_net_forward(linna_net_t* n, const float* X, int ldx, int B, void* ws, 
         hin = Y; ldh = ldy;
     }
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
 static void net_ensure_loss(linna_net* n, const NsDense& dn) {
     const int nl = (int)n->L.size();
@@ -453,16 +467,16 @@ static void net_ensure_loss(linna_net* n, const NsDense& dn) {
 static bool net_tb_usable(const linna_net* n, int B) {
     return n->stream_tb == 1 && n->packed_tb.ready() && net_stream_rows(B) == 4;     // (batches of up to 1024 rows)
 }
-int linna_loss_targets(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* YN, int ldyn, void* stream) {
+int linna_loss_targets(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* YN, int ldyn, void* stream) try {
     if (!d || !Y || !YN || nrows < 1 || ldyn < d->nout) { set_error("loss_targets: bad arguments"); return LINNA_ERR_INVALID; }
     return launch_loss_targets(Y, ldy, nrows, *d, YN, ldyn, S(stream));
-}
-int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) {
+} LINNA_CATCH_INT
+int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) try {
     if (!n || !d) { set_error("net_prepare_loss: null argument"); return LINNA_ERR_INVALID; }
     const NsDense dn{d->Cinv, d->ldc, nullptr, nullptr};
     if (n->stream_loss < 0 || n->loss_dn.S != dn.S || n->loss_dn.lds != dn.lds) net_ensure_loss(n, dn);
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 // Forward pass of a training step AND its loss in ONE launch (net_stream.hip, STORE == 3): the batch rows are gathered
 // from the resident set and X-transformed in the kernel's prologue, every activation the backward needs is stored, the
 // network's normalised-space inverse covariance is the program's last segment and the finish writes the per-row loss and
@@ -482,10 +496,10 @@ int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const flo
                            const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
                            int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
                            float* loss_mean, float* dPRED, int lddp, float* hyper, int* step_dev, float b1, float b2,
-                           void* stream) {
+                           void* stream) try {
     return net_forward_loss_impl(n, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, ws, PRED, ldp, YN, ldyn, den, inv_batch, loss_rows,
                                  loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, false);
-}
+} LINNA_CATCH_INT
 // One optimiser step up to the gradients in ONE call: linna_net_forward_loss followed by linna_net_backward(param_grads = 1)
 // on the rows it gathered, with the step's two single-thread jobs (batch mean of the loss, AdamW step counter and bias
 // corrections) riding in the backward's dX-chain launch as one extra workgroup instead of a launch of their own between
@@ -548,7 +562,7 @@ int linna_net_train_step(linna_net_t* n, const linna_loss_desc_t* d, const float
                          const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* fwd_ws, float* PRED,
                          int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
                          float* loss_mean, float* dPRED, int lddp, void* bwd_ws, float* hyper, int* step_dev, float b1, float b2,
-                         void* stream) {
+                         void* stream) try {
     if (!bwd_ws) { set_error("net_train_step: backward workspace required"); return LINNA_ERR_INVALID; }
     TRY(net_train_ensure_loss(n, d, stream));
     if (net_tb_usable(n, B)) {
@@ -563,7 +577,7 @@ int linna_net_train_step(linna_net_t* n, const linna_loss_desc_t* d, const float
     const bool prep = hyper && step_dev;
     const NsPost post{loss_rows, (loss_mean || prep) ? B : 0, inv_batch, loss_mean, prep ? step_dev : nullptr, prep ? hyper : nullptr, b1, b2};
     return net_backward_impl(n, XB, ldxb, B, fwd_ws, bwd_ws, dPRED, lddp, nullptr, 0, 1, stream, post.n ? &post : nullptr);
-}
+} LINNA_CATCH_INT
 static int net_forward_loss_impl(linna_net_t* n, const linna_loss_desc_t* d, const float* X, int ldx, const int* ROWS, int B,
                                  const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* ws, float* PRED,
                                  int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
@@ -609,24 +623,24 @@ static int net_forward_loss_impl(linna_net_t* n, const linna_loss_desc_t* d, con
     return LINNA_OK;
 }
 
-int linna_net_train_launches(const linna_net_t* n, int B) {
+int linna_net_train_launches(const linna_net_t* n, int B) try {
     if (!n || B < 1) { set_error("net_train_launches: bad arguments"); return LINNA_ERR_INVALID; }
     if (n->stream_loss != 1) return 0;
     if (net_tb_usable(n, B)) return 2;
     return n->stream_bwd[0] == 1 ? 3 : 0;
-}
-int linna_net_stream_state(const linna_net_t* n, int* fwd, int* dx, int* dx_input) {
+} LINNA_CATCH_INT
+int linna_net_stream_state(const linna_net_t* n, int* fwd, int* dx, int* dx_input) try {
     if (!n) { set_error("net_stream_state: null network"); return LINNA_ERR_INVALID; }
     if (fwd) *fwd = n->stream_fwd;
     if (dx) *dx = n->stream_bwd[0];
     if (dx_input) *dx_input = n->stream_bwd[1];
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
 int linna_net_backward(linna_net_t* n, const float* X, int ldx, int B, void* fwd_ws, void* bwd_ws, const float* dOUT,
-                       int lddo, float* dX, int lddx, int pg, void* stream) {
+                       int lddo, float* dX, int lddx, int pg, void* stream) try {
     return net_backward_impl(n, X, ldx, B, fwd_ws, bwd_ws, dOUT, lddo, dX, lddx, pg, stream, nullptr);
-}
+} LINNA_CATCH_INT
 // `post`: the loss mean / AdamW step constants of this step (linna_net_train_step): they ride in the one-launch dX chain
 // as an extra workgroup, or run as the launch of their own they otherwise are, in front of the GEMM chain
 // `upd`: the optimiser rides in the grouped parameter-gradient launch (linna_net_train_step_update; the caller has checked
@@ -844,30 +858,30 @@ static int net_backward_impl(linna_net_t* n, const float* X, int ldx, int B, voi
 // ------------------------------------------------------------------ prior map
 int linna_prior_map_fwd(linna_ctx_t*, const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1,
                         const float* a2, const int* lg, const float* xmean, const float* xstd, float* X, int ldx,
-                        float* TH, int ldt, void* stream) {
+                        float* TH, int ldt, void* stream) try {
     if (ldx < nin || ldz < nin) { set_error("prior_map_fwd: leading dimension < nin"); return LINNA_ERR_INVALID; }
     return launch_prior_map_fwd(Z, ldz, B, nin, is_flat, a1, a2, lg, xmean, xstd, X, ldx, TH, ldt, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_prior_map_bwd(linna_ctx_t*, const float* Z, int ldz, int B, int nin, const int* is_flat, const float* a1,
                         const float* a2, const int* lg, const float* xstd, const float* dX, int lddx, float* dZ,
-                        int lddz, void* stream) {
+                        int lddz, void* stream) try {
     return launch_prior_map_bwd(Z, ldz, B, nin, is_flat, a1, a2, lg, xstd, dX, lddx, dZ, lddz, S(stream));
-}
+} LINNA_CATCH_INT
 
 // ------------------------------------------------------------------ log-likelihood
 int linna_gauss_loglike_diag(linna_ctx_t*, const float* D, int ldd, int B, int nout, const float* w, const float* Z,
-                             int ldz, int nin, float T, float* out, void* stream) {
+                             int ldz, int nin, float T, float* out, void* stream) try {
     return launch_loglike_diag(D, ldd, B, nout, w, Z, ldz, nin, T, out, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_gauss_loglike_dense(linna_ctx_t*, const float* D, int ldd, int B, int nout, const float* Sm, int lds,
-                              const float* Z, int ldz, int nin, float T, float* scratch, float* out, void* stream) {
+                              const float* Z, int ldz, int nin, float T, float* scratch, float* out, void* stream) try {
     const int slots = gemm_slots(B, nout);
     GemmArgs a = gemm_zero();          // rows of (D S) dotted with D, no C store
     set_pair(a, 0, D, ldd, LAY_K, Sm, lds, LAY_MN, nout);
     a.M = B; a.N = nout; a.dotwith = D; a.lddot = ldd; a.dot_partial = scratch; a.dot_slots = slots;
     TRY(gemm_launch(a, S(stream)));
     return launch_loglike_finish(scratch, slots, slots, B, Z, ldz, nin, T, out, S(stream));
-}
+} LINNA_CATCH_INT
 
 }  // extern "C"
 
@@ -970,7 +984,7 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
 
 extern "C" {
 
-int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc, linna_logprob_t** out) {
+int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc, linna_logprob_t** out) try {
     if (!net || !desc || !out) { set_error("logprob_create: null argument"); return LINNA_ERR_INVALID; }
     if (desc->nin != net->in_size || desc->nout != net->out_size) {
         set_error("logprob_create: network is %d->%d, descriptor says %d->%d", net->in_size, net->out_size, desc->nin, desc->nout);
@@ -1006,43 +1020,43 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     }
     *out = lp;
     return LINNA_OK;
-}
-int linna_logprob_destroy(linna_logprob_t* lp) {
+} LINNA_CATCH_INT
+int linna_logprob_destroy(linna_logprob_t* lp) try {
     if (lp) { lp->packed.release(); lp->packed_g2.release(); }
     delete lp;
     return LINNA_OK;
-}
-int linna_weights_changed(linna_ctx_t*) { g_weights_epoch.fetch_add(1); return LINNA_OK; }
-int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size, int rows, int dense_nout, char* buf, size_t n) {
+} LINNA_CATCH_INT
+int linna_weights_changed(linna_ctx_t*) try { g_weights_epoch.fetch_add(1); return LINNA_OK; } LINNA_CATCH_INT
+int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size, int rows, int dense_nout, char* buf, size_t n) try {
     if (!layers || nlayers < 1 || !buf || !n) { set_error("program_describe: bad arguments"); return LINNA_ERR_INVALID; }
     // (pointers are only compared, never read: a placeholder stands for the dense inverse covariance)
     static float dummy;
     NsDense dn{&dummy, (dense_nout + 3) & ~3, nullptr, nullptr};
     if (dense_nout == -1) return net_stream_describe(layers, nlayers, in_size, 3, nullptr, rows, 1, buf, n);   // the one-launch gradient's program
     return net_stream_describe(layers, nlayers, in_size, 0, dense_nout > 0 ? &dn : nullptr, rows, 1, buf, n);
-}
-int linna_engine_rows(int rows) {
+} LINNA_CATCH_INT
+int linna_engine_rows(int rows) try {
     const int prev = net_stream_force_rows(rows);
     if (prev < 0) { set_error("linna_engine_rows: %d (0, 4, 8 or 16)", rows); return LINNA_ERR_INVALID; }
     return prev;
-}
-size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad) {
+} LINNA_CATCH_INT
+size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad) try {
     return (lp_layout(lp, B, with_grad).total + 16) * sizeof(float);
-}
+} LINNA_CATCH_SIZE
 
 int linna_logprob_eval(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* TH, int ldt,
-                       void* stream) {
+                       void* stream) try {
     if (!lp || !Z || !ws || !lnP || B < 1) { set_error("logprob_eval: bad arguments"); return LINNA_ERR_INVALID; }
     const LpLayout L = lp_layout(lp, B, 0);
     return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false);
-}
+} LINNA_CATCH_INT
 
 int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* TH, int ldt,
-                          const int* gate, void* stream) {
+                          const int* gate, void* stream) try {
     if (!lp || !Z || !ws || !lnP || B < 1) { set_error("logprob_eval_if: bad arguments"); return LINNA_ERR_INVALID; }
     const LpLayout L = lp_layout(lp, B, 0);
     return lp_forward(lp, Z, ldz, B, static_cast<float*>(ws), L, lnP, TH, ldt, stream, false, gate);
-}
+} LINNA_CATCH_INT
 
 // `list` / `count` / `mul`: only the trial points list[0 .. count[0] * mul) are evaluated (device-side count; the launch is
 // sized for all nrep * ns); `b_engine`: the batch size the engine is chosen for (the expected number of live rows)
@@ -1073,9 +1087,9 @@ static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ld
 }
 int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
                                     const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
-                                    void* stream) {
+                                    void* stream) try {
     return lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, w, nrep, lnP, gate, nullptr, nullptr, 0, 0, stream);
-}
+} LINNA_CATCH_INT
 
 // One half step of the ensemble slice sampler (zeus behind sampler.py:728-735) in ONE call: the differential-move directions
 // and slice heights, `nexp_rounds` speculative stepping-out rounds of `m_sched[r]` bracket ends per side, `nshr_rounds`
@@ -1086,7 +1100,7 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
                           const int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched, int nshr_rounds,
                           float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt, int* list, int* counters,
-                          int zero_totals, void* stream) {
+                          int zero_totals, void* stream) try {
     if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !mu || !step_dev || !DIR || !state || !flags || !W || !Wd ||
         !Zt || !list || !counters || ns < 1 || nc < 2 || !m_sched || !nt_sched || nexp_rounds < 1 || nshr_rounds < 1 || (half != 0 && half != 1)) {
         set_error("slice_half_step: bad arguments"); return LINNA_ERR_INVALID;
@@ -1128,11 +1142,11 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
                                       trials, list, seed, step_dev, 2 + half, st));
     }
     return launch_slice_commit_checked(coords, ldc, ndim, logp, S_idx, ns, DIR, ldd, Wacc, Zacc, flags, counters, st);
-}
+} LINNA_CATCH_INT
 
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                             const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
-                            int step_offset, int stream_id, float a, int* naccept, void* stream) {
+                            int step_offset, int stream_id, float a, int* naccept, void* stream) try {
     if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !step_dev || ns < 1 || nc < 1) {
         set_error("stretch_half_step: bad arguments"); return LINNA_ERR_INVALID;
     }
@@ -1154,7 +1168,7 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
                              df ? nullptr : d.w, d.temperature, nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, rows,
                              df ? &dn : nullptr, S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr,
                              d.outmap.cexp ? d.outmap.cshift2 : nullptr);
-}
+} LINNA_CATCH_INT
 
 }  // extern "C"
 
@@ -1220,18 +1234,18 @@ static int logprob_grad_impl(linna_logprob_t* lp, const float* Z, int ldz, int B
 extern "C" {
 
 int linna_logprob_grad(linna_logprob_t* lp, const float* Z, int ldz, int B, void* ws, float* lnP, float* G, int ldg,
-                       void* stream) {
+                       void* stream) try {
     return logprob_grad_impl(lp, Z, ldz, B, ws, lnP, G, ldg, nullptr, stream);
-}
+} LINNA_CATCH_INT
 
 // One leapfrog step's gradient, kick and drift (HMCSampler.py:35-49): lnP and G = d lnP / d z at Q, then P += eps_kick G and
 // Q += eps_drift P / mass.  ONE launch where linna_logprob_grad is one (the kick and the drift ride in its finish).
 int linna_logprob_grad_leapfrog(linna_logprob_t* lp, float* Q, int ldq, int B, void* ws, float* lnP, float* G, int ldg, float* P,
-                                int ldp, const float* mass, float eps_kick, float eps_drift, void* stream) {
+                                int ldp, const float* mass, float eps_kick, float eps_drift, void* stream) try {
     if (!P || !mass || !Q) { set_error("logprob_grad_leapfrog: bad arguments"); return LINNA_ERR_INVALID; }
     NsGrad leap{nullptr, nullptr, 0, P, ldp, Q, mass, eps_kick, eps_drift};
     return logprob_grad_impl(lp, Q, ldq, B, ws, lnP, G, ldg, &leap, stream);
-}
+} LINNA_CATCH_INT
 
 // ------------------------------------------------------------------ training
 // scratch layout for the loss entry points: DELTA[B][ld] | U[B][ld] | partial[B][slots]
@@ -1251,19 +1265,19 @@ static int chi2_partials(const linna_loss_desc_t* d, int mode, const float* PRED
     return gemm_launch(a, st);
 }
 
-size_t linna_loss_scratch_bytes(int B, int nout) { return (loss_scratch_floats(B, nout) + 16) * sizeof(float); }
+size_t linna_loss_scratch_bytes(int B, int nout) try { return (loss_scratch_floats(B, nout) + 16) * sizeof(float); } LINNA_CATCH_SIZE
 
 int linna_chi2_md(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* scratch,
-                  float* den, void* stream) {
+                  float* den, void* stream) try {
     const int slots = gemm_slots(nrows, d->nout);
     TRY(chi2_partials(d, 1, nullptr, 0, Y, ldy, nullptr, nrows, scratch, false, S(stream)));
     return launch_loss_rows(0, scratch + 2 * (size_t)nrows * ld4(d->nout), slots, slots, nrows, nullptr, nullptr,
                             0.5f * (float)d->nout, den, S(stream));
-}
+} LINNA_CATCH_INT
 
 int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y,
                                   int ldy, const float* den, const int* ROWS, int B, float* scratch, float* loss_rows,
-                                  float* loss_mean, float* dPRED, int lddp, float inv_batch, void* stream) {
+                                  float* loss_mean, float* dPRED, int lddp, float inv_batch, void* stream) try {
     const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
     hipStream_t st = S(stream);
     if (ctx && d->nout <= 64 && lddp >= 0) {
@@ -1282,32 +1296,32 @@ int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, 
     if (loss_mean) TRY(launch_sum_scale(loss_rows, B, inv_batch, loss_mean, st));
     if (dPRED) TRY(launch_loss_grad(scratch + (size_t)B * ld, ld, Y, ldy, ROWS, B, d->nout, d->data_norm, den, inv_batch, dPRED, lddp, st));
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
 int linna_val_rows(linna_ctx_t*, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y, int ldy,
-                   const float* den, int B, float* scratch, float* loss_rows, float* frac_rows, void* stream) {
+                   const float* den, int B, float* scratch, float* loss_rows, float* frac_rows, void* stream) try {
     const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
     hipStream_t st = S(stream);
     TRY(chi2_partials(d, 0, PRED, ldp, Y, ldy, nullptr, B, scratch, false, st));
     TRY(launch_loss_rows(1, scratch + 2 * (size_t)B * ld, slots, slots, B, den, nullptr, 0.f, loss_rows, st));
     TRY(chi2_partials(d, 2, PRED, ldp, Y, ldy, nullptr, B, scratch, false, st));
     return launch_val_frac(scratch + 2 * (size_t)B * ld, slots, slots, B, den, frac_rows, st);
-}
+} LINNA_CATCH_INT
 
 int linna_gather_xform(linna_ctx_t*, const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg,
-                       const float* xmean, const float* xstd, float* XB, int ldxb, void* stream) {
+                       const float* xmean, const float* xstd, float* XB, int ldxb, void* stream) try {
     return launch_gather_xform(X, ldx, ROWS, B, nin, lg, xmean, xstd, XB, ldxb, S(stream));
-}
+} LINNA_CATCH_INT
 
 int linna_adamw_step(linna_ctx_t*, float* p, const float* g, float* m, float* v, size_t n, float* hyper, int* step_dev,
-                     float b1, float b2, float eps, int prepared, void* stream) {
+                     float b1, float b2, float eps, int prepared, void* stream) try {
     if (!p || !g || !m || !v || !hyper || !step_dev) { set_error("adamw_step: null pointer"); return LINNA_ERR_INVALID; }
     g_weights_epoch.fetch_add(1);
     // The step counter and the bias corrections are a single-thread launch of their own (folding them into the update
     // with an arrival counter measured 5 us slower than the extra launch): in front of the update here, or -- `prepared`
     // -- already advanced by linna_net_forward_loss, in the launch that takes the batch mean of the loss.
     return launch_adamw(p, g, m, v, n, hyper, prepared ? nullptr : step_dev, b1, b2, eps, S(stream));
-}
+} LINNA_CATCH_INT
 
 // AdamW over the network's flat parameter buffer AND the re-layout of the updated weights into the two weight streams a
 // training step reads (linna_net_forward_loss's and the backward's dX chain), in ONE launch: what linna_adamw_step
@@ -1334,7 +1348,7 @@ static int net_ensure_as_args(linna_net_t* net, int B, const float* p, size_t n)
 }
 
 int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, float* m, float* v, size_t n, float* hyper,
-                         int* step_dev, float b1, float b2, float eps, int prepared, void* stream) {
+                         int* step_dev, float b1, float b2, float eps, int prepared, void* stream) try {
     if (!net || !p || !g || !m || !v || !hyper || !step_dev || B < 1) { set_error("net_adamw_step: bad arguments"); return LINNA_ERR_INVALID; }
     TRY(net_ensure_as_args(net, B, p, n));
     const int rows = net_stream_rows(B), k = rows < 16 ? 1 : 0;
@@ -1357,7 +1371,7 @@ int linna_net_adamw_step(linna_net_t* net, int B, float* p, const float* g, floa
         else { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
     }
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
 // ONE optimiser step in ONE call and THREE launches: linna_net_train_step with AdamW in the epilogue of its grouped
 // parameter-gradient launch -- every 64 x 64 gradient tile updates its block of the weight matrix (and its moments) as soon as
@@ -1369,7 +1383,7 @@ int linna_net_train_step_update(linna_net_t* net, const linna_loss_desc_t* d, co
                                 const int* lg, const float* xmean, const float* xstd, float* XB, int ldxb, void* fwd_ws, float* PRED,
                                 int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
                                 float* loss_mean, float* dPRED, int lddp, void* bwd_ws, float* params, float* m, float* v,
-                                size_t n, float* hyper, int* step_dev, float b1, float b2, float eps, void* stream) {
+                                size_t n, float* hyper, int* step_dev, float b1, float b2, float eps, void* stream) try {
     if (!net || !params || !m || !v || !hyper || !step_dev || !bwd_ws || B < 1) { set_error("net_train_step_update: bad arguments"); return LINNA_ERR_INVALID; }
     static const bool off = getenv("LINNA_ADAMW_IN_GEMM") && getenv("LINNA_ADAMW_IN_GEMM")[0] == '0';
     if (off || net->has_inskip) { set_error("net_train_step_update: switched off / input-skip network"); return LINNA_ERR_UNSUPPORTED; }
@@ -1425,71 +1439,71 @@ int linna_net_train_step_update(linna_net_t* net, const linna_loss_desc_t* d, co
         else { net->packed_loss.epoch[k] = epoch; net->packed_dx[0].epoch[k] = epoch; }
     }
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
 // ------------------------------------------------------------------ moves
 int linna_stretch_propose(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, uint64_t seed, const int* step_dev,
-                          int stream_id, float a, float* Q, int ldq, float* factors, void* stream) {
+                          int stream_id, float a, float* Q, int ldq, float* factors, void* stream) try {
     if (ns < 1 || nc < 1) { set_error("stretch_propose: empty walker set"); return LINNA_ERR_INVALID; }
     return launch_stretch_propose(coords, ldc, ndim, S_idx, ns, ccoords, ldcc, C_idx, nc, seed, step_dev, stream_id, a, Q,
                                   ldq, factors, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_stretch_accept(linna_ctx_t*, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                          const float* Q, int ldq, const float* logp_new, const float* factors, uint64_t seed,
-                         const int* step_dev, int stream_id, int* naccept, void* stream) {
+                         const int* step_dev, int stream_id, int* naccept, void* stream) try {
     return launch_stretch_accept(coords, ldc, ndim, logp, S_idx, ns, Q, ldq, logp_new, factors, seed, step_dev, stream_id, naccept, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_hmc_init(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
-                   const float* P0, int ldp0, float* P, int ldp, float* H0, void* stream) {
+                   const float* P0, int ldp0, float* P, int ldp, float* H0, void* stream) try {
     return launch_hmc_init(B, ndim, mass, seed, step_dev, lnp, P0, ldp0, P, ldp, H0, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_hmc_start(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* lnp,
                     const float* P0, int ldp0, const float* G, int ldg, float eps_kick, float eps_drift, const float* X, int ldx,
-                    float* P, int ldp, float* Q, int ldq, float* H0, void* stream) {
+                    float* P, int ldp, float* Q, int ldq, float* H0, void* stream) try {
     if (B < 1 || ndim < 1 || !mass || !step_dev || !lnp || !G || !X || !P || !Q || !H0) { set_error("hmc_start: bad arguments"); return LINNA_ERR_INVALID; }
     return launch_hmc_start(B, ndim, mass, seed, step_dev, lnp, P0, ldp0, G, ldg, eps_kick, eps_drift, X, ldx, P, ldp, Q, ldq, H0, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_hmc_kick_drift(linna_ctx_t*, int B, int ndim, const float* mass, float ek, float ed, const float* G, int ldg,
-                         float* P, int ldp, float* Q, int ldq, void* stream) {
+                         float* P, int ldp, float* Q, int ldq, void* stream) try {
     return launch_hmc_kick_drift(B, ndim, mass, ek, ed, G, ldg, P, ldp, Q, ldq, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_hmc_accept(linna_ctx_t*, int B, int ndim, const float* mass, uint64_t seed, const int* step_dev, const float* H0,
                      const float* P, int ldp, const float* Qn, int ldq, const float* lnp_new, const float* Gn, int ldg,
-                     const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, void* stream) {
+                     const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, void* stream) try {
     return launch_hmc_accept(B, ndim, mass, seed, step_dev, H0, P, ldp, Qn, ldq, lnp_new, Gn, ldg, U, X, ldx, lnp, G, naccept, S(stream));
-}
-int linna_step_increment(linna_ctx_t*, int* step_dev, void* stream) { return launch_step_increment(step_dev, S(stream)); }
+} LINNA_CATCH_INT
+int linna_step_increment(linna_ctx_t*, int* step_dev, void* stream) try { return launch_step_increment(step_dev, S(stream)); } LINNA_CATCH_INT
 
 int linna_slice_init(linna_ctx_t*, const float* logp, const int* S_idx, int ns, const float* cc, int ldcc, const int* C_idx,
                      int nc, int ndim, const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR,
-                     int ldd, float* Z0, float* L, float* R, int* flags, void* stream) {
+                     int ldd, float* Z0, float* L, float* R, int* flags, void* stream) try {
     if (ns < 1 || nc < 2) { set_error("slice_init: need >= 2 complementary walkers"); return LINNA_ERR_INVALID; }
     return launch_slice_init(logp, S_idx, ns, cc, ldcc, C_idx, nc, ndim, mu, seed, step_dev, stream_id, DIR, ldd, Z0, L, R,
                              flags, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_slice_points(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns, const float* DIR,
-                       int ldd, const float* w, float* Q, int ldq, int nrep, void* stream) {
+                       int ldd, const float* w, float* Q, int ldq, int nrep, void* stream) try {
     if (nrep < 1) { set_error("slice_points: nrep < 1"); return LINNA_ERR_INVALID; }
     return launch_slice_points(coords, ldc, ndim, S_idx, ns, DIR, ldd, w, Q, ldq, nrep, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_slice_expand(linna_ctx_t*, const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags,
-                       int ns, int* counters, int slot, void* stream) {
+                       int ns, int* counters, int slot, void* stream) try {
     return launch_slice_expand(Z0, ZL, ZR, L, R, flags, ns, counters, slot, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_slice_draw(linna_ctx_t*, const float* L, const float* R, const int* S_idx, float* W, const int* flags, int ns,
-                     uint64_t seed, const int* step_dev, int stream_id, int round, int ntrial, void* stream) {
+                     uint64_t seed, const int* step_dev, int stream_id, int round, int ntrial, void* stream) try {
     if (ntrial < 1) { set_error("slice_draw: ntrial < 1"); return LINNA_ERR_INVALID; }
     return launch_slice_draw(L, R, S_idx, W, flags, ns, seed, step_dev, stream_id, round, ntrial, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_slice_shrink(linna_ctx_t*, const float* Z0, const float* Zt, float* L, float* R, const float* W, int* flags,
-                       float* Wacc, float* Zacc, int ns, int* counters, int slot, int ntrial, void* stream) {
+                       float* Wacc, float* Zacc, int ns, int* counters, int slot, int ntrial, void* stream) try {
     if (ntrial < 1) { set_error("slice_shrink: ntrial < 1"); return LINNA_ERR_INVALID; }
     return launch_slice_shrink(Z0, Zt, L, R, W, flags, Wacc, Zacc, ns, counters, slot, ntrial, S(stream));
-}
+} LINNA_CATCH_INT
 int linna_slice_commit(linna_ctx_t*, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
-                       const float* DIR, int ldd, const float* Wacc, const float* Zacc, void* stream) {
+                       const float* DIR, int ldd, const float* Wacc, const float* Zacc, void* stream) try {
     return launch_slice_commit(coords, ldc, ndim, logp, S_idx, ns, DIR, ldd, Wacc, Zacc, S(stream));
-}
+} LINNA_CATCH_INT
 
 }  // extern "C"

@@ -86,16 +86,16 @@ static CommState* state_of(linna_ctx_t* ctx) {
     return ctx ? static_cast<CommState*>(*linna_ctx_comm_slot(ctx)) : nullptr;
 }
 
-int linna_comm_unique_id(void* id) {
+int linna_comm_unique_id(void* id) try {
     if (!id) { set_error("comm_unique_id: null id"); return LINNA_ERR_INVALID; }
     TRYC(rccl());
     UniqueId u;
     TRYC(check_rccl(g_rccl.GetUniqueId(&u), "ncclGetUniqueId"));
     memcpy(id, u.internal, LINNA_COMM_ID_BYTES);
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
-int linna_comm_init(linna_ctx_t* ctx, int rank, int nranks, const void* id) {
+int linna_comm_init(linna_ctx_t* ctx, int rank, int nranks, const void* id) try {
     if (!ctx || !id || nranks < 1 || rank < 0 || rank >= nranks) {
         set_error("comm_init: bad arguments (rank %d of %d)", rank, nranks);
         return LINNA_ERR_INVALID;
@@ -112,9 +112,9 @@ int linna_comm_init(linna_ctx_t* ctx, int rank, int nranks, const void* id) {
     st->comm = c; st->rank = rank; st->nranks = nranks;
     *linna_ctx_comm_slot(ctx) = st;
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
-int linna_comm_destroy(linna_ctx_t* ctx) {
+int linna_comm_destroy(linna_ctx_t* ctx) try {
     CommState* st = state_of(ctx);
     if (!st) return LINNA_OK;
     int rc = LINNA_OK;
@@ -122,9 +122,9 @@ int linna_comm_destroy(linna_ctx_t* ctx) {
     delete st;
     *linna_ctx_comm_slot(ctx) = nullptr;
     return rc;
-}
+} LINNA_CATCH_INT
 
-int linna_comm_info(linna_ctx_t* ctx, int* rank, int* nranks, int* rccl_version) {
+int linna_comm_info(linna_ctx_t* ctx, int* rank, int* nranks, int* rccl_version) try {
     CommState* st = state_of(ctx);
     if (rank) *rank = st ? st->rank : 0;
     if (nranks) *nranks = st ? st->nranks : 0;           // 0: no communicator
@@ -133,28 +133,28 @@ int linna_comm_info(linna_ctx_t* ctx, int* rank, int* nranks, int* rccl_version)
         if (rccl() == LINNA_OK) (void)g_rccl.GetVersion(rccl_version);
     }
     return LINNA_OK;
-}
+} LINNA_CATCH_INT
 
-int linna_allreduce_sum_f32(linna_ctx_t* ctx, float* buf, size_t n, void* stream) {
+int linna_allreduce_sum_f32(linna_ctx_t* ctx, float* buf, size_t n, void* stream) try {
     CommState* st = state_of(ctx);
     if (!st) { set_error("allreduce_sum_f32: linna_comm_init has not been called on this context"); return LINNA_ERR_INVALID; }
     if (n == 0) return LINNA_OK;
     if (!buf) { set_error("allreduce_sum_f32: null buffer"); return LINNA_ERR_INVALID; }
     return check_rccl(g_rccl.AllReduce(buf, buf, n, kFloat32, kSum, st->comm, reinterpret_cast<hipStream_t>(stream)), "ncclAllReduce");
-}
+} LINNA_CATCH_INT
 
-int linna_allgather_f32(linna_ctx_t* ctx, const float* send, float* recv, size_t n_per_rank, void* stream) {
+int linna_allgather_f32(linna_ctx_t* ctx, const float* send, float* recv, size_t n_per_rank, void* stream) try {
     CommState* st = state_of(ctx);
     if (!st) { set_error("allgather_f32: linna_comm_init has not been called on this context"); return LINNA_ERR_INVALID; }
     if (n_per_rank == 0) return LINNA_OK;
     if (!send || !recv) { set_error("allgather_f32: null buffer"); return LINNA_ERR_INVALID; }
     return check_rccl(g_rccl.AllGather(send, recv, n_per_rank, kFloat32, st->comm, reinterpret_cast<hipStream_t>(stream)), "ncclAllGather");
-}
+} LINNA_CATCH_INT
 
-int linna_broadcast_f32(linna_ctx_t* ctx, float* buf, size_t n, int root, void* stream) {
+int linna_broadcast_f32(linna_ctx_t* ctx, float* buf, size_t n, int root, void* stream) try {
     CommState* st = state_of(ctx);
     if (!st) { set_error("broadcast_f32: linna_comm_init has not been called on this context"); return LINNA_ERR_INVALID; }
     if (n == 0) return LINNA_OK;
     if (!buf || root < 0 || root >= st->nranks) { set_error("broadcast_f32: bad arguments"); return LINNA_ERR_INVALID; }
     return check_rccl(g_rccl.Broadcast(buf, buf, n, kFloat32, root, st->comm, reinterpret_cast<hipStream_t>(stream)), "ncclBroadcast");
-}
+} LINNA_CATCH_INT

@@ -3,12 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <exception>
 #include "../../include/linna_hip.h"
 
-#define LINNA_OK 0
-#define LINNA_ERR_INVALID (-1)
-#define LINNA_ERR_HIP (-2)
-#define LINNA_ERR_UNSUPPORTED (-3)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,6 +40,17 @@ __device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t st
 
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
+// The exception barrier of the C ABI (include/linna_hip.h: "No C++ exception crosses the boundary").  Every extern "C"
+// entry is a function-try-block closed by one of these: the host side uses std::vector / std::string / std::unordered_map
+// (program planning, descriptor tables), so bad_alloc / length_error can be thrown under an entry; it becomes a return
+// code and a text in linna_last_error() instead of unwinding into ctypes (= std::terminate in the caller's process).
+int caught_exception(const char* what) noexcept;      // sets the text, returns LINNA_ERR_INTERNAL (api.hip)
+#define LINNA_CATCH_INT \
+    catch (const std::exception& e_) { return ::linna::caught_exception(e_.what()); } \
+    catch (...) { return ::linna::caught_exception(nullptr); }
+#define LINNA_CATCH_SIZE \
+    catch (const std::exception& e_) { (void)::linna::caught_exception(e_.what()); return 0; } \
+    catch (...) { (void)::linna::caught_exception(nullptr); return 0; }
 
 // Operand storage seen by the GEMM: LAY_K = contraction index contiguous
 // (A as [M][K], B as [N][K]); LAY_MN = k-major (A as [K][M], B as [K][N]).

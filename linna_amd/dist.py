@@ -138,7 +138,28 @@ def _f32(t):
     return C.c_void_p(t.data_ptr())
 
 
-_state = {"collectives": None}
+_state = {"collectives": None, "control": None}
+
+# Control plane vs data path.  The waits of the host-only phases -- ranks > 0 parked while rank 0 alone designs training
+# points and runs the user's theory code (main.py:110, 297-334: minutes to hours), decisions read from the file system --
+# must not sit in the data path's process group: an NCCL (RCCL) collective that waits longer than the group's timeout
+# (torch 2.10: 10 minutes) makes the watchdog of the WAITING ranks abort the whole job.  `barrier`, `agree` and
+# `broadcast_object` therefore run on a gloo side group with its own, long timeout (LINNA_CONTROL_TIMEOUT_S, default one
+# week); the data path (gradient all-reduce, walker exchange, chain gather) keeps the short one, where a wait that long IS
+# a hang.
+CONTROL_TIMEOUT_S = float(os.environ.get("LINNA_CONTROL_TIMEOUT_S", str(7 * 24 * 3600)))
+
+
+def control_group():
+    """The gloo side group of the control plane (None for one rank / before ``init()``)."""
+    return _state["control"]
+
+
+def _make_control_group():
+    import datetime
+    if _state["control"] is None and dist.is_initialized() and dist.get_world_size() > 1:
+        _state["control"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CONTROL_TIMEOUT_S))
+    return _state["control"]
 
 
 def collectives():
@@ -167,6 +188,10 @@ def init(backend=None, device=None, comm=None, timeout=120.0):
         return world
     local_rank = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
     ndev = torch.cuda.device_count()
+    import datetime
+    pg_kw = {}
+    if os.environ.get("LINNA_PG_TIMEOUT_S"):              # the data path's timeout (default: torch's)
+        pg_kw["timeout"] = datetime.timedelta(seconds=float(os.environ["LINNA_PG_TIMEOUT_S"]))
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if (ndev >= 1 and local_rank < ndev and int(os.environ.get("LOCAL_WORLD_SIZE", world)) <= ndev) else "gloo"
@@ -176,11 +201,12 @@ def init(backend=None, device=None, comm=None, timeout=120.0):
             if device is None:
                 device = torch.device("cuda", local_rank)
             torch.cuda.set_device(device)
-            dist.init_process_group("nccl", device_id=torch.device(device))
+            dist.init_process_group("nccl", device_id=torch.device(device), **pg_kw)
         else:
             if ndev:
                 torch.cuda.set_device(local_rank % ndev if device is None else device)
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **pg_kw)
+    _make_control_group()                                  # (collective: every rank passes here)
     backend = dist.get_backend()
     if _state["collectives"] is not None:
         return world
@@ -219,6 +245,7 @@ def shutdown():
         dist.barrier()
     comm_destroy()
     _state["collectives"] = None
+    _state["control"] = None
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
@@ -236,9 +263,21 @@ def rank(group=None):
 
 
 def barrier(group=None):
-    """Host-side barrier of the control plane; no-op for one rank."""
+    """Host-side barrier of the control plane (on the gloo side group when ``init()`` made one: a rank may wait here for
+    hours while rank 0 runs host-only work); no-op for one rank."""
     if world_size(group) > 1 and dist.is_available() and dist.is_initialized():
+        if group is None and _state["control"] is not None:
+            group = _state["control"]
         dist.barrier(group=group)
+
+
+def broadcast_object(obj, src=0):
+    """Rank ``src``'s picklable object on every rank, over the control plane (the result of a host-only phase)."""
+    if world_size() == 1 or not (dist.is_available() and dist.is_initialized()):
+        return obj
+    box = [obj if rank() == src else None]
+    dist.broadcast_object_list(box, src=src, group=_state["control"])
+    return box[0]
 
 
 def agree(flag, group=None):
@@ -246,6 +285,8 @@ def agree(flag, group=None):
     files, so that no rank can see a different answer and leave the others in a collective)."""
     if world_size(group) == 1 or not (dist.is_available() and dist.is_initialized()):
         return bool(flag)
+    if group is None and _state["control"] is not None:
+        group = _state["control"]
     box = [bool(flag)]
     dist.broadcast_object_list(box, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
     return bool(box[0])

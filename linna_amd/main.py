@@ -165,8 +165,7 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
         w = w / np.sum(w)
         np.save(os.path.join(outdir, "weight_im.npy"), [log_prob_samples_x.flatten(), logp, w])
     if "nimp" in params and world > 1:
-        import torch.distributed as tdist
-        box = [(chain, log_prob_samples_x) if rank == 0 else None]
-        tdist.broadcast_object_list(box, src=0)
-        chain, log_prob_samples_x = box[0]
+        # (control plane: the other ranks wait here while rank 0 runs the nimp theory evaluations -- dist.broadcast_object
+        # goes over the gloo side group with the long timeout, not over the data path's NCCL group)
+        chain, log_prob_samples_x = ldist.broadcast_object((chain, log_prob_samples_x) if rank == 0 else None)
     return chain, log_prob_samples_x

@@ -121,3 +121,34 @@ def test_gradient_program_planning_without_a_gpu():
     # the signs of the forward activations (the backward's gates) are a bit matrix in LDS: 2688 columns x 16 rows fit
     assert lines[-1].startswith("lds ") and "2688 sign-bit columns" in lines[-1] and lines[-1].endswith("one launch")
     assert int(lines[-1].split()[1]) <= 160 * 1024
+
+
+def test_no_cpp_exception_crosses_the_c_boundary():
+    """include/linna_hip.h: "No C++ exception crosses the boundary".  The host side of the library plans programs with
+    std::vector / std::string / std::unordered_map; every extern "C" entry is a function-try-block that turns an exception
+    into LINNA_ERR_INTERNAL + a text.  linna_debug_raise throws inside such an entry: the process survives, the code and the
+    text come back, and the next call works."""
+    from linna_amd import _lib
+    lib = _lib.load()
+    for kind, word in ((1, "bad_alloc"), (2, "vector"), (3, "unknown type"), (4, "at")):
+        rc = lib.linna_debug_raise(kind)
+        assert rc == _lib.ERR_INTERNAL, (kind, rc)
+        text = lib.linna_last_error().decode()
+        assert "C++ exception at the C boundary" in text and word in text, text
+        with pytest.raises(_lib.LinnaHipError, match="C\\+\\+ exception"):
+            _lib.check(rc)
+    assert lib.linna_debug_raise(0) == 0
+    assert lib.linna_abi_version() == _lib.ABI_VERSION
+
+
+def test_every_entry_definition_is_a_function_try_block():
+    """Source-level: each function the header declares (bar the two that cannot throw: version, error text) is defined
+    as `... ) try {` and closed by LINNA_CATCH_INT / LINNA_CATCH_SIZE in api.hip / comm.hip."""
+    csrc = os.path.join(ROOT, "linna_amd", "csrc")
+    src = open(os.path.join(csrc, "api.hip")).read() + open(os.path.join(csrc, "comm.hip")).read()
+    guarded = set()
+    for m in re.finditer(r"^(?:int|size_t) (linna_\w+)\(([^{;]*)\) try \{", src, flags=re.M):
+        guarded.add(m.group(1))
+    decl = set(header_functions()) - {"linna_abi_version", "linna_last_error"}
+    assert decl <= guarded, sorted(decl - guarded)
+    assert src.count("LINNA_CATCH_INT") + src.count("LINNA_CATCH_SIZE") >= len(decl)

@@ -129,3 +129,66 @@ def test_bench_launches_its_own_ranks_from_a_bare_shell():
     assert d["launch_check"] and d["world"] == 2 and d["rank_sum"] == 3.0 and "gloo" in d["collectives"]
     bad = _bench("--gpus", "2", "--backend", "gloo", "--launch-check", LINNA_BENCH_FAIL_RANK="1")
     assert bad.returncode != 0 and not bad.stdout.strip()
+
+
+def test_bench_watchdog_prints_the_line_and_leaves_non_zero():
+    """bench._Watchdog (N > 1): a section that hangs -> the held headline line on stdout with the reason under "watchdog",
+    exit code EXIT_HANG (3); a section that raises -> the line, exit code EXIT_RAISED (4); a run that emits normally is not
+    touched by the timer.  (The two-rank run of it is tests/test_gpu_dist.py::test_two_rank_bench_line_and_its_watchdog.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "d = bench._Watchdog(0.2, 0); d.arm({'metric': 'm', 'value': 1.0}); d.stage = 'training'\n"
+            "mode = sys.argv[1]\n"
+            "if mode == 'hang': time.sleep(30)\n"
+            "if mode == 'raise':\n"
+            "    try: raise RuntimeError('collective broke')\n"
+            "    except Exception as e: d.failed(e)\n"
+            "if mode == 'ok': d.emit({'metric': 'm', 'value': 2.0}); time.sleep(0.6); sys.exit(0)\n") % root
+    out = {}
+    for mode in ("hang", "raise", "ok"):
+        r = subprocess.run([sys.executable, "-c", prog, mode], capture_output=True, text=True, timeout=120)
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+        assert len(lines) == 1, (mode, r.stdout, r.stderr[-1000:])
+        out[mode] = (r.returncode, json.loads(lines[0]))
+    assert out["hang"][0] == 3 and "did not finish" in out["hang"][1]["watchdog"] and "training" in out["hang"][1]["watchdog"]
+    assert out["raise"][0] == 4 and "collective broke" in out["raise"][1]["watchdog"]
+    assert out["ok"][0] == 0 and "watchdog" not in out["ok"][1] and out["ok"][1]["value"] == 2.0
+
+
+def _slow_rank0_worker(rank, world, port, ret):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      LINNA_PG_TIMEOUT_S="3")                 # the DATA path's timeout: a wait that long there is a hang
+    from linna_amd import dist as ldist
+    assert ldist.init(backend="gloo", comm=False) == world
+    cg = ldist.control_group()
+    assert cg is not None and dist.get_backend(cg) == "gloo"
+    t0 = time.time()
+    if rank == 0:
+        time.sleep(8.0)                                       # rank 0 alone in the user's theory code (main.py:110)
+    ldist.barrier()                                           # ranks > 0 wait here, past the data path's 3 s
+    waited = time.time() - t0
+    ok = ldist.agree(rank == 0)                               # rank 0's answer everywhere
+    if rank == 0:
+        time.sleep(5.0)                                       # ... and in the nimp theory evaluations (main.py:297-334)
+    obj = ldist.broadcast_object({"chain": [1, 2, 3]} if rank == 0 else None)
+    x = torch.ones(4) * (rank + 1)                            # the data path still works, on its own (short-timeout) group
+    ldist.allreduce_grads(x)
+    ret[rank] = (waited, ok, obj, float(x[0]))
+    ldist.shutdown()
+
+
+def test_control_plane_waits_do_not_sit_in_the_data_path_group():
+    """ADVICE r3 (main.py:110): ranks > 0 park in a barrier while rank 0 alone runs generate_training_point / the nimp
+    theory evaluations.  On the data path's group that wait is bounded by the group's timeout (NCCL: 10 minutes, then the
+    watchdog of the WAITING ranks aborts the job); dist.barrier / agree / broadcast_object therefore run on a gloo side group
+    with a week's timeout.  Here the data path's timeout is 3 s and rank 0 is 8 s and 5 s late: nothing times out."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_slow_rank0_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert ret[1][0] >= 7.0                                   # rank 1 really waited past the 3 s
+    for r in (0, 1):
+        assert ret[r][1] is True and ret[r][2] == {"chain": [1, 2, 3]} and ret[r][3] == 3.0

@@ -323,8 +323,9 @@ def test_two_rank_bench_line_and_its_watchdog():
     """`python bench.py --gpus 2` from a bare shell on the GPU box (two ranks share the device, gloo carries the collectives):
     ONE JSON line with the whole-job value, the strong-scaling, training and ensemble sections.  With the watchdog's budget
     set to nothing, the sections behind the headline are cut off: the line still comes out -- headline and roofline intact,
-    the reason under "watchdog" -- and the launcher exits 0 (a collective that hangs on a node this code has never seen must
-    not cost the driver its scaling point)."""
+    the reason under "watchdog" (a collective that hangs on a node this code has never seen must not cost the driver its
+    scaling point) -- and the launcher exits NON-ZERO: rank 0 leaves with bench._Watchdog.EXIT_HANG, so the driver's `rc`
+    does not call a hung section a clean run."""
     import json
     r = _bench2({})
     assert r.returncode == 0, r.stderr[-3000:]
@@ -335,7 +336,8 @@ def test_two_rank_bench_line_and_its_watchdog():
     assert d["strong_scaling"]["nwalkers_per_gpu"] == 2048 and "error" not in d["training"] and "error" not in d["mcmc"]
     assert abs(d["value"] - 2 * 4096 * 30 / (d["ms_per_step"] * 1e-3 * 30)) < 1e-6 * d["value"]
     w = _bench2({"LINNA_BENCH_WATCHDOG_S": "0.5"})
-    assert w.returncode == 0, w.stderr[-3000:]
+    assert w.returncode != 0, "a cut-off run must not exit 0"
+    assert "watchdog: leaving at stage" in w.stderr, w.stderr[-3000:]
     lines = [ln for ln in w.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1
     dw = json.loads(lines[0])
