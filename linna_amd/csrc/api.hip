@@ -1038,6 +1038,9 @@ int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size
 int linna_engine_rows(int rows) try {
     const int prev = net_stream_force_rows(rows);
     if (prev < 0) { set_error("linna_engine_rows: %d (0, 4, 8 or 16)", rows); return LINNA_ERR_INVALID; }
+    // the packed-stream copies are cached per (16-row | small-batch) layout, not per engine: whatever was laid out under the
+    // previous setting is re-laid before the next launch
+    if (prev != rows) g_weights_epoch.fetch_add(1);
     return prev;
 } LINNA_CATCH_INT
 size_t linna_logprob_ws_bytes(const linna_logprob_t* lp, int B, int with_grad) try {

@@ -1606,12 +1606,7 @@ size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size
 // (linna_engine_rows forces one for tests and measurements; LINNA_NS_ROWS in the environment sets the initial value,
 // read ONCE -- the launch path reads an atomic, not the environment).
 static std::atomic<int> g_forced_rows{-1};
-int net_stream_force_rows(int rows) {
-    if (rows != 0 && rows != 4 && rows != 8 && rows != 16) return -1;
-    const int prev = g_forced_rows.exchange(rows);
-    return prev < 0 ? 0 : prev;
-}
-int net_stream_rows(int B) {
+static int ns_forced_rows_resolved() {             // -1 (never read) -> the environment's value, once
     int forced = g_forced_rows.load(std::memory_order_relaxed);
     if (forced < 0) {
         const char* const env = getenv("LINNA_NS_ROWS");
@@ -1621,6 +1616,15 @@ int net_stream_rows(int B) {
         g_forced_rows.compare_exchange_strong(expect, forced);
         forced = g_forced_rows.load(std::memory_order_relaxed);
     }
+    return forced;
+}
+int net_stream_force_rows(int rows) {
+    if (rows != 0 && rows != 4 && rows != 8 && rows != 16) return -1;
+    (void)ns_forced_rows_resolved();               // the environment's value is what `prev = engine_rows(4); ...; engine_rows(prev)` must restore
+    return g_forced_rows.exchange(rows);
+}
+int net_stream_rows(int B) {
+    const int forced = ns_forced_rows_resolved();
     if (forced) return forced;
     static int ncu = 0;
     if (!ncu) {

@@ -52,7 +52,10 @@ def _numpy_module_names():
 def _rename_numpy_globals(pkl):
     """One pickle stream with the module text of its numpy globals renamed (GLOBAL opcodes and the string pushes a
     STACK_GLOBAL consumes); everything else byte for byte.  Nothing is unpickled: ``pickletools.genops`` only walks the
-    opcodes.  Returns (new bytes, number of bytes of ``pkl`` the stream occupied)."""
+    opcodes.  Renaming changes the length of a string, so the FRAME opcodes of a protocol >= 4 stream (which promise the
+    byte length of what follows) are DROPPED from the copy -- frames are optional, every unpickler reads a frameless
+    stream -- instead of left stale ("pickle exhausted before end of frame").  Returns (new bytes, number of bytes of
+    ``pkl`` the stream occupied)."""
     import io
     import pickletools
     import struct
@@ -65,10 +68,15 @@ def _rename_numpy_globals(pkl):
         if op.name == "GLOBAL" and arg.encode().startswith(old):
             mod, name = arg.split(" ", 1)
             repl = b"c" + new + mod.encode()[len(old):] + b"\n" + name.encode() + b"\n"
-        elif op.name in ("SHORT_BINUNICODE", "BINUNICODE") and isinstance(arg, str) and arg.encode().startswith(old):
+        elif op.name in ("SHORT_BINUNICODE", "BINUNICODE", "BINUNICODE8") and isinstance(arg, str) and arg.encode().startswith(old):
             txt = new + arg.encode()[len(old):]
-            repl = (b"\x8c" + bytes([len(txt)])) if (op.name == "SHORT_BINUNICODE" and len(txt) < 256) else (b"X" + struct.pack("<I", len(txt)))
+            if op.name == "BINUNICODE8":
+                repl = b"\x8d" + struct.pack("<Q", len(txt))
+            else:
+                repl = (b"\x8c" + bytes([len(txt)])) if (op.name == "SHORT_BINUNICODE" and len(txt) < 256) else (b"X" + struct.pack("<I", len(txt)))
             repl += txt
+        elif op.name == "FRAME":
+            repl = b""
         else:
             continue
         out.append(pkl[last:pos]); out.append(repl)

@@ -974,7 +974,14 @@ class SliceEnsembleSampler(EnsembleSampler):
 
     def _tune_mu(self, nexp, ncon):
         """zeus: mu *= 2 nexp / (nexp + ncon) until the expansion fraction stays within ``tolerance`` of 1/2 for
-        ``patience`` iterations."""
+        ``patience`` iterations.  One ensemble sharded over ranks tunes ONE mu from the WHOLE ensemble's counts (zeus and
+        the reference do: sampler.py:728-735): the two counts are summed over the ranks first, so every rank carries the
+        same mu, leaves tuning at the same iteration and the chain is comparable to the single-rank one."""
+        if self._shared():
+            from . import dist as ldist
+            t = torch.tensor([float(nexp), float(ncon)], dtype=torch.float32, device=self.mu_dev.device)
+            ldist.allreduce_grads(t, None, self.group)
+            nexp, ncon = (int(round(v)) for v in t.tolist())
         self._last_nexp = nexp
         nexp = max(1, nexp)
         self.mu *= 2.0 * nexp / (nexp + ncon)

@@ -12,6 +12,8 @@ for p in (ROOT, GOLDEN, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import parity
+    parity.install()        # LINNA_PARITY_REPORT=<file>: every assert_allclose records its measured worst error (tests/parity.py)
 
 
 def pytest_sessionstart(session):

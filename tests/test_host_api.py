@@ -301,6 +301,38 @@ def test_checkpoint_written_under_the_other_numpy_generation_loads(tmp_path):
         nnutils.read_checkpoint(p)
 
 
+def test_renaming_pickled_numpy_globals_keeps_framed_streams_loadable(monkeypatch):
+    """ADVICE r3 (nnutils.py:52): protocol >= 4 pickles are FRAMED, and a renamed module string changes the byte length a
+    FRAME opcode promised.  The copy drops the FRAME opcodes (frames are optional) and handles BINUNICODE8: a protocol-4 and
+    a protocol-5 stream of our own, renamed towards the OTHER numpy generation's module name, still unpickle to the same
+    value (the stub module ``numpy.core`` resolves it)."""
+    import pickle
+    import pickletools
+    import warnings
+    from linna_amd import nnutils
+    old, new = nnutils._numpy_module_names()
+    monkeypatch.setattr(nnutils, "_numpy_module_names", lambda: (new, old))       # rename THIS numpy's name to the other one
+    obj = {"lr": np.float64(2e-3), "wd": np.float32(1e-4), "pad": "x" * 300}
+    for proto in (2, 4, 5):
+        raw = pickle.dumps(obj, protocol=proto)
+        names = [op.name for op, _, _ in pickletools.genops(raw)]
+        assert ("FRAME" in names) == (proto >= 4)
+        out, used = nnutils._rename_numpy_globals(raw + b"trailing")
+        assert used == len(raw) and new not in out and old in out
+        assert "FRAME" not in [op.name for op, _, _ in pickletools.genops(out)]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                back = pickle.loads(out)                                          # (bytes this test made itself)
+            except (ImportError, AttributeError):
+                continue                                                          # a numpy without the forwarding stub: the walk above is the check
+        assert back == obj and type(back["lr"]) is np.float64
+    # the stale-frame failure this replaces: the same rename with the FRAME opcodes left in place does not load
+    raw = pickle.dumps(obj, protocol=4)
+    with pytest.raises(Exception):
+        pickle.loads(raw.replace(new, old))
+
+
 def test_quadratic_forms_of_the_post_steps_are_float64():
     """``logp_theory_data`` / ``chisqcut_all`` (util.py:1506-1517, 1260-1270) feed the importance weights
     ``w = exp(logp - lp)``: float64 on the host as in the reference.  With an inverse covariance of condition number
