@@ -124,6 +124,7 @@ typedef struct {
 #define LINNA_GEMM_ABL_NOSTAGE 0x20     /* timing only: skip LDS restaging + barrier */
 #define LINNA_GEMM_ABL_NOMFMA 0x40      /* timing only: skip the MFMAs */
 #define LINNA_GEMM_NOSPLIT 0x80         /* timing only: no K split inside the workgroup for small grids */
+#define LINNA_GEMM_DOT_SELF 0x100       /* the row-dot is taken with the product itself: sum_n C[m][n]^2 (dotwith only says "on") */
 
 int linna_gemm_f32(linna_ctx_t* ctx, const linna_gemm_t* desc, void* stream);
 int linna_gemm_dot_slots(int M, int N);
@@ -248,6 +249,11 @@ typedef struct {
     const float* w;               /* diagonal of S when S is diagonal (or NULL) */
     const float* gscale;          /* [nout] d(d)/d(raw output) = y_std*sigma, for the gradient */
     float temperature;
+    const float* Sfac;            /* optional, dense only: lower-triangular L [nout][lds] with S = L L^T (float64 Cholesky of S on
+                                   * the host, rounded to fp32).  lnP is then taken as |d L|^2 instead of d S d^T: the same one
+                                   * GEMM, but a sum of squares -- no cancellation between the stiff and the soft directions of an
+                                   * ill-conditioned covariance (error ~ sqrt(cond) eps instead of ~ cond eps).
+                                   * NULL: the direct form.  The gradient keeps S (Ssym). */
 } linna_logprob_desc_t;
 
 int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc,

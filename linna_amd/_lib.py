@@ -49,7 +49,7 @@ class LogprobDesc(C.Structure):
     _fields_ = [("nin", C.c_int), ("nout", C.c_int), ("is_flat", C.c_void_p), ("a1", C.c_void_p), ("a2", C.c_void_p),
                 ("log10_flag", C.c_void_p), ("xmean", C.c_void_p), ("xstd", C.c_void_p), ("outmap", ColMap),
                 ("S", C.c_void_p), ("lds", C.c_int), ("Ssym", C.c_void_p), ("w", C.c_void_p), ("gscale", C.c_void_p),
-                ("temperature", C.c_float)]
+                ("temperature", C.c_float), ("Sfac", C.c_void_p)]
 
 
 class LossDesc(C.Structure):

@@ -873,14 +873,20 @@ int linna_gauss_loglike_diag(linna_ctx_t*, const float* D, int ldd, int B, int n
                              int ldz, int nin, float T, float* out, void* stream) try {
     return launch_loglike_diag(D, ldd, B, nout, w, Z, ldz, nin, T, out, S(stream));
 } LINNA_CATCH_INT
-int linna_gauss_loglike_dense(linna_ctx_t*, const float* D, int ldd, int B, int nout, const float* Sm, int lds,
-                              const float* Z, int ldz, int nin, float T, float* scratch, float* out, void* stream) try {
+// factored: Sm holds L with S = L L^T and the row-dot is |d L|^2 (linna_logprob_desc_t::Sfac)
+static int loglike_dense_impl(const float* D, int ldd, int B, int nout, const float* Sm, int lds, bool factored,
+                              const float* Z, int ldz, int nin, float T, float* scratch, float* out, void* stream) {
     const int slots = gemm_slots(B, nout);
-    GemmArgs a = gemm_zero();          // rows of (D S) dotted with D, no C store
+    GemmArgs a = gemm_zero();          // rows of (D S) dotted with D (or with themselves), no C store
     set_pair(a, 0, D, ldd, LAY_K, Sm, lds, LAY_MN, nout);
     a.M = B; a.N = nout; a.dotwith = D; a.lddot = ldd; a.dot_partial = scratch; a.dot_slots = slots;
+    if (factored) a.flags |= LINNA_GEMM_DOT_SELF;
     TRY(gemm_launch(a, S(stream)));
     return launch_loglike_finish(scratch, slots, slots, B, Z, ldz, nin, T, out, S(stream));
+}
+int linna_gauss_loglike_dense(linna_ctx_t*, const float* D, int ldd, int B, int nout, const float* Sm, int lds,
+                              const float* Z, int ldz, int nin, float T, float* scratch, float* out, void* stream) try {
+    return loglike_dense_impl(D, ldd, B, nout, Sm, lds, false, Z, ldz, nin, T, scratch, out, stream);
 } LINNA_CATCH_INT
 
 }  // extern "C"
@@ -895,7 +901,7 @@ struct linna_logprob {
     StreamCopy packed_g2;                    // forward + dX chain down to the input in one stream (any network: residual blocks, ...)
     bool grad2 = false;
     bool dense_fused = false;                // the streams end in the dense inverse covariance (output map folded in)
-    NsDense dense() const { return NsDense{d.S, d.lds, d.outmap.cscale, d.outmap.cshift}; }
+    NsDense dense() const { return NsDense{d.Sfac ? d.Sfac : d.S, d.lds, d.outmap.cscale, d.outmap.cshift, d.Sfac ? 1 : 0}; }
 };
 
 struct LpLayout { size_t x0, fwd, d, part, dh, bwd, dx, total; int slots; };
@@ -971,14 +977,14 @@ static int lp_forward(linna_logprob* lp, const float* Z, int ldz, int B, float* 
                               d.w ? lnP : nullptr, d.w ? nullptr : w + L.d, ldd, TH, ldt, nullptr, nullptr, gate, rows, nullptr,
                               S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr, d.outmap.cexp ? d.outmap.cshift2 : nullptr));
         if (d.w) return LINNA_OK;
-        return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
+        return loglike_dense_impl(w + L.d, ldd, B, d.nout, d.Sfac ? d.Sfac : d.S, d.lds, d.Sfac != nullptr, Z, ldz, d.nin, d.temperature,
                                          w + L.part, lnP, stream);
     }
     TRY(launch_prior_map_fwd(Z, ldz, B, d.nin, d.is_flat, d.a1, d.a2, d.log10_flag, d.xmean, d.xstd, w + L.x0, ldx, TH,
                              ldt, S(stream)));
     TRY(linna_net_forward(lp->net, w + L.x0, ldx, B, w + L.fwd, w + L.d, ldd, &d.outmap, stream));
     if (d.w) return launch_loglike_diag(w + L.d, ldd, B, d.nout, d.w, Z, ldz, d.nin, d.temperature, lnP, S(stream));
-    return linna_gauss_loglike_dense(nullptr, w + L.d, ldd, B, d.nout, d.S, d.lds, Z, ldz, d.nin, d.temperature,
+    return loglike_dense_impl(w + L.d, ldd, B, d.nout, d.Sfac ? d.Sfac : d.S, d.lds, d.Sfac != nullptr, Z, ldz, d.nin, d.temperature,
                                      w + L.part, lnP, stream);
 }
 

@@ -521,7 +521,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
                 if (a.cscale || a.cshift) v = v * cs + ct;
                 if (a.cexp) v = expf(v) * cp + ct2;
                 if (a.C) a.C[(size_t)row * a.ldc + col] = v;
-                if (a.dotwith) dot[i][e] += v * a.dotwith[(size_t)row * a.lddot + col];
+                if (a.dotwith) dot[i][e] += v * ((a.flags & LINNA_GEMM_DOT_SELF) ? v : a.dotwith[(size_t)row * a.lddot + col]);
             }
         }
     }

@@ -1254,10 +1254,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             // the last segment multiplied d (output map folded into the last layer) by the dense inverse covariance
             const float* const Dv = a.u_same ? F : act + (P ^ 1) * ABUF + pr * LD;
             const float* const U = a.u_same ? F + a.u_col : F;
+            const bool fac = a.dense == 2;      // the segment multiplied by L (S = L L^T): chi2 = |d L|^2, a sum of squares
             for (int c = pc0; c < nout; c += RG) {
                 const float d = Dv[c];
                 if (a.D && rok) a.D[(size_t)(row0 + pr) * a.ldd + c] = d;
-                chi += d * U[c];
+                const float u = U[c];
+                chi += (fac ? u : d) * u;
             }
         } else {
 #pragma unroll
@@ -1431,6 +1433,9 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         const bool behind = no <= 256;                                          // SPLIT: U behind d in the same buffer
         Lin Q{dn->S, dn->lds, no, npad, nullptr, 0, 0, 0.f, nullptr, 0.f, no, 0, behind ? npad : 0, behind};
         Q.op = nl;
+        // factored: the matrix is L (S = L L^T, not symmetric) and the segment must produce d L: U_n = sum_k d_k L[k][n] -- the
+        // pack kernel reads it transposed (the row-dot GEMM of the layered path reads S[k][n] as it is)
+        if (dn->factored) Q.transA = 1;
         lins.push_back(Q);
         p.dense = 1; p.u_col = Q.dst_col; p.u_same = behind ? 1 : 0;
     }
@@ -1667,6 +1672,7 @@ static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int i
         const void* const ptrs[3] = {dn->S, dn->cscale, dn->cshift};
         key.append(reinterpret_cast<const char*>(ptrs), sizeof(ptrs));
         key.append(reinterpret_cast<const char*>(&dn->lds), sizeof(int));
+        key.append(reinterpret_cast<const char*>(&dn->factored), sizeof(int));
     }
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
@@ -2010,7 +2016,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
     a.LD = p.LD; a.kpad0 = p.kpad0; a.nout = p.nout; a.bias_total = p.bias_total;
     a.cscale = cscale; a.cshift = cshift; a.w = w; a.T = T;
     a.cpost = cpost; a.cshift2 = cshift2;
-    a.dense = p.dense; a.u_col = p.u_col; a.u_same = p.u_same; a.x0_keep = p.x0_keep;
+    a.dense = p.dense ? (dn && dn->factored ? 2 : 1) : 0; a.u_col = p.u_col; a.u_same = p.u_same; a.x0_keep = p.x0_keep;
     a.lnP = lnP; a.D = D; a.ldd = ldd; a.TH = TH; a.ldt = ldt;
     for (int i = 0; i < (int)p.seg.size(); ++i) a.seg[i] = p.seg[i];
     a.stamps = nullptr; a.gate = gate;

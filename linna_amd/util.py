@@ -380,6 +380,16 @@ class Log_prob(object):
             k["S"] = f32(pad(S))
             k["Ssym"] = f32(pad(0.5 * (S.astype(np.float64) + S.astype(np.float64).T)))
             d.S, d.lds, d.Ssym = _lib.ptr(k["S"]), ldS, _lib.ptr(k["Ssym"])
+            # lnP as |d L|^2 with S = L L^T (float64 Cholesky of the matrix the caller gave, i.e. of the reference's fp32
+            # invcov): the same GEMM, without the cancellation d S d^T has when the covariance is ill-conditioned
+            # (SURVEY 7 "hard parts"; measured in tests/test_gpu_cond.py).  Not positive definite: the direct form.
+            if os.environ.get("LINNA_DENSE_FACTORED", "1") != "0":
+                try:
+                    Lf = np.linalg.cholesky(0.5 * (S.astype(np.float64) + S.astype(np.float64).T))
+                    k["Sfac"] = f32(pad(Lf))
+                    d.Sfac = _lib.ptr(k["Sfac"])
+                except np.linalg.LinAlgError:
+                    pass
         d.gscale = _lib.ptr(k["gscale"])
         d.temperature = self.T
         h = C.c_void_p()

@@ -651,7 +651,80 @@ def gen_host_designs(out):
     print("host designs", {k: v.shape for k, v in rec.items()}, flush=True)
 
 
-GENERATORS = [("host_designs", gen_host_designs), ("importance", gen_importance), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
+# ------------------------------------------------------------------ ill-conditioned dense covariance
+COND = dict(name="cond_26_457", kind="ChtoModelv2", nin=26, nout=457, seed=110, conds=(1e2, 1e4, 1e6), nanchor=4,
+            deltas=(1e-4, 1e-3, 1e-2, 1e-1), ndir=3, temperature=1.0)
+
+
+def cond_points(nin, seed, nanchor, deltas, ndir):
+    """Walker positions [nanchor][1 + len(deltas) * ndir][nin]: an anchor z0 and points at growing distances from it."""
+    rs = np.random.RandomState(seed + 17)
+    z0 = 0.5 * rs.standard_normal((nanchor, nin))
+    pts = [z0[:, None, :]]
+    for dl in deltas:
+        u = rs.standard_normal((nanchor, ndir, nin))
+        u /= np.linalg.norm(u, axis=-1, keepdims=True)
+        pts.append(z0[:, None, :] + dl * np.sqrt(nin) * u)
+    return np.concatenate(pts, axis=1).astype(np.float32)
+
+
+def gen_cond(out):
+    """``Log_prob`` of the LIVE reference (util.py:953-955, 990-1021: fp32 ``(m - data) @ invcov @ (m - data).T``) where the
+    order of summation matters: dense covariances of condition 1e2 / 1e4 / 1e6 at (26, 457), with the data vector placed so
+    that the residual at each anchor is a draw from the covariance itself (chi^2 ~ nout: what a converged chain sees; the
+    stiff directions then cancel against each other inside d S d^T) and points at distances 1e-4 ... 1e-1 around it (the
+    stiff directions take over, chi^2 up to 1e7).  Stored: the reference's fp32 lnP and m, lnP in float64 from the
+    reference's own m and the SAME fp32-rounded inverse covariance (isolates the summation error), lnP with the unrounded
+    inverse, and the autograd gradient."""
+    c = COND
+    nin, nout, seed = c["nin"], c["nout"], c["seed"]
+    z = cond_points(nin, seed, c["nanchor"], c["deltas"], c["ndir"])
+    K, P = z.shape[:2]
+    X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
+    _, _, priors = synth.gaussian_problem(nin, nout, seed, dense=False)
+    model = build_model(c["kind"], nin, nout, seed)
+    Xt = rutil.X_transform_class(t32(X_mean), t32(X_std), "cpu", None)
+    Yt = rutil.Y_transform_class(t32(y_mean), t32(y_std), "cpu", ypositive=False)
+    pred = rpred.Predictor(nin, nout, model=model, X_transform=Xt, y_transform=Yt, device="cpu")
+    transform = rutil.Transform(priors)
+    rs = np.random.RandomState(seed + 23)
+    xi = rs.standard_normal((K, nout))
+    rec = dict(z=z, conds=np.array(c["conds"]), xi=xi)
+    for ci, cond in enumerate(c["conds"]):
+        cov, inv, half = synth.cond_problem(nin, nout, seed, cond)
+        sigma = np.sqrt(np.diag(cov))
+        yinv = rutil.Y_invtransform_data(sigma, "cpu")
+        inv32 = inv.astype(np.float32)
+        data = np.zeros((K, nout)); m = np.zeros((K, P, nout), np.float32)
+        l32 = np.zeros((K, P), np.float32); l64 = np.zeros((K, P)); l64u = np.zeros((K, P)); gr = np.zeros((K, P, nin), np.float32)
+        for k in range(K):
+            theta = np.stack([np.atleast_1d(transform(zi)) for zi in z[k]]).astype(np.float32)
+            with torch.no_grad():
+                mk = np.stack([yinv(pred.predict(t32(th))[None, :])[0].numpy() for th in theta])
+            data[k] = mk[0].astype(np.float64) - half @ xi[k]                 # residual at the anchor: a draw from the covariance
+            lp = rutil.Log_prob(t32(data[k]), torch.from_numpy(inv32), pred, yinv, transform, c["temperature"],
+                                rutil.gaussianlogliklihood, nograd=True)
+            lpg = rutil.Log_prob(t32(data[k]), torch.from_numpy(inv32), pred, yinv, transform, c["temperature"],
+                                 rutil.gaussianlogliklihood, nograd=False)
+            d32 = data[k].astype(np.float32)
+            for i, zi in enumerate(z[k]):
+                l32[k, i] = float(lp(zi))
+                x = t32(zi).clone().requires_grad_()
+                gr[k, i] = torch.autograd.grad(lpg(x, inputnumpy=False), x)[0].numpy()
+                dd = mk[i].astype(np.float64) - d32.astype(np.float64)
+                prior = -0.5 * float(np.sum(zi.astype(np.float64) ** 2))
+                l64[k, i] = -0.5 * dd @ inv32.astype(np.float64) @ dd / c["temperature"] + prior
+                l64u[k, i] = -0.5 * dd @ inv @ dd / c["temperature"] + prior
+            m[k] = mk
+        for key, v in (("data", data), ("m", m), ("lnP32", l32), ("lnP64", l64), ("lnP64_exact_inv", l64u), ("grad", gr)):
+            rec["%s/%d" % (key, ci)] = v
+        e = np.abs(l32 - l64)
+        print("cond %.0e: chi2 at anchors %s; |lnP32 - lnP64| anchors max %.3g, all points max rel %.3g" % (
+            cond, np.round(-2 * (l64[:, 0] + 0.5 * np.sum(z[:, 0].astype(np.float64) ** 2, -1))), e[:, 0].max(), (e / np.abs(l64)).max()), flush=True)
+    out[c["name"]] = rec
+
+
+GENERATORS = [("cond", gen_cond), ("host_designs", gen_host_designs), ("importance", gen_importance), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
               ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc), ("hmc_move", gen_hmc_move), ("callbacks", gen_callbacks),
               ("init_parity", gen_init_parity), ("train33", gen_train33)]
 

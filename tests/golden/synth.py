@@ -76,6 +76,19 @@ def gaussian_problem(nin, nout, seed, dense=False, cond=1e3):
     return data, cov, priors
 
 
+def cond_problem(nin, nout, seed, cond):
+    """Dense SPD covariance of a stated condition number WITH its inverse from the same eigen-decomposition (the generator
+    and the tests then hold the same inverse to the last bits that survive fp32 rounding, whatever LAPACK's ``inv`` does
+    at condition 1e6), and the covariance's symmetric square root (to draw residuals the covariance calls likely)."""
+    rs = np.random.RandomState(seed)
+    q, _ = np.linalg.qr(rs.standard_normal((nout, nout)))
+    ev = np.logspace(0, -np.log10(cond), nout) * 0.1
+    cov = (q * ev[None, :]) @ q.T
+    inv = (q / ev[None, :]) @ q.T
+    half = (q * np.sqrt(ev)[None, :]) @ q.T
+    return 0.5 * (cov + cov.T), 0.5 * (inv + inv.T), half
+
+
 def transform_constants(nin, nout, seed):
     rs = np.random.RandomState(seed + 7)
     X_mean = rs.uniform(-0.5, 0.5, nin).astype(np.float32)

@@ -180,3 +180,34 @@ def test_per_walker_hmc_move_matches_the_references_integrator():
     np.testing.assert_allclose(det["q"], g["q"], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(det["lnp_new"], g["lnp_new"], rtol=5e-4)
     np.testing.assert_allclose(det["factor"], g["factor"], rtol=5e-3, atol=5e-3)
+
+
+def test_oracle_under_ill_conditioned_covariances():
+    """tests/golden/cond_26_457.npz (make_golden.py ``cond``, live reference): dense covariances of condition 1e2 / 1e4 /
+    1e6 with residuals that are draws from the covariance at the anchors.  The oracle's emulator reproduces the reference's
+    m; its float64 log-probability equals the float64 value stored with the golden (same fp32-rounded inverse covariance)
+    to 1e-9, and the reference's own fp32 value sits within the summation error this condition number allows -- the
+    numbers tests/test_gpu_cond.py holds the HIP path to."""
+    g = cases.golden("cond_26_457")
+    nin, nout, seed = 26, 457, 110
+    X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
+    _, _, priors = synth.gaussian_problem(nin, nout, seed, dense=False)
+    w = synth.weights("ChtoModelv2", nin, nout, seed)
+    worst = {}
+    for ci, cond in enumerate(g["conds"]):
+        cov, inv, half = synth.cond_problem(nin, nout, seed, float(cond))
+        emu = likelihood.Emulator("ChtoModelv2", nin, nout, w, X_mean, X_std, y_mean, y_std, np.sqrt(np.diag(cov)))
+        inv32 = inv.astype(np.float32)
+        for k in range(g["z"].shape[0]):
+            z = g["z"][k]
+            m = emu.predict(likelihood.prior_map(z, priors))
+            scale = np.abs(g["m/%d" % ci][k]).max()
+            np.testing.assert_allclose(m, g["m/%d" % ci][k], rtol=2e-4, atol=2e-5 * scale)
+            # the anchor's residual is the stored draw: data = m(z0) - cov^(1/2) xi
+            np.testing.assert_allclose(g["m/%d" % ci][k][0].astype(np.float64) - g["data/%d" % ci][k], half @ g["xi"][k], atol=1e-9)
+            d = g["m/%d" % ci][k].astype(np.float64) - g["data/%d" % ci][k].astype(np.float32).astype(np.float64)
+            l64 = -0.5 * np.einsum("bi,ij,bj->b", d, inv32.astype(np.float64), d) - 0.5 * (z.astype(np.float64) ** 2).sum(-1)
+            np.testing.assert_allclose(l64, g["lnP64/%d" % ci][k], rtol=1e-9)
+            worst[float(cond)] = max(worst.get(float(cond), 0.0), float(np.abs(g["lnP32/%d" % ci][k] - l64)[0]))
+    # the reference's own fp32 error at the anchors (chi^2 ~ nout) grows with the condition number
+    assert worst[1e2] < 1e-3 and worst[1e4] < 1e-2 and 1e-3 < worst[1e6] < 0.5, worst
