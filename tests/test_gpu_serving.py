@@ -130,14 +130,14 @@ def test_predict_and_logprob_match_reference(name):
     lp, pred, yinv, prob = build_logprob(name)
     m = yinv(pred.predict(torch.as_tensor(g["theta"]))).cpu().numpy()
     scale = np.abs(g["m"]).max()
-    np.testing.assert_allclose(m, g["m"], rtol=3e-4, atol=3e-5 * scale)
+    np.testing.assert_allclose(m, g["m"], rtol=8e-5, atol=8e-6 * scale)
     for j, T in enumerate(g["temps"]):
         lpT = build_logprob(name, float(T))[0]
         got = lpT(g["z"], returntorch=False)
-        np.testing.assert_allclose(got, g["loglike"][:, j], rtol=6e-4)
+        np.testing.assert_allclose(got, g["loglike"][:, j], rtol=2e-5)
         one = lpT(g["z"][3])                      # single-walker call: reference semantics (scalar)
         assert one.dim() == 0
-        np.testing.assert_allclose(float(one), g["loglike"][3, j], rtol=6e-4)
+        np.testing.assert_allclose(float(one), g["loglike"][3, j], rtol=1e-5)
 
 
 @pytest.mark.parametrize("name", [c[0] for c in cases.SERVING if not c[8]])
@@ -146,9 +146,9 @@ def test_logprob_gradient_matches_autograd(name):
     lp = build_logprob(name)[0]
     z, _ = lp._to_device(g["z"])
     lnp, grad = lp.evaluate_with_grad(z)
-    np.testing.assert_allclose(lnp.cpu().numpy(), g["loglike"][:, 0], rtol=6e-4)
+    np.testing.assert_allclose(lnp.cpu().numpy(), g["loglike"][:, 0], rtol=1.5e-5)
     import parity
-    parity.rowmax_close(grad.cpu().numpy(), g["grad"], 3e-3, 1e-5)
+    parity.rowmax_close(grad.cpu().numpy(), g["grad"], 4e-5, 1.5e-7)
 
 
 def test_oracle_agrees_at_large_batch():
@@ -159,7 +159,7 @@ def test_oracle_agrees_at_large_batch():
     z = np.random.RandomState(3).standard_normal((4096, 33)).astype(np.float32)
     got = lp(z, returntorch=False)
     ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0, dtype=np.float64)
-    np.testing.assert_allclose(got, ref, rtol=5e-4)
+    np.testing.assert_allclose(got, ref, rtol=1.5e-5)
 
 
 def test_very_large_ragged_batch():
@@ -178,7 +178,7 @@ def test_very_large_ragged_batch():
     assert np.isfinite(got).all()
     idx = np.r_[0:64, 65500:65600, n - 64:n]
     ref = likelihood.log_prob(z[idx], emu, prob["priors"], prob["data"], prob["invcov"], 1.0, dtype=np.float64)
-    np.testing.assert_allclose(got[idx], ref, rtol=6e-4)
+    np.testing.assert_allclose(got[idx], ref, rtol=4e-6)
     # a batch of 8192 rows runs the same 16-row engine: same rows, same bits, wherever they sit in the big batch
     lo = 61440                                                    # a multiple of 16: the same row <-> lane map
     part = torch.empty(8192, device="cuda")
@@ -197,8 +197,8 @@ def test_reference_fixture_known_answers():
     lp = util.Log_prob(np.array([0.1, 1.0]), np.linalg.inv(np.diag([0.5, 0.2])), model, yinv, util.Transform(priors),
                        1.0, util.gaussianlogliklihood, nograd=True)
     got = lp(g["z"], returntorch=False)
-    np.testing.assert_allclose(got, g["loglike"], rtol=2e-5, atol=2e-6)
-    np.testing.assert_allclose(got[:4], [-2.9208457, -3.2061472, -4.2610073, -4.2800837], rtol=2e-5)
+    np.testing.assert_allclose(got, g["loglike"], rtol=5e-6, atol=5e-7)
+    np.testing.assert_allclose(got[:4], [-2.9208457, -3.2061472, -4.2610073, -4.2800837], rtol=3e-6)
 
 
 def test_nan_maps_to_minus_inf_and_empty_edge():
@@ -242,8 +242,8 @@ def test_whole_network_kernel_edges_and_agreement_with_layered_path():
         layered = layered.cpu().numpy()
         ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0)
         ok = np.isfinite(ref)
-        np.testing.assert_allclose(fused[ok], ref[ok], rtol=5e-4)
-        np.testing.assert_allclose(fused[ok], layered[ok], rtol=2e-4)
+        np.testing.assert_allclose(fused[ok], ref[ok], rtol=1.5e-5)
+        np.testing.assert_allclose(fused[ok], layered[ok], rtol=2e-6)
         assert np.all(fused[~ok] == -np.inf)
         th_ref = likelihood.prior_map(z, prob["priors"])
         np.testing.assert_allclose(theta.cpu().numpy()[ok], th_ref[ok], rtol=1e-5, atol=1e-5)
@@ -253,7 +253,7 @@ def test_whole_network_kernel_edges_and_agreement_with_layered_path():
     got = lpd(z, returntorch=False)
     ref = likelihood.log_prob(z, cases.oracle_emulator(probd), probd["priors"], probd["data"], probd["invcov"], 1.0,
                               dtype=np.float64)
-    np.testing.assert_allclose(got, ref, rtol=6e-4)
+    np.testing.assert_allclose(got, ref, rtol=1e-5)
 
 
 def test_ypositive_output_map_runs_in_the_whole_network_kernel(monkeypatch):
@@ -264,14 +264,14 @@ def test_ypositive_output_map_runs_in_the_whole_network_kernel(monkeypatch):
     lp, pred, yinv, prob = build_logprob("v2_4_2_ypos")
     g = cases.golden("v2_4_2_ypos")
     got = lp(g["z"], returntorch=False)
-    np.testing.assert_allclose(got, g["loglike"][:, 0], rtol=6e-4, atol=1e-5)
+    np.testing.assert_allclose(got, g["loglike"][:, 0], rtol=3e-6, atol=5e-8)
     z = torch.as_tensor(np.random.RandomState(4).standard_normal((777, 4)).astype(np.float32) * 0.4, device="cuda")
     fused = lp.evaluate(z).cpu().numpy()
     monkeypatch.setenv("LINNA_DISABLE_FUSED", "1")
     lp2 = build_logprob("v2_4_2_ypos")[0]
     layered = lp2.evaluate(z).cpu().numpy()
     monkeypatch.delenv("LINNA_DISABLE_FUSED")
-    np.testing.assert_allclose(fused, layered, rtol=3e-4, atol=1e-5)
+    np.testing.assert_allclose(fused, layered, rtol=2e-6, atol=8e-8)
     x0 = np.random.RandomState(1).standard_normal((64, 4)).astype(np.float32) * 0.3
     a = sampler.EnsembleSampler(64, 4, lp, seed=3, randomize_split=False)
     b = sampler.EnsembleSampler(64, 4, lp, seed=3, randomize_split=False, fused=False)
@@ -305,11 +305,11 @@ def test_input_skip_network_runs_in_the_whole_network_kernel(nin, nout, monkeypa
     zd = torch.as_tensor(z, device="cuda")
     fused = lp.evaluate(zd).cpu().numpy()
     ref = likelihood.log_prob(z, cases.oracle_emulator(prob), priors, data, prob["invcov"], 1.0)
-    np.testing.assert_allclose(fused, ref, rtol=6e-4, atol=1e-4)
+    np.testing.assert_allclose(fused, ref, rtol=2e-5, atol=3e-6)
     monkeypatch.setenv("LINNA_DISABLE_FUSED", "1")
     layered = build_logprob(None, 1.0, prob)[0].evaluate(zd).cpu().numpy()
     monkeypatch.delenv("LINNA_DISABLE_FUSED")
-    np.testing.assert_allclose(fused, layered, rtol=3e-4, atol=1e-4)
+    np.testing.assert_allclose(fused, layered, rtol=2e-6, atol=8e-7)
     # without the skip the values differ: the branch is really in the kernel
     w0 = dict(w); w0["linearlayer.weight"] = np.zeros_like(w["linearlayer.weight"]); w0["linearlayer.bias"] = np.zeros_like(w["linearlayer.bias"])
     noskip = build_logprob(None, 1.0, dict(prob, weights=w0))[0].evaluate(zd).cpu().numpy()
@@ -369,8 +369,8 @@ def test_whole_network_kernels_against_oracle(nin, nout, width, depth, which, mo
                 _lib.engine_rows(int(rows))
             theta = torch.empty_like(zd)
             got = lp.evaluate(zd, theta=theta).cpu().numpy()
-            np.testing.assert_allclose(got, ref, rtol=5e-4, atol=1e-3, err_msg="rows %s B %d" % (rows, B))
-            np.testing.assert_allclose(got, layered, rtol=2e-4, atol=1e-3, err_msg="rows %s B %d" % (rows, B))
+            np.testing.assert_allclose(got, ref, rtol=2e-5, atol=4e-5, err_msg="rows %s B %d" % (rows, B))
+            np.testing.assert_allclose(got, layered, rtol=1.5e-5, atol=8e-5, err_msg="rows %s B %d" % (rows, B))
             np.testing.assert_allclose(theta.cpu().numpy(), likelihood.prior_map(z, prob["priors"]), rtol=1e-5, atol=1e-5)
         _lib.engine_rows(0)
 
@@ -392,7 +392,7 @@ def test_stream_kernel_follows_weight_updates():
         p2 = dict(prob, weights=sd)
         ref = likelihood.log_prob(z, cases.oracle_emulator(p2), prob["priors"], prob["data"], prob["invcov"], 1.0)
         got = lp.evaluate(zd).cpu().numpy()
-        np.testing.assert_allclose(got, ref, rtol=5e-4, atol=1e-3)
+        np.testing.assert_allclose(got, ref, rtol=1.5e-5, atol=3e-5)
         return got
 
     a = check()
@@ -443,11 +443,11 @@ def test_fused_gradient_against_layered_path_and_oracle(nin, nout, width, depth,
         ll, gl = layered.evaluate_with_grad(zd)
         lf, gf, ll, gl = lf.cpu().numpy(), gf.cpu().numpy(), ll.cpu().numpy(), gl.cpu().numpy()
         scale = np.abs(gl).max()
-        np.testing.assert_allclose(lf, ll, rtol=3e-4, atol=1e-3)
-        np.testing.assert_allclose(gf, gl, rtol=2e-3, atol=2e-4 * scale)
+        np.testing.assert_allclose(lf, ll, rtol=5e-6, atol=2e-5)
+        np.testing.assert_allclose(gf, gl, rtol=2e-6, atol=2e-7 * scale)
         _, gref = likelihood.grad_log_prob(z.astype(np.float64), emu, prob["priors"], prob["data"], prob["invcov"], 2.0,
                                            dtype=np.float64)
-        np.testing.assert_allclose(gf, gref, rtol=5e-3, atol=5e-4 * scale)
+        np.testing.assert_allclose(gf, gref, rtol=1e-4, atol=1e-5 * scale)
     _lib.engine_rows(0)
     # the two objects really took different routes (meaningful on the big shape only; best of several
     # short runs: a stray hipFree from garbage collection in the middle of a run costs milliseconds)
@@ -492,21 +492,21 @@ def test_full_size_properties(name):
         if name in ("mlp_33_33", "v2_33_33") and n > 2048:              # same engine as the full batch: same bits
             np.testing.assert_array_equal(got, base[:n])
         else:
-            np.testing.assert_allclose(got, base[:n], rtol=2e-5)
+            np.testing.assert_allclose(got, base[:n], rtol=1.5e-5)
     # one walker repeated in every row
     rep = lp1(np.repeat(z[7:8], 257, axis=0), returntorch=False)
     assert np.all(rep == rep[0])
-    np.testing.assert_allclose(rep[0], base[7], rtol=2e-5)
+    np.testing.assert_allclose(rep[0], base[7], rtol=5e-6)
     # temperature: lnP_T + |z|^2/2 = (lnP_1 + |z|^2/2) / T
     half = 0.5 * np.sum(z.astype(np.float64) ** 2, axis=1)
     for T in (4.0, 16.0):
         lpT = build_logprob(name, T)[0](z, returntorch=False)
-        np.testing.assert_allclose((lpT + half) * T, base + half, rtol=2e-5, atol=2e-4)
+        np.testing.assert_allclose((lpT + half) * T, base + half, rtol=8e-6, atol=8e-5)
     # a sample of rows against the oracle (float64 accumulation)
     idx = rs.choice(B, 96, replace=False)
     ref = likelihood.log_prob(z[idx], cases.oracle_emulator(prob), prob["priors"], prob["data"], prob["invcov"], 1.0,
                               dtype=np.float64)
-    np.testing.assert_allclose(base[idx], ref, rtol=6e-4)
+    np.testing.assert_allclose(base[idx], ref, rtol=8e-6)
 
 
 @pytest.mark.parametrize("name", ["mlp_33_33", "v2_33_33"])
@@ -521,7 +521,7 @@ def test_full_size_gradient_properties(name):
     zd, _ = lp._to_device(z)
     lnp, g = lp.evaluate_with_grad(zd)
     lnp, g = lnp.cpu().numpy().copy(), g.cpu().numpy()[:, :nin].copy()
-    np.testing.assert_allclose(lnp, lp(z, returntorch=False), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(lnp, lp(z, returntorch=False), rtol=4e-6, atol=4e-6)
     perm = rs.permutation(B)
     zp, _ = lp._to_device(z[perm])
     lnp_p, g_p = lp.evaluate_with_grad(zp)
@@ -533,8 +533,8 @@ def test_full_size_gradient_properties(name):
     idx = rs.choice(B, 64, replace=False)
     lref, gref = likelihood.grad_log_prob(z[idx], cases.oracle_emulator(prob), prob["priors"], prob["data"],
                                           prob["invcov"], 1.0)
-    np.testing.assert_allclose(lnp[idx], lref, rtol=6e-4)
-    np.testing.assert_allclose(g[idx], gref, rtol=0, atol=3e-3 * np.abs(gref).max())
+    np.testing.assert_allclose(lnp[idx], lref, rtol=1e-5)
+    np.testing.assert_allclose(g[idx], gref, rtol=0, atol=2e-5 * np.abs(gref).max())
 
 
 @pytest.mark.parametrize("nin,nout,width,depth", [
@@ -563,7 +563,7 @@ def test_dense_covariance_as_last_segment(nin, nout, width, depth, monkeypatch):
         zd = torch.as_tensor(z, device="cuda")
         ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 4.0, dtype=np.float64)
         base = unfused.evaluate(zd).cpu().numpy()
-        np.testing.assert_allclose(base, ref, rtol=6e-4)
+        np.testing.assert_allclose(base, ref, rtol=2e-5)
         for rows in (None, 4, 8, 16):
             if rows is None:
                 _lib.engine_rows(0)
@@ -571,8 +571,8 @@ def test_dense_covariance_as_last_segment(nin, nout, width, depth, monkeypatch):
                 _lib.engine_rows(int(rows))
             theta = torch.empty_like(zd)
             got = fused.evaluate(zd, theta=theta).cpu().numpy()
-            np.testing.assert_allclose(got, ref, rtol=6e-4, err_msg="rows %s B %d" % (rows, B))
-            np.testing.assert_allclose(got, base, rtol=3e-4, err_msg="rows %s B %d" % (rows, B))
+            np.testing.assert_allclose(got, ref, rtol=2e-5, err_msg="rows %s B %d" % (rows, B))
+            np.testing.assert_allclose(got, base, rtol=2e-5, err_msg="rows %s B %d" % (rows, B))
             np.testing.assert_allclose(theta.cpu().numpy(), likelihood.prior_map(z, prob["priors"]), rtol=1e-5, atol=1e-5)
     _lib.engine_rows(0)
     # one-launch half step on the dense problem, bit-identical to propose / evaluate / accept
