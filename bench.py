@@ -447,31 +447,147 @@ def _events_us(fn, iters, warm_s=0.3):
     return 1e3 * ms.value / iters
 
 
-def hmc_rate(device, nchains=4096, nleap=5):
+def identity_state(kind, seed=1234, shift=2.0):
+    """Weights that make `kind`(33, 33) compute h(x) = x EXACTLY on |x| < shift while every other unit keeps random
+    (He-scaled) weights -- the trained emulator of the README problem (theory = identity) that no offline training has to
+    be waited for, with the arithmetic (and the power draw) of a real weight set.  x passes as relu(x) - relu(-x) through
+    66 units of every hidden layer (identity rows there, zero rows in the layers that would mix other units in);
+    ChtoModelv2's 33-unit ReLU bottleneck before its last layer (nn.py:85-86, 127-129) passes x + shift > 0 and the last
+    layer's bias takes the shift off again."""
+    rs = np.random.RandomState(seed)
+    n = NIN
+    I = np.eye(n, dtype=np.float32)
+    he = lambda N, K: (np.sqrt(2.0 / K) * rs.standard_normal((N, K))).astype(np.float32)
+    sd = {}
+
+    def first(key, N):                       # [x] -> [relu(x); relu(-x); random units]
+        W, b = he(N, n), (0.1 * rs.standard_normal(N)).astype(np.float32)
+        W[:n], W[n:2 * n], b[:2 * n] = I, -I, 0.0
+        sd[key + ".weight"], sd[key + ".bias"] = W, b
+
+    def carry(key, N, K, bias=True):         # units 0..65 pass through, the others are random
+        W = he(N, K)
+        W[:2 * n] = 0.0
+        W[np.arange(2 * n), np.arange(2 * n)] = 1.0
+        sd[key + ".weight"] = W
+        if bias:
+            b = (0.1 * rs.standard_normal(N)).astype(np.float32); b[:2 * n] = 0.0
+            sd[key + ".bias"] = b
+
+    if kind == "MLP":
+        first("layer1", WIDTH)
+        for i in range(2, DEPTH + 1):
+            carry("layer%d" % i, WIDTH, WIDTH)
+        W = np.zeros((n, WIDTH), np.float32); W[:, :n], W[:, n:2 * n] = I, -I
+        sd["layer%d.weight" % (DEPTH + 1)], sd["layer%d.bias" % (DEPTH + 1)] = W, np.zeros(n, np.float32)
+        return sd
+    assert kind == "ChtoModelv2"
+    h = 1000
+    first("layer1", h)
+    for name, c in (("layer2", 16), ("layer3", 32), ("layer4", 64)):
+        sd[name + ".layer1.weight"], sd[name + ".layer1.bias"] = he(c, h), (0.1 * rs.standard_normal(c)).astype(np.float32)
+        W2, b2 = he(h // 2, c), (0.1 * rs.standard_normal(h // 2)).astype(np.float32)
+        W2[:2 * n], b2[:2 * n] = 0.0, 0.0                            # 0.1 (W2 h + b2) adds nothing to the carried units
+        sd[name + ".layer2.weight"], sd[name + ".layer2.bias"] = W2, b2
+        carry(name + ".skip_layer", h // 2, h, bias=False)
+        h //= 2
+    carry("layer6", 4 * h, h)
+    W7 = np.zeros((n, 4 * h), np.float32); W7[:, :n], W7[:, n:2 * n] = I, -I
+    sd["layer7.weight"], sd["layer7.bias"] = W7, np.full(n, shift, np.float32)     # relu(x + shift) = x + shift
+    sd["layer8.weight"], sd["layer8.bias"] = I.copy(), np.full(n, -shift, np.float32)
+    return sd
+
+
+def _problem33_identity(device, kind):
+    """README problem (README.rst:69-83: 33-D Gaussian likelihood, flat priors [-5, 5], theory = identity) behind an
+    emulator of class `kind` that IS the identity (identity_state): the posterior is the analytic one, so acceptance
+    rates and autocorrelation times mean what they would in a converged LINNA iteration."""
+    import torch
+    from linna_amd import nn, util, predictor_gpu
+    rs = np.random.RandomState(11)
+    data = rs.uniform(size=NOUT)
+    cov = np.diag(0.1 * rs.uniform(0.05, 1.0, size=NOUT))
+    sigma = np.sqrt(np.diag(cov))
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(NIN)]
+    model = getattr(nn, kind)(NIN, NOUT, None)
+    model.load_state_dict(identity_state(kind))
+    t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+    xs = 10.0 / np.sqrt(12.0)                 # x = theta / xs in (-1.74, 1.74); m = (h * (xs / sigma) + 0) * sigma = theta
+    pred = predictor_gpu.Predictor(NIN, NOUT, model=model, device=device,
+                                   X_transform=util.X_transform_class(t(np.zeros(NIN)), t(np.full(NIN, xs)), "cpu", None),
+                                   y_transform=util.Y_transform_class(t(np.zeros(NOUT)), t(xs / sigma), "cpu"))
+    lp = util.Log_prob(t(data), t(np.linalg.inv(cov)), pred, util.Y_invtransform_data(sigma, "cpu"), util.Transform(priors), 1.0,
+                       util.gaussianlogliklihood, nograd=True)
+    return lp, model, data, sigma
+
+
+def hmc_rate(device, nchains=4096, nleap=5, nsamp=400):
     """BASELINE configs[4] (HMCSampler.py:19-68 batched over walkers; one process per GPU, chains are independent: no
     collective): lnP + d lnP / d z per launch (linna_logprob_grad), and whole HMC transitions of `nleap` leapfrog steps
-    (momentum draw, half kick, nleap x (drift, gradient, kick), Metropolis test: 3 + nleap launches, every kick and drift
-    after the first riding in the finish of a gradient launch).  For the reference's network class
-    ChtoModelv2(33,33) and the 4 x 512 MLP.  One gradient evaluation = forward + dX-only backward = 2 x the forward FLOP
-    (SURVEY 8d)."""
+    (momentum draw, half kick, nleap x (drift, gradient, kick), Metropolis test: 3 + nleap launches).  For the reference's
+    network class ChtoModelv2(33,33) and the 4 x 512 MLP, each holding the identity-exact emulator of the README problem
+    (identity_state), unit mass, the step size tuned per model to an acceptance of 0.65-0.8.
+    Reported next to the kernel figure: acceptance, the integrated autocorrelation time of the chains (emcee's estimator
+    on the device, averaged over chains, worst parameter) and effective samples per second = chains x samples / tau / time.
+    One gradient evaluation = forward + dX-only backward = 2 x the forward FLOP."""
     import torch
+    from scipy.special import erf
     from linna_amd import sampler
-    out = {"chains": nchains, "leapfrog_per_sample": nleap, "workload": "33-D Gaussian, %d independent chains, lnP and its gradient in one launch" % nchains}
+    out = {"chains": nchains, "leapfrog_per_sample": nleap,
+           "workload": "33-D Gaussian (README), identity-exact emulator, %d independent chains, unit mass, step size tuned to 0.65-0.8 acceptance" % nchains}
     for key, kind in (("chto_v2", "ChtoModelv2"), ("mlp4x512", "MLP")):
-        lp, model = _problem33(device, kind)
-        z = torch.as_tensor(np.random.RandomState(5).standard_normal((nchains, NIN)).astype(np.float32), device=device)
+        lp, model, data, sigma = _problem33_identity(device, kind)
+        rs = np.random.RandomState(5)
+        # start at the posterior: theta ~ N(data, sigma^2), z = Phi^-1((theta + 5) / 10)
+        from scipy.special import ndtri
+        theta0 = data[None, :] + sigma[None, :] * rs.standard_normal((nchains, NIN))
+        z0 = ndtri((theta0 + 5.0) / 10.0).astype(np.float32)
+        z = torch.as_tensor(z0, device=device)
         lnp = torch.empty(nchains, dtype=torch.float32, device=device)
         g = torch.empty(nchains, NIN, dtype=torch.float32, device=device)
+        lp.evaluate_with_grad(z, out=lnp, grad=g)
+        # the emulator is the identity: lnP equals the analytic log-posterior
+        th = 10.0 * 0.5 * (1.0 + erf(z0.astype(np.float64) / np.sqrt(2.0))) - 5.0
+        exact = -0.5 * (((th - data[None, :]) / sigma[None, :]) ** 2).sum(1) - 0.5 * (z0.astype(np.float64) ** 2).sum(1)
+        ident_err = float(np.max(np.abs(lnp.cpu().numpy() - exact) / np.abs(exact)))
         us = _events_us(lambda: lp.evaluate_with_grad(z, out=lnp, grad=g), 300)
         assert torch.isfinite(g).all() and torch.isfinite(lnp).all()
         flop = nchains * 2.0 * (2.0 * model.macs_per_eval())
-        h = sampler.BatchedHMC(lp, 0.05 * np.random.RandomState(1).standard_normal((nchains, NIN)).astype(np.float32))
-        us_s = _events_us(lambda: h.step(nleap, 2e-2), 60)
+        # step size: short pilot runs, multiplicative search into the 0.65-0.8 band (same chains, same seed policy)
+        h = sampler.BatchedHMC(lp, z0, seed=3)
+        eps, acc, tuned = 0.05, 0.0, []
+        for _ in range(14):
+            a0, s0 = int(h.naccept.sum().item()), int(h.step_dev.item())
+            for _ in range(15):
+                h.step(nleap, eps)
+            acc = (int(h.naccept.sum().item()) - a0) / float(nchains * (int(h.step_dev.item()) - s0))
+            tuned.append((round(eps, 5), round(acc, 3)))
+            if 0.68 <= acc <= 0.78:
+                break
+            eps *= (1.25 if acc > 0.78 else 0.8) if abs(acc - 0.73) < 0.2 else (1.6 if acc > 0.73 else 0.6)
+        us_s = _events_us(lambda: h.step(nleap, eps), 60)
+        a0, s0 = int(h.naccept.sum().item()), int(h.step_dev.item())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        chain, _ = h.sample(nsamp, nleap, eps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        acc = (int(h.naccept.sum().item()) - a0) / float(nchains * (int(h.step_dev.item()) - s0))
+        dc = sampler.DeviceChain()
+        dc.append(chain)
+        tau = dc.integrated_time()
+        tau_max, tau_med = float(np.nanmax(tau)), float(np.nanmedian(tau))
+        zs = chain[nsamp // 4:].reshape(-1, NIN).double()
+        thm = (10.0 * 0.5 * (1.0 + torch.erf(zs / np.sqrt(2.0))) - 5.0).mean(0).cpu().numpy()
         out[key] = {"us_per_gradient_eval": us, "gradient_evals_per_s": nchains / (us * 1e-6), "achieved": flop / (us * 1e-6) / 1e12,
                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / (us * 1e-6) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                     "flop_per_gradient_eval": flop / nchains, "us_per_hmc_sample": us_s, "launches_per_hmc_sample": 3 + nleap,
                     "leapfrog_steps_per_s": nleap * nchains / (us_s * 1e-6), "hmc_iterations_per_s": 1.0 / (us_s * 1e-6),
-                    "acceptance": float(h.naccept.float().mean()) / max(1, int(h.step_dev.item()))}
+                    "step_size": eps, "step_size_search": tuned, "acceptance": acc, "samples_per_chain": nsamp,
+                    "tau_worst_parameter": tau_max, "tau_median_parameter": tau_med,
+                    "ess_per_s": nchains * nsamp / tau_max / dt, "ess_per_s_per_chain": nsamp / tau_max / dt,
+                    "emulator_identity_max_rel_err": ident_err,
+                    "posterior_mean_max_abs_dev_sigma": float(np.max(np.abs(thm - data) / sigma))}
     return out
 
 
@@ -769,6 +885,21 @@ def main():
     except Exception as e:                                          # noqa: BLE001
         mcmc = {"error": repr(e)[:300]}
 
+    if world == 1 and isinstance(mcmc, dict) and "error" not in mcmc:
+        # the stretch move at the reference's production ensemble size (cosmolike_run.py:184: 128 walkers; README: 4)
+        try:
+            nw = 128
+            _, m128 = mcmc_rate(lp, nw, 1, None, 4000, 1000)
+            ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            half = nw // 2
+            m128 = {"steps_per_s": m128["steps_per_s"], "us_per_half_step": 0.5e6 / m128["steps_per_s"],
+                    "walker_updates_per_s": m128["walker_updates_per_s"], "acceptance": m128["acceptance"],
+                    "proposals_per_half_step": half, "workgroups_per_half_step": (half + 3) // 4,
+                    "engine_rows": 4 if half <= 4 * ncu else 8 if half <= 8 * ncu else 16,
+                    "note": "one launch per half step (proposal + lnP + Metropolis test); a launch of <= 1024 rows lasts as long as ONE 4-row workgroup needs for the whole network"}
+            mcmc["walkers_128"] = m128
+        except Exception as e:                                      # noqa: BLE001
+            mcmc["walkers_128"] = {"error": repr(e)[:300]}
     _at("mcmc done: %s" % (mcmc,))
     if rank == 0:
         if strong is not None:

@@ -141,7 +141,10 @@ struct KSplit { int kz; float* scratch; int* counters; };
 // counter at four points of every workgroup of the LAST gemm_body launch -- entry, first K tile requested, K loop done,
 // epilogue stores drained -- plus the hardware id (which CU the workgroup ran on)
 __device__ unsigned long long g_gemm_stamps[8 * 1024];
-#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); } while (0)
+__device__ unsigned long long g_gemm_rt[2 * 1024];       // s_memrealtime (100 MHz, one origin for the whole chip) at entry and at the end
+#define GEMM_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) { g_gemm_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+        if ((i) == 0) g_gemm_rt[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime(); \
+        if ((i) == 3) g_gemm_rt[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define GEMM_STAMP(i) do {} while (0)
 #endif
@@ -555,18 +558,22 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_kernel(GemmArgs a, KSp
 // one-launch forward + loss + dX chain cannot hold it: the rows are complete only when every workgroup has passed its
 // turnaround).  sum_scale_prepare_kernel's arithmetic in its order: 1024 strided partial sums (four per thread here),
 // sixteen wave sums, added in wave order.
+template <int NT = 256>                   // threads of the workgroup (256 or 128): the same 1024 partial sums, 1024 / NT per thread
 __device__ __forceinline__ void gemm_post_mean(const GemmPost& q) {
     __shared__ float post_part[16];
+    constexpr int NP = 1024 / NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[NP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-        for (int i = tid + 256 * j; i < q.n; i += 1024) acc[j] += q.rows[i];
+    for (int j = 0; j < NP; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NP; ++j)
+        for (int i = tid + NT * j; i < q.n; i += 1024) acc[j] += q.rows[i];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
-        if (lane == 0) post_part[wave + 4 * j] = acc[j];
+        if (lane == 0) post_part[wave + (NT / 64) * j] = acc[j];
     }
     __syncthreads();
     if (tid == 0) {
@@ -578,7 +585,7 @@ __device__ __forceinline__ void gemm_post_mean(const GemmPost& q) {
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
 __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const GemmGroupArgs g, const GemmPost post) {
-    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean(post); return; }
+    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean<WM * WN * KS * 64>(post); return; }
     int p = 0;
     while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
     const GemmGroupProb q = g.p[p];
@@ -594,7 +601,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const Gem
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
 __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_update_kernel(const GemmGroupArgsS g, const GemmUpdate u, const GemmPost post) {
-    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean(post); return; }
+    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean<WM * WN * KS * 64>(post); return; }
     int p = 0;
     while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
     const GemmGroupProb q = g.p[p];
@@ -825,10 +832,12 @@ __global__ __launch_bounds__(256) void dw_group_update_kernel(const GemmGroupArg
 
 // Which K loop the grouped parameter-gradient launches run: 2 (default) = operands straight to registers on 64 x 32
 // half-batch work items, 1 = the same on 64 x 64 tiles, 0 = the LDS-DMA ring of gemm_body (LINNA_DW_DIRECT, read once).
+// 3 = the LDS-DMA ring on 64 x 32 tiles of two waves (740 instead of 370 workgroups at (26,457), three resident per CU).
 static int dw_mode() {
-    static const int m = [] { const char* e = getenv("LINNA_DW_DIRECT"); const int v = e ? atoi(e) : 2; return v < 0 || v > 2 ? 2 : v; }();
+    static const int m = [] { const char* e = getenv("LINNA_DW_DIRECT"); const int v = e ? atoi(e) : 0; return v < 0 || v > 3 ? 0 : v; }();
     return m;
 }
+static bool dw_half_tiles() { return dw_mode() >= 2; }
 
 // ---------------------------------------------------------------------------- launcher
 struct TileCfg { int wm, wn, tm, tn; };
@@ -932,15 +941,20 @@ bool gemm_group_ok(const GemmArgs& a) {
     return a.npairs == 1 && a.p[0].alay == LAY_MN && a.p[0].blay == LAY_MN && (cfg == 1 || cfg == 2) && !a.dotwith &&
            ((a.p[0].lda | a.p[0].ldb) & 3) == 0;
 }
-int gemm_group_blocks(const GemmArgs& a) { return ((a.M + 63) / 64) * ((a.N + (dw_mode() == 2 ? 31 : 63)) / (dw_mode() == 2 ? 32 : 64)); }
+int gemm_group_blocks(const GemmArgs& a) { return ((a.M + 63) / 64) * ((a.N + (dw_half_tiles() ? 31 : 63)) / (dw_half_tiles() ? 32 : 64)); }
 int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream, const GemmPost* post) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
     const GemmPost q = post ? *post : GemmPost{nullptr, 0, 0.f, nullptr};
-    if (dw_mode()) {
+    if (dw_mode() == 1 || dw_mode() == 2) {
         const dim3 grid(nblocks + (q.n > 0 ? 1 : 0));
         if (dw_mode() == 2) hipLaunchKernelGGL((dw_group_kernel<32, 2, GemmGroupArgs>), grid, dim3(256), 0, stream, g, q);
         else hipLaunchKernelGGL((dw_group_kernel<64, 1, GemmGroupArgs>), grid, dim3(256), 0, stream, g, q);
         return check_hip(hipGetLastError(), "dw group launch");
+    }
+    if (dw_mode() == 3) {
+        constexpr size_t lds3 = (size_t)4 * (64 + 32) * BK * sizeof(float);
+        hipLaunchKernelGGL((gemm_group_kernel<2, 1, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(128), lds3, stream, g, q);
+        return check_hip(hipGetLastError(), "gemm group launch (64 x 32)");
     }
     hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(256), lds, stream, g, q);
     return check_hip(hipGetLastError(), "gemm group launch");
@@ -949,11 +963,16 @@ int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream, c
 int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream, const GemmPost* post) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
     const GemmPost q = post ? *post : GemmPost{nullptr, 0, 0.f, nullptr};
-    if (dw_mode()) {
+    if (dw_mode() == 1 || dw_mode() == 2) {
         const dim3 grid(nblocks + (q.n > 0 ? 1 : 0));
         if (dw_mode() == 2) hipLaunchKernelGGL((dw_group_update_kernel<32, 2>), grid, dim3(256), 0, stream, g, u, q);
         else hipLaunchKernelGGL((dw_group_update_kernel<64, 1>), grid, dim3(256), 0, stream, g, u, q);
         return check_hip(hipGetLastError(), "dw group update launch");
+    }
+    if (dw_mode() == 3) {
+        constexpr size_t lds3 = (size_t)4 * (64 + 32) * BK * sizeof(float);
+        hipLaunchKernelGGL((gemm_group_update_kernel<2, 1, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(128), lds3, stream, g, u, q);
+        return check_hip(hipGetLastError(), "gemm group update launch (64 x 32)");
     }
     hipLaunchKernelGGL((gemm_group_update_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(256), lds, stream, g, u, q);
     return check_hip(hipGetLastError(), "gemm group update launch");
@@ -986,5 +1005,8 @@ int gemm_launch(const GemmArgs& a, hipStream_t stream) {
 #ifdef GEMM_STAMPS
 extern "C" int linna_debug_gemm_stamps(unsigned long long* out, int nwords) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(linna::g_gemm_stamps), sizeof(unsigned long long) * (size_t)nwords, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int linna_debug_gemm_realtime(unsigned long long* out, int nwords) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(linna::g_gemm_rt), sizeof(unsigned long long) * (size_t)nwords, 0, hipMemcpyDeviceToHost);
 }
 #endif

@@ -32,8 +32,18 @@ buf = (C.c_ulonglong * (8 * 1024))()
 rc = lib.linna_debug_gemm_stamps(buf, 8 * 1024)
 assert rc == 0, rc
 s = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
-s = s[s[:, 0] > 0]
-s = s[s[:, 3] > 0]                       # workgroups of the update launch (the extra mean workgroup leaves early)
+rbuf = (C.c_ulonglong * (2 * 1024))()
+lib.linna_debug_gemm_realtime.restype = C.c_int
+assert lib.linna_debug_gemm_realtime(rbuf, 2 * 1024) == 0
+rt = np.frombuffer(rbuf, dtype=np.uint64).reshape(1024, 2).astype(np.int64)
+keep = (s[:, 0] > 0) & (s[:, 3] > 0)     # workgroups of the update launch (the extra mean workgroup leaves early)
+s, rt = s[keep], rt[keep]
+# chip-wide timeline (s_memrealtime, 100 MHz): when the workgroups entered and left, relative to the first entry
+e_us, x_us = (rt[:, 0] - rt[:, 0].min()) / 100.0, (rt[:, 1] - rt[:, 0].min()) / 100.0
+print("realtime: entry  median %.2f p90 %.2f max %.2f us;  end  median %.2f p90 %.2f max %.2f us  (launch = first entry -> last end: %.2f us)" % (
+    np.median(e_us), np.percentile(e_us, 90), e_us.max(), np.median(x_us), np.percentile(x_us, 90), x_us.max(), x_us.max()))
+late = e_us > 1.0
+print("  %d workgroups entered more than 1 us after the first (median entry of those %.2f us)" % (late.sum(), np.median(e_us[late]) if late.any() else 0.0))
 t0 = s[:, 0].min()
 hw = s[:, 4] & 0xFFFFFFFF
 xcc = s[:, 4] >> 32
@@ -42,6 +52,11 @@ print("%d workgroups on %d CUs" % (len(s), len(set(cu.tolist()))))
 # (the cycle counters of different XCDs have different origins: spans are taken per XCD)
 spans = [(s[xcc == x, 3].max() - s[xcc == x, 0].min()) / 1e3 for x in sorted(set(xcc.tolist()))]
 print("per-XCD span, first entry -> last drained: " + " ".join("%.1f" % v for v in spans) + " k cycles")
+# when the workgroups entered, relative to the first entry of their XCD (dispatch ramp; late entries = second round on a busy CU)
+ent = np.concatenate([(s[xcc == x, 0] - s[xcc == x, 0].min()) / 1e3 for x in sorted(set(xcc.tolist()))])
+end = np.concatenate([(s[xcc == x, 3] - s[xcc == x, 0].min()) / 1e3 for x in sorted(set(xcc.tolist()))])
+print("entry after the XCD's first entry: median %.1f  p90 %.1f  max %.1f k cycles;  drained: median %.1f  p90 %.1f  max %.1f k cycles" % (
+    np.median(ent), np.percentile(ent, 90), ent.max(), np.median(end), np.percentile(end, 90), end.max()))
 d = lambda a, b: (s[:, b] - s[:, a]) / 1e3
 for name, v in (("prologue (first tiles requested)", d(0, 1)), ("K loop", d(1, 2)), ("epilogue (AdamW, streams, drained)", d(2, 3)), ("whole workgroup", d(0, 3))):
     print("  %-36s min %7.1f  median %7.1f  p90 %7.1f  max %7.1f k cycles" % (name, v.min(), np.median(v), np.percentile(v, 90), v.max()))
