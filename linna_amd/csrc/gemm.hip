@@ -485,9 +485,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
                     *reinterpret_cast<f32x4*>(q.out + as_slot(q, up->small, col, q.koff + r0)) =
                         f32x4{q.scale * pv[4 * eg], q.scale * pv[4 * eg + 1], q.scale * pv[4 * eg + 2], q.scale * pv[4 * eg + 3]};
                 } else {
+                    // rows r0 .. r0 + 3 (r0 a multiple of 4) sit 4 floats apart in either stream layout: one slot computation
+                    const size_t s0 = as_slot(q, up->small, r0, q.koff + col);
 #pragma unroll
                     for (int e4 = 0; e4 < 4; ++e4)
-                        if (r0 + e4 < a.M) q.out[as_slot(q, up->small, r0 + e4, q.koff + col)] = q.scale * pv[4 * eg + e4];
+                        if (r0 + e4 < a.M) q.out[s0 + 4 * e4] = q.scale * pv[4 * eg + e4];
                 }
             }
         }
@@ -618,227 +620,6 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_update_kernel(co
     gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS, true>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db, &up);
 }
 
-// ---------------------------------------------------------------------------- parameter gradients, operands straight to registers
-// dW[m][n] = alpha * sum_k dY[k][m] X[k][n] over the batch rows k (predictor_gpu.py:285: what autograd accumulates into
-// every nn.Linear weight), for all layers of a training step in ONE grid -- the grouped launch above with another K loop.
-//
-// Both operands are k-major ([batch][features]).  For v_mfma_f32_32x32x2_f32 the A fragment of lane (i = lane & 31,
-// h = lane >> 5) is A[k = 2 j + h][m0 + i]: 32 consecutive floats of row 2 j and 32 of row 2 j + 1 -- a k-major operand IS
-// the MFMA fragment, one coalesced global_load_dword away.  So this K loop has no LDS image, no DMA ring and no barrier:
-// every wave owns a 32 x 32 tile, streams its two operand panels through a ring of P - 1 register pairs (inline-asm loads
-// the compiler does not count, one counted s_waitcnt vmcnt per MFMA: the whole-network kernel's discipline) and issues one
-// MFMA per k pair.  The LDS version above spent 2.0 k cycles per 32-row K tile on a lone workgroup (16 MFMAs = 1.0 k) on
-// the DMA -> barrier -> first-fragment turnaround (tools/gemm_stamps.py); here the wave's chain of MFMAs is the only
-// serial thing left.  L1 traffic doubles (512 B per MFMA instead of 256: no sharing through LDS), to half the 64 B/clk a
-// CU can take in.
-//
-// Workgroup = 4 waves.  BN = 64, KS = 1: a 64 x 64 tile, one quadrant per wave, every wave the whole batch.
-// BN = 32, KS = 2: a 64 x 32 tile, two 32 x 32 quadrants x two halves of the batch; the second half's accumulators and
-// column sums go through LDS and are added to the first half's (fixed order: first half + second half).  Finer work items
-// balance better: 370 tiles of 64 x 64 put two workgroups on 114 of the 256 CUs and one on the rest; 740 half-K tiles of
-// 64 x 32 put three waves on most SIMDs (24.6 k cycles of MFMA on the busiest SIMD instead of 32.8 k).
-// Summation order over k: pairs (2 j, 2 j + 1) in order inside each half -- one fixed order for every caller, so the update
-// forms that share this launch stay bit-identical to each other (tests/test_gpu_training.py).
-constexpr int DW_P = 16;                         // ring slots; P - 1 k pairs (2 loads each) in flight per wave
-
-__device__ __forceinline__ void dw_gload(float& dst, unsigned voff, const float* sbase) {
-    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory");
-}
-
-template <int BN, int KS, bool UPD>
-__device__ __forceinline__ void dw_body(const GemmGroupProb& q, const int block, const GemmUpd1* const up) {
-    static_assert((BN == 64 && KS == 1) || (BN == 32 && KS == 2), "four waves per workgroup");
-    constexpr int P = DW_P;
-    __shared__ float red[KS > 1 ? 2 * 16 * 64 : 1];           // second batch half -> first: [quadrant][e][lane]
-    __shared__ float cred[4 * 32];                            // column sums of the waves that do not own the bias
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int kh = KS > 1 ? wave >> 1 : 0;                    // batch half
-    const int wm = KS > 1 ? wave & 1 : wave >> 1, wn = KS > 1 ? 0 : wave & 1;
-    const int i = lane & 31, h = lane >> 5;
-    const int M = q.M, N = q.N, K = q.K;
-    const int ntn = (N + BN - 1) / BN;
-    const int tm_ = block / ntn, tn_ = block % ntn;
-    const int m0 = tm_ * 64 + wm * 32, n0 = tn_ * BN + wn * 32;      // this wave's quadrant
-    // batch rows of this wave: [kbeg, kbeg + kcnt)
-    const int ksplit = KS > 1 ? min(K, (((K + 1) >> 1) + 1) & ~1) : K;
-    const int kbeg = kh ? ksplit : 0, kcnt = kh ? K - ksplit : ksplit;
-    const int nfull = kcnt >> 1;                              // whole k pairs
-
-    // UPD: parameters and moments of this quadrant, requested before the first operand (older than every ring load)
-    float pv[16], mv[16], vv[16];
-    const int col = n0 + i;
-    if constexpr (UPD) {
-        if (kh == 0) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const float* const gp = q.C + (size_t)min(row, M - 1) * q.ldc + min(col, N - 1);
-                pv[e] = gp[up->pdiff]; mv[e] = gp[up->mdiff]; vv[e] = gp[up->vdiff];
-            }
-        }
-    }
-
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    float csum = 0.f;
-    if (nfull > 0) {
-        const unsigned voa = 4u * ((unsigned)h * (unsigned)q.lda + (unsigned)min(m0 + i, M - 1));
-        const unsigned vob = 4u * ((unsigned)h * (unsigned)q.ldb + (unsigned)min(n0 + i, N - 1));
-        const float* const A0 = q.A + (size_t)kbeg * q.lda;
-        const float* const B0 = q.B + (size_t)kbeg * q.ldb;
-        const size_t sta = 2 * (size_t)q.lda, stb = 2 * (size_t)q.ldb;
-        float ra[P], rb[P];
-        int jl = 0;                                           // next pair to request (clamped: the ring always holds P - 1 requests)
-        auto issue = [&](float& a, float& b) {
-            const int jc = min(jl, nfull - 1);
-            dw_gload(a, voa, A0 + (size_t)jc * sta);
-            dw_gload(b, vob, B0 + (size_t)jc * stb);
-            ++jl;
-        };
-#pragma unroll
-        for (int d = 0; d < P - 1; ++d) issue(ra[d], rb[d]);
-        ra[P - 1] = 0.f; rb[P - 1] = 0.f;
-        const int ngroups = (nfull + P - 1) / P;
-        for (int g = 0; g < ngroups; ++g) {
-#pragma unroll
-            for (int d = 0; d < P; ++d) {
-                // slot d has landed when at most the P - 2 younger slots (two loads each) are still in flight
-                asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[d]), "+v"(rb[d]) : "n"(2 * P - 4) : "memory");
-                if (g * P + d < nfull) {                      // (wave-uniform)
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ra[d], rb[d], acc, 0, 0, 0);
-                    csum += ra[d];
-                }
-                // the refill goes to the slot the PREVIOUS step consumed (a load into registers the MFMA just issued still
-                // reads would wait for it)
-                issue(ra[(d + P - 1) % P], rb[(d + P - 1) % P]);
-            }
-        }
-        // every request has landed before its registers mean anything else (the clamped ones past the end included)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]), "+v"(ra[4]), "+v"(ra[5]), "+v"(ra[6]), "+v"(ra[7]),
-                       "+v"(ra[8]), "+v"(ra[9]), "+v"(ra[10]), "+v"(ra[11]), "+v"(ra[12]), "+v"(ra[13]), "+v"(ra[14]), "+v"(ra[15])
-                     :: "memory");
-        asm volatile("" : "+v"(rb[0]), "+v"(rb[1]), "+v"(rb[2]), "+v"(rb[3]), "+v"(rb[4]), "+v"(rb[5]), "+v"(rb[6]), "+v"(rb[7]),
-                          "+v"(rb[8]), "+v"(rb[9]), "+v"(rb[10]), "+v"(rb[11]), "+v"(rb[12]), "+v"(rb[13]), "+v"(rb[14]), "+v"(rb[15]));
-    }
-    if (kcnt & 1) {                                           // the odd last row: lanes of the second k of the pair multiply zeros
-        const int k = kbeg + kcnt - 1;
-        const float a = q.A[(size_t)k * q.lda + min(m0 + i, M - 1)], b = q.B[(size_t)k * q.ldb + min(n0 + i, N - 1)];
-        const float az = h ? 0.f : a, bz = h ? 0.f : b;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(az, bz, acc, 0, 0, 0);
-        csum += az;
-    }
-
-    // ---- second batch half -> first (fixed order), column sums of the tiles of the first tile column
-    const bool do_colsum = q.db != nullptr && tn_ == 0 && wn == 0;
-    csum += __shfl_xor(csum, 32, 64);                         // even rows + odd rows of the batch (both lane halves hold the sum)
-    if constexpr (KS > 1) {
-        if (kh == 1) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) red[(wm * 16 + e) * 64 + lane] = acc[e];
-            if (lane < 32) cred[wm * 32 + lane] = csum;
-        }
-        __syncthreads();
-        if (kh == 1) return;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = acc[e] + red[(wm * 16 + e) * 64 + lane];
-        csum = csum + cred[wm * 32 + i];
-    }
-    if (do_colsum && lane < 32 && m0 + lane < M) {
-        const float gb = q.alpha * csum;
-        q.db[m0 + lane] = gb;
-        if constexpr (UPD) {                                  // the bias element's AdamW step, and its slot in the forward stream's bias block
-            float* const gp = q.db + m0 + lane;
-            float pi = gp[up->pdiff], mi = gp[up->mdiff], vi = gp[up->vdiff];
-            adamw_one(pi, gb, mi, vi, up->hyper[0], up->hyper[1], up->hyper[2], up->hyper[3], up->beta1, up->beta2, up->eps);
-            gp[up->pdiff] = pi; gp[up->mdiff] = mi; gp[up->vdiff] = vi;
-            if (up->bias.out) up->bias.out[m0 + lane] = up->bias.scale * pi;
-        }
-    }
-
-    // ---- epilogue.  C/D layout of v_mfma_f32_32x32x2_f32: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-    const bool cok = col < N;
-    if constexpr (UPD) {
-        // AdamW on the block of the weight matrix whose gradient this is, then the updated block into the two weight streams
-        // of the next step (gemm_body's update epilogue, operation for operation)
-        const float lr = up->hyper[0], wd = up->hyper[1], bc1 = up->hyper[2], sbc2 = up->hyper[3];
-        bool okv[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) okv[e] = cok && m0 + (e & 3) + 8 * (e >> 2) + 4 * h < M;
-        float gv[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            gv[e] = q.alpha * acc[e];
-            adamw_one(pv[e], gv[e], mv[e], vv[e], lr, wd, bc1, sbc2, up->beta1, up->beta2, up->eps);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (okv[e]) {
-                const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                float* const gp = q.C + (size_t)row * q.ldc + col;
-                *gp = gv[e]; gp[up->pdiff] = pv[e]; gp[up->mdiff] = mv[e]; gp[up->vdiff] = vv[e];
-            } else {
-                pv[e] = 0.f;                        // the streams' padding
-            }
-        }
-#pragma unroll
-        for (int eg = 0; eg < 4; ++eg) {
-            const int r0 = m0 + 8 * eg + 4 * h;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const AsPlace& pl = up->pl[j];
-                if (!pl.out || !cok || r0 >= M) continue;
-                if (pl.trans) {
-                    *reinterpret_cast<f32x4*>(pl.out + as_slot(pl, up->small, col, pl.koff + r0)) =
-                        f32x4{pl.scale * pv[4 * eg], pl.scale * pv[4 * eg + 1], pl.scale * pv[4 * eg + 2], pl.scale * pv[4 * eg + 3]};
-                } else {
-#pragma unroll
-                    for (int e4 = 0; e4 < 4; ++e4)
-                        if (r0 + e4 < M) pl.out[as_slot(pl, up->small, r0 + e4, pl.koff + col)] = pl.scale * pv[4 * eg + e4];
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row = m0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (cok && row < M) q.C[(size_t)row * q.ldc + col] = q.alpha * acc[e];
-    }
-}
-
-template <int BN, int KS, typename ARGS>
-__global__ __launch_bounds__(256) void dw_group_kernel(const ARGS g, const GemmPost post) {
-    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean(post); return; }
-    int p = 0;
-    while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
-    const GemmGroupProb q = g.p[p];
-    dw_body<BN, KS, false>(q, (int)blockIdx.x - q.first, nullptr);
-}
-
-template <int BN, int KS>
-__global__ __launch_bounds__(256) void dw_group_update_kernel(const GemmGroupArgsS g, const GemmUpdate u, const GemmPost post) {
-    if (post.n > 0 && blockIdx.x == gridDim.x - 1) { gemm_post_mean(post); return; }
-    int p = 0;
-    while (p + 1 < g.nprob && (int)blockIdx.x >= g.p[p + 1].first) ++p;
-    const GemmGroupProb q = g.p[p];
-    GemmUpd1 up;
-    up.pdiff = u.pdiff; up.mdiff = u.mdiff; up.vdiff = u.vdiff; up.hyper = u.hyper; up.beta1 = u.beta1; up.beta2 = u.beta2;
-    up.eps = u.eps; up.small = u.small; up.pl[0] = u.pl[p][0]; up.pl[1] = u.pl[p][1]; up.bias = u.bias[p];
-    dw_body<BN, KS, true>(q, (int)blockIdx.x - q.first, &up);
-}
-
-// Which K loop the grouped parameter-gradient launches run: 2 (default) = operands straight to registers on 64 x 32
-// half-batch work items, 1 = the same on 64 x 64 tiles, 0 = the LDS-DMA ring of gemm_body (LINNA_DW_DIRECT, read once).
-// 3 = the LDS-DMA ring on 64 x 32 tiles of two waves (740 instead of 370 workgroups at (26,457), three resident per CU).
-static int dw_mode() {
-    static const int m = [] { const char* e = getenv("LINNA_DW_DIRECT"); const int v = e ? atoi(e) : 0; return v < 0 || v > 3 ? 0 : v; }();
-    return m;
-}
-static bool dw_half_tiles() { return dw_mode() >= 2; }
-
 // ---------------------------------------------------------------------------- launcher
 struct TileCfg { int wm, wn, tm, tn; };
 static const TileCfg kCfgs[3] = {{2, 2, 2, 1}, {2, 2, 1, 1}, {1, 1, 1, 1}};   // 128x64, 64x64, 32x32
@@ -941,21 +722,10 @@ bool gemm_group_ok(const GemmArgs& a) {
     return a.npairs == 1 && a.p[0].alay == LAY_MN && a.p[0].blay == LAY_MN && (cfg == 1 || cfg == 2) && !a.dotwith &&
            ((a.p[0].lda | a.p[0].ldb) & 3) == 0;
 }
-int gemm_group_blocks(const GemmArgs& a) { return ((a.M + 63) / 64) * ((a.N + (dw_half_tiles() ? 31 : 63)) / (dw_half_tiles() ? 32 : 64)); }
+int gemm_group_blocks(const GemmArgs& a) { return ((a.M + 63) / 64) * ((a.N + 63) / 64); }
 int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream, const GemmPost* post) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
     const GemmPost q = post ? *post : GemmPost{nullptr, 0, 0.f, nullptr};
-    if (dw_mode() == 1 || dw_mode() == 2) {
-        const dim3 grid(nblocks + (q.n > 0 ? 1 : 0));
-        if (dw_mode() == 2) hipLaunchKernelGGL((dw_group_kernel<32, 2, GemmGroupArgs>), grid, dim3(256), 0, stream, g, q);
-        else hipLaunchKernelGGL((dw_group_kernel<64, 1, GemmGroupArgs>), grid, dim3(256), 0, stream, g, q);
-        return check_hip(hipGetLastError(), "dw group launch");
-    }
-    if (dw_mode() == 3) {
-        constexpr size_t lds3 = (size_t)4 * (64 + 32) * BK * sizeof(float);
-        hipLaunchKernelGGL((gemm_group_kernel<2, 1, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(128), lds3, stream, g, q);
-        return check_hip(hipGetLastError(), "gemm group launch (64 x 32)");
-    }
     hipLaunchKernelGGL((gemm_group_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(256), lds, stream, g, q);
     return check_hip(hipGetLastError(), "gemm group launch");
 }
@@ -963,17 +733,6 @@ int gemm_launch_group(const GemmGroupArgs& g, int nblocks, hipStream_t stream, c
 int gemm_launch_group_update(const GemmGroupArgsS& g, const GemmUpdate& u, int nblocks, hipStream_t stream, const GemmPost* post) {
     constexpr size_t lds = (size_t)4 * (64 + 64) * BK * sizeof(float);
     const GemmPost q = post ? *post : GemmPost{nullptr, 0, 0.f, nullptr};
-    if (dw_mode() == 1 || dw_mode() == 2) {
-        const dim3 grid(nblocks + (q.n > 0 ? 1 : 0));
-        if (dw_mode() == 2) hipLaunchKernelGGL((dw_group_update_kernel<32, 2>), grid, dim3(256), 0, stream, g, u, q);
-        else hipLaunchKernelGGL((dw_group_update_kernel<64, 1>), grid, dim3(256), 0, stream, g, u, q);
-        return check_hip(hipGetLastError(), "dw group update launch");
-    }
-    if (dw_mode() == 3) {
-        constexpr size_t lds3 = (size_t)4 * (64 + 32) * BK * sizeof(float);
-        hipLaunchKernelGGL((gemm_group_update_kernel<2, 1, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(128), lds3, stream, g, u, q);
-        return check_hip(hipGetLastError(), "gemm group update launch (64 x 32)");
-    }
     hipLaunchKernelGGL((gemm_group_update_kernel<2, 2, 1, 1, LAY_MN, LAY_MN, 4, 1>), dim3(nblocks + (q.n > 0 ? 1 : 0)), dim3(256), lds, stream, g, u, q);
     return check_hip(hipGetLastError(), "gemm group update launch");
 }
