@@ -149,9 +149,15 @@ __device__ unsigned long long g_gemm_rt[2 * 1024];       // s_memrealtime (100 M
 #define GEMM_STAMP(i) do {} while (0)
 #endif
 
-template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS, bool UPD = false>
+// CH2 (the grouped parameter-gradient launches): a 64 x 64 workgroup gives every wave ONE accumulator tile, and sixteen
+// MFMAs per K tile that each wait for the one before run at ~100-115 cycles apiece instead of 64 (tools/gemm_stamps.py: a
+// workgroup alone on its CU spends 1.65 k cycles per K tile in fragments + MFMAs for 1.0 k of matrix pipe).  With CH2 the k
+// steps alternate between two accumulators -- dependent MFMAs sit two issues apart -- which are added once after the K
+// loop (one fixed order: even k steps + odd k steps; every update form of a training step shares this kernel).
+template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS, bool UPD = false, bool CH2 = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all, const KSplit ks, float* const db = nullptr,
                                           const GemmUpd1* const up = nullptr) {
+    static_assert(!CH2 || (TM == 1 && TN == 1), "two accumulator chains: one tile per wave");
     constexpr int NW = WM * WN, NT = NW * 64;                 // waves / threads of one K group
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     using TA = Tile<BM, ALAY, NW>;
@@ -200,6 +206,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    f32x16 acc_odd;                                           // CH2: the odd k steps' chain
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_odd[e] = 0.f;
 
     // Bias gradient fused into the parameter-gradient GEMM (db != null; k-major A = dY[batch][n], one K group): the column
     // sums of the A tile over the batch rows, taken from LDS by the tiles of the first tile column -- wave w adds the
@@ -231,8 +240,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        if (CH2 && (s & 1)) acc_odd = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc_odd, 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][s], bf[g & 1][j][s], acc[i][j], 0, 0, 0);
+                    }
         }
     };
 
@@ -356,6 +367,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int block_all
         }
     }
 
+    if constexpr (CH2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] = acc[0][0][e] + acc_odd[e];
+    }
     GEMM_STAMP(2);
     if (db != nullptr && ALAY == LAY_MN && KS == 1 && TM == 1 && BM == 64 && ks.kz <= 1) {   // (block-uniform)
         if (do_colsum) {
@@ -598,7 +613,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_kernel(const Gem
     a.bias0 = nullptr; a.bias1 = nullptr; a.alpha0 = q.alpha; a.R = nullptr; a.ldr = 0; a.relu = 0; a.mask = nullptr; a.ldmask = 0;
     a.cscale = nullptr; a.cshift = nullptr; a.cexp = 0; a.cpost = nullptr; a.cshift2 = nullptr;
     a.dotwith = nullptr; a.lddot = 0; a.dot_partial = nullptr; a.dot_slots = 0; a.flags = 0;
-    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db);
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS, false, true>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db);
 }
 
 template <int WM, int WN, int TM, int TN, int ALAY, int BLAY, int NS, int KS>
@@ -617,7 +632,7 @@ __global__ __launch_bounds__(WM * WN * KS * 64) void gemm_group_update_kernel(co
     GemmUpd1 up;
     up.pdiff = u.pdiff; up.mdiff = u.mdiff; up.vdiff = u.vdiff; up.hyper = u.hyper; up.beta1 = u.beta1; up.beta2 = u.beta2;
     up.eps = u.eps; up.small = u.small; up.pl[0] = u.pl[p][0]; up.pl[1] = u.pl[p][1]; up.bias = u.bias[p];
-    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS, true>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db, &up);
+    gemm_body<WM, WN, TM, TN, ALAY, BLAY, NS, KS, true, true>(a, (int)blockIdx.x - q.first, KSplit{1, nullptr, nullptr}, q.db, &up);
 }
 
 // ---------------------------------------------------------------------------- launcher

@@ -341,8 +341,9 @@ class Log_prob(object):
         if dev.type != "cuda":
             raise _lib.LinnaHipError("Log_prob needs the emulator on the GPU (no CPU fallback)")
         nin, nout = net.in_size, net.out_size
-        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32), device=dev)
-        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.int32), device=dev)
+        # (a private writable copy: torch warns on read-only arrays, e.g. views of an .npz member)
+        f32 = lambda a: torch.as_tensor(np.array(a, dtype=np.float32, order="C", copy=True), device=dev)
+        i32 = lambda a: torch.as_tensor(np.array(a, dtype=np.int32, order="C", copy=True), device=dev)
         is_flat, a1, a2 = self.transform.arrays()
         if len(is_flat) != nin:
             raise ValueError("%d priors for a %d-input emulator" % (len(is_flat), nin))

@@ -104,6 +104,7 @@ def test_gradient_and_fused_half_step_at_condition_1e6(monkeypatch):
     from linna_amd import sampler
     g = cases.golden(NAME)
     ci = len(g["conds"]) - 1
+    worst = []
     for k in range(g["z"].shape[0]):
         prob, cond = problem(ci, k, g)
         lp = build_logprob(None, 1.0, prob)[0]
@@ -111,8 +112,21 @@ def test_gradient_and_fused_half_step_at_condition_1e6(monkeypatch):
         lnp, grad = lp.evaluate_with_grad(z)
         l64 = truth64(prob, g["z"][k])
         assert np.all(np.abs(lnp.cpu().numpy() - l64) <= bound(l64, cond, True))
-        # the gradient is dominated by the stiff directions (|g| up to 1e8 at the far points): row-wise against autograd
-        parity.rowmax_close(grad.cpu().numpy(), g["grad/%d" % ci][k], 2e-4, 0.0)
+        # the gradient is dominated by the stiff directions (|g| up to 1e8 at the far points).  Both fp32 paths -- the
+        # reference's autograd and this one (forward in fp32, dense S d as an fp32 GEMM) -- are measured row-wise against the
+        # oracle's float64 gradient: ours within 3 x the reference's worst error (floor 2e-4 of the row maximum; measured
+        # round 4: both 2e-4 ... 4e-4), and the two fp32 gradients within 2e-3 of each other
+        from oracle import likelihood
+        _, g64 = likelihood.grad_log_prob(g["z"][k], cases.oracle_emulator(prob), prob["priors"], prob["data"].astype(np.float32),
+                                          prob["invcov"].astype(np.float32), 1.0, dtype=np.float64)
+        rowmax = np.abs(g64).max(axis=1, keepdims=True)
+        e_ours = (np.abs(grad.cpu().numpy() - g64) / rowmax).max()
+        e_ref = (np.abs(g["grad/%d" % ci][k] - g64) / rowmax).max()
+        worst.append((e_ours, e_ref))
+        assert e_ours <= max(3 * e_ref, 2e-4), (k, e_ours, e_ref)
+        parity.rowmax_close(grad.cpu().numpy(), g["grad/%d" % ci][k], 2e-3, 0.0)
+    print("gradient at condition 1e6, worst |g - g64| / row max: ours %.3g, reference fp32 autograd %.3g" % (
+        max(w[0] for w in worst), max(w[1] for w in worst)))
     # the one-launch half step on this likelihood: same Philox counters, same arithmetic as the three entries
     prob, cond = problem(ci, 0, g)
     lp = build_logprob(None, 1.0, prob)[0]
