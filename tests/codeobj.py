@@ -1,7 +1,7 @@
 """Kernel metadata of the code objects inside liblinna_hip.so (or one .o): registers, scratch, LDS per kernel.
 Test / diagnostic helper -- the clang offload bundles of the `.hip_fatbin` section are unpacked by hand (roc-obj-ls needs
 a perl module this image lacks) and their AMDGPU metadata notes read with llvm-readelf.
-usage: python -m linna_amd._codeobj [file]"""
+usage: python tests/codeobj.py [file]   (a test helper: tests/test_abi.py reads every kernel's scratch size with it)"""
 import os, re, struct, subprocess, sys, tempfile
 
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"

@@ -97,7 +97,8 @@ def test_no_kernel_of_the_library_uses_scratch():
     objects says 0 bytes of private segment for all of them.  (A change of the weight ring's refill order once left the
     merged training launch with 2.3 KB of scratch per lane and the step 40 % slower -- results unchanged, so no parity test
     could see it.)"""
-    from linna_amd import _codeobj, _lib
+    import codeobj as _codeobj
+    from linna_amd import _lib
     ks = _codeobj.kernels(_lib.LIB_PATH)
     names = [k["name"] for k in ks]
     assert len(ks) >= 70 and sum("net_stream_kernel" in n for n in names) >= 24 and any("gemm_group_update_kernel" in n for n in names)
