@@ -64,7 +64,10 @@ def test_train33_tracks_the_live_reference(tmp_path, capsys):
     tl, vm = pred.train_history
     ref_tl, ref_vm = g["train_losses"], g["val_metrics"]
     assert len(tl) == len(ref_tl) == 20 * nep and vm.shape == ref_vm.shape == (nep, 3)
-    np.testing.assert_allclose(tl[:20], ref_tl[:20], rtol=2e-5)                      # measured: 6 digits over 12 steps
+    # per-step losses of the first epoch: a different summation order of one gradient (fp32, ~1e-7) is amplified by every
+    # optimiser step -- measured round 4: 9e-7 ... 4e-5 over 20 steps depending on the parameter-gradient kernel's k order
+    np.testing.assert_allclose(tl[:4], ref_tl[:4], rtol=2e-5)
+    np.testing.assert_allclose(tl[:20], ref_tl[:20], rtol=5e-4)
     np.testing.assert_allclose(vm[:3, 0], ref_vm[:3, 0], rtol=2e-2)
     # through epoch 99 no controller rule can have fired in either run: within 6 % at epoch 50 and smoothed over 50-99
     assert abs(vm[49, 0] - ref_vm[49, 0]) < 0.06 * ref_vm[49, 0], (vm[49, 0], ref_vm[49, 0])

@@ -540,3 +540,19 @@ def test_chainstore_grows_the_hdf5_file_in_place(tmp_path):
     d4 = ChainStore.load(st3.h5)
     np.testing.assert_array_equal(d4["chain"], cat(0, 4).astype(np.float32))
     assert d4["chain"].dtype == np.float32
+
+
+def test_bench_identity_emulators_are_the_identity():
+    """bench.identity_state (the `hmc` object of the bench line: an emulator of the README problem that IS theory = identity,
+    with random weights in every unit that does not carry x): the oracle's forward pass returns x to fp32 rounding for the
+    4 x 512 MLP and for ChtoModelv2(33,33) on the whole prior range (|x| < 1.74 in normalised units), and most weights are
+    non-trivial (the arithmetic of a real weight set, not a sparse toy)."""
+    import bench
+    from oracle import emulator
+    x = np.random.RandomState(0).uniform(-1.74, 1.74, (64, 33)).astype(np.float32)
+    for kind, kw in (("MLP", dict(width=512, depth=4)), ("ChtoModelv2", {})):
+        sd = bench.identity_state(kind)
+        h = emulator.forward(sd, x, kind, 33, 33, **kw)
+        assert np.abs(h - x).max() <= 2.5e-7, kind
+        nz = sum(int(np.count_nonzero(v)) for v in sd.values()) / float(sum(v.size for v in sd.values()))
+        assert nz > 0.8, (kind, nz)
