@@ -171,8 +171,10 @@ class DeviceChain(object):
     _pending = []
 
     @classmethod
-    def join_prewarm(cls, timeout=60.0):
-        """Wait for every plan-creating thread started so far."""
+    def join_prewarm(cls, timeout=None):
+        """Wait for every plan-creating thread started so far -- without a bound by default: a process that leaves while
+        such a thread is still inside rocFFT dies in the runtime's teardown, so a join that gives up would only move the
+        abort to the exit (plan creation is 0.2-0.4 s per transform length)."""
         while cls._pending:
             cls._pending.pop().join(timeout)
 
