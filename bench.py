@@ -167,7 +167,7 @@ def cpu_baseline(consts, z, budget_s=15.0):
                       "thread): %.0f evals/s over %d calls" % (best[2], len(z), best[1], cores, per_walker, m)}
 
 
-TRAFFIC_FILE = "r03_pmc_traffic.json"
+TRAFFIC_FILE = "r04_pmc_traffic.json"
 
 
 def pmc_traffic():
