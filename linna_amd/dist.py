@@ -158,7 +158,12 @@ def control_group():
 def _make_control_group():
     import datetime
     if _state["control"] is None and dist.is_initialized() and dist.get_world_size() > 1:
-        _state["control"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CONTROL_TIMEOUT_S))
+        try:
+            _state["control"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CONTROL_TIMEOUT_S))
+        except Exception as e:                                  # noqa: BLE001  (same environment on every rank of a node: all fail alike)
+            import sys
+            sys.stderr.write("linna_amd.dist: no gloo control group (%r); control-plane waits stay on the %s group\n" % (e, dist.get_backend()))
+            _state["control"] = None
     return _state["control"]
 
 
