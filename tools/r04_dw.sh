@@ -1,5 +1,6 @@
 #!/bin/bash
-# GPU box, round 4: K loops / tile shapes of the grouped parameter-gradient launch (gemm.hip), LINNA_DW_DIRECT =
+# GPU box, round 4: K loops / tile shapes of the grouped parameter-gradient launch (gemm.hip) AS OF COMMIT 594ad1e (the variants
+# were removed afterwards: at HEAD only mode 0 exists and the switch is ignored), LINNA_DW_DIRECT =
 # 0 LDS-DMA ring on 64 x 64 tiles, 1 operands straight to registers on 64 x 64, 2 the same on 64 x 32 half-batch items,
 # 3 LDS-DMA ring on 64 x 32 two-wave tiles.  usage: tools/r04_dw.sh "<modes to test>" "<modes to time>"
 # A step that dies (not: fails) ends the script.
