@@ -68,3 +68,48 @@ def rowmax_close(got, ref, tol, floor=0.0, err_msg=""):
 def install():
     if REPORT and np.testing.assert_allclose is not assert_allclose:
         np.testing.assert_allclose = assert_allclose
+
+
+def near_relu_kink(z_row, emu, priors, radius=8 * 2.0 ** -24):
+    """THE ReLU-kink exception of the gradient comparisons (one formula).  A row is exempt iff some hidden unit of that
+    row has a pre-activation within fp32 rounding of zero:
+
+        min over hidden units of  |a| / (sum_k |w_k x_k| + |b|)  <=  8 eps32        (a = w . x + b, float64 oracle)
+
+    -- the sum's rounding error is a few eps32 of the magnitude sum, so which side of zero the unit falls on depends on
+    the order of summation: the unit is on in one fp32 implementation and off in another (or in float64), and the row's
+    gradient differs by a finite amount while lnP agrees to 1e-7.  Typical rows have a minimum of 2e-5 ... 5e-5 over the
+    ~3000 hidden units of a ChtoModelv2; about one row in a thousand falls below 5e-7."""
+    from oracle import likelihood, emulator
+    x = likelihood.x_transform(likelihood.prior_map(np.asarray(z_row, np.float64)[None, :], priors), emu.X_mean, emu.X_std, emu.dolog10index)
+    w = {k: np.asarray(v, np.float64) for k, v in emu.params.items()}
+    h, worst = np.asarray(x, np.float64), np.inf
+
+    def unit(pre, mag):
+        nonlocal worst
+        worst = min(worst, float((np.abs(pre) / np.maximum(mag, 1e-300)).min()))
+
+    for op in emulator.topology(emu.kind, emu.in_size, emu.out_size, **emu.topo_kw):
+        if op[0] == "linear":
+            _, key, K, N, relu = op
+            W, b = w[key + ".weight"], w[key + ".bias"]
+            pre = h @ W.T + b
+            if relu:
+                unit(pre, np.abs(h) @ np.abs(W).T + np.abs(b))
+                h = np.maximum(pre, 0.0)
+            else:
+                h = pre
+        elif op[0] == "resblock":
+            _, key, K, C, N = op
+            W1, b1, W2, b2 = w[key + ".layer1.weight"], w[key + ".layer1.bias"], w[key + ".layer2.weight"], w[key + ".layer2.bias"]
+            p1 = h @ W1.T + b1
+            unit(p1, np.abs(h) @ np.abs(W1).T + np.abs(b1))
+            t = np.maximum(p1, 0.0)
+            Ws = w.get(key + ".skip_layer.weight")
+            skip, mskip = (h @ Ws.T, np.abs(h) @ np.abs(Ws).T) if (Ws is not None and K != N) else (h, np.abs(h))
+            p2 = (t @ W2.T + b2) * 0.1 + skip
+            unit(p2, (np.abs(t) @ np.abs(W2).T + np.abs(b2)) * 0.1 + mskip)
+            h = np.maximum(p2, 0.0)
+        else:                                   # input skip: linear in the input, no gate
+            break
+    return worst <= radius

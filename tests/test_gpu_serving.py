@@ -586,3 +586,36 @@ def test_dense_covariance_as_last_segment(nin, nout, width, depth, monkeypatch):
     torch.cuda.synchronize()
     assert a.fused is True
     assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp) and torch.equal(a.naccept, b.naccept)
+
+
+@pytest.mark.parametrize("nout,dense", [(1100, False), (1100, True)])
+def test_networks_wider_than_the_whole_network_kernel(nout, dense):
+    """``ChtoModelv2(nin, nout > 1024)`` -- layer8 is nout x nout -- is outside the whole-network kernel (layers <= 1024 wide):
+    the layer-by-layer GEMM path serves evaluation and gradient.  lnP of 1000 walkers against the float64 oracle; the
+    gradient row-wise, with THE ReLU-kink exception (tests/parity.py near_relu_kink: with 3000 hidden units about one row
+    in a thousand has a unit within fp32 rounding of zero) -- every row beyond the tolerance must be such a row, and there
+    are at most 0.5 % of them."""
+    import synth
+    import parity
+    from oracle import likelihood
+    nin, seed = 12, 900 + nout
+    data, cov, priors = synth.gaussian_problem(nin, nout, seed, dense=dense, cond=1e2)
+    X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
+    prob = dict(kind="ChtoModelv2", nin=nin, nout=nout, kw={}, weights=synth.weights("ChtoModelv2", nin, nout, seed), priors=priors,
+                data=data, cov=cov, invcov=np.linalg.inv(cov), sigma=np.sqrt(np.diag(cov)), X_mean=X_mean, X_std=X_std, y_mean=y_mean,
+                y_std=y_std, dolog10=None, ypositive=False)
+    lp = build_logprob(None, 1.0, prob)[0]
+    emu = cases.oracle_emulator(prob)
+    B = 1000
+    z = np.random.RandomState(B).standard_normal((B, nin)).astype(np.float32) * 0.5
+    got = lp(z, returntorch=False)
+    ref, gref = likelihood.grad_log_prob(z, emu, priors, data, prob["invcov"], 1.0, dtype=np.float64)
+    np.testing.assert_allclose(got, ref, rtol=1e-5)
+    zd, _ = lp._to_device(z)
+    lnp, g = lp.evaluate_with_grad(zd)
+    np.testing.assert_allclose(lnp.cpu().numpy(), ref, rtol=1e-5)
+    rowerr = (np.abs(g.cpu().numpy() - gref) / np.abs(gref).max(axis=1, keepdims=True)).max(axis=1)
+    beyond = np.where(rowerr > 5e-5)[0]
+    assert len(beyond) <= B // 200, (len(beyond), rowerr.max())
+    for r in beyond:
+        assert parity.near_relu_kink(z[r], emu, priors), "row %d differs by %.2e of its maximum away from any ReLU kink" % (r, rowerr[r])

@@ -73,17 +73,8 @@ def run(ncfg, seed0):
             kinks = int((rowerr_all > 5e-3).sum())
             # ... and a row whose forward path passes within 1e-6 of a ReLU kink is not counted at all: the float64 and the
             # float32 forward of the oracle disagree on which units are zero there, or a positive unit is that small
-            def near_kink(r):
-                pats = []
-                for dt in (np.float64, np.float32):
-                    zz = z[r:r + 1].astype(dt)
-                    xx = likelihood.x_transform(likelihood.prior_map(zz, prob["priors"]), emu.X_mean, emu.X_std, emu.dolog10index)
-                    _, caches = emu.network(xx, keep=True)
-                    acts = [a[0] for c in caches for a in c[1:]]
-                    if any((a > 0).any() and a[a > 0].min() < 1e-6 * np.abs(a).max() for a in acts):
-                        return True
-                    pats.append(np.concatenate([a == 0 for a in acts]))
-                return bool((pats[0] != pats[1]).any())
+            import parity                        # (tests/parity.py: THE ReLU-kink criterion, one formula for tests and tools)
+            near_kink = lambda r: parity.near_relu_kink(z[r], emu, prob["priors"])
             explained = sum(1 for r in np.where(rowerr_all > 5e-3)[0] if near_kink(int(r)))
             ok = e1 < 1e-3 and e2 < 1e-3 and kinks - explained <= max(1, B // 200) and e4 < 2e-3 and e5 < 2e-3
             if kinks:
