@@ -12,6 +12,9 @@ from oracle import training
 from linna_amd import nn, util, predictor_gpu, trainer
 
 
+FIXED = os.environ.get("FUZZ_TRAIN_SHAPE", "").split(":") if os.environ.get("FUZZ_TRAIN_SHAPE") else None
+
+
 def run(n, seed0):
     bad = 0
     for it in range(n):
@@ -21,6 +24,9 @@ def run(n, seed0):
         nout = int(rs.choice([1, 2, 5, 16, 30, 31, 33, 64, 65, 100, 300]))
         kw = {"width": int(rs.choice([16, 48, 128, 300, 512])), "depth": int(rs.randint(1, 4))} if kind == "MLP" else {}
         B = int(rs.choice([1, 4, 5, 17, 64, 200, 500]))
+        if FIXED:                                   # "kind:nin:nout:B": one stated shape (e.g. layers past the whole-network kernel's 1024)
+            kind, nin, nout, B = FIXED[0], int(FIXED[1]), int(FIXED[2]), int(FIXED[3])
+            kw = {"width": 512, "depth": 2} if kind == "MLP" else {}
         tag = "train cfg %d: %s nin %d nout %d %s B %d" % (seed0 + it, kind, nin, nout, kw, B)
         try:
             seed = 13000 + seed0 + it

@@ -10,8 +10,9 @@ import cases, synth
 from test_gpu_serving import build_logprob
 from oracle import likelihood
 
+NIN = int(os.environ.get("WIDE_NIN", "12"))
 for nout in [int(a) for a in sys.argv[1:]] or [1100, 1500]:
-    nin, seed = 12, 900 + nout
+    nin, seed = NIN, 900 + nout
     for dense in (False, True):
         data, cov, priors = synth.gaussian_problem(nin, nout, seed, dense=dense, cond=1e2)
         X_mean, X_std, y_mean, y_std = synth.transform_constants(nin, nout, seed)
