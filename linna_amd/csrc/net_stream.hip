@@ -241,7 +241,8 @@ __global__ void ns_pack_side_kernel(NsPackArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = k0 + e;
-                if (k < S.Ka) v[e] = S.Wa[(size_t)n * S.lda + k];
+                if (S.Wa) { if (k < S.Ka) v[e] = S.Wa[(size_t)n * S.lda + k]; }
+                else if (k < S.Kb) v[e] = S.alpha * (S.transB ? S.Wb[(size_t)k * S.ldb + n] : S.Wb[(size_t)n * S.ldb + k]);   // d/dh: the second K part alone
             }
         }
         reinterpret_cast<f32x4*>(p.out + S.side_off)[idx - base] = v;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     constexpr int RS = SM ? ROWS / 4 : 1;
     constexpr int NQ = SM ? RS : NT;               // result quads per lane: (row set) or (column tile)
     constexpr int NACC = SM ? 4 * RS : NT;
-    constexpr bool K4 = !SM && STORE == 0;         // serving instantiations of the 16-row engine: programs may hold SIDE segments
+    constexpr bool K4 = !SM && (STORE == 0 || (GRAD && STORE == 2));   // 16-row engine, serving and the one-launch gradient: programs may hold SIDE segments
     // (the one-launch gradient with SIDE segments in its forward half was measured SLOWER: 156.4 against 154.2 us at ChtoModelv2(33,33))
     // TRB: a whole training step's network work in ONE launch (linna_net_train_step): gather + transform + forward with the
     // activations kept + chi^2-ratio loss (STORE == 3) as the forward half, the loss finish as the TURNAROUND (loss rows,
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // launch with the refill one slot back in round 3).  Through the kernel-argument segment itself they are scalar loads.
     // (Only in the instantiations where that copy has appeared -- the training ones: the serving ones and the one-launch
     // gradient lose 0.3-0.7 % to the explicit pointer; tests/test_abi.py watches every kernel's scratch size.)
-    constexpr bool KA = STORE == 3 || STORE == 1;
+    constexpr bool KA = STORE == 3 || STORE == 1 || (GRAD && STORE == 2);    // (G2 since it holds SIDE code: R4)
     const NsArgs* const ka = KA ? reinterpret_cast<const NsArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) : &a;
     float* const act = smem;                       // [2][ROWS][LD]
     float* const lbias = smem + 2 * ABUF;          // packed biases of every segment
@@ -1134,15 +1135,27 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                                 for (int kp = 0; kp < NW; ++kp) v += x[kp];
                                 v += lbias[s_bias + c];
                                 if (s_relu) v = fmaxf(v, 0.f);
+                                if constexpr (LB) {     // a backward SIDE segment (d/dh): gated by the sign bits of h
+                                    if (s_mbit >= 0 && !(c < ((s_gn + 63) & ~63) && ((lbits[pr * nbw + ((s_mbit + c) >> 5)] >> (c & 31)) & 1u))) v = 0.f;
+                                }
                             }
                             cur[c] = v;
+                            if constexpr (LB) {
+                                if (s_gbit >= 0) {      // the sign of this h, for the gate of its gradient (the SPLIT reduce's form)
+                                    const unsigned long long bb = __ballot(v > 0.f);
+                                    const bool mine = c < ((s_gn + 63) & ~63);
+                                    if ((lane & 31) == 0 && mine) lbits[pr * nbw + ((s_gbit + c) >> 5)] = (unsigned)(bb >> (lane & 32));
+                                }
+                            }
                         }
                     }
                     lds_barrier();
                     NS_STAMP();
                     ++si;
-                    const NsSeg N2 = ka->seg[__builtin_amdgcn_readfirstlane(min(si, nseg - 1))];
+                    const int n2i = __builtin_amdgcn_readfirstlane(min(si, nseg - 1));
+                    const NsSeg N2 = ka->seg[n2i];
                     take_seg(N2);
+                    if constexpr (LB) { s_gbit = ka->gbit[n2i]; s_mbit = ka->mbit[n2i]; s_gn = ka->gn[n2i]; }
                 }
             }
             if (si < nseg) {
@@ -1487,8 +1500,12 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         const int side_steps = (ksteps + NS_NW * kc - 1) / (NS_NW * kc);
         // (never the first segment nor the last forward one: the kernel runs a SIDE segment between two runs of the step loop;
         // kc = 1, <= 64 columns: the SPLIT mapping itself, run out of the stream -- 250 -> 64 is two steps per wave)
-        const bool side = k4 && split && ncg == 1 && side_steps <= 2 && i > 0 && (int)i < nfwd - 1 && p.seg.back().type != NS_SIDE &&
-                          !L.Wb && !L.transA && L.Wa && !L.rscale && !L.rshift && !L.b2 && !L.x0_col;
+        // ... and, in the one-launch gradient, d/dh of a residual block (0.1 dy W2 gated by h: 500 / 250 / 125 -> 16 / 32 / 64,
+        // the second K part alone, read transposed): one SIDE step each instead of 4 / 2 / 1 SPLIT steps and a SPLIT boundary
+        const bool side_fwd = (int)i < nfwd - 1 && !L.Wb && !L.transA && L.Wa;
+        const bool side_bwd = fwd_dxi && (int)i > nfwd && !L.Wa && L.Wb && L.transB && L.Kapad == 0 && !L.relu;
+        const bool side = k4 && split && ncg == 1 && side_steps <= 2 && i > 0 && (side_fwd || side_bwd) && p.seg.back().type != NS_SIDE &&
+                          !L.rscale && !L.rshift && !L.b2 && !L.x0_col;
         if (side) {
             s.type = NS_SIDE; s.steps = side_steps; s.passes = 1; s.kslice = 16 * kc * s.steps;
             s.ncg_log2 = 0; s.kcl = kc == 4 ? 2 : kc == 2 ? 1 : 0;
@@ -1646,7 +1663,20 @@ bool net_stream_k4(int rows, int serve) {
     return on && serve && rows == 16;
 }
 
+// SIDE segments in the forward half of the one-launch gradient (16-row engine).  Round 3 measured them slower there (with the
+// activations stored for the gates); with the gates as sign bits in LDS and the per-segment tables read through the
+// kernel-argument segment (without that the instantiation spilled 2.5 KB per lane): 151.4 -> 148.7 us at ChtoModelv2(33,33),
+// 4096 chains (NOTES R4).  LINNA_G2_SIDE=0 turns them off.
+bool net_stream_g2_side() {
+    static const bool on = !(getenv("LINNA_G2_SIDE") && getenv("LINNA_G2_SIDE")[0] == '0');
+    return on;
+}
+
 static NsProgram ns_build_prog_uncached(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn, bool k4) {
+    if (k4 && prog == 3) {
+        NsProgram p = ns_build_one(layers, nl, in_size, NS_PROG_FWD_DXI, nullptr, true);
+        if (p.ok && p.dxi_ok) return p;
+    }
     if (k4 && prog == 0) {                     // the serving programs of the 16-row engine; the plain program where this one does not fit
         NsProgram p = dn ? ns_build_one(layers, nl, in_size, NS_PROG_FWD_DENSE, dn, true) : ns_build(layers, nl, in_size, true);
         if (p.ok) return p;
@@ -1685,7 +1715,7 @@ static int ns_g2_cols(const NsProgram& p, const linna_layer_t* layers, int nl);
 // Text form of a program (tests, diagnostics): one line per segment, "type steps passes ncg kc dst_col zext".
 int net_stream_describe(const linna_layer_t* layers, int nl, int in_size, int prog, const NsDense* dn, int rows, int serve, char* buf,
                         size_t n) {
-    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn, prog == 0 && net_stream_k4(rows, serve));
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn, (prog == 0 && net_stream_k4(rows, serve)) || (prog == 3 && rows == 16 && net_stream_g2_side()));
     std::string out = p.ok ? "ok" : "not eligible";
     char line[160];
     snprintf(line, sizeof line, " G %d Gstride %d nseg_f %d LD %d kpad0 %d packed_floats %zu grad %d\n", p.G, p.Gstride, p.nseg_f, p.LD,
@@ -1731,7 +1761,7 @@ size_t net_stream_dx_packed_floats(const linna_layer_t* layers, int nl, int in_s
 // prog: 0 the forward program (+ the fused gradient's backward half), 1 / 2 the dX chain without / with op 0
 int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, float* packed, int rows, int prog,
                            const NsDense* dn, hipStream_t s, int serve) {
-    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn, prog == 0 && net_stream_k4(rows, serve));
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, prog, dn, (prog == 0 && net_stream_k4(rows, serve)) || (prog == 3 && rows == 16 && net_stream_g2_side()));
     if (!p.ok) { set_error("net_stream: network not eligible"); return LINNA_ERR_UNSUPPORTED; }
     NsPackArgs a;
     ::memset(static_cast<void*>(&a), 0, sizeof(a));
@@ -1990,7 +2020,10 @@ bool net_stream_dxi_eligible(const linna_layer_t* layers, int nl, int in_size) {
     if (!p.ok || !p.dxi_ok) return false;
     return ((p.lds_for(NS_ROWS, true) + 7) & ~(size_t)7) + (size_t)NS_ROWS * (ns_g2_cols(p, layers, nl) / 32) * sizeof(unsigned) <= (size_t)NS_LDS_BYTES;
 }
-size_t net_stream_dxi_packed_floats(const linna_layer_t* layers, int nl, int in_size) { return ns_build_prog(layers, nl, in_size, 3).packed_floats; }
+size_t net_stream_dxi_packed_floats(const linna_layer_t* layers, int nl, int in_size) {
+    const size_t a = ns_build_prog(layers, nl, in_size, 3).packed_floats;
+    return net_stream_g2_side() ? std::max(a, ns_build_prog(layers, nl, in_size, 3, nullptr, true).packed_floats) : a;
+}
 
 int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* Z, int ldz, int B,
                       int nin, const int* is_flat, const float* a1, const float* a2, const int* lg, const float* xmean,
@@ -2071,7 +2104,7 @@ int launch_net_stream_grad2(const linna_layer_t* layers, int nl, int in_size, co
                             const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                             const NsGrad& gr, float* const* y, const int* ldy, float* const* t, const int* ldt, int rows,
                             hipStream_t s) {
-    const NsProgram& p = ns_build_prog(layers, nl, in_size, 3);
+    const NsProgram& p = ns_build_prog(layers, nl, in_size, 3, nullptr, rows == 16 && net_stream_g2_side());
     if (!p.ok || !p.dxi_ok) { set_error("net_stream: no forward + dX program for this network"); return LINNA_ERR_UNSUPPORTED; }
     if (!w || !lnP || !gr.gscale || !gr.G) { set_error("net_stream: the one-launch gradient needs a diagonal covariance"); return LINNA_ERR_INVALID; }
     NsArgs a;

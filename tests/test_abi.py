@@ -109,16 +109,20 @@ def test_no_kernel_of_the_library_uses_scratch():
 
 def test_gradient_program_planning_without_a_gpu():
     """``linna_program_describe(dense_nout = -1)``: the program of the one-launch gradient for ChtoModelv2(33,33) on the 16-row
-    engine -- the forward segments (hidden h of the residual blocks as SPLIT segments: no SIDE segments in this launch,
-    measured slower there), then the dX chain down to the 33 inputs: 121 + 119 steps in one weight stream."""
+    engine -- the forward segments with the hidden h of the residual blocks as SIDE segments (R4: they pay in this launch
+    too since its gates are sign bits and its tables come through the kernel-argument segment), then the dX chain down to
+    the 33 inputs with d/dh of every block as a one-step SIDE segment: 107 + 112 steps in one weight stream."""
     import torch
     from linna_amd import nn
     n, txt = nn.describe_program(nn.ChtoModelv2(33, 33, None), 16, -1)
     lines = txt.strip().splitlines()
-    assert n == 20 and lines[0].startswith("ok G 121 Gstride 240 nseg_f 10")
-    assert not any(ln.startswith("SIDE") for ln in lines)
+    assert n == 20 and lines[0].startswith("ok G 107 Gstride 219 nseg_f 10")
+    kinds = [ln.split()[0] for ln in lines[1:21]]
+    assert kinds[:10] == ["WIDE", "SIDE", "WIDE", "SIDE", "SPLIT", "SIDE", "SPLIT", "WIDE", "SPLIT", "WIDE"]
+    assert kinds[10:] == ["WIDE", "WIDE", "SPLIT", "SIDE", "SPLIT", "SIDE", "WIDE", "SIDE", "WIDE", "SPLIT"]
+    assert all(ln.startswith("SIDE steps 1 ") for ln in (lines[14], lines[16], lines[18]))          # d/dh: 125 -> 64, 250 -> 32, 500 -> 16
     assert lines[-2].startswith("SPLIT steps 8") and lines[-2].endswith("N 33")          # d lnP / d x of the 1000-wide first layer
-    assert sum(int(ln.split()[2]) * int(ln.split()[4]) for ln in lines[1:11]) == 121
+    assert sum(int(ln.split()[2]) * int(ln.split()[4]) for ln in lines[1:11] if not ln.startswith("SIDE")) == 107
     # the signs of the forward activations (the backward's gates) are a bit matrix in LDS: 2688 columns x 16 rows fit
     assert lines[-1].startswith("lds ") and "2688 sign-bit columns" in lines[-1] and lines[-1].endswith("one launch")
     assert int(lines[-1].split()[1]) <= 160 * 1024
