@@ -1502,9 +1502,13 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         // kc = 1, <= 64 columns: the SPLIT mapping itself, run out of the stream -- 250 -> 64 is two steps per wave)
         // ... and, in the one-launch gradient, d/dh of a residual block (0.1 dy W2 gated by h: 500 / 250 / 125 -> 16 / 32 / 64,
         // the second K part alone, read transposed): one SIDE step each instead of 4 / 2 / 1 SPLIT steps and a SPLIT boundary
-        const bool side_fwd = (int)i < nfwd - 1 && !L.Wb && !L.transA && L.Wa;
+        // (the LAST forward segment too where nothing follows it in the launch -- serving programs without a backward half:
+        // ChtoModelv2's 33 -> 33 last layer is one SIDE step instead of a three-step WIDE run)
+        const bool last_ok = (int)i == nfwd - 1 && !want_grad && !fwd_dxi && !train && !dx_prog;
+        const bool side_fwd = ((int)i < nfwd - 1 || last_ok) && !L.Wb && !L.transA && L.Wa;
         const bool side_bwd = fwd_dxi && (int)i > nfwd && !L.Wa && L.Wb && L.transB && L.Kapad == 0 && !L.relu;
-        const bool side = k4 && split && ncg == 1 && side_steps <= 2 && i > 0 && (side_fwd || side_bwd) && p.seg.back().type != NS_SIDE &&
+        const bool side_pays = split || (side_fwd && !L.force_wide && side_steps < ksteps * passes);   // (a short WIDE run of <= 64 columns)
+        const bool side = k4 && side_pays && ncg == 1 && side_steps <= 2 && i > 0 && (side_fwd || side_bwd) && p.seg.back().type != NS_SIDE &&
                           !L.rscale && !L.rshift && !L.b2 && !L.x0_col;
         if (side) {
             s.type = NS_SIDE; s.steps = side_steps; s.passes = 1; s.kslice = 16 * kc * s.steps;

@@ -73,19 +73,21 @@ def test_no_gpu_means_loud_failure():
 def test_serving_programs_are_planned_on_the_host_without_a_gpu():
     """linna_program_describe: the segment program of the whole-network kernel for the reference's network class
     (nn.py:59-133) -- on the 16-row serving engine the hidden h of the three residual blocks (1000 -> 16, 500 -> 32,
-    250 -> 64) are SIDE segments of 4 / 2 / 1 k chunks and two steps, outside the weight stream (107 steps instead of 121);
-    the small-batch engines keep them as SPLIT segments; a plain MLP has none."""
+    250 -> 64) are SIDE segments of 4 / 2 / 1 k chunks and two steps, outside the weight stream, and so is the 33 -> 33 last
+    layer (R4: one SIDE step instead of a three-step WIDE run; 104 steps instead of 121); the small-batch engines keep them
+    as SPLIT / WIDE segments; the bench's plain MLP has none."""
     import torch  # noqa: F401
     from linna_amd import nn
     m = nn.ChtoModelv2(33, 33, None)
     n16, t16 = nn.describe_program(m, 16)
     n4, t4 = nn.describe_program(m, 4)
-    assert n16 == n4 == 10 and t16.startswith("ok G 107 ") and t4.startswith("ok G 121 ")
+    assert n16 == n4 == 10 and t16.startswith("ok G 104 ") and t4.startswith("ok G 121 ")
     seg16, seg4 = t16.splitlines()[1:], t4.splitlines()[1:]
     assert seg16[1].startswith("SIDE steps 2 passes 1 ncg 1 kc 4") and seg16[3].startswith("SIDE steps 2 passes 1 ncg 1 kc 2")
     assert seg4[1].startswith("SPLIT steps 8") and seg4[3].startswith("SPLIT steps 4")
     assert seg16[5].startswith("SIDE steps 2 passes 1 ncg 1 kc 1")
-    assert [ln.split()[0] for ln in seg16] == ["WIDE", "SIDE", "WIDE", "SIDE", "SPLIT", "SIDE", "SPLIT", "WIDE", "SPLIT", "WIDE"]
+    assert [ln.split()[0] for ln in seg16] == ["WIDE", "SIDE", "WIDE", "SIDE", "SPLIT", "SIDE", "SPLIT", "WIDE", "SPLIT", "SIDE"]
+    assert seg16[9].startswith("SIDE steps 1 passes 1 ncg 1 kc 1") and seg4[9].startswith("WIDE steps 3")
     nd, td = nn.describe_program(nn.ChtoModelv2(40, 1000, None), 16, dense_nout=1000)
     assert nd == 11 and td.count("SIDE") == 3 and td.splitlines()[-1].startswith("WIDE steps 63 passes 2")    # the inverse covariance: last segment
     nm, tm = nn.describe_program(nn.MLP(33, 33, None), 16)
