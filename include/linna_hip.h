@@ -253,6 +253,8 @@ typedef struct {
                                    * the host, rounded to fp32).  lnP is then taken as |d L|^2 instead of d S d^T: the same one
                                    * GEMM, but a sum of squares -- no cancellation between the stiff and the soft directions of an
                                    * ill-conditioned covariance (error ~ sqrt(cond) eps instead of ~ cond eps).
+                                   * L MUST be lower triangular (zeros above the diagonal, as numpy.linalg.cholesky returns it): for
+                                   * nout > 512 the second column pass starts at row 512 -- the block above it is never read.
                                    * NULL: the direct form.  The gradient keeps S (Ssym). */
 } linna_logprob_desc_t;
 

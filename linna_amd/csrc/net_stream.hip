@@ -79,6 +79,8 @@ enum { NS_WIDE = 0, NS_SPLIT = 1, NS_SIDE = 2 };
 struct NsSeg {            // kernel-side view of a segment
     int type, steps, passes, bias_off;
     int dst_col, relu, kslice, zext;   // SPLIT: kslice = k offset between K parts (16*steps), zext = columns written
+                                       // WIDE with a SHORT second pass (zext > 0): pass 1 runs zext steps from k offset kslice -- the
+                                       // lower-triangular factor of a dense inverse covariance has no rows k < 512 in columns >= 512
     int ncg_log2;                      // SPLIT: log2 of the number of 64-column groups
     int mask_store, mask_apply;        // GRAD: 1 + LDS slot of the ReLU sign bits this WIDE segment records / applies (0: none)
     int x0_n;                          // ... that many columns of them (a multiple of 16)
@@ -149,6 +151,7 @@ struct NsPackSeg {
     int transB;                                   // the same for Wb
     const float* rscale; const float* rshift;     // per output column: weights and bias * rscale, bias + rshift (folded output map)
     int kc, side_off;                             // SIDE segments: k chunks per wave and step (2 or 4), float offset of their block
+    int koff2;                                    // WIDE with a short second pass: k offset of pass 1 (NsSeg::kslice)
 };
 // SIDE segments (serving programs of the 16-row engine): a SPLIT segment of <= 32 output columns -- the hidden
 // h = relu(W1 x + b1) of a residual block, 1000 -> 16 and 500 -> 32 in ChtoModelv2 -- costs the step loop 8 + 4 steps of
@@ -185,7 +188,7 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
         const int s = g - p.run_first[r];
         const int nl = p.small ? lane : 16 * t + (lane & 15), kl = p.small ? 4 * t : 4 * (lane >> 4);
         int n, k0;
-        if (S.type == NS_WIDE) { n = 512 * p.run_pass[r] + 64 * w + nl; k0 = 16 * s + kl; }
+        if (S.type == NS_WIDE) { n = 512 * p.run_pass[r] + 64 * w + nl; k0 = 16 * s + kl + (p.run_pass[r] ? S.koff2 : 0); }
         else { n = 64 * (w % S.ncg) + nl; k0 = 16 * ((w / S.ncg) * S.steps + s) + kl; }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n < S.N && S.Wa && !S.transA && k0 + 3 < S.Ka && (S.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(S.Wa) & 15) == 0) {
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // launch with the refill one slot back in round 3).  Through the kernel-argument segment itself they are scalar loads.
     // (Only in the instantiations where that copy has appeared -- the training ones: the serving ones and the one-launch
     // gradient lose 0.3-0.7 % to the explicit pointer; tests/test_abi.py watches every kernel's scratch size.)
-    constexpr bool KA = STORE == 3 || STORE == 1 || (GRAD && STORE == 2);    // (G2 since it holds SIDE code: R4)
+    constexpr bool KA = STORE == 3 || STORE == 1 || GRAD;    // (R4: every GRAD instantiation -- G2 since it holds SIDE code, the MLP gradient since the short-second-pass selects)
     const NsArgs* const ka = KA ? reinterpret_cast<const NsArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr()) : &a;
     float* const act = smem;                       // [2][ROWS][LD]
     float* const lbias = smem + 2 * ABUF;          // packed biases of every segment
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     acc[t] = f32x4{b, b, b, b};
                 }
             }
-            ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak);
+            ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (pass ? s_kslice : 0));   // (kslice: 0 but for a short second pass)
         } else {
             ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (wave >> s_ncgl) * s_kslice);
         }
@@ -874,7 +877,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     P ^= 1; pass = 0; ++si;
                     take_next();
                 } else {
-                    kleft = cur_steps;
+                    kleft = s_zext > 0 ? s_zext : cur_steps;    // (a short second pass: NsSeg::zext)
                     seg_done = false;
                 }
             } else {
@@ -1341,6 +1344,8 @@ struct NsProgram {
 };
 
 static int ceil16(int k) { return (k + 15) & ~15; }
+// steps of a segment in every wave's stream (a WIDE segment's second pass may be shorter: NsSeg::zext)
+static int ns_seg_steps(const NsSeg& s) { return s.type == NS_WIDE && s.zext > 0 ? s.steps + (s.passes - 1) * s.zext : s.steps * s.passes; }
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
 enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4, NS_PROG_FWD_DXI = 5,
@@ -1539,7 +1544,12 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
             zero_pad += grow; q.bias_pad = grow;            // (the first backward segment's record carries the block; later ones extend it)
         }
         bias_off += q.bias_pad;
-        if (!side) G += s.steps * s.passes;        // (a SIDE segment is not part of the weight stream)
+        // the Cholesky factor of a dense inverse covariance (NsDense::factored) is lower triangular: in the second pass (columns
+        // >= 512) the rows k < 512 are zero -- that pass starts at k = 512 (bit-identical: the skipped products are zeros)
+        static const bool tri_on = !(getenv("LINNA_DENSE_TRI") && getenv("LINNA_DENSE_TRI")[0] == '0');
+        if (tri_on && s.type == NS_WIDE && dn && dn->factored && L.Wa == dn->S && passes == 2 && ksteps > 32 && !train) { s.kslice = 512; s.zext = ksteps - 32; }
+        q.koff2 = s.type == NS_WIDE ? s.kslice : 0;
+        if (!side) G += ns_seg_steps(s);           // (a SIDE segment is not part of the weight stream)
         p.seg.push_back(s); p.pack.push_back(q);
     }
     if (want_grad) {
@@ -1558,13 +1568,13 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         }
         if (want_grad) p.mask_slots = slot;
         else {   // drop the backward half again
-            for (size_t j = lins.size(); j-- > (size_t)nfwd;) { G -= p.seg[j].steps * p.seg[j].passes; bias_off -= p.pack[j].bias_pad; }
+            for (size_t j = lins.size(); j-- > (size_t)nfwd;) { G -= ns_seg_steps(p.seg[j]); bias_off -= p.pack[j].bias_pad; }
             p.seg.resize(nfwd); p.pack.resize(nfwd); lins.resize(nfwd); in_ext.resize(nfwd);
             for (int i = 0; i < nfwd; ++i) p.seg[i].mask_store = 0;
         }
     }
     int Gf = 0;
-    for (int i = 0; i < nfwd; ++i) if (p.seg[i].type != NS_SIDE) Gf += p.seg[i].steps * p.seg[i].passes;
+    for (int i = 0; i < nfwd; ++i) if (p.seg[i].type != NS_SIDE) Gf += ns_seg_steps(p.seg[i]);
 
     // 3. every column a segment reads must have been WRITTEN (finite; zero where the weights are zero):
     //    track the defined prefix [0, def) of the current buffer and widen the zero fill of the last
@@ -1777,7 +1787,7 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
         if (p.seg[i].type == NS_SIDE) continue;                 // not in the stream: ns_pack_side_kernel below
         for (int ps = 0; ps < p.seg[i].passes; ++ps) {
             a.run_seg[nrun] = i; a.run_pass[nrun] = ps; a.run_first[nrun] = first;
-            first += p.seg[i].steps; ++nrun;
+            first += (ps > 0 && p.seg[i].type == NS_WIDE && p.seg[i].zext > 0) ? p.seg[i].zext : p.seg[i].steps; ++nrun;
         }
     }
     a.run_first[nrun] = first; a.nrun = nrun;
@@ -1943,7 +1953,7 @@ int net_stream_adamw_args(const linna_layer_t* layers, int nl, int in_size, int 
     if ((int)ts.size() > AS_MAXR) { set_error("adamw_streams: %d tensors", (int)ts.size()); return LINNA_ERR_UNSUPPORTED; }
     auto runs_first = [](const NsProgram& p, int seg, int pass) {
         int first = 0;
-        for (int i = 0; i < seg; ++i) first += p.seg[i].steps * p.seg[i].passes;
+        for (int i = 0; i < seg; ++i) first += ns_seg_steps(p.seg[i]);
         return first + pass * p.seg[seg].steps;
     };
     auto place = [&](const NsProgram& p, float* base, const float* W, AsPlace* q, size_t lo, size_t hi) -> int {
