@@ -10,6 +10,7 @@ for w in "$@"; do
   case $w in
     hmc_v2) tag=r04_hmc_chto_v2; cmd="tools/hmc_probe.py ChtoModelv2"; pm=hmc_v2;;
     chto_v2) tag=r04_chto_v2; cmd="tools/serve_probe.py ChtoModelv2 33 33 0 4096 2000"; pm=v2;;
+    dense_1000) tag=r04_dense_1000; cmd="tools/serve_probe.py ChtoModelv2 40 1000 1 4096 1000"; pm=dense;;
     *) echo "unknown workload $w"; exit 1;;
   esac
   tools/profile_cmd.sh $tag python $cmd > $out/$w.log 2>&1; tail -3 $out/$w.log
