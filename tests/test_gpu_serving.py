@@ -619,3 +619,24 @@ def test_networks_wider_than_the_whole_network_kernel(nout, dense):
     assert len(beyond) <= B // 200, (len(beyond), rowerr.max())
     for r in beyond:
         assert parity.near_relu_kink(z[r], emu, priors), "row %d differs by %.2e of its maximum away from any ReLU kink" % (r, rowerr[r])
+
+
+@pytest.mark.parametrize("nout", [513, 640, 1000, 1024])
+def test_dense_factor_second_pass_starts_at_row_512(nout):
+    """Dense inverse covariances wider than 512: the log-likelihood segment multiplies by the lower-triangular Cholesky
+    factor, whose second column pass (columns >= 512) starts at row 512 -- ``nout = 513`` leaves that pass ONE step, 1024 the
+    full 32.  lnP against the float64 oracle on every engine (bit-identity with the full pass: tools/dense_tri_probe.py)."""
+    from oracle import likelihood
+    from linna_amd import _lib
+    prob = _custom_problem(10, nout, 700 + nout, 64, 1, dense=True)
+    emu = cases.oracle_emulator(prob)
+    z = np.random.RandomState(nout).standard_normal((300, 10)).astype(np.float32) * 0.5
+    ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0, dtype=np.float64)
+    for rows in (16, 8, 4):
+        prev = _lib.engine_rows(rows)
+        try:
+            lp = build_logprob(None, 1.0, prob)[0]
+            got = lp(z, returntorch=False)
+        finally:
+            _lib.engine_rows(prev)
+        np.testing.assert_allclose(got, ref, rtol=2e-5, err_msg="engine %d" % rows)
