@@ -400,9 +400,16 @@ def secondary_serving(device, kind, nin, nout, dense, nwalkers=4096, iters=400):
     us = 1e3 * ms.value / iters
     flop_eval = 2.0 * model.macs_per_eval() + (2.0 * nout * nout + nout if dense else 3.0 * nout)
     tf = nwalkers * flop_eval / (us * 1e-6) / 1e12
-    return {"workload": "%s(%d,%d), %s inverse covariance, %d walkers, one launch per step" % (kind, nin, nout, "dense" if dense else "diagonal", nwalkers),
-            "us_per_launch": us, "evals_per_s": nwalkers / (us * 1e-6), "flop_per_eval": flop_eval, "achieved": tf,
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+    res = {"workload": "%s(%d,%d), %s inverse covariance, %d walkers, one launch per step" % (kind, nin, nout, "dense" if dense else "diagonal", nwalkers),
+           "us_per_launch": us, "evals_per_s": nwalkers / (us * 1e-6), "flop_per_eval": flop_eval, "achieved": tf,
+           "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TFLOPS}
+    if dense:
+        # SURVEY 8d prices the dense quadratic form at 2 nout^2 FLOP per evaluation; the kernel takes it as |d L|^2 with the
+        # lower-triangular Cholesky factor of the inverse covariance and skips the zero block of the second column pass
+        # (nout > 512): 3/4 of those MACs are executed at nout = 1000 -- `achieved` / `frac` price the algorithmic count
+        res["note"] = ("chi^2 = |d L|^2, L = chol(Sigma^-1) lower triangular: for nout > 512 the second column pass starts at row 512 "
+                       "(bit-identical to the full pass); achieved / frac use SURVEY's 2 nout^2 FLOP for the quadratic form")
+    return res
 
 
 def _problem33(device, kind):
