@@ -668,6 +668,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         a_read(Aq[(U + 1) & 1]);                   // next step's A (speculative at a run end)
         const f32x4 av = Aq[U & 1];
         if constexpr (SM) {
+#ifdef NS_SM_EARLY
+            // experiment (R4): the L1-fill-bound engines request the refill at the TOP of the step (the slot the previous step
+            // consumed: no MFMA of this step reads it) instead of behind its MFMAs
+            if constexpr (refill) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Bq[RU][t] = wload(t);
+            }
+#endif
             // acc[4 r + c] += A(rows of set r, k chunk c, element e) x B(k chunk c = load c, element e); ABID = block 4 c + r
 #define NS_M4(r, c, e) acc[4 * (r) + (c)] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], Bq[U][c][e], acc[4 * (r) + (c)], 4, 4 * (c) + (r), 0);
 #define NS_M4R(r, e) NS_M4(r, 0, e) NS_M4(r, 1, e) NS_M4(r, 2, e) NS_M4(r, 3, e)
@@ -678,10 +686,12 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
 #undef NS_M4R
 #undef NS_M4
+#ifndef NS_SM_EARLY
             if constexpr (refill) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) Bq[RU][t] = wload(t);
             }
+#endif
         } else {
 #pragma unroll
             for (int h = 0; h < NT; h += 2) {
