@@ -207,13 +207,14 @@ def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
                 "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
-def driver_rate(lp, nwalkers, nsamp=2000):
+def driver_rate(lp, nwalkers, nsamp=2000, tmpdir=None, prefix="driver_"):
     """The reference's emcee driver end to end (sampler.py:458-554 -> linna_amd.sampler.HMCSampler.sample): 100 burn-in
     iterations + restart, then `nsamp` iterations with everything a run does -- chain blocks device -> host, the
     reference's HDF5 layout appended every 100 iterations (chain + chain_transformed + log_prob: 1.1 MB per iteration
-    at 4096 walkers), theta of every stored sample, integrated-autocorrelation checks -- into a temporary directory
-    that is removed afterwards.  The FFT plans of the checks are created beforehand (DeviceChain.prewarm, what
-    ml_sampler_core does while the emulator trains: 0.2-0.4 s per plan, once per process)."""
+    at 4096 walkers), theta of every stored sample, the integrated-autocorrelation check at EVERY 100 iterations (the
+    reference's cadence; incremental on the device, csrc/autocorr.hip) -- into a directory that is removed afterwards.
+    `breakdown`: the driver's own profile (host seconds / device seconds per phase; the phases overlap: sampling, the
+    statistics stream and the two writer threads run concurrently)."""
     import shutil
     import tempfile
     import contextlib
@@ -221,22 +222,29 @@ def driver_rate(lp, nwalkers, nsamp=2000):
     import torch
     from linna_amd import sampler, util
     priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(NIN)]
-    sampler.DeviceChain.prewarm(nwalkers, NIN, torch.device("cuda", torch.cuda.current_device())).join()
     x0 = 0.05 * np.random.RandomState(7).standard_normal((nwalkers, NIN))
-    out = tempfile.mkdtemp(prefix="linna_bench_chain_")
+    out = tempfile.mkdtemp(prefix="linna_bench_chain_", dir=tmpdir)
+    prof = {}
     try:
         drv = sampler.HMCSampler(lp, None, None, NIN, nwalkers, x0=x0, transform=util.Transform(priors))
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
-            store = drv.sample(None, nsamp, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True)   # never "converged": runs nsamp
+            store = drv.sample(None, nsamp, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True, profile=prof)   # never "converged": runs nsamp
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         n = sum(len(c) for c in store.chain)
         size = os.path.getsize(os.path.join(out, "chemcee_256.h5"))
     finally:
         shutil.rmtree(out, ignore_errors=True)
-    return {"driver_steps_per_s": (n + 100) / dt, "driver_iterations": n + 100, "driver_seconds": dt, "driver_chain_file_bytes": size,
-            "driver_tmp_fs": _fs_type(tempfile.gettempdir())}
+    checks = n // 100
+    bd = {k: round(v, 4) if isinstance(v, float) else v for k, v in sorted(prof.items())}
+    bd["checks"] = checks
+    if checks and "gpu_stats_s" in prof:
+        bd["stats_us_per_check"] = 1e6 * prof["gpu_stats_s"] / checks
+        bd["stats_frac_of_sampling"] = prof["gpu_stats_s"] / max(prof.get("gpu_sampling_s", 0.0), 1e-12)
+    return {prefix + "steps_per_s": (n + 100) / dt, prefix + "iterations": n + 100, prefix + "seconds": dt,
+            prefix + "chain_file_bytes": size, prefix + "tmp_fs": _fs_type(tmpdir or tempfile.gettempdir()),
+            prefix + "breakdown": bd}
 
 
 def _fs_type(path):
@@ -917,8 +925,15 @@ def main():
         if world == 1 and not args.no_driver and isinstance(mcmc, dict) and "error" not in mcmc:
             try:
                 res["mcmc"].update(driver_rate(lp, NWALKERS))
+                if os.path.isdir("/dev/shm"):                      # the same run with the chain file in memory: pipeline cost without the disk
+                    res["mcmc"].update(driver_rate(lp, NWALKERS, tmpdir="/dev/shm", prefix="driver_shm_"))
             except Exception as e:                                  # noqa: BLE001
                 res["mcmc"]["driver_error"] = repr(e)[:300]
+            if isinstance(mcmc.get("walkers_128"), dict) and "error" not in mcmc["walkers_128"]:
+                try:                                                # the reference's production ensemble, a chain as long as its runs
+                    mcmc["walkers_128"].update(driver_rate(lp, 128, nsamp=20000))
+                except Exception as e:                              # noqa: BLE001
+                    mcmc["walkers_128"]["driver_error"] = repr(e)[:300]
         if collectives is not None:
             res["collectives"] = collectives
             res["rccl_ranks"] = comm_ranks          # linna_comm_info: ranks of the library's communicator (0 = torch.distributed carries the data path)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 8   /* 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
+#define LINNA_ABI_VERSION 9   /* 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -495,6 +495,52 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
                           const int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched,
                           int nshr_rounds, float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt,
                           int* list, int* counters, int zero_totals, void* stream);
+
+/* `nsteps` ensemble iterations in ONE call: 2 nsteps launches of linna_stretch_half_step's kernel with the same Philox
+ * counters (step = step_dev[0] + step_offset + i, stream = half), so the chain is bit-identical to a host loop over that
+ * entry.  Iteration i moves the walkers splits[i * split_stride + 0 .. ns) against splits[i * split_stride + ns .. 2 ns) and
+ * then the other way round (emcee's RedBlueMove draws a random equal split per iteration; split_stride = 0 reuses one split;
+ * DEVICE int32, ns = nw / 2).  chain != NULL: the kernels' finish also writes each walker's position and log-probability
+ * after iteration i to chain[i][nw][ndim] / logps[i][nw] (every walker moves in exactly one of the two half steps), which
+ * replaces two device copies per iteration; the whole ensemble is on this rank (no complementary exchange).  Replaces the
+ * per-walker loop of emcee's sample() behind linna/sampler.py:530.  LINNA_ERR_UNSUPPORTED as linna_stretch_half_step. */
+int linna_stretch_run(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, int nw, const int* splits,
+                      int split_stride, int nsteps, uint64_t seed, const int* step_dev, int step_offset, float a,
+                      int* naccept, float* chain, float* logps, void* stream);
+
+/* ------------------------------------------------------------------ convergence statistics of a chain (autocorr.hip)
+ * The reference recomputes emcee's integrated autocorrelation time of the WHOLE chain every 100 iterations
+ * (linna/sampler.py:532-552 `get_autocorr_time(tol=0)`; zeus: :667-696, first 20 % discarded) and compares the halves of the
+ * chain's tail (`checkmeanstd`, :370-387).  Here the statistics' copy of the chain is CT[row][ndim][nwp] (fp32; time x
+ * parameter x walker lane, nwp = walkers rounded up to a multiple of 64, padding zero; every wstride-th walker -- the subset
+ * a routine check may average over -- takes the first ceil(nw / wstride) lanes, the others follow in order) and the
+ * estimator runs on RUNNING sums in float64 (the only double-precision pointers of this ABI) over the first nwc lanes of
+ * every parameter (nwc a multiple of 64, <= nwp; nlive of them are walkers):
+ *   Ssum[k][ndim][nwc] = sum_{t = lo+k}^{hi-1} x_t x_{t-k}  (k < K, K a multiple of 32),  Tsum[ndim][nwc] = sum_{t=lo}^{hi-1} x_t,
+ * x relative to the series' row 0.  The caller zeroes the sums once and then keeps them current:
+ *   linna_chain_append_t : rows row0 .. row0 + nsteps of CT from a chain block[nsteps][nw][ldb]
+ *   linna_acorr_update   : remove = 0: rows [a0, a1) entered at the end of the window [lo, hi) (hi = a1): adds their products
+ *                          with the rows up to K - 1 back (never before lo) for the lags [k0, k1); the same call with
+ *                          [a0, a1) = [lo, hi) computes lags from scratch (more lags on demand).  remove = 1: rows [a0, a1)
+ *                          = [lo, new lo) leave at the front: subtracts their products with the rows up to K - 1 ahead.
+ *                          Tsum is updated by the call whose k0 is 0.
+ *   linna_acorr_tau      : emcee's estimate from the sums for the lags 0..kuse (kuse <= min(K, hi - lo) - 1): per series
+ *                          acf_k = S_k - m (2 T - tail_k - head_k) + (N - k) m^2, normalised by acf_0, averaged over the nlive
+ *                          walkers; tau_M = 2 sum_{k<=M} f_k - 1 at the first M with M >= c tau_M.  out[ndim] = tau (NaN as the
+ *                          host estimator gives it for a constant series), out[ndim + d] = M, out[2 ndim + d] = 1 when no such
+ *                          M <= kuse exists and kuse < hi - lo - 1 (the caller adds lags and asks again), else 0.
+ *                          scratch: linna_acorr_scratch_bytes(ndim, nwc, kuse) bytes.
+ *   linna_chain_meanstd  : out[d][h][2] = mean and population standard deviation of parameter d over rows [t0, tm) (h = 0) and
+ *                          [tm, t1) (h = 1), the first nws lanes (all walkers): the moments checkmeanstd compares. */
+int linna_chain_append_t(linna_ctx_t* ctx, const float* block, int ldb, int nsteps, int nw, int ndim, int wstride, float* CT,
+                         int nwp, int64_t row0, void* stream);
+int linna_acorr_update(linna_ctx_t* ctx, const float* CT, int ndim, int nwp, int nwc, int64_t a0, int64_t a1, int64_t lo,
+                       int64_t hi, int k0, int k1, double* Ssum, double* Tsum, int remove, void* stream);
+size_t linna_acorr_scratch_bytes(int ndim, int nwc, int kuse);
+int linna_acorr_tau(linna_ctx_t* ctx, const float* CT, int ndim, int nwp, int nwc, int nlive, int64_t lo, int64_t hi, int kuse,
+                    const double* Ssum, const double* Tsum, double c, double* scratch, double* out, void* stream);
+int linna_chain_meanstd(linna_ctx_t* ctx, const float* CT, int ndim, int nwp, int nws, int64_t t0, int64_t tm, int64_t t1,
+                        double* out, void* stream);
 
 #ifdef __cplusplus
 }

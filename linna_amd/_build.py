@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblinna_hip.so")
-SOURCES = ["gemm.hip", "pointwise.hip", "net_stream.hip", "api.hip", "comm.hip"]
+SOURCES = ["gemm.hip", "pointwise.hip", "net_stream.hip", "autocorr.hip", "api.hip", "comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off"]
 
 

@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LINNA_LIB_PATH") or os.path.join(_HERE, "liblinna_hip.so")   # (LINNA_LIB_PATH: a diagnostic build, tools/ns_stamps.py)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
@@ -62,6 +62,7 @@ COMM_ID_BYTES = 128
 LAY_K, LAY_MN = 0, 1
 
 _V, _I, _F, _SZ, _U64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
+_I64, _D = C.c_int64, C.c_double
 _PV = C.POINTER(C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/linna_hip.h one to one
@@ -134,6 +135,12 @@ _SIGNATURES = {
     "linna_logprob_eval_if": (_I, [_V, _V, _I, _I, _V, _V, _V, _I, _V, _V]),
     "linna_logprob_eval_slice_points": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V]),
     "linna_stretch_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _U64, _V, _I, _I, _F, _V, _V]),
+    "linna_stretch_run": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _I, _U64, _V, _I, _F, _V, _V, _V, _V]),
+    "linna_chain_append_t": (_I, [_V, _V, _I, _I, _I, _I, _I, _V, _I, _I64, _V]),
+    "linna_acorr_update": (_I, [_V, _V, _I, _I, _I, _I64, _I64, _I64, _I64, _I, _I, _V, _V, _I, _V]),
+    "linna_acorr_scratch_bytes": (_SZ, [_I, _I, _I]),
+    "linna_acorr_tau": (_I, [_V, _V, _I, _I, _I, _I, _I64, _I64, _I, _V, _V, _D, _V, _V, _V]),
+    "linna_chain_meanstd": (_I, [_V, _V, _I, _I, _I, _I64, _I64, _I64, _V, _V]),
     "linna_hmc_init": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V]),
     "linna_hmc_start": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _F, _F, _V, _I, _V, _I, _V, _I, _V, _V]),
     "linna_hmc_kick_drift": (_I, [_V, _I, _I, _V, _F, _F, _V, _I, _V, _I, _V, _I, _V]),

@@ -1179,6 +1179,81 @@ int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndi
                              d.outmap.cexp ? d.outmap.cshift2 : nullptr);
 } LINNA_CATCH_INT
 
+
+int linna_stretch_run(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, int nw, const int* splits,
+                      int split_stride, int nsteps, uint64_t seed, const int* step_dev, int step_offset, float a, int* naccept,
+                      float* chain, float* logps, void* stream) try {
+    if (!lp || !coords || !logp || !splits || !step_dev || nw < 2 || (nw & 1) || nsteps < 1 || split_stride < 0 ||
+        (chain != nullptr) != (logps != nullptr)) {
+        set_error("stretch_run: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    const linna_logprob_desc_t& d = lp->d;
+    if (ndim != d.nin) { set_error("stretch_run: ndim %d, log-probability has %d parameters", ndim, d.nin); return LINNA_ERR_INVALID; }
+    if (!fused_enabled() || !lp->packed.ready() || (d.outmap.cexp && (!d.w || !d.outmap.cpost || !d.outmap.cshift2)) ||
+        (!d.w && !lp->dense_fused) || d.nin > 64) {
+        set_error("stretch_run: this log-probability does not run the whole-network kernel");
+        return LINNA_ERR_UNSUPPORTED;          // the caller loops over linna_stretch_half_step / the three-launch form
+    }
+    const int ns = nw / 2;
+    const float* packed = nullptr; int rows = 16;
+    TRY(lp_refresh_stream(lp, ns, stream, &packed, &rows));
+    const linna_net* n = lp->net;
+    const NsDense dn = lp->dense();
+    const bool df = lp->dense_fused;
+    for (int i = 0; i < nsteps; ++i) {
+        const int* sp = splits + (size_t)i * split_stride;
+        for (int h = 0; h < 2; ++h) {
+            NsMove mv{coords, ldc, logp, sp + h * ns, coords, ldc, sp + (1 - h) * ns, ns, seed, step_dev, step_offset + i, h, a, naccept, 0};
+            if (chain) { mv.chain = chain + (size_t)i * nw * ndim; mv.lps = logps + (size_t)i * nw; }
+            TRY(launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, nullptr, 0, ns, d.nin, d.is_flat, d.a1,
+                                  d.a2, d.log10_flag, d.xmean, d.xstd, df ? nullptr : d.outmap.cscale, df ? nullptr : d.outmap.cshift,
+                                  df ? nullptr : d.w, d.temperature, nullptr, nullptr, 0, nullptr, 0, &mv, nullptr, nullptr, rows,
+                                  df ? &dn : nullptr, S(stream), d.outmap.cexp ? d.outmap.cpost : nullptr,
+                                  d.outmap.cexp ? d.outmap.cshift2 : nullptr));
+        }
+    }
+    return LINNA_OK;
+} LINNA_CATCH_INT
+
+// ---- convergence statistics of a chain (autocorr.hip)
+static bool ac_shape_ok(int ndim, int nwp) { return ndim >= 1 && nwp >= 64 && (nwp & 63) == 0; }
+int linna_chain_append_t(linna_ctx_t*, const float* block, int ldb, int nsteps, int nw, int ndim, int wstride, float* CT, int nwp,
+                         int64_t row0, void* stream) try {
+    if (!block || !CT || nsteps < 1 || nw < 1 || wstride < 1 || ldb < ndim || row0 < 0 || !ac_shape_ok(ndim, nwp) ||
+        nw > nwp || nsteps > 65535 || (size_t)64 * (ndim + 1) * sizeof(float) > 64 * 1024) {
+        set_error("chain_append_t: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    return launch_chain_append_t(block, ldb, nsteps, nw, ndim, wstride, CT, nwp, row0, S(stream));
+} LINNA_CATCH_INT
+static bool ac_cover_ok(int nwp, int nwc, int nlive) { return nwc >= 64 && (nwc & 63) == 0 && nwc <= nwp && nlive >= 1 && nlive <= nwc; }
+int linna_acorr_update(linna_ctx_t*, const float* CT, int ndim, int nwp, int nwc, int64_t a0, int64_t a1, int64_t lo, int64_t hi, int k0,
+                       int k1, double* Ssum, double* Tsum, int remove, void* stream) try {
+    if (!CT || !Ssum || !ac_shape_ok(ndim, nwp) || !ac_cover_ok(nwp, nwc, 1) || k0 < 0 || k1 < k0 || (k0 & 31) || (k1 & 31) || lo < 0 ||
+        hi < lo || a0 < lo || a1 > hi || a1 < a0 || (k1 - k0) / 32 > 4 * 65535 || hi > 0x7fffff00) {
+        set_error("acorr_update: bad arguments (lag ranges are multiples of 32, anchors inside [lo, hi))"); return LINNA_ERR_INVALID;
+    }
+    return launch_acorr_update(CT, ndim, nwp, nwc, a0, a1, lo, hi, k0, k1, Ssum, Tsum, remove, S(stream));
+} LINNA_CATCH_INT
+size_t linna_acorr_scratch_bytes(int ndim, int nwc, int kuse) try {
+    if (ndim < 1 || nwc < 64 || (nwc & 63) || kuse < 0) return 0;
+    return acorr_scratch_doubles(ndim * nwc, kuse, ndim) * sizeof(double);
+} LINNA_CATCH_SIZE
+int linna_acorr_tau(linna_ctx_t*, const float* CT, int ndim, int nwp, int nwc, int nlive, int64_t lo, int64_t hi, int kuse,
+                    const double* Ssum, const double* Tsum, double c, double* scratch, double* out, void* stream) try {
+    if (!CT || !Ssum || !Tsum || !scratch || !out || !ac_shape_ok(ndim, nwp) || !ac_cover_ok(nwp, nwc, nlive) || lo < 0 || hi <= lo ||
+        kuse < 0 || (int64_t)kuse > hi - lo - 1 || kuse / 32 + 1 > 65535 || !(c > 0.0) || hi > 0x7fffff00) {
+        set_error("acorr_tau: bad arguments (0 <= kuse <= hi - lo - 1)"); return LINNA_ERR_INVALID;
+    }
+    return launch_acorr_tau(CT, ndim, nwp, nwc, nlive, lo, hi, kuse, Ssum, Tsum, c, scratch, out, S(stream));
+} LINNA_CATCH_INT
+int linna_chain_meanstd(linna_ctx_t*, const float* CT, int ndim, int nwp, int nws, int64_t t0, int64_t tm, int64_t t1, double* out,
+                        void* stream) try {
+    if (!CT || !out || !ac_shape_ok(ndim, nwp) || nws < 1 || nws > nwp || t0 < 0 || tm < t0 || t1 < tm || ndim > 65535) {
+        set_error("chain_meanstd: bad arguments"); return LINNA_ERR_INVALID;
+    }
+    return launch_chain_meanstd(CT, ndim, nwp, nws, t0, tm, t1, out, S(stream));
+} LINNA_CATCH_INT
+
 }  // extern "C"
 
 // lnP and its gradient at Z; `leap` (hm_* of an NsGrad, the rest unset): the leapfrog's kick and drift behind it -- in the

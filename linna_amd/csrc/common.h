@@ -169,6 +169,7 @@ struct NsMove {
     const float* cc; int ldcc; const int* C; int nc;
     unsigned long long seed; const int* step; int step_off; int stream; float a; int* naccept;
     int slice;
+    float* chain = nullptr; float* lps = nullptr;      // stretch move: this iteration's row of the chain block ([nw][ndim], [nw]); null: none
 };
 // training / validation forward: every op's output stored for the backward (STORE instantiation)
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,
@@ -237,6 +238,17 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
                       const float* xstd, const float* cscale, const float* cshift, const float* w, float T, float* lnP,
                       float* D, int ldd, float* TH, int ldt, const NsMove* mv, const NsGrad* gr, const int* gate, int rows,
                       const NsDense* dn, hipStream_t s, const float* cpost = nullptr, const float* cshift2 = nullptr);
+
+// autocorr.hip: convergence statistics of a walker chain (running lagged products, emcee's estimator, checkmeanstd's moments)
+int launch_chain_append_t(const float* block, int ldb, int nsteps, int nw, int ndim, int wstride, float* CT, int nwp,
+                          int64_t row0, hipStream_t s);
+int launch_acorr_update(const float* CT, int nd, int nwp, int nwc, int64_t a0, int64_t a1, int64_t lo, int64_t hi, int k0, int k1,
+                        double* S, double* T, int remove, hipStream_t s);
+size_t acorr_scratch_doubles(int nser, int kuse, int nd);
+int launch_acorr_tau(const float* CT, int ndim, int nwp, int nwc, int nlive, int64_t lo, int64_t hi, int kuse, const double* S,
+                     const double* T, double c, double* scratch, double* out, hipStream_t s);
+int launch_chain_meanstd(const float* CT, int ndim, int nwp, int nws, int64_t t0, int64_t tm, int64_t t1, double* out,
+                         hipStream_t s);
 
 int gemm_slots(int M, int N);            // number of row-dot partial slots gemm_launch will write
 int gemm_launch(const GemmArgs& a, hipStream_t stream);

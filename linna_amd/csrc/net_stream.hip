@@ -137,6 +137,7 @@ struct NsArgs {
     float* mv_coords; int mv_ldc; float* mv_logp; const int* mv_S;
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
     unsigned long long mv_seed; const int* mv_step; int mv_step_off; int mv_stream; float mv_a; int* mv_naccept;
+    float* mv_chain; float* mv_lps;     // MOVE == 1: row of the chain block this iteration fills (linna_stretch_run), [nw][nin] / [nw]
     NsSeg seg[NS_MAXSEG];
 };
 
@@ -1305,7 +1306,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         }
         if constexpr (MOVE == 1) {
             // Metropolis test of the stretch move (linna_stretch_accept); every lane of the row agrees
-            if (rok && mv_factor + lnp_new - mv_lnp_old > mv_logu) {
+            const bool mv_acc = rok && mv_factor + lnp_new - mv_lnp_old > mv_logu;
+            if (mv_acc) {
 #pragma unroll
                 for (int j = 0; j < ZPRE; ++j)
                     if (pc0 + j * RG < nin) a.mv_coords[(size_t)mv_wk * a.mv_ldc + pc0 + j * RG] = zr[j];
@@ -1313,6 +1315,15 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     a.mv_logp[mv_wk] = lnp_new;
                     if (a.mv_naccept) a.mv_naccept[mv_wk] += 1;
                 }
+            }
+            if (a.mv_chain && rok) {
+                // the walker's position after this iteration goes straight into the chain block (a walker moves in ONE of the
+                // two half steps of an iteration: the two launches together fill the row)
+#pragma unroll
+                for (int j = 0; j < ZPRE; ++j)
+                    if (pc0 + j * RG < nin)
+                        a.mv_chain[(size_t)mv_wk * nin + pc0 + j * RG] = mv_acc ? zr[j] : a.mv_coords[(size_t)mv_wk * a.mv_ldc + pc0 + j * RG];
+                if (pc0 == 0) a.mv_lps[mv_wk] = mv_acc ? lnp_new : mv_lnp_old;
             }
         }
         if (a.TH && rok) {
@@ -2081,6 +2092,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         a.mv_coords = mv->coords; a.mv_ldc = mv->ldc; a.mv_logp = mv->logp; a.mv_S = mv->S;
         a.mv_cc = mv->cc; a.mv_ldcc = mv->ldcc; a.mv_C = mv->C; a.mv_nc = mv->nc;
         a.mv_seed = mv->seed; a.mv_step = mv->step; a.mv_step_off = mv->step_off; a.mv_stream = mv->stream; a.mv_a = mv->a; a.mv_naccept = mv->naccept;
+        a.mv_chain = mv->chain; a.mv_lps = mv->lps;
         if (mv->slice) return ns_launch_kernel<2, false>(a, B, p, rows, s);
         return ns_launch_kernel<1, false>(a, B, p, rows, s);
     }

@@ -681,11 +681,14 @@ class Appender(object):
         self.eof = self.fh.tell()
         self._bulk, self._pool = [], None
 
-    # Bulk chunk data goes out by positional writes (os.pwrite releases the GIL) from a few threads: one thread copying
-    # into the page cache sustains ~4 GB/s, a 4096-walker chain produces 13 GB/s of samples at full sampling rate.
+    # Bulk chunk data goes out by positional writes (os.pwrite releases the GIL) off the caller's thread.  Buffered writes
+    # to ONE file are serialised by the kernel (the inode lock): measured on the MI355X boxes (tools/io_write_probe.py, R5) one
+    # writer sustains 5.8 GB/s into tmpfs and 9.8 GB/s into the overlay file system's page cache, four writers 4.6 / 9.8,
+    # eight 3.0 / 9.3, copies into a shared mapping 3-6 -- so one writer it is (a 4096-walker chain produces 13.8 GB/s of
+    # samples at the full sampling rate: at that size the chain file, not the GPU, bounds a run).
     BULK_MIN = 4 << 20
     BULK_PIECE = int(os.environ.get("LINNA_H5_PIECE_MB", "32")) << 20
-    BULK_THREADS = int(os.environ.get("LINNA_H5_WRITERS", "4"))
+    BULK_THREADS = int(os.environ.get("LINNA_H5_WRITERS", "1"))
 
     def _write_at(self, addr, view):
         if view.nbytes < self.BULK_MIN:

@@ -83,10 +83,6 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
             raise ValueError("not implement dist : {0}".format(item["dist"]))
     transform = Transform(priors)
     init = invTransform(priors)(np.asarray(init, np.float64))
-    if torch.cuda.is_available():
-        # the FFT plans of the convergence checks are created while the points are designed and the emulator trains
-        from .sampler import DeviceChain
-        DeviceChain.prewarm(nwalkers, ndim, torch.device("cuda", torch.cuda.current_device()))
     master = (pool is None or pool.is_master()) and rank == 0
     store = None
     nk = ntimes = None

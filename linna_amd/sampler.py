@@ -70,125 +70,200 @@ def integrated_time(x, c=5.0):
 
 
 class DeviceChain(object):
-    """The chain blocks of a run kept on the GPU for the convergence statistics: the reference
-    recomputes the autocorrelation time of the WHOLE chain every 100 iterations on the host
-    (sampler.py:538, 684); at 4096 walkers that host pass (135 k FFTs in a Python loop, after
-    concatenating every block again) cost ~200x the 100 iterations it judges.  Same estimators,
-    float64, on the device: per parameter one batched FFT over all walkers (torch.fft is used as
-    plumbing here; nothing of it is on the sampling path)."""
+    """The chain of a run kept on the GPU for the convergence statistics, which are computed there INCREMENTALLY.
 
-    def __init__(self):
-        self.buf = None          # [capacity, nw, nd] on the device, grown by doubling: no re-concatenation per check
+    The reference recomputes emcee's integrated autocorrelation time of the WHOLE chain every 100 iterations on the
+    host (sampler.py:538, 684) -- quadratic in the chain length over a run.  Only the lags up to Sokal's window enter
+    that estimate, so this class keeps per (walker, parameter) series the running lagged products ``S_k`` for ``k < K``
+    and the running sum in float64 (``linna_acorr_update``: each check adds the products of the ~100 new rows, and takes
+    out those of the rows zeus' moving discard drops), and ``linna_acorr_tau`` turns them into emcee's estimate: mean
+    removal through prefix sums, normalisation, walker average, cumulative sum, window -- kernels of this library
+    (csrc/autocorr.hip), no FFT.  ``K`` starts at 512 lags and grows (new lags computed from the stored chain) whenever
+    the window is not found below it or comes within a third of it.  The statistics' copy of the chain is
+    ``ct[row][parameter][walker]`` (walkers padded to a multiple of 64).  All work is enqueued on the current stream;
+    ``tau_begin`` / ``tau_end`` let a driver collect the result one block later without stalling the sampler."""
+
+    MAX_WALKERS = 1024      # the running sums (8 bytes x lags per series, read and written at every check) cover an evenly spaced
+                            # subset of at most so many walkers; the drivers confirm a positive check with ALL walkers (sums
+                            # of their own, from the stored chain) before they stop.  None: every walker, always.
+    LAGS0 = 512             # initial lag capacity (a multiple of 32)
+
+    def __init__(self, max_walkers=-1):
+        self.ct = None           # [capacity, nd, nwp] fp32 on the device, grown by doubling
         self.n = 0
+        self.nw = self.nd = self.nws = self.nwp = self.nwc = self.wstride = None
+        self.max_walkers = self.MAX_WALKERS if max_walkers == -1 else max_walkers
+        self._S = self._T = None     # running sums of the window [_lo, _hi) over the subset's lanes
+        self._lo = self._hi = 0
+        self._scratch = None
+        self.lag_growths = 0
+
+    # -- storage
+    def _setup(self, z):
+        self.nw, self.nd = int(z.shape[1]), int(z.shape[2])
+        self.wstride = 1 if not self.max_walkers else max(1, -(-self.nw // int(self.max_walkers)))
+        self.nws = len(range(0, self.nw, self.wstride))
+        self.nwp = (self.nw + 63) & ~63              # lanes per parameter in ct: the subset's walkers first, then the others
+        self.nwc = (self.nws + 63) & ~63             # lanes the running sums cover
+        self.dev = z.device
+        self.ctx = _lib.ctx(self.dev.index)
+
+    @property
+    def subset(self):
+        """True when the routine estimate averages over fewer walkers than the ensemble has."""
+        return self.nws < self.nw
 
     def append(self, z_block):
         z = torch.as_tensor(z_block)
-        z = z if z.is_cuda else z.cuda()
+        z = (z if z.is_cuda else z.cuda()).to(torch.float32).contiguous()
+        if z.ndim != 3 or len(z) == 0:
+            raise ValueError("chain blocks are [nsteps, nwalkers, ndim]")
+        if self.ct is None:
+            self._setup(z)
+        elif (int(z.shape[1]), int(z.shape[2])) != (self.nw, self.nd):
+            raise ValueError("chain block of another ensemble")
         need = self.n + len(z)
-        if self.buf is None or need > len(self.buf):
-            cap = max(need, 2 * (0 if self.buf is None else len(self.buf)), 1024)
-            buf = torch.empty((cap,) + tuple(z.shape[1:]), dtype=z.dtype, device=z.device)
+        if self.ct is None or need > len(self.ct):
+            cap = max(need, 2 * (0 if self.ct is None else len(self.ct)), 1024)
+            buf = torch.empty((cap, self.nd, self.nwp), dtype=torch.float32, device=self.dev)
             if self.n:
-                buf[:self.n] = self.buf[:self.n]
-            self.buf = buf
-        self.buf[self.n:need] = z
+                buf[:self.n] = self.ct[:self.n]
+            self.ct = buf
+        for i0 in range(0, len(z), 32768):                   # (grid.y of the transposing kernel is the step count)
+            blk = z[i0:i0 + 32768]
+            _lib.call("linna_chain_append_t", self.ctx, _lib.ptr(blk), self.nd, len(blk), self.nw, self.nd, self.wstride,
+                      _lib.ptr(self.ct), self.nwp, self.n + i0, _lib.stream())
         self.n = need
 
     def __len__(self):
         return self.n
 
     def last(self, n):
-        """The last ``n`` steps as one device tensor [n, nw, nd]."""
-        return self.buf[max(0, self.n - int(n)):self.n]
+        """The last ``n`` steps as one device tensor [n, nw, nd] (walkers in the ensemble's order)."""
+        w = np.arange(self.nw)
+        lane = np.where(w % self.wstride == 0, w // self.wstride, self.nws + w - w // self.wstride - 1)
+        idx = torch.as_tensor(lane, device=self.dev)
+        return self.ct[max(0, self.n - int(n)):self.n].index_select(2, idx).permute(0, 2, 1).contiguous()
 
-    MAX_WALKERS = 512       # the estimator averages the autocorrelation function over walkers: beyond this many the routine
-                            # checks use an evenly spaced subset of them (135 k FFTs per check at 4096 walkers otherwise);
-                            # the drivers confirm a positive check with all walkers (all_walkers=True) before they stop
+    # -- running sums
+    def _dptr(self, t):
+        return _lib.ptr(t, torch.float64)
+
+    def _update(self, S, T, a0, a1, lo, hi, k0, k1, remove):
+        _lib.call("linna_acorr_update", self.ctx, _lib.ptr(self.ct), self.nd, self.nwp, int(S.shape[2]), int(a0), int(a1), int(lo),
+                  int(hi), int(k0), int(k1), self._dptr(S), self._dptr(T) if T is not None else None, 1 if remove else 0, _lib.stream())
+
+    def _fresh(self, lags, full=False):
+        z = lambda *sh: torch.zeros(sh, dtype=torch.float64, device=self.dev)
+        nwc = self.nwp if full else self.nwc
+        return z(lags, self.nd, nwc), z(self.nd, nwc)
+
+    def _advance(self, lo, hi):
+        """Bring the running sums to the window [lo, hi)."""
+        if self._S is None or lo < self._lo or hi < self._hi or lo > self._hi:
+            lags = self.LAGS0 if self._S is None else len(self._S)
+            self._S, self._T = self._fresh(lags)
+            self._lo = self._hi = lo
+        if hi > self._hi:
+            self._update(self._S, self._T, self._hi, hi, self._lo, hi, 0, len(self._S), False)
+            self._hi = hi
+        if lo > self._lo:
+            self._update(self._S, self._T, self._lo, lo, self._lo, self._hi, 0, len(self._S), True)
+            self._lo = lo
+
+    def _grow(self, S, lo, hi, lags):
+        """More lags: the old rows are kept, the new ones computed from the stored chain."""
+        lags = min((int(lags) + 31) & ~31, (hi - lo + 31) & ~31)
+        if lags <= len(S):
+            return S
+        big = torch.zeros((lags,) + tuple(S.shape[1:]), dtype=torch.float64, device=self.dev)
+        big[:len(S)] = S
+        self._update(big, None, lo, hi, lo, hi, len(S), lags, False)
+        self.lag_growths += 1
+        return big
+
+    def _estimate(self, S, T, lo, hi, c, nlive):
+        """Enqueue emcee's estimate from the sums; returns the device result [3 nd] (tau | window | more lags needed)."""
+        kuse = min(len(S), hi - lo) - 1
+        nwc = int(S.shape[2])
+        nb = int(_lib.load().linna_acorr_scratch_bytes(self.nd, nwc, kuse))
+        if self._scratch is None or self._scratch.numel() * 8 < nb:
+            self._scratch = torch.empty((nb + 7) // 8, dtype=torch.float64, device=self.dev)
+        out = torch.empty(3 * self.nd, dtype=torch.float64, device=self.dev)
+        _lib.call("linna_acorr_tau", self.ctx, _lib.ptr(self.ct), self.nd, self.nwp, nwc, int(nlive),
+                  int(lo), int(hi), int(kuse), self._dptr(S), self._dptr(T), float(c), self._dptr(self._scratch), self._dptr(out), _lib.stream())
+        return out
+
+    def tau_begin(self, discard=0, c=5.0, upto=None, all_walkers=False):
+        """Enqueue everything a check needs on the current stream -- the sums' update, the estimate, its copy into pinned
+        memory -- and return a token for ``tau_end``; nothing waits.  ``all_walkers``: the estimate over every walker of
+        the ensemble (sums of their own, computed from the stored chain) instead of the routine subset."""
+        hi = self.n if upto is None else int(upto)
+        lo = int(discard)
+        if not 0 <= lo < hi <= self.n:
+            raise ValueError("empty chain window")
+        full = bool(all_walkers) and self.subset
+        live = (upto is None or hi == self.n) and not full
+        if live:
+            self._advance(lo, hi)
+            S, T = self._S, self._T
+        else:                                              # another window, or every walker: sums of their own, from scratch
+            S, T = self._fresh(min(len(self._S) if self._S is not None else self.LAGS0, (hi - lo + 31) & ~31), full)
+            self._update(S, T, lo, hi, lo, hi, 0, len(S), False)
+        nlive = self.nw if full else self.nws
+        out = self._estimate(S, T, lo, hi, c, nlive)
+        pin = torch.empty(3 * self.nd, dtype=torch.float64).pin_memory()
+        pin.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        return dict(pin=pin, ev=ev, lo=lo, hi=hi, c=c, live=live, S=S, T=T, nlive=nlive)
+
+    def tau_end(self, tok):
+        """The estimate of ``tau_begin`` as numpy [nd].  When Sokal's window lies beyond the lags kept so far they are doubled
+        (new lags from the stored chain) and the estimate repeated -- early in a run, while the estimate still grows with
+        the chain; afterwards the capacity stays ahead of the window (1.5 x)."""
+        nd = self.nd
+        while True:
+            tok["ev"].synchronize()
+            r = tok["pin"].numpy()
+            tau, win, more = r[:nd].copy(), r[nd:2 * nd].copy(), r[2 * nd:]
+            lo, hi, S = tok["lo"], tok["hi"], tok["S"]
+            if not np.any(more > 0):
+                break
+            S = self._grow(S, lo, hi, 2 * len(S))
+            if tok["live"]:
+                self._S = S
+            tok["S"] = S
+            out = self._estimate(S, tok["T"], lo, hi, tok["c"], tok["nlive"])
+            tok["pin"].copy_(out, non_blocking=True)
+            tok["ev"] = torch.cuda.Event()
+            tok["ev"].record(torch.cuda.current_stream(self.dev))
+        if tok["live"] and np.all(np.isfinite(win)):
+            want = int(1.5 * float(np.max(win))) + 64
+            if want > len(self._S) and len(self._S) < ((hi - lo + 31) & ~31):
+                self._S = self._grow(self._S, lo, hi, max(want, 2 * len(self._S)))
+        self.last_window = win
+        return tau
 
     def integrated_time(self, discard=0, c=5.0, upto=None, all_walkers=False):
-        """emcee's estimator (FFT autocorrelation averaged over walkers, Sokal window, tol=0) per
-        parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %); ``upto``: only
-        the first ``upto`` steps (the chain as it was at an earlier check)."""
-        nt_all, nd = (self.n if upto is None else int(upto)), self.buf.shape[2]
-        nt = nt_all - int(discard)
-        wstride = 1 if all_walkers else max(1, self.buf.shape[1] // self.MAX_WALKERS)
-        nw = len(range(0, self.buf.shape[1], wstride))
-        # every new transform length costs rocFFT a plan (0.2-0.4 s the first time on a machine): chains shorter than
-        # 4096 steps all use the 8192-point transform (more zero padding leaves the linear autocorrelation unchanged)
-        n = max(_next_pow_two(nt), 4096)
-        dev = self.buf.device
-        ar = torch.arange(nt, device=dev, dtype=torch.float64)[None, :]
-        out = torch.empty(nd, dtype=torch.float64, device=dev)
-        # all walkers and as many parameters per FFT as ~1 GiB of complex128 allows; no host round trip inside.
-        # The series are laid out time-last ([nw, per, nt] contiguous): the transform then runs over unit stride.
-        per = max(1, min(nd, int((1 << 30) // max(1, 16 * 2 * n * nw))))
-        for d0 in range(0, nd, per):
-            x = self.buf[int(discard):nt_all, ::wstride, d0:d0 + per].permute(1, 2, 0).to(torch.float64).contiguous()   # [nw, per, nt]
-            x = x - x.mean(2, keepdim=True)
-            f = torch.fft.rfft(x, n=2 * n, dim=2)
-            acf = torch.fft.irfft(f * f.conj(), n=2 * n, dim=2)[:, :, :nt]
-            fbar = (acf / acf[:, :, 0:1]).mean(0)               # [per, nt]; 0/0 -> nan, as the host estimator
-            t = 2.0 * torch.cumsum(fbar, 1) - 1.0
-            m = ar < c * t                                      # Sokal window: first step with step >= c tau
-            first_false = torch.argmin(m.to(torch.int8), dim=1)
-            win = torch.where(m.any(1), first_false, torch.full_like(first_false, nt - 1))    # emcee's auto_window
-            out[d0:d0 + per] = t.gather(1, win[:, None])[:, 0]
-        return out.cpu().numpy()
-
-    @classmethod
-    def prewarm(cls, nwalkers, ndim, device, lengths=(4096, 8192, 16384)):
-        """Create the FFT plans ``integrated_time`` will ask for, on a background thread and a stream of its own, while
-        the sampler burns in: every new (transform length, batch) costs rocFFT 0.2-0.4 s the first time in a process --
-        3 s of a 10000-iteration run at 4096 walkers when paid at the checks.  Returns the thread."""
-        import threading
-        dev = torch.device(device)
-
-        def work():
-            try:
-                wstride = max(1, nwalkers // cls.MAX_WALKERS)
-                nw = len(range(0, nwalkers, wstride))
-                with torch.cuda.device(dev), torch.cuda.stream(torch.cuda.Stream(device=dev)):
-                    for n in lengths:
-                        per = max(1, min(ndim, int((1 << 30) // max(1, 16 * 2 * n * nw))))
-                        for width in sorted({per, ndim % per} - {0}):
-                            x = torch.zeros((nw, width, 8), dtype=torch.float64, device=dev)
-                            f = torch.fft.rfft(x, n=2 * n, dim=2)
-                            torch.fft.irfft(f * f.conj(), n=2 * n, dim=2)
-                    torch.cuda.current_stream(dev).synchronize()
-            except Exception:                            # a warm-up only: the checks create what is missing
-                pass
-        t = threading.Thread(target=work, name="linna-fft-prewarm", daemon=True)
-        # A process that exits while this thread is still inside rocFFT dies in the runtime's teardown ("terminate called
-        # without an active exception" / a segmentation fault at exit: seen when a short run finished before its plans
-        # did): the thread is joined at interpreter exit, and by the drivers when they return.
-        if not cls._pending:
-            import atexit
-            atexit.register(cls.join_prewarm)
-        cls._pending.append(t)
-        t.start()
-        return t
-
-    _pending = []
-
-    @classmethod
-    def join_prewarm(cls, timeout=None):
-        """Wait for every plan-creating thread started so far -- without a bound by default: a process that leaves while
-        such a thread is still inside rocFFT dies in the runtime's teardown, so a join that gives up would only move the
-        abort to the exit (plan creation is 0.2-0.4 s per transform length)."""
-        while cls._pending:
-            cls._pending.pop().join(timeout)
+        """emcee's estimator (autocovariance of the mean-removed series normalised at lag 0, averaged over walkers, Sokal
+        window, tol=0) per parameter -> numpy [nd]; ``discard`` leading steps are dropped (zeus: 20 %); ``upto``: only the
+        first ``upto`` steps (the chain as it was at an earlier check); ``all_walkers``: see ``tau_begin``."""
+        return self.tau_end(self.tau_begin(discard, c, upto, all_walkers))
 
     def checkmeanstd(self, nlast, meanshift, stdshift):
-        """sampler.py:370-387 on the last ``nlast`` steps: first-half / second-half drift."""
-        s = self.last(nlast).to(torch.float64)
-        half = int(len(s) / 2)
-        a = s[:half].reshape(-1, s.shape[-1])
-        b = s[half:].reshape(-1, s.shape[-1])
-        sb = b.std(0, unbiased=False)
-        meanshifte = float(torch.median((a.mean(0) - b.mean(0)).abs() / sb))
-        stdshifte = float(torch.median((a.std(0, unbiased=False) - sb) / sb))
+        """sampler.py:370-387 on the last ``nlast`` steps: first-half / second-half drift (moments: linna_chain_meanstd)."""
+        t0 = max(0, self.n - int(nlast))
+        half = int((self.n - t0) / 2)
+        out = torch.empty((self.nd, 2, 2), dtype=torch.float64, device=self.dev)
+        _lib.call("linna_chain_meanstd", self.ctx, _lib.ptr(self.ct), self.nd, self.nwp, self.nw, t0, t0 + half, self.n,
+                  self._dptr(out), _lib.stream())
+        m = out.cpu().numpy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            meanshifte = np.median(np.abs(m[:, 0, 0] - m[:, 1, 0]) / m[:, 1, 1])
+            stdshifte = np.median((m[:, 0, 1] - m[:, 1, 1]) / m[:, 1, 1])
         print(meanshifte, stdshifte, flush=True)
-        return (meanshifte < meanshift) and (stdshifte < stdshift)
+        return bool((meanshifte < meanshift) and (stdshifte < stdshift))
 
 
 def checkmeanstd(samples, meanshift, stdshift):
@@ -239,6 +314,7 @@ class ChainStore(object):
         self._writer, self._queue, self._error = None, None, None
         self._events, self._copy_stream = {}, None
         self._appender, self._appended = None, 0
+        self.busy = {"fetch": 0.0, "append": 0.0}      # seconds the two background threads spent working (driver profiles)
 
     # Incremental flushes run on two background threads in a pipeline: the first brings a block from the device to the
     # host (copy stream of its own, after the event recorded when the block was appended), the second appends it to the
@@ -248,7 +324,7 @@ class ChainStore(object):
     # rate.  numpy's file I/O, os.pwrite and the device copies release the GIL; the sampling thread spends its time
     # inside ctypes calls, which release it too.
     def _enqueue(self, path, arrays):
-        import queue, threading
+        import queue, threading, time
         if self._writer is None:
             self._queue, self._wqueue = queue.Queue(maxsize=self.MAX_QUEUED), queue.Queue(maxsize=8)
 
@@ -257,9 +333,11 @@ class ChainStore(object):
                     item = self._queue.get()
                     try:
                         if item is not None and self._error is None:
+                            t0 = time.perf_counter()
                             self._to_host(item[1])                    # device blocks come to the host HERE, off the sampling thread
                             if torch.is_tensor(item[2]):
                                 item = (item[0], item[1], self._acc_host(item[2]))
+                            self.busy["fetch"] += time.perf_counter() - t0
                     except Exception as e:          # surfaced by the next drain()
                         self._error = e
                     self._wqueue.put(item)
@@ -273,7 +351,9 @@ class ChainStore(object):
                         if item is None:
                             return
                         if self._error is None:
+                            t0 = time.perf_counter()
                             self._append_block(item[1], item[2])
+                            self.busy["append"] += time.perf_counter() - t0
                     except Exception as e:
                         self._error = e
                     finally:
@@ -648,7 +728,8 @@ class EnsembleSampler(object):
         self._dev_steps = 0                          # value of the device step counter (== iteration unless fused)
         self._rs = np.random.RandomState(self.seed ^ 0x5EED)
         self._split_pos, self._split_host, self._split_dev, self._split_evt = 0, None, None, None
-        self._split = None
+        self._split, self._draws, self._split_idx = None, 0, np.arange(self.nw)
+        self.block_run = None                        # None: try linna_stretch_run (a whole block of iterations per C call)
         from . import dist as ldist
         self.rank, self.world = ldist.rank(dist_group), ldist.world_size(dist_group)
         self._gathered = None
@@ -673,36 +754,52 @@ class EnsembleSampler(object):
 
     _SPLIT_CHUNK = 64
 
+    def _draw_splits(self, n):
+        """Device int32 [n, 2, nw/2]: the random equal splits of the next ``n`` iterations (== the shuffled ``arange % 2``
+        of emcee's RedBlueMove), drawn on the host in one go and shipped in ONE asynchronous copy from pinned memory (a
+        per-iteration blocking copy left the GPU idle for ~25 us of every 150 us iteration)."""
+        slot = self._draws & 1
+        self._draws += 1
+        if self._split_host is None:
+            self._split_host, self._split_evt = [None, None], [None, None]
+        if self._split_evt[slot] is not None:
+            self._split_evt[slot].synchronize()                 # the copy that last read this pinned buffer is done
+        if self._split_host[slot] is None or len(self._split_host[slot]) < n:
+            self._split_host[slot] = torch.empty((max(n, self._SPLIT_CHUNK), 2, self.half), dtype=torch.int32).pin_memory()
+        host = self._split_host[slot].numpy()
+        idx = self._split_idx
+        for i in range(n):
+            self._rs.shuffle(idx)
+            host[i] = idx.reshape(2, self.half)
+        dev = torch.empty((n, 2, self.half), dtype=torch.int32, device=self.dev)
+        dev.copy_(self._split_host[slot][:n], non_blocking=True)
+        self._split_evt[slot] = torch.cuda.Event()
+        self._split_evt[slot].record()
+        return dev
+
     def _splits(self):
-        """Device int32 [2, nw/2]: this iteration's random equal split (== the shuffled ``arange % 2`` of
-        emcee's RedBlueMove).  The host permutations are drawn 64 iterations at a time and shipped in
-        ONE asynchronous copy from pinned memory: a per-iteration blocking copy left the GPU idle for
-        ~25 us of every 150 us iteration."""
+        """This iteration's split, device int32 [2, nw/2] (drawn 64 iterations at a time)."""
         if not self.randomize_split:
             if self._split is None:
                 self._split = torch.as_tensor(np.arange(self.nw, dtype=np.int32).reshape(2, self.half), device=self.dev)
             return self._split
-        n = self._SPLIT_CHUNK
-        k = self._split_pos % n
-        if k == 0:
-            slot = (self._split_pos // n) % 2
-            if self._split_host is None:
-                self._split_host = [torch.empty((n, 2, self.half), dtype=torch.int32).pin_memory() for _ in range(2)]
-                self._split_dev = [torch.empty((n, 2, self.half), dtype=torch.int32, device=self.dev) for _ in range(2)]
-                self._split_evt = [None, None]
-            if self._split_evt[slot] is not None:
-                self._split_evt[slot].synchronize()             # the copy that last read this pinned buffer is done
-            host = self._split_host[slot].numpy()
-            idx = np.arange(self.nw)
-            for i in range(n):
-                self._rs.shuffle(idx)
-                host[i] = idx.reshape(2, self.half)
-            self._split_dev[slot].copy_(self._split_host[slot], non_blocking=True)
-            self._split_evt[slot] = torch.cuda.Event()
-            self._split_evt[slot].record()
-        halves = self._split_dev[(self._split_pos // n) % 2][k]
+        if self._split_dev is None or self._split_pos >= len(self._split_dev):
+            self._split_dev, self._split_pos = self._draw_splits(self._SPLIT_CHUNK), 0
+        halves = self._split_dev[self._split_pos]
         self._split_pos += 1
         return halves
+
+    def _splits_block(self, n):
+        """The splits of the next ``n`` iterations as one device tensor [n, 2, nw/2] (what is left of the chunk `_splits`
+        was handing out first: both routes consume the same sequence of permutations)."""
+        rem = None
+        if self._split_dev is not None and self._split_pos < len(self._split_dev):
+            rem = self._split_dev[self._split_pos:self._split_pos + n]
+            self._split_pos += len(rem)
+            if len(rem) == n:
+                return rem
+        new = self._draw_splits(n - (0 if rem is None else len(rem)))
+        return new if rem is None else torch.cat([rem, new])
 
     def step(self):
         """One ensemble iteration (both halves).  Everything is enqueued on the current stream."""
@@ -748,9 +845,41 @@ class EnsembleSampler(object):
         return gathered, self._gidx, gathered.shape[0]
 
     def run(self, nsteps, store=True):
-        """Advance ``nsteps``; returns (chain[nsteps, nw, ndim], logp[nsteps, nw]) as device tensors."""
+        """Advance ``nsteps``; returns (chain[nsteps, nw, ndim], logp[nsteps, nw]) as device tensors.  One rank, fused half
+        steps: ONE C call enqueues the whole block (linna_stretch_run: 2 launches per iteration whose finish also writes the
+        chain rows -- the per-iteration host work of the loop below, two ctypes calls and two device copies, cost as much
+        as the 60 us an iteration of 128 walkers takes on the GPU); bit-identical to that loop."""
         chain = torch.empty((nsteps, self.nw, self.ndim), dtype=torch.float32, device=self.dev) if store else None
         lps = torch.empty((nsteps, self.nw), dtype=torch.float32, device=self.dev) if store else None
+        if (nsteps > 0 and self.block_run is not False and self.fused is not False and type(self).step is EnsembleSampler.step
+                and not (self.exchange == "allgather" and self.world > 1)):
+            # the splits are host draws (41 us each at 4096 walkers): big ensembles go out in pieces of a few iterations, so
+            # that the GPU starts on the first piece while the host shuffles the next
+            piece = nsteps if not self.randomize_split else max(8, min(nsteps, 65536 // self.nw))
+            lib_seed = C.c_uint64(self.seed + 0x9E3779B97F4A7C15 * (self.rank + 1) & 0xFFFFFFFFFFFFFFFF)
+            i0 = 0
+            while i0 < nsteps:
+                n = min(piece, nsteps - i0)
+                if self.randomize_split:
+                    sp, stride = self._splits_block(n), self.nw
+                else:
+                    sp, stride = self._splits(), 0
+                rc = _lib.load().linna_stretch_run(
+                    self.lp._ensure()["handle"], _lib.ptr(self.coords), self.ld, self.ndim, _lib.ptr(self.logp), self.nw, _lib.iptr(sp),
+                    stride, n, lib_seed, _lib.iptr(self.step_dev), self.iteration - self._dev_steps, self.a, _lib.iptr(self.naccept),
+                    _lib.ptr(chain[i0:]) if store else None, _lib.ptr(lps[i0:]) if store else None, _lib.stream())
+                if rc != 0:
+                    break
+                self.block_run = self.fused = True
+                self.iteration += n
+                i0 += n
+            if i0 == nsteps:
+                return chain, lps
+            if rc != _lib.ERR_UNSUPPORTED or self.block_run is True:
+                _lib.check(rc)
+            self.block_run = False
+            if self.randomize_split:                 # hand the drawn splits back to the per-iteration route
+                self._split_dev, self._split_pos = sp, 0
         for i in range(nsteps):
             self.step()
             if store:
@@ -1007,13 +1136,10 @@ class SliceEnsembleSampler(EnsembleSampler):
         return mine
 
     def _snapshot(self):
-        slot = None
-        if self._split_dev is not None:
-            slot = [t.clone() for t in self._split_dev]
         return dict(coords=self.coords.clone(), logp=self.logp.clone(), naccept=self.naccept.clone(), step_dev=self.step_dev.clone(),
                     mu=self.mu, tune=self.tune, tune_count=self._tune_count, last_nexp=self._last_nexp, iteration=self.iteration,
-                    dev_steps=self._dev_steps, rs=self._rs.get_state(), split_pos=self._split_pos, split_dev=slot,
-                    neval=self._neval_host)
+                    dev_steps=self._dev_steps, rs=self._rs.get_state(), split_pos=self._split_pos, split_dev=self._split_dev,
+                    split_idx=self._split_idx.copy(), neval=self._neval_host)      # (a drawn chunk of splits is never written again)
 
     def _restore(self, k):
         torch.cuda.current_stream(self.dev).synchronize()
@@ -1021,10 +1147,8 @@ class SliceEnsembleSampler(EnsembleSampler):
         self.mu, self.tune, self._tune_count, self._last_nexp = k["mu"], k["tune"], k["tune_count"], k["last_nexp"]
         self.mu_dev.fill_(self.mu)
         self.iteration, self._dev_steps, self._neval_host = k["iteration"], k["dev_steps"], k["neval"]
-        self._rs.set_state(k["rs"]); self._split_pos = k["split_pos"]
-        if k["split_dev"] is not None:
-            for dst, src in zip(self._split_dev, k["split_dev"]):
-                dst.copy_(src)
+        self._rs.set_state(k["rs"]); self._split_pos, self._split_dev = k["split_pos"], k["split_dev"]
+        self._split_idx[:] = k["split_idx"]
         if self._fast_bufs is not None:
             self._fast_bufs["counters"][2:3].zero_()
 
@@ -1232,6 +1356,98 @@ class _Ranks(object):
             tdist.barrier(group=self.group)
 
 
+class _Prof(object):
+    """Where a driver run spends its time (``sample(..., profile={})``): host seconds per phase and, from event pairs on
+    the streams the work was enqueued on, device seconds per phase.  Without a dict every hook is a no-op."""
+
+    def __init__(self, out):
+        import collections
+        self.out, self.h, self.ev = out, collections.defaultdict(float), collections.defaultdict(list)
+
+    class _Span(object):
+        __slots__ = ("p", "key", "stream", "t0", "e0")
+
+        def __init__(self, p, key, stream):
+            self.p, self.key, self.stream = p, key, stream
+
+        def __enter__(self):
+            import time
+            if self.p.out is not None:
+                if self.stream is not False:
+                    self.e0 = torch.cuda.Event(enable_timing=True)
+                    self.e0.record(self.stream if self.stream is not None else torch.cuda.current_stream())
+                self.t0 = time.perf_counter()
+
+        def __exit__(self, *a):
+            import time
+            if self.p.out is not None:
+                self.p.h[self.key] += time.perf_counter() - self.t0
+                if self.stream is not False:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.stream if self.stream is not None else torch.cuda.current_stream())
+                    self.p.ev[self.key].append((self.e0, e1))
+
+    def host(self, key):
+        return self._Span(self, key, False)
+
+    def both(self, key, stream=None):
+        """Host seconds inside the block and device seconds between two events recorded on ``stream`` around it."""
+        return self._Span(self, key, stream)
+
+    def finish(self, **extra):
+        if self.out is None:
+            return
+        torch.cuda.synchronize()
+        for k, v in self.h.items():
+            self.out["host_%s_s" % k] = v
+        for k, pairs in self.ev.items():
+            self.out["gpu_%s_s" % k] = 1e-3 * sum(a.elapsed_time(b) for a, b in pairs)
+        self.out.update(extra)
+
+
+def _run_blocks(ens, rk, store, dchain, done, nsamp, ncheck, incremental, begin_check, decide, prof):
+    """The sampling loop of both drivers (sampler.py:530-552, :728-735): blocks of ``ncheck`` iterations, each followed by
+    the chain-file append and a convergence check.  Software-pipelined: the statistics of block i run on a stream of
+    their own WHILE the sampler already advances block i + 1, and the host reads their verdict (33 numbers in pinned
+    memory) only after it has enqueued that block -- neither the GPU nor the host waits for a check.  When the verdict is
+    "stop" the block sampled meanwhile is dropped, so the chain ends exactly where the reference's criterion ends it."""
+    dev = ens.dev
+    stats = torch.cuda.Stream(device=dev) if rk.rank == 0 else None
+    pending = None
+    while done < nsamp:
+        with prof.both("sampling"):
+            c, l = ens.run(ncheck)
+        c, l, acc = rk.gather(ens, c, l)
+        stop = False
+        if rk.rank == 0 and pending is not None:
+            with prof.host("wait_check"), torch.cuda.stream(stats):
+                stop = decide(pending, done)
+            pending = None
+        if rk.bcast(stop):
+            break
+        done += ncheck
+        if rk.rank == 0:
+            with prof.both("theta"):
+                th = ens.theta_of(c)
+            with prof.host("store_append"):
+                store.append(c, th, l, acc)                               # device tensors: copied off this thread
+                if incremental:
+                    store.flush(final=False)
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            stats.wait_event(ready)
+            with torch.cuda.stream(stats), prof.both("stats", stats):
+                c.record_stream(stats)
+                dchain.append(c)
+                pending = begin_check(done)
+    if rk.rank == 0 and pending is not None:                              # the last block's check: printed, not acted upon
+        with prof.host("wait_check"), torch.cuda.stream(stats):
+            decide(pending, done)
+    if stats is not None:
+        stats.synchronize()
+    return done
+
+
 class HMCSampler(object):
     """The reference's emcee driver (sampler.py:389-554): burn-in, restart from the best region,
     sample until the integrated autocorrelation time and the mean/std drift have converged.
@@ -1247,10 +1463,13 @@ class HMCSampler(object):
 
     def sample(self, pool, nsamp, samp_steps=0, samp_eps=0, Madapt=1000, outdir="./", progress=False, overwrite=False,
                ntimes=10, tautol=0.01, method="emcee", incremental=True, meanshift=0.1, stdshift=0.1, nk=2, ncheck=100,
-               burnin=100):
+               burnin=100, profile=None):
         if method != "emcee":
             # sampler.py's "hmc"/"nuts" branches are unreachable in the reference
             raise NotImplementedError(method)
+        import time
+        t_start = time.perf_counter()
+        prof = _Prof(profile)
         rk = _Ranks(self.nwalkers, self.group)
         filename = os.path.join(outdir, "chemcee_256.h5")
         store = ChainStore(filename, self.transform)
@@ -1267,81 +1486,62 @@ class HMCSampler(object):
         x0, resume = rk.bcast((x0, resume))
         ens = EnsembleSampler(rk.nw, self.nparams, self.lnp, seed=self.seed, dist_group=self.group, exchange=rk.exchange)
         self.sampler = ens
-        if rk.rank == 0:
-            DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)       # FFT plans of the convergence checks, off the critical path
         print("start", flush=True)
         if not resume:
             print("burnin...", flush=True)                                   # sampler.py:519-529
-            ens.set_state(rk.mine(x0))
-            c, l = ens.run(burnin)
-            c, l, _ = rk.gather(ens, c, l)
-            if rk.rank == 0:
-                flat, lp = c.reshape(-1, self.nparams).cpu().numpy(), l.reshape(-1).cpu().numpy()
-                pos = flat[np.argsort(lp)[::-1][:int(50 * self.nwalkers)]]
-                x0 = pos[np.random.randint(0, len(pos), self.nwalkers), :]
-            x0 = rk.bcast(x0)
+            with prof.host("burnin"):
+                ens.set_state(rk.mine(x0))
+                c, l = ens.run(burnin)
+                c, l, _ = rk.gather(ens, c, l)
+                if rk.rank == 0:
+                    # the 50 nwalkers best burn-in samples, nwalkers of them drawn with numpy's generator as the reference
+                    # does (sampler.py:524-528); ranked on the device, only the drawn rows come to the host (at 4096
+                    # walkers the host's argsort of 409600 log-probabilities took as long as 400 iterations)
+                    order = torch.argsort(l.reshape(-1), descending=True, stable=True)[:int(50 * self.nwalkers)]
+                    pick = torch.as_tensor(np.random.randint(0, len(order), self.nwalkers), device=order.device)
+                    x0 = c.reshape(-1, self.nparams)[order[pick]].cpu().numpy()
+                x0 = rk.bcast(x0)
             print("burnin done...", flush=True)
             ens.naccept.zero_()
         ens.set_state(rk.mine(x0))
-        st = {"old_tau": np.inf, "next": 0, "last": -1}
+        st = {"old_tau": np.inf}
         done = 0 if not resume else sum(len(c) for c in store.chain)
         done = rk.bcast(done)
         dchain = DeviceChain()                                               # convergence statistics stay on the GPU
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
 
-        def check(done):
-            """True = stop.  The reference evaluates its criterion every `ncheck` iterations on the whole chain --
-            quadratic in the chain length (a 270 k-iteration run spent 15 of 17 minutes here).  Same criterion, evaluated
-            at every check up to 2000 iterations and then whenever the chain has grown by 2 %: tau now against tau
-            `ncheck` iterations earlier, exactly the pair the reference compares at that iteration.  A check is also
-            skipped while the chain is shorter than 0.9 x ntimes x the last tau estimate: the criterion's first clause
-            cannot hold there unless the estimate drops by more than 10 % (each check is a batch of FFTs over the whole
-            chain, and every new chain length costs rocFFT a new plan)."""
-            if done < st["next"]:
-                return False
-            tau = dchain.integrated_time()                                    # sampler.py:538
+        def decide(tok, done_now):
+            """True = stop (sampler.py:532-552, at every `ncheck` iterations as there: tau of the whole chain now against
+            tau `ncheck` iterations earlier).  The estimate is incremental (DeviceChain), so a check costs the same however
+            long the chain has grown -- rounds 1-4 thinned the checks out because each was a batch of FFTs over the chain."""
+            n = tok["hi"]
+            tau = dchain.tau_end(tok)                                         # sampler.py:538
             old_tau = st["old_tau"]
-            if st["last"] != done - ncheck and done > ncheck:
-                old_tau = dchain.integrated_time(upto=done - ncheck)
-            st["last"] = done
-            nxt = int(done * 1.02) if done > 2000 else done + ncheck
-            if np.all(np.isfinite(tau)):
-                nxt = max(nxt, min(int(0.9 * ntimes * float(np.max(tau))), nsamp - nsamp % ncheck))
-            st["next"] = nxt
-            if np.isnan(np.sum(tau)) and done > 10:
-                return True
-            converged = np.all(tau * ntimes < done)                           # :545-547
-            converged &= np.all(np.abs(old_tau - tau) / tau < tautol)
-            if converged and self.nwalkers > dchain.MAX_WALKERS:
-                # the estimate above averaged over a subset of the walkers: the decision is taken on all of them
-                tau = dchain.integrated_time(all_walkers=True)
-                old_tau = dchain.integrated_time(upto=done - ncheck, all_walkers=True) if done > ncheck else old_tau
-                converged = np.all(tau * ntimes < done) and np.all(np.abs(old_tau - tau) / tau < tautol)
-            converged = converged and dchain.checkmeanstd(max(2, int(nk * np.mean(tau))), meanshift, stdshift)
-            print("max, min tau diff, max tau, ninter: {0}, {1}, {2}, {3}\n".format(
-                np.max(np.abs(old_tau - tau) / tau), np.min(np.abs(old_tau - tau) / tau), np.max(tau), done), flush=True)
             st["old_tau"] = tau
+            if np.isnan(np.sum(tau)) and n > 10:
+                return True
+            with np.errstate(invalid="ignore", divide="ignore"):
+                converged = np.all(tau * ntimes < n)                          # :545-547
+                converged &= np.all(np.abs(old_tau - tau) / tau < tautol)
+                if converged and dchain.subset:
+                    # the estimate above averaged over a subset of the walkers: the decision is taken on all of them
+                    tau = dchain.integrated_time(upto=n, all_walkers=True)
+                    old_tau = dchain.integrated_time(upto=n - ncheck, all_walkers=True) if n > ncheck else np.inf
+                    converged = np.all(tau * ntimes < n) and np.all(np.abs(old_tau - tau) / tau < tautol)
+                converged = converged and dchain.checkmeanstd(max(2, int(nk * np.mean(tau))), meanshift, stdshift)
+                print("max, min tau diff, max tau, ninter: {0}, {1}, {2}, {3}\n".format(
+                    np.max(np.abs(old_tau - tau) / tau), np.min(np.abs(old_tau - tau) / tau), np.max(tau), n), flush=True)
             return bool(converged)
 
-        while done < nsamp:
-            c, l = ens.run(ncheck)
-            c, l, acc = rk.gather(ens, c, l)
-            done += ncheck
-            stop = False
-            if rk.rank == 0:
-                th = ens.theta_of(c)
-                store.append(c, th, l, acc)                                   # device tensors: copied off this thread
-                dchain.append(c)
-                if incremental:
-                    store.flush(final=False)
-                stop = check(done)
-            if rk.bcast(stop):
-                break
+        done = _run_blocks(ens, rk, store, dchain, done, nsamp, ncheck, incremental, lambda n: dchain.tau_begin(), decide, prof)
         if rk.rank == 0:
-            store.flush()
-            DeviceChain.join_prewarm()
+            with prof.host("final_flush"):
+                store.flush()
         rk.barrier()                                                          # the file is complete before any rank reads it
+        prof.finish(total_s=time.perf_counter() - t_start, iterations=done, writer_fetch_s=store.busy["fetch"],
+                    writer_append_s=store.busy["append"], lag_capacity=0 if dchain._S is None else len(dchain._S),
+                    lag_growths=dchain.lag_growths)
         self.sampler = None
         return store
 
@@ -1357,7 +1557,10 @@ class ZeusSampler(object):
         self.seed, self.group = seed, dist_group
 
     def sample(self, pool, nsamp, outdir="./", progress=False, overwrite=False, ntimes=10, tautol=0.01, incremental=True,
-               meanshift=0.1, stdshift=0.1, nk=2, ncheck=100):
+               meanshift=0.1, stdshift=0.1, nk=2, ncheck=100, profile=None):
+        import time
+        t_start = time.perf_counter()
+        prof = _Prof(profile)
         rk = _Ranks(self.nwalkers, self.group)
         store = ChainStore(os.path.join(outdir, "zeus_256.h5"), self.transform)
         x0 = self.x0
@@ -1372,55 +1575,36 @@ class ZeusSampler(object):
         x0 = rk.bcast(x0)
         ens = SliceEnsembleSampler(rk.nw, self.nparams, self.lnp, seed=self.seed, dist_group=self.group, exchange=rk.exchange)
         self.sampler = ens
-        if rk.rank == 0:
-            DeviceChain.prewarm(self.nwalkers, self.nparams, ens.dev)
         ens.set_state(rk.mine(x0))
-        st = {"old_tau": np.inf, "next": 0, "last": -1}
+        st = {"old_tau": np.inf}
         done = rk.bcast(sum(len(c) for c in store.chain))
         dchain = DeviceChain()
         for blk in store.chain:
             dchain.append(np.asarray(blk, np.float32))
 
-        def check(done):                                    # checks thin out as in HMCSampler.sample (same criterion)
-            if done < st["next"]:
-                return False
+        def decide(tok, done_now):                          # sampler.py:667-696 (zeus' callback: every `ncheck` iterations)
+            n = tok["hi"]
+            tau = float(np.mean(dchain.tau_end(tok)))       # discard=0.2, sampler.py:684,729
             old_tau = st["old_tau"]
-            if st["last"] != done - ncheck and done > ncheck:
-                prev = done - ncheck
-                old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev)))
-            tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2))))   # discard=0.2, sampler.py:684,729
-            st["last"] = done
-            nxt = int(done * 1.02) if done > 2000 else done + ncheck
-            if np.isfinite(tau):
-                nxt = max(nxt, int(0.9 * ntimes * tau))
-            st["next"] = nxt
-            converged = tau * ntimes < done
-            converged &= abs(old_tau - tau) / tau < tautol
-            if converged and self.nwalkers > dchain.MAX_WALKERS:      # decide on all walkers (the routine checks use a subset)
-                tau = float(np.mean(dchain.integrated_time(discard=int(done * 0.2), all_walkers=True)))
-                if done > ncheck:
-                    prev = done - ncheck
-                    old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev, all_walkers=True)))
-                converged = tau * ntimes < done and abs(old_tau - tau) / tau < tautol
-            converged = converged and bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
             st["old_tau"] = tau
+            with np.errstate(invalid="ignore", divide="ignore"):
+                converged = tau * ntimes < n
+                converged &= abs(old_tau - tau) / tau < tautol
+                if converged and dchain.subset:               # decide on all walkers (the routine checks use a subset)
+                    tau = float(np.mean(dchain.integrated_time(discard=int(n * 0.2), upto=n, all_walkers=True)))
+                    prev = n - ncheck
+                    old_tau = float(np.mean(dchain.integrated_time(discard=int(prev * 0.2), upto=prev, all_walkers=True))) if prev > 0 else np.inf
+                    converged = tau * ntimes < n and abs(old_tau - tau) / tau < tautol
+                converged = converged and bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
             return bool(converged)
 
-        while done < min(nsamp, 100000):
-            c, l = ens.run(ncheck)
-            c, l, acc = rk.gather(ens, c, l)
-            done += ncheck
-            stop = False
-            if rk.rank == 0:
-                store.append(c, ens.theta_of(c), l, acc)
-                dchain.append(c)
-                if incremental:
-                    store.flush(final=False)
-                stop = check(done)
-            if rk.bcast(stop):
-                break
+        done = _run_blocks(ens, rk, store, dchain, done, min(nsamp, 100000), ncheck, incremental,
+                           lambda n: dchain.tau_begin(discard=int(n * 0.2)), decide, prof)
         if rk.rank == 0:
-            store.flush()
-            DeviceChain.join_prewarm()
+            with prof.host("final_flush"):
+                store.flush()
         rk.barrier()
+        prof.finish(total_s=time.perf_counter() - t_start, iterations=done, writer_fetch_s=store.busy["fetch"],
+                    writer_append_s=store.busy["append"], lag_capacity=0 if dchain._S is None else len(dchain._S),
+                    lag_growths=dchain.lag_growths)
         return store

@@ -11,6 +11,11 @@ TEST INFRASTRUCTURE ONLY.
   a third-party dependency (requirements.txt:14) absent from the reference tree and from
   this image; anchored on the reference call sites sampler.py:493-495, 519-530, its geometry pinned by
   the reference-held emcee chain (tests/test_stretch_fixture.py).
+* ``integrated_time`` restates emcee 3.0.2 ``autocorr.integrated_time`` as the reference calls it
+  (``get_autocorr_time(tol=0)``, sampler.py:538; zeus' ``AutoCorrTime`` callback with ``discard=0.2``,
+  sampler.py:684): FFT autocorrelation per series, averaged over walkers, Sokal window c = 5.  PARITY UNPINNED for the
+  same reason (emcee absent); exercised on the reference-held emcee chain ``chemcee_256.h5``.
+* ``checkmeanstd`` restates sampler.py:370-387.
 * ``philox4x32`` is the published Philox4x32-10 generator (Salmon et al. 2011); the HIP
   sampler kernels use the same counter layout so draws can be replayed here.
 """
@@ -163,3 +168,63 @@ def hmc_batched_step(lnp_and_grad_rows, x, lnp, grad, mass, num_steps, step_size
     ln = np.where(acc, l, lnp)
     gn = np.where(acc[:, None], g, grad)
     return xn.astype(f), ln.astype(f), gn.astype(f), acc
+
+
+# --------------------------------------------------------------------------- convergence statistics
+def _next_pow_two(n):
+    i = 1
+    while i < n:
+        i = i << 1
+    return i
+
+
+def function_1d(x):
+    """emcee.autocorr.function_1d: normalised autocorrelation function of one series through a zero-padded FFT."""
+    x = np.atleast_1d(np.asarray(x, np.float64))
+    n = _next_pow_two(len(x))
+    f = np.fft.fft(x - np.mean(x), n=2 * n)
+    acf = np.fft.ifft(f * np.conjugate(f))[:len(x)].real
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return acf / acf[0]
+
+
+def auto_window(taus, c):
+    """emcee.autocorr.auto_window."""
+    m = np.arange(len(taus)) < c * taus
+    if np.any(m):
+        return int(np.argmin(m))
+    return len(taus) - 1
+
+
+def integrated_time(x, c=5.0):
+    """emcee.autocorr.integrated_time(x, c=5, tol=0) for a chain ``x[nstep, nwalker, ndim]`` -> tau[ndim]
+    (what ``sampler.get_autocorr_time(tol=0)`` returns at sampler.py:538)."""
+    x = np.atleast_1d(np.asarray(x, np.float64))
+    if x.ndim == 1:
+        x = x[:, None, None]
+    if x.ndim == 2:
+        x = x[:, :, None]
+    nt, nw, nd = x.shape
+    tau = np.empty(nd)
+    windows = np.empty(nd, int)
+    for d in range(nd):
+        f = np.zeros(nt)
+        for k in range(nw):
+            f += function_1d(x[:, k, d])
+        f /= nw
+        taus = 2.0 * np.cumsum(f) - 1.0
+        windows[d] = auto_window(taus, c)
+        tau[d] = taus[windows[d]]
+    return tau
+
+
+def checkmeanstd_stats(samples):
+    """The two numbers sampler.py:370-387 compares with its thresholds: median over parameters of the first-half /
+    second-half shift of the mean (in units of the second half's standard deviation) and of the standard deviation."""
+    samples = np.asarray(samples, np.float64)
+    half = int(len(samples) / 2)
+    a = samples[:half].reshape(-1, samples.shape[-1])
+    b = samples[half:].reshape(-1, samples.shape[-1])
+    meanshifte = np.median(np.abs(np.mean(a, axis=0) - np.mean(b, axis=0)) / np.std(b, axis=0))
+    stdshifte = np.median((np.std(a, axis=0) - np.std(b, axis=0)) / np.std(b, axis=0))
+    return meanshifte, stdshifte

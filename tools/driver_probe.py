@@ -1,6 +1,9 @@
 """Driver-level sampling rate: sampler.HMCSampler.sample (emcee driver: burn-in, chain blocks to the host, HDF5 appends,
-convergence checks) against the raw EnsembleSampler.run rate, on the bench problem; where the wall time goes."""
-import sys, os, time, tempfile
+convergence checks at every 100 iterations) against the raw EnsembleSampler.run rate, on the bench problem; where the wall
+time goes (the driver's own profile: host seconds and device seconds per phase).
+usage: driver_probe.py [nwalkers ...]; LINNA_PROBE_DIR = directory of the chain file (default: the temporary directory),
+LINNA_PROBE_NSAMP = iterations."""
+import sys, os, time, tempfile, json, shutil, contextlib, io
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, bench
 from linna_amd import sampler, util
@@ -15,27 +18,20 @@ for nw in sizes:
     raw = 1000 / (time.perf_counter() - t0)
     t0 = time.perf_counter(); ens.run(1000, store=True); torch.cuda.synchronize()
     raw_store = 1000 / (time.perf_counter() - t0)
-    sampler.DeviceChain.prewarm(nw, 33, torch.device("cuda", 0)).join()      # (ml_sampler_core does this while the emulator trains)
+    ens.block_run = False
+    t0 = time.perf_counter(); ens.run(1000, store=True); torch.cuda.synchronize()
+    raw_loop = 1000 / (time.perf_counter() - t0)
     out = tempfile.mkdtemp(dir=os.environ.get("LINNA_PROBE_DIR"))
     drv = sampler.HMCSampler(lp, None, None, 33, nw, x0=x0, transform=util.Transform(priors))
     nsamp = int(os.environ.get("LINNA_PROBE_NSAMP", "3000" if nw > 1000 else "20000"))
-    marks = {}
-    orig_flush = sampler.ChainStore.flush
-    def flush(self, final=True):
-        t = time.perf_counter(); r = orig_flush(self, final); marks[final] = marks.get(final, 0.0) + time.perf_counter() - t; return r
-    sampler.ChainStore.flush = flush
-    orig_it = sampler.DeviceChain.integrated_time
-    def it(self, *a, **k):
-        t = time.perf_counter(); r = orig_it(self, *a, **k); marks["tau"] = marks.get("tau", 0.0) + time.perf_counter() - t; return r
-    sampler.DeviceChain.integrated_time = it
-    t0 = time.perf_counter()
-    store = drv.sample(None, nsamp, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True)     # never converges: runs nsamp
-    torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    sampler.ChainStore.flush, sampler.DeviceChain.integrated_time = orig_flush, orig_it
+    prof = {}
+    with contextlib.redirect_stdout(io.StringIO()):
+        t0 = time.perf_counter()
+        store = drv.sample(None, nsamp, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True, profile=prof)     # never converges: runs nsamp
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
     n = sum(len(c) for c in store.chain)
     sz = os.path.getsize(os.path.join(out, "chemcee_256.h5")) / 1e6
-    import shutil
     shutil.rmtree(out, ignore_errors=True)
-    print("nw %d: raw %.0f it/s (storing the chain on the device: %.0f); driver %d iterations (+100 burn-in) in %.2f s = %.0f it/s; "
-          "incremental flushes %.2f s, final flush %.2f s, tau estimates %.2f s; file %.0f MB in %s" % (
-              nw, raw, raw_store, n, dt, (n + 100) / dt, marks.get(False, 0), marks.get(True, 0), marks.get("tau", 0), sz, out), flush=True)
+    print("nw %d: raw %.0f it/s (one C call per block, chain rows from the kernels: %.0f; per-iteration loop + copies: %.0f); driver %d "
+          "iterations (+100 burn-in) in %.2f s = %.0f it/s; file %.0f MB in %s" % (nw, raw, raw_store, raw_loop, n, dt, (n + 100) / dt, sz, out), flush=True)
+    print("   profile: " + json.dumps({k: (round(v, 4) if isinstance(v, float) else v) for k, v in sorted(prof.items())}), flush=True)
