@@ -132,7 +132,7 @@ def build_problem(device):
     return lp, model, consts
 
 
-def cpu_baseline(consts, z, budget_s=15.0):
+def cpu_baseline(consts, z, budget_s=15.0, gpu_out=None):
     """The numpy oracle (CPU restatement of the reference path) timed on this host: batched
     BLAS evaluation (value; the faster of a 32-thread and an all-core BLAS pool) and the
     reference-faithful per-walker loop (batch 1, one thread)."""
@@ -155,16 +155,43 @@ def cpu_baseline(consts, z, budget_s=15.0):
             rate = n * len(z) / (time.perf_counter() - t0)
         if rate > best[0]:
             best = (rate, nthreads, n)
+    check = {}
+    if gpu_out is not None:               # the GPU's lnP of the SAME walkers against the oracle's (fp32 both; a free self-check)
+        ref = f(z).astype(np.float64)
+        check = {"max_rel_err_vs_oracle": float(np.max(np.abs(np.asarray(gpu_out, np.float64) - ref) / np.abs(ref)))}
     with threadpool_limits(limits=1):
         m, t0 = 0, time.perf_counter()
         while time.perf_counter() - t0 < budget_s * 0.3:
             f(z[m % len(z)][None, :])
             m += 1
         per_walker = m / (time.perf_counter() - t0)
-    return {"value": best[0], "unit": "evals/s", "cores": best[1], "kind": "port",
-            "sample": "numpy oracle (oracle/likelihood.log_prob), fp32: %d passes of the same %d-walker batch with a "
-                      "%d-thread BLAS pool (this process may use %d CPUs); reference-faithful per-walker loop (batch 1, one "
-                      "thread): %.0f evals/s over %d calls" % (best[2], len(z), best[1], cores, per_walker, m)}
+    return dict({"value": best[0], "unit": "evals/s", "cores": best[1], "kind": "port",
+                 "sample": "numpy oracle (oracle/likelihood.log_prob), fp32: %d passes of the same %d-walker batch with a "
+                           "%d-thread BLAS pool (this process may use %d CPUs); reference-faithful per-walker loop (batch 1, one "
+                           "thread): %.0f evals/s over %d calls" % (best[2], len(z), best[1], cores, per_walker, m)}, **check)
+
+
+def _cpu_timed(fn, units_per_call, unit, what, budget_s=5.0):
+    """`cpu_baseline` object of a secondary bench entry: the numpy oracle's restatement of the same work, timed on this
+    host with the BLAS pool the CPU quota allows, on a bounded sample (`budget_s` seconds of calls)."""
+    from threadpoolctl import threadpool_limits
+    from linna_amd.util import cpu_quota
+    cores = cpu_quota()
+    with threadpool_limits(limits=cores):
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s:
+            fn()
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": n * units_per_call / dt, "unit": unit, "cores": cores, "kind": "port",
+            "sample": "%s: %d calls in %.1f s, %d-thread BLAS pool, fp32" % (what, n, dt, cores)}
+
+
+def _oracle_emulator(kind, nin, nout, model, X_mean, X_std, y_mean, y_std, sigma, **kw):
+    from oracle import likelihood
+    w = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+    return likelihood.Emulator(kind, nin, nout, w, X_mean, X_std, y_mean, y_std, sigma, **kw)
 
 
 TRAFFIC_FILE = "r04_pmc_traffic.json"
@@ -342,6 +369,19 @@ def training_rate(device, world, rank, backend, nsteps=150):
     flop = B * (3 * 2.0 * model.macs_per_eval() + 6.0 * nout * nout)
     res["roofline"] = {"bound": "mfma", "flop_per_step": flop, "achieved": flop / (dt / nsteps) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
                        "unit": "TFLOP/s per GPU", "frac": flop / (dt / nsteps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    if world == 1:
+        try:                               # the oracle's optimiser step (forward, loss, backward, AdamW), batch 500, all cores
+            from oracle import training as otr
+            stats = dict(X_mean=X_mean, X_std=X_std, y_mean=y_mean, y_std=y_std, sigma=sigma.astype(np.float32),
+                         data_norm=otr.normalise_target(data[None, :], sigma, y_mean, y_std)[0],
+                         icov_norm=otr.normalised_inverse_cov(cov, sigma, y_std))
+            params = {k_: v_.detach().cpu().numpy().copy() for k_, v_ in model.state_dict().items()}
+            ost = otr.new_opt_state(params)
+            Xb, Yb = X[:B], Y[:B]
+            res["cpu_baseline"] = _cpu_timed(lambda: otr.train_step(params, ost, Xb, Yb, stats, "ChtoModelv2", nin, nout, 1e-4), B, "samples/s",
+                                             "numpy oracle (oracle/training.train_step: forward, chi2-ratio loss, backward, AdamW), batch %d" % B, 5.0)
+        except Exception as e:                                      # noqa: BLE001
+            res["cpu_baseline"] = {"error": repr(e)[:200]}
     if world > 1:
         # the gradient all-reduce alone (flat fp32 buffer + the loss scalar), HIP events on the launch stream
         from linna_amd import dist as ldist, _lib
@@ -414,9 +454,24 @@ def secondary_serving(device, kind, nin, nout, dense, nwalkers=4096, iters=400):
     if dense:
         # SURVEY 8d prices the dense quadratic form at 2 nout^2 FLOP per evaluation; the kernel takes it as |d L|^2 with the
         # lower-triangular Cholesky factor of the inverse covariance and skips the zero block of the second column pass
-        # (nout > 512): 3/4 of those MACs are executed at nout = 1000 -- `achieved` / `frac` price the algorithmic count
-        res["note"] = ("chi^2 = |d L|^2, L = chol(Sigma^-1) lower triangular: for nout > 512 the second column pass starts at row 512 "
-                       "(bit-identical to the full pass); achieved / frac use SURVEY's 2 nout^2 FLOP for the quadratic form")
+        # (nout > 512): `frac` is priced on the FLOP the kernel EXECUTES, `frac_priced` on the algorithmic 2 nout^2
+        skipped = 2.0 * 512 * (nout - 512) if (nout > 512 and os.environ.get("LINNA_DENSE_TRI", "1") != "0"
+                                               and os.environ.get("LINNA_DENSE_FACTORED", "1") != "0") else 0.0
+        tf_exec = nwalkers * (flop_eval - skipped) / (us * 1e-6) / 1e12
+        res.update({"achieved_priced": tf, "frac_priced": tf / FP32_MFMA_PEAK_TFLOPS, "achieved": tf_exec, "frac": tf_exec / FP32_MFMA_PEAK_TFLOPS,
+                    "executed_flop_per_eval": flop_eval - skipped,
+                    "note": "chi^2 = |d L|^2, L = chol(Sigma^-1) lower triangular: for nout > 512 the second column pass starts at row 512 "
+                            "(bit-identical to the full pass); achieved / frac count the FLOP executed, *_priced SURVEY's 2 nout^2 for the quadratic form"})
+    try:                                   # the oracle on the host, same walkers, and the GPU's lnP against it
+        from oracle import likelihood
+        emu = _oracle_emulator(kind, nin, nout, model, np.zeros(nin), np.full(nin, 10.0 / np.sqrt(12.0)), data / sigma, np.ones(nout), sigma)
+        zh, icov = z.cpu().numpy(), np.linalg.inv(cov)
+        f = lambda: likelihood.log_prob(zh, emu, priors, data, icov, 1.0)
+        ref = f().astype(np.float64)
+        res["max_rel_err_vs_oracle"] = float(np.max(np.abs(out.cpu().numpy().astype(np.float64) - ref) / np.abs(ref)))
+        res["cpu_baseline"] = _cpu_timed(f, nwalkers, "evals/s", "numpy oracle (oracle/likelihood.log_prob), the same %d walkers per call" % nwalkers, 4.0)
+    except Exception as e:                                          # noqa: BLE001
+        res["cpu_baseline"] = {"error": repr(e)[:200]}
     return res
 
 
@@ -567,6 +622,20 @@ def hmc_rate(device, nchains=4096, nleap=5, nsamp=400):
         ident_err = float(np.max(np.abs(lnp.cpu().numpy() - exact) / np.abs(exact)))
         us = _events_us(lambda: lp.evaluate_with_grad(z, out=lnp, grad=g), 300)
         assert torch.isfinite(g).all() and torch.isfinite(lnp).all()
+        cpu = None
+        try:                               # the oracle's lnP + gradient of the same chains on the host (oracle/likelihood.grad_log_prob)
+            from oracle import likelihood
+            xs_ = 10.0 / np.sqrt(12.0)
+            emu = _oracle_emulator(kind, NIN, NOUT, model, np.zeros(NIN), np.full(NIN, xs_), np.zeros(NOUT), xs_ / sigma, sigma,
+                                   **({"width": WIDTH, "depth": DEPTH} if kind == "MLP" else {}))
+            pri = [{"param": "p%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(NIN)]
+            icov = np.diag(1.0 / sigma ** 2)
+            fg = lambda: likelihood.grad_log_prob(z0, emu, pri, data, icov, 1.0)
+            _, gref = fg()
+            cpu = _cpu_timed(fg, nchains, "gradient evals/s", "numpy oracle (oracle/likelihood.grad_log_prob), the same %d chains per call" % nchains, 4.0)
+            cpu["max_grad_err_vs_oracle_rowmax"] = float(np.max(np.abs(g.cpu().numpy() - gref) / np.abs(gref).max(axis=1, keepdims=True)))
+        except Exception as e:                                      # noqa: BLE001
+            cpu = {"error": repr(e)[:200]}
         flop = nchains * 2.0 * (2.0 * model.macs_per_eval())
         # step size: short pilot runs, multiplicative search into the 0.65-0.8 band (same chains, same seed policy)
         h = sampler.BatchedHMC(lp, z0, seed=3)
@@ -602,7 +671,8 @@ def hmc_rate(device, nchains=4096, nleap=5, nsamp=400):
                     "tau_worst_parameter": tau_max, "tau_median_parameter": tau_med,
                     "ess_per_s": nchains * nsamp / tau_max / dt, "ess_per_s_per_chain": nsamp / tau_max / dt,
                     "emulator_identity_max_rel_err": ident_err,
-                    "posterior_mean_max_abs_dev_sigma": float(np.max(np.abs(thm - data) / sigma))}
+                    "posterior_mean_max_abs_dev_sigma": float(np.max(np.abs(thm - data) / sigma)),
+                    "cpu_baseline": cpu}
     return out
 
 
@@ -949,7 +1019,8 @@ def main():
                 except Exception as e:                              # noqa: BLE001
                     res[key] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
-            res["cpu_baseline"] = cpu_baseline(consts, z_host)
+            lp.evaluate(z, out=out)
+            res["cpu_baseline"] = cpu_baseline(consts, z_host, gpu_out=out.cpu().numpy())
         if dog is None:
             print(json.dumps(res), flush=True)
         else:

@@ -314,7 +314,7 @@ int linna_logprob_grad_leapfrog(linna_logprob_t* lp, float* Q, int ldq, int B, v
 
 /* ------------------------------------------------------------------ training
  * chi^2-ratio loss of util.py:1070-1088,1114-1116 on the raw network output PRED:
- *   delta = mask ? 0 : ((y/sigma - ymean)/ystd - pred);  chi2 = delta Cinv delta^T
+ *   delta = mask ? 0 : ((y/sigma - ymean)/ystd - pred)  [ylog: log(y/sigma) for y/sigma];  chi2 = delta Cinv delta^T
  *   loss_b = chi2 / den_b ; L = inv_batch * sum_b loss_b ;  dPRED = -2 (delta Cinv) inv_batch/den_b
  *   (Cinv symmetric; inv_batch = 1/global batch so data-parallel shards sum to the mean)
  * den_b = max(chisqMd_b, nout/2) is precomputed per dataset row (linna_chi2_md).
@@ -324,6 +324,9 @@ typedef struct {
     const float* sigma; const float* ymean; const float* ystd;   /* [nout] */
     const float* data_norm;                                       /* [nout] */
     const float* Cinv; int ldc;                                   /* [nout][nout], symmetric */
+    int ylog;   /* ABI 9 (fills what was tail padding: the struct's size is unchanged): 1 = `ypositive` training, the target is
+                 * normalised as (log(y/sigma) - ymean)/ystd (util.py:567-571, 1444-1447); ymean / ystd / data_norm / Cinv are
+                 * then the log-space constants the caller computed (util.py:1444-1447, 573-586) */
 } linna_loss_desc_t;
 
 /* floats of scratch the three loss entry points need for a batch of B rows, in bytes */

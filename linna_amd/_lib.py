@@ -54,7 +54,7 @@ class LogprobDesc(C.Structure):
 
 class LossDesc(C.Structure):
     _fields_ = [("nout", C.c_int), ("sigma", C.c_void_p), ("ymean", C.c_void_p), ("ystd", C.c_void_p),
-                ("data_norm", C.c_void_p), ("Cinv", C.c_void_p), ("ldc", C.c_int)]
+                ("data_norm", C.c_void_p), ("Cinv", C.c_void_p), ("ldc", C.c_int), ("ylog", C.c_int)]
 
 
 OP_LINEAR, OP_RESBLOCK, OP_INSKIP = 0, 1, 2

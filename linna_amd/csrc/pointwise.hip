@@ -137,7 +137,7 @@ __global__ void loglike_diag_grad_kernel(const float* __restrict__ D, int ldd, i
 // mode 0: delta = ynorm - pred ; mode 1: ynorm - data_norm ; mode 2: pred - data_norm ; masked -> 0
 __global__ void loss_delta_kernel(int mode, const float* __restrict__ PRED, int ldp, const float* __restrict__ Y, int ldy,
                                   const int* __restrict__ ROWS, int B, int nout, const float* __restrict__ sigma,
-                                  const float* __restrict__ ymean, const float* __restrict__ ystd,
+                                  const float* __restrict__ ymean, const float* __restrict__ ystd, int ylog,
                                   const float* __restrict__ data_norm, float* __restrict__ DELTA, int ldd) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * ldd) return;
@@ -147,7 +147,7 @@ __global__ void loss_delta_kernel(int mode, const float* __restrict__ PRED, int 
     const float y = Y[(size_t)r * ldy + j];
     const float dn = data_norm[j];
     const bool masked = (y == 1e-30f) | (y == 1e10f) | (dn == 1e-30f);
-    const float yn = (y / sigma[j] - ymean[j]) / ystd[j];
+    const float yn = ((ylog ? logf(y / sigma[j]) : y / sigma[j]) - ymean[j]) / ystd[j];   // ylog: util.py:567-571 (ypositive)
     float v;
     if (mode == 0) v = yn - PRED[(size_t)i * ldp + j];
     else if (mode == 1) v = yn - dn;
@@ -158,7 +158,7 @@ __global__ void loss_delta_kernel(int mode, const float* __restrict__ PRED, int 
 // Normalised targets of a whole data set, once: YN = (y / sigma - ymean) / ystd (loss_delta_kernel's formula), NaN where
 // the element is masked (util.py:1072) -- what the one-launch training forward subtracts its prediction from.
 __global__ void loss_targets_kernel(const float* __restrict__ Y, int ldy, int n, int nout, const float* __restrict__ sigma,
-                                    const float* __restrict__ ymean, const float* __restrict__ ystd,
+                                    const float* __restrict__ ymean, const float* __restrict__ ystd, int ylog,
                                     const float* __restrict__ data_norm, float* __restrict__ YN, int ldyn) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)n * ldyn) return;
@@ -166,7 +166,7 @@ __global__ void loss_targets_kernel(const float* __restrict__ Y, int ldy, int n,
     if (j >= nout) { YN[idx] = 0.f; return; }
     const float y = Y[(size_t)i * ldy + j];
     const bool masked = (y == 1e-30f) | (y == 1e10f) | (data_norm[j] == 1e-30f);
-    YN[idx] = masked ? __builtin_nanf("") : (y / sigma[j] - ymean[j]) / ystd[j];
+    YN[idx] = masked ? __builtin_nanf("") : ((ylog ? logf(y / sigma[j]) : y / sigma[j]) - ymean[j]) / ystd[j];
 }
 
 // chi2_b = sum_s partial[b][s]; mode 0: out[b] = max(chi2, floor) (denominator, util.py:1086)
@@ -203,7 +203,7 @@ __global__ void loss_grad_kernel(const float* __restrict__ U, int ldu, const flo
 // `counter` is a zeroed int that wraps back to zero by itself (atomicInc).
 __global__ __launch_bounds__(256) void loss_fused_small_kernel(
         const float* __restrict__ PRED, int ldp, const float* __restrict__ Y, int ldy, const int* __restrict__ ROWS, int B,
-        int nout, const float* __restrict__ sigma, const float* __restrict__ ymean, const float* __restrict__ ystd,
+        int nout, const float* __restrict__ sigma, const float* __restrict__ ymean, const float* __restrict__ ystd, int ylog,
         const float* __restrict__ data_norm, const float* __restrict__ Cinv, int ldc, const float* __restrict__ den,
         float inv_batch, float* __restrict__ loss_rows, float* __restrict__ loss_mean, float* __restrict__ dP, int lddp,
         unsigned* counter) {
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void loss_fused_small_kernel(
         const int j = in ? lane : 0;
         const float y = Y[(size_t)r * ldy + j], dn = data_norm[j];
         const bool masked = !in | (y == 1e-30f) | (y == 1e10f) | (dn == 1e-30f);
-        const float yn = (y / sigma[j] - ymean[j]) / ystd[j];
+        const float yn = ((ylog ? logf(y / sigma[j]) : y / sigma[j]) - ymean[j]) / ystd[j];
         const float delta = masked ? 0.f : yn - PRED[(size_t)b * ldp + j];
         float u = 0.f;
         for (int k = 0; k < nout; ++k) u += __shfl(delta, k, 64) * C[k * 65 + j];
@@ -778,19 +778,19 @@ int launch_loglike_diag_grad(const float* D, int ldd, int B, int nout, const flo
 int launch_loss_delta(int mode, const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
                       const linna_loss_desc_t& d, float* DELTA, int ldd, hipStream_t s) {
     hipLaunchKernelGGL(loss_delta_kernel, grid1d((size_t)B * ldd, 256), dim3(256), 0, s, mode, PRED, ldp, Y, ldy, ROWS,
-                       B, d.nout, d.sigma, d.ymean, d.ystd, d.data_norm, DELTA, ldd);
+                       B, d.nout, d.sigma, d.ymean, d.ystd, d.ylog, d.data_norm, DELTA, ldd);
     LAUNCH_CHECK("loss_delta");
 }
 int launch_loss_targets(const float* Y, int ldy, int n, const linna_loss_desc_t& d, float* YN, int ldyn, hipStream_t s) {
     hipLaunchKernelGGL(loss_targets_kernel, grid1d((size_t)n * ldyn, 256), dim3(256), 0, s, Y, ldy, n, d.nout, d.sigma, d.ymean,
-                       d.ystd, d.data_norm, YN, ldyn);
+                       d.ystd, d.ylog, d.data_norm, YN, ldyn);
     LAUNCH_CHECK("loss_targets");
 }
 int launch_loss_fused_small(const float* PRED, int ldp, const float* Y, int ldy, const int* ROWS, int B,
                             const linna_loss_desc_t& d, const float* den, float inv_batch, float* loss_rows, float* loss_mean,
                             float* dP, int lddp, unsigned* counter, hipStream_t s) {
     hipLaunchKernelGGL(loss_fused_small_kernel, dim3((B + 3) / 4), dim3(256), 0, s, PRED, ldp, Y, ldy, ROWS, B, d.nout, d.sigma,
-                       d.ymean, d.ystd, d.data_norm, d.Cinv, d.ldc, den, inv_batch, loss_rows, loss_mean, dP, lddp, counter);
+                       d.ymean, d.ystd, d.ylog, d.data_norm, d.Cinv, d.ldc, den, inv_batch, loss_rows, loss_mean, dP, lddp, counter);
     LAUNCH_CHECK("loss_fused_small");
 }
 int launch_loss_rows(int mode, const float* partial, int slots_ld, int nslots, int B, const float* den, const int* ROWS,

@@ -54,8 +54,6 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
         filename = "zeus_256.h5"
     else:
         raise NotImplementedError(method)
-    if nbest is not None and not (isinstance(nbest, list) and all(n <= 0 for n in nbest)):
-        raise NotImplementedError("nbest (optimizer-seeded training points) is outside the hot path")
     if nnmodel_in is None:
         nnmodel_in = lnn.ChtoModelv2
     limit_threads_to_quota()
@@ -98,15 +96,27 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
             prev = os.path.join(outdir, "iter_{0}/".format(i - 1), filename[:-3])
             chain, _, _ = read_chain_and_cut(prev, nk, ntimes, method=method)
         nnsampler = NN_samplerv1(outdir_in, prior_range)
+        nbest_in = nbest[i] if isinstance(nbest, list) else nbest                # main.py:140-152
+        if nbest_in is not None and nbest_in <= 0:
+            nbest_in = None
+        negloglike = None
+        if nbest_in is not None:
+            import tempfile
+            tempdir = tempfile.TemporaryDirectory()
+
+            def negloglike(x, tempdir=tempdir):
+                d = data - theory([-1, x], tempdir)
+                return d.dot(inv_cov.dot(d))
         if rank == 0:
             generate_training_point(theory, nnsampler, pool, outdir_in, nt, nv, data, inv_cov, chain, nsigma=nsigma,
-                                    omegab2cut=omegab2cut, options=params.get("trainingoption", 0), chisqcut=chisqcut)
+                                    omegab2cut=omegab2cut, options=params.get("trainingoption", 0), negloglike=negloglike,
+                                    nbest_in=nbest_in, chisqcut=chisqcut)
         chain = None
         gc.collect()
         ldist.barrier()                                                          # the training points are on disk
         outdir_list = [os.path.join(outdir, "iter_{0}/".format(m)) for m in range(i + 1)]
         args = [None, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog10index, ypositive, False, 2, temperature,
-                True, None, world, None, params, False]
+                True, None, world, None, params, nbest_in is not None]
         if master:
             with open(os.path.join(outdir_in, "model_args.pkl"), "wb") as f:     # main.py:192-198 (artefact parity)
                 pickle.dump(args, f)

@@ -25,7 +25,7 @@ import torch
 from . import _lib, h5lite
 
 __all__ = ["EnsembleSampler", "SliceEnsembleSampler", "BatchedHMC", "HMCSampler", "ZeusSampler", "checkmeanstd", "integrated_time",
-           "ChainStore", "DeviceChain", "read_chain_and_cut"]
+           "ChainStore", "DeviceChain", "read_chain_and_cut", "get_good_walker_list"]
 
 
 # ------------------------------------------------------------------ convergence statistics (host)
@@ -664,12 +664,22 @@ class ChainStore(object):
         return self.load(self.base)["chain"][-1]
 
 
+def get_good_walker_list(log_prob_samples):
+    """util.py:57-66 (``walkercut=True``; no caller in the reference passes it): the walkers whose mean log-probability over
+    the last 10000 steps, truncated to an integer, falls into the highest of sklearn's ``KMeans()`` clusters (8 clusters,
+    unseeded, as there; ``np.int`` of the reference's numpy is today's ``int``)."""
+    from sklearn.cluster import KMeans
+    x = np.mean(log_prob_samples[-10000:, :], axis=0)
+    X = np.array(list(zip(x, np.zeros(len(x)))), dtype=int)
+    ms = KMeans()
+    ms.fit(X)
+    best = ms.labels_[np.argmax(ms.cluster_centers_[:, 0])]
+    print(np.where(ms.labels_ == best)[0], ms.cluster_centers_, ms.labels_)
+    return np.where(ms.labels_ == best)[0]
+
+
 def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee", flat=False):
     """util.py:68-94: last ``nk`` autocorrelation times of the stored chain (theta space)."""
-    if walkercut:
-        # util.py:57-66 selects walkers with an unseeded sklearn KMeans over integer-cast mean log-probabilities; no caller
-        # in the reference ever passes walkercut=True (main.py:164,290,303), and its np.int no longer exists in numpy
-        raise NotImplementedError("walkercut=True (KMeans walker selection, util.py:57-66) is not part of the hot path")
     d = ChainStore.load(chainname)
     if nk > ntimes:
         print("Error: keep number greater then chain samples. nk: {0}, ntimes: {1}. This will lead to inclusion of all "
@@ -683,8 +693,9 @@ def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee"
     nkeep = int(np.nanmedian(tau) * nk)
     chain = d["chain_transformed"]
     lp = d["log_prob"]
-    chain = np.asarray(chain[-nkeep:].reshape(-1, chain.shape[-1]), np.float64)
-    lp = np.asarray(lp[-nkeep:], np.float64)
+    good = get_good_walker_list(np.asarray(lp)) if walkercut else slice(None)       # util.py:86-89
+    chain = np.asarray(chain[-nkeep:][:, good].reshape(-1, chain.shape[-1]), np.float64)
+    lp = np.asarray(lp[-nkeep:][:, good], np.float64)
     if flat:
         lp = lp.reshape(-1, 1)
     return chain, lp, d

@@ -46,6 +46,7 @@ class TrainEngine(object):
         d.nout = self.nout
         d.sigma, d.ymean, d.ystd = (_lib.ptr(self._keep[n]) for n in ("sigma", "ymean", "ystd"))
         d.data_norm, d.Cinv, d.ldc = _lib.ptr(self._keep["data_norm"]), _lib.ptr(self._keep["cinv"]), ldc
+        d.ylog = 1 if getattr(loss_fn.auxileryfunction.y_inv_transform, "ypositive", False) else 0     # util.py:567-571
         self.desc = d
         self.den = self._chi2_md(self.Y)
         self.val = None

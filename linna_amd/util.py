@@ -610,8 +610,9 @@ def median_absolute_deviation(y, median, dim):
     return torch.abs(y - median).median(axis=dim).values
 
 
-def _load_samples(outdir_list):
-    """util.py:1342-1373: concatenate the samples of all iterations so far."""
+def _load_samples(outdir_list, usebest=False):
+    """util.py:1342-1409: concatenate the samples of all iterations so far; ``usebest``: with the optimizer-seeded samples
+    (``best_samples_*``, util.py:1235-1252) in front."""
     tx, ty, vx, vy = [], [], [], []
     for outdir in outdir_list:
         for lst, name, loader in ((tx, "train_samples_x.txt", np.loadtxt), (ty, "train_samples_y.npy", np.load),
@@ -623,6 +624,25 @@ def _load_samples(outdir_list):
     train_y_last = np.load(outdir_list[0] + "train_samples_y.npy")
     if len(train_y_last) == 0:
         train_y_last = train_y
+    if usebest:                                                                            # util.py:1375-1408
+        bx = [a for a in (np.loadtxt(o + "best_samples_x.txt") for o in outdir_list) if len(a) > 1]
+        by = [a for a in (np.load(o + "best_samples_y.npy") for o in outdir_list) if len(a) > 1]
+        try:
+            bx, by = np.concatenate(bx), np.concatenate(by)
+        except ValueError:
+            bx, by = np.array(bx), np.array(by)
+        if bx.ndim > 1:
+            if train_x.ndim > 1:
+                train_x, train_y = np.concatenate([bx, train_x]), np.concatenate([by, train_y])
+            else:
+                train_x, train_y, train_y_last = bx, by, by
+        vbx = np.concatenate([np.loadtxt(o + "best_samples_x_val.txt") for o in outdir_list])
+        vby = np.concatenate([np.load(o + "best_samples_y_val.npy") for o in outdir_list])
+        if vbx.ndim > 1:
+            if val_x.ndim > 1:
+                val_x, val_y = np.concatenate([vbx, val_x]), np.concatenate([vby, val_y])
+            else:
+                val_x, val_y = vbx, vby
     return train_x, train_y, val_x, val_y, train_y_last
 
 
@@ -649,10 +669,6 @@ def train_NN(nnsampler, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog
     """Prepare statistics, transforms and loss, then train (util.py:1315-1472).  Same positional
     signature as the reference (``model_args.pkl`` holds the first 18 arguments, main.py:197).
     ``docuda`` is accepted for parity; training always runs on the GPU here."""
-    if ypositive:
-        raise NotImplementedError("ypositive=True training (log-space targets) is not on the ml_sampler path (main.py:66)")
-    if usebest:
-        raise NotImplementedError("usebest (optimizer-generated samples, main.py:146-152) is outside the hot path")
     if device is None:
         device = "cuda"
     sigma = np.asarray(sigma)
@@ -662,24 +678,50 @@ def train_NN(nnsampler, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog
         y_transform_data.pickle(os.path.join(outdir_in, "y_transform_data.pkl"))
         y_invtransform_data.pickle(os.path.join(outdir_in, "y_invtransform_data.pkl"))
     data_tensor = torch.from_numpy(np.asarray(data).astype(np.float32))
-    train_x, train_y, val_x, val_y, train_y_last = _load_samples(outdir_list)
+    train_x, train_y, val_x, val_y, train_y_last = _load_samples(outdir_list, usebest)
     print(train_x.shape, train_y.shape, val_x.shape, val_y.shape)
-    # sentinel clipping, util.py:1433-1438
-    train_y = np.clip(train_y, -1e5, 1e10)
-    val_y = np.clip(val_y, -1e5, 1e8)
-    train_y_last = np.clip(train_y_last, -1e5, 1e10)
+    if ypositive:
+        # util.py:1410-1431: positive data vectors are emulated in log space.  Clip to [1e-30, 1e10] (both ends are the
+        # loss's mask sentinels, util.py:1072), drop rows that are 1e-30 throughout -- with the reference's own loop, which
+        # deletes by the indices found BEFORE the first deletion (two or more such rows: the later deletions hit the rows
+        # one further down, as there)
+        train_y, val_y, train_y_last = np.array(train_y, np.float64), np.array(val_y, np.float64), np.array(train_y_last, np.float64)
+        train_y[np.where(train_y > 1e10)] = 1e10
+        train_y[np.where(train_y < 1e-30)] = 1e-30
+        train_y_last[np.where(train_y_last < 1e-30)] = 1e-30
+        val_y[np.where(val_y > 1e10)] = 1e10
+        val_y[np.where(val_y < 1e-30)] = 1e-30
+        for item in np.where(np.mean(train_y, axis=1) == 1e-30)[0]:
+            train_y = np.delete(train_y, item, 0)
+            train_x = np.delete(train_x, item, 0)
+        for item in np.where(np.mean(train_y_last, axis=1) == 1e-30)[0]:
+            train_y_last = np.delete(train_y_last, item, 0)
+        for item in np.where(np.mean(val_y, axis=1) == 1e-30)[0]:
+            val_y = np.delete(val_y, item, 0)
+            val_x = np.delete(val_x, item, 0)
+    else:
+        # sentinel clipping, util.py:1433-1438
+        train_y = np.clip(train_y, -1e5, 1e10)
+        val_y = np.clip(val_y, -1e5, 1e8)
+        train_y_last = np.clip(train_y_last, -1e5, 1e10)
     X1 = torch.tensor(train_x, dtype=torch.float32)
     if dolog10index is not None:
         for ind in dolog10index:
             X1[:, ind] = torch.log10(X1[:, ind])
     X_mean, X_std = X1.mean(axis=0), X1.std(axis=0)                                       # util.py:1440-1441
     X_transform = X_transform_class(X_mean, X_std, "cpu", dolog10index)
-    ys = y_transform_data(torch.tensor(train_y_last, dtype=torch.float32))
-    y_mean = ys.median(axis=0).values                                                     # util.py:1449
-    y_std = median_absolute_deviation(ys, y_mean, 0)
-    y_std[y_std < 1e-10] = 1.0                                                            # util.py:1451
-    y_transform = Y_transform_class(y_mean, y_std, "cpu", ypositive=False)
-    y_inv_transform = Y_invtransform_class(y_mean, y_std, data_tensor, "cpu", ypositive=False)
+    if ypositive:
+        # util.py:1444-1447: median / median absolute deviation of log(y / sigma) over ALL training rows (no floor on y_std)
+        ys = torch.log(y_transform_data(torch.tensor(train_y, dtype=torch.float32)))
+        y_mean = ys.median(axis=0).values
+        y_std = median_absolute_deviation(ys, y_mean, 0)
+    else:
+        ys = y_transform_data(torch.tensor(train_y_last, dtype=torch.float32))
+        y_mean = ys.median(axis=0).values                                                 # util.py:1449
+        y_std = median_absolute_deviation(ys, y_mean, 0)
+        y_std[y_std < 1e-10] = 1.0                                                        # util.py:1451
+    y_transform = Y_transform_class(y_mean, y_std, "cpu", ypositive=bool(ypositive))
+    y_inv_transform = Y_invtransform_class(y_mean, y_std, data_tensor, "cpu", ypositive=bool(ypositive))
     if rank == 0:
         X_transform.pickle(os.path.join(outdir_in, "X_transform.pkl"))
         y_transform.pickle(os.path.join(outdir_in, "y_transform.pkl"))
@@ -850,8 +892,6 @@ def generate_training_point(theory, nnsampler, pool, outdir, ntrain, nval, data,
                             omegab2cut=None, options=0, negloglike=None, nbest_in=None, chisqcut=None):
     """util.py:1167-1258: design the training / validation parameters, evaluate the user's theory
     on them, store ``{train,val}_samples_{x.txt,y.npy}`` (skipping whatever already exists)."""
-    if negloglike is not None:
-        raise NotImplementedError("nbest (optimizer-seeded samples, util.py:1235-1252) is outside the hot path")
     if not (pool is None or pool.is_master()):
         return
     os.makedirs(outdir, exist_ok=True)
@@ -874,6 +914,58 @@ def generate_training_point(theory, nnsampler, pool, outdir, ntrain, nval, data,
             np.save(fy, nnsampler.generate_training_data(zip(range(len(x)), x), theory, pool=pool, args=[sub]))
         if chisqcut is not None:
             chisqcut_all(data, invcov, chisqcut, fy, fx)
+    if negloglike is not None:
+        # util.py:1235-1252 (`nbest`): one Nelder-Mead fit of the true theory from the first training point, then nbest_in
+        # (and nbest_in nval / ntrain validation) draws from N(best fit, inverse Hessian) and the theory at them.  The
+        # reference takes the Hessian from numdifftools (third party, absent from its tree and from this image): here central
+        # second differences with steps of 1e-4 (|x| + 1e-2) -- PARITY UNPINNED for that matrix; the draws are unseeded there too.
+        from scipy.optimize import minimize
+        from scipy.stats import multivariate_normal
+        import tempfile
+        fbx, fbv = os.path.join(outdir, "best_samples_x.txt"), os.path.join(outdir, "best_samples_x_val.txt")
+        if not os.path.isfile(fbx):
+            x0 = np.loadtxt(os.path.join(outdir, "train_samples_x.txt"))[0]
+            best = minimize(negloglike, x0, method="Nelder-Mead", tol=1e-6).x
+            inv_hess = np.linalg.inv(makepositivedefinite(numerical_hessian(negloglike, best)))
+            np.savetxt(fbx, multivariate_normal.rvs(mean=best, cov=inv_hess, size=nbest_in, random_state=None))
+            np.savetxt(fbv, multivariate_normal.rvs(mean=best, cov=inv_hess, size=int(nbest_in / ntrain * nval), random_state=None))
+        if not os.path.isfile(os.path.join(outdir, "best_samples_y.npy")):
+            for fx, fy in ((fbx, "best_samples_y.npy"), (fbv, "best_samples_y_val.npy")):
+                x = np.loadtxt(fx)
+                with tempfile.TemporaryDirectory() as tmp:
+                    np.save(outdir + fy, nnsampler.generate_training_data(zip(range(len(x)), x), theory, pool=pool, args=[tmp]))
+        if chisqcut is not None:
+            chisqcut_all(data, invcov, chisqcut, os.path.join(outdir, "best_samples_y.npy"), fbx)
+            chisqcut_all(data, invcov, chisqcut, os.path.join(outdir, "best_samples_y_val.npy"), fbv)
+
+
+def makepositivedefinite(cov, fcut=0.99):
+    """util.py:38-48 (without its stray plot): eigenvalues below zero set to zero, those past the `fcut` point of the
+    cumulative spectrum raised to the value there."""
+    eigvals, eigvec = np.linalg.eigh(cov)
+    eigvals, eigvec = eigvals[::-1].copy(), eigvec[:, ::-1]
+    eigvals[eigvals < 0] = 0
+    cumsum = np.cumsum(eigvals)
+    cumsum = cumsum / np.max(cumsum)
+    ind = np.argmin(np.abs(cumsum - fcut))
+    eigvals[ind:] = eigvals[ind]
+    return eigvec @ np.diag(eigvals) @ eigvec.T
+
+
+def numerical_hessian(f, x):
+    """Central second differences of a scalar function (stands in for numdifftools.Hessian, util.py:1240)."""
+    x = np.asarray(x, np.float64)
+    n = len(x)
+    h = 1e-4 * (np.abs(x) + 1e-2)
+    H = np.zeros((n, n))
+    f0 = f(x)
+    for i in range(n):
+        ei = np.zeros(n); ei[i] = h[i]
+        H[i, i] = (f(x + ei) - 2 * f0 + f(x - ei)) / h[i] ** 2
+        for j in range(i):
+            ej = np.zeros(n); ej[j] = h[j]
+            H[i, j] = H[j, i] = (f(x + ei + ej) - f(x + ei - ej) - f(x - ei + ej) + f(x - ei - ej)) / (4 * h[i] * h[j])
+    return H
 
 
 class LogPrior(object):

@@ -21,19 +21,50 @@ def lower_median(a, axis=0):
     return np.take(s, (n - 1) // 2, axis=axis)
 
 
-def data_statistics(train_x, train_y, train_y_last, sigma, dolog10index=None):
-    """X_mean/X_std, y_mean/y_std of util.py:1433-1451 (``ypositive=False`` branch).
+def ypositive_clip(train_x, train_y, train_y_last, val_x, val_y):
+    """util.py:1410-1431 (``ypositive=True``): clip to [1e-30, 1e10] and delete the rows that are 1e-30 throughout -- with
+    the reference's loop, which uses the indices found before the first deletion.  Returns copies."""
+    train_x, val_x = np.array(train_x), np.array(val_x)
+    train_y, train_y_last, val_y = (np.array(a, np.float64) for a in (train_y, train_y_last, val_y))
+    train_y[np.where(train_y > 1e10)] = 1e10
+    train_y[np.where(train_y < 1e-30)] = 1e-30
+    train_y_last[np.where(train_y_last < 1e-30)] = 1e-30
+    val_y[np.where(val_y > 1e10)] = 1e10
+    val_y[np.where(val_y < 1e-30)] = 1e-30
+    for item in np.where(np.mean(train_y, axis=1) == 1e-30)[0]:
+        train_y = np.delete(train_y, item, 0)
+        train_x = np.delete(train_x, item, 0)
+    for item in np.where(np.mean(train_y_last, axis=1) == 1e-30)[0]:
+        train_y_last = np.delete(train_y_last, item, 0)
+    for item in np.where(np.mean(val_y, axis=1) == 1e-30)[0]:
+        val_y = np.delete(val_y, item, 0)
+        val_x = np.delete(val_x, item, 0)
+    return train_x, train_y, train_y_last, val_x, val_y
 
-    Sentinel clipping (util.py:1433-1438) is applied to copies.  Returns float32 arrays.
+
+def data_statistics(train_x, train_y, train_y_last, sigma, dolog10index=None, ypositive=False):
+    """X_mean/X_std, y_mean/y_std of util.py:1433-1451.
+
+    ``ypositive=False``: sentinel clipping (util.py:1433-1438) is applied to copies; y statistics of the first iteration's
+    targets.  ``ypositive=True`` (arrays already through ``ypositive_clip``): lower median / median absolute deviation of
+    log(y / sigma) over ALL training rows, no floor on y_std (util.py:1444-1447).  Returns float32 arrays.
     """
-    train_y = np.clip(np.array(train_y, np.float64), -1e5, 1e10)
-    train_y_last = np.clip(np.array(train_y_last, np.float64), -1e5, 1e10)
+    if ypositive:
+        train_y = np.array(train_y, np.float64)
+    else:
+        train_y = np.clip(np.array(train_y, np.float64), -1e5, 1e10)
+        train_y_last = np.clip(np.array(train_y_last, np.float64), -1e5, 1e10)
     X1 = np.array(train_x, np.float32)
     if dolog10index is not None:
         for i in dolog10index:
             X1[:, i] = np.log10(X1[:, i])
     X_mean = X1.mean(axis=0, dtype=np.float32)
     X_std = X1.std(axis=0, ddof=1, dtype=np.float32)              # torch .std is unbiased
+    if ypositive:
+        ys = np.log(train_y.astype(np.float32) / np.asarray(sigma, np.float32)[None, :])
+        y_mean = lower_median(ys, 0)
+        y_std = lower_median(np.abs(ys - y_mean[None, :]), 0)
+        return X_mean, X_std.astype(np.float32), y_mean.astype(np.float32), y_std.astype(np.float32)
     ys = train_y_last.astype(np.float32) / np.asarray(sigma, np.float32)[None, :]
     y_mean = lower_median(ys, 0)
     y_std = lower_median(np.abs(ys - y_mean[None, :]), 0)
@@ -41,23 +72,41 @@ def data_statistics(train_x, train_y, train_y_last, sigma, dolog10index=None):
     return X_mean, X_std.astype(np.float32), y_mean.astype(np.float32), y_std.astype(np.float32)
 
 
-def normalised_inverse_cov(cov, sigma, y_std):
+def normalised_inverse_cov(cov, sigma, y_std, ypositive=False, data=None):
     """util.py:1063-1064 with util.py:447 and :590: C~ = D2 (D1 cov^T D1)^T D2 in fp64 with
-    D1 = diag(1/sigma_f32), D2 = diag(1/y_std_f32); returns inverse cast to fp32."""
+    D1 = diag(1/sigma_f32), D2 = diag(1/y_std_f32); returns inverse cast to fp32.
+    ``ypositive`` (util.py:579-585): between the two scalings the matrix becomes log(1 + E c E), E = diag(1 / data) with
+    the fp32 data vector in PHYSICAL units as the reference passes it, entries <= -1 set to 1e-10 - 1 first."""
     d1 = 1.0 / np.asarray(sigma, np.float32).astype(np.float64)
     d2 = 1.0 / np.asarray(y_std, np.float32).astype(np.float64)
     c1 = (np.diag(d1) @ np.asarray(cov, np.float64).T) @ np.diag(d1).T
+    if ypositive:
+        e = np.diag(1.0 / np.asarray(data, np.float32).astype(np.float64))
+        c0 = (e @ c1.T) @ e.T
+        c0[c0 <= -1] = 1e-10 - 1
+        c1 = np.log(1 + c0)
     c2 = (np.diag(d2) @ c1.T) @ np.diag(d2).T
     return np.linalg.inv(c2).astype(np.float32)
 
 
-def normalise_target(y, sigma, y_mean, y_std):
-    """y_inv_transform(y_transform_data(y)) (util.py:1071): ((y/sigma) - y_mean)/y_std."""
+def normalise_target(y, sigma, y_mean, y_std, ypositive=False):
+    """y_inv_transform(y_transform_data(y)) (util.py:1071): ((y/sigma) - y_mean)/y_std; ``ypositive`` (util.py:567-571):
+    log(y/sigma) in place of y/sigma."""
     y = np.asarray(y, np.float32)
-    return (y / np.asarray(sigma, np.float32)[None, :] - y_mean[None, :]) / y_std[None, :]
+    v = y / np.asarray(sigma, np.float32)[None, :]
+    if ypositive:
+        with np.errstate(invalid="ignore", divide="ignore"):
+            v = np.log(v)
+    return (v - y_mean[None, :]) / y_std[None, :]
 
 
-def aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+def normalise_data(data, sigma, y_mean, y_std, ypositive=False):
+    """util.py:1069: the data vector in the network's output space, NaN -> 1e-30 (the mask sentinel of util.py:1072)."""
+    d = normalise_target(np.asarray(data, np.float32)[None, :], sigma, y_mean, y_std, ypositive)[0]
+    return np.where(np.isnan(d), np.float32(1e-30), d).astype(np.float32)
+
+
+def aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std, ypositive=False):
     """util.py:1070-1088.  ``pred`` is the raw network output (normalised space),
     ``target`` is the physical data vector batch, ``data_norm`` the normalised data.
 
@@ -65,7 +114,7 @@ def aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
     """
     dt = pred.dtype
     target = np.asarray(target, dt)
-    tnorm = normalise_target(target, sigma, y_mean, y_std).astype(dt)
+    tnorm = normalise_target(target, sigma, y_mean, y_std, ypositive).astype(dt)
     mask = (target == dt.type(1e-30)) | (target == dt.type(1e10)) | (data_norm[None, :] == dt.type(1e-30))
     C = icov_norm.astype(dt)
 
@@ -81,21 +130,21 @@ def aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
     return chisqMnn / chisqMd, chisqMd, chisqnnd, delta, ~mask
 
 
-def loss(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+def loss(pred, target, data_norm, icov_norm, sigma, y_mean, y_std, ypositive=False):
     """util.py:1105-1116: mean over the batch."""
-    return aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std)[0].mean(dtype=pred.dtype)
+    return aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std, ypositive)[0].mean(dtype=pred.dtype)
 
 
-def val_metric(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+def val_metric(pred, target, data_norm, icov_norm, sigma, y_mean, y_std, ypositive=False):
     """util.py:1124-1127: [median(loss), max|chisqnnd/chisqMd - 1|, median(same)]."""
-    l, cMd, cnnd, _, _ = aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std)
+    l, cMd, cnnd, _, _ = aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std, ypositive)
     frac = np.abs(cnnd / cMd - 1)
     return np.array([lower_median(l), frac.max(), lower_median(frac)], np.float32)
 
 
-def loss_grad(pred, target, data_norm, icov_norm, sigma, y_mean, y_std):
+def loss_grad(pred, target, data_norm, icov_norm, sigma, y_mean, y_std, ypositive=False):
     """d mean(loss) / d pred: -(delta (C + C^T)) / (B * chisqMd), zero where masked."""
-    l, cMd, _, delta, notmask = aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std)
+    l, cMd, _, delta, notmask = aux(pred, target, data_norm, icov_norm, sigma, y_mean, y_std, ypositive)
     C = icov_norm.astype(pred.dtype)
     g = -(delta @ C + delta @ C.T) / (pred.dtype.type(pred.shape[0]) * cMd[:, None])
     return l.mean(dtype=pred.dtype), np.where(notmask, g, 0).astype(pred.dtype)
@@ -125,7 +174,7 @@ def train_step(params, opt_state, X, y, stats, kind, in_size, out_size, lr, weig
     x = (np.asarray(X, np.float32) - stats["X_mean"][None, :]) / stats["X_std"][None, :]
     pred, caches = emulator.forward(params, x, kind, in_size, out_size, keep=True, **topo_kw)
     l, dpred = loss_grad(pred, y, stats["data_norm"], stats["icov_norm"], stats["sigma"],
-                         stats["y_mean"], stats["y_std"])
+                         stats["y_mean"], stats["y_std"], stats.get("ypositive", False))
     _, grads = emulator.backward(params, caches, dpred, kind, in_size, out_size, **topo_kw)
     opt_state["step"] += 1
     for k in params:

@@ -312,6 +312,103 @@ def gen_train_nn(out):
     print("train_NN run: losses", np.asarray(train_losses)[:4], "val", np.asarray(val_metrics)[:2], flush=True)
 
 
+def _run_reference_train_nn(tmp, cov, sigma, data, w0, nep, batch, lr, ypositive=False, usebest=False):
+    """The live reference's train_NN on the sample files under `tmp`; returns what Predictor.train saw and produced."""
+    def factory(in_size, out_size, linearmodel, docpu=False):
+        m = rnn.ChtoModelv2(in_size, out_size, linearmodel, docpu=docpu)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in w0.items()})
+        return m
+    np.save(tmp + "lr.npy", lr)
+
+    class _S(object):
+        pass
+    captured = {}
+    orig_train = rpred.Predictor.train
+
+    def spy(self, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, *a, **k):
+        captured["icov_norm"] = loss_fn.auxileryfunction.inv_transformed_cov.numpy().copy()
+        captured["data_norm"] = loss_fn.auxileryfunction.data_in.numpy().copy()
+        captured["ntrain"], captured["nval"] = len(dataset.dataset), len(val_dataset.dataset)
+        r = orig_train(self, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, *a, **k)
+        captured["ret"] = r
+        captured["state"] = {kk: vv.detach().numpy().copy() for kk, vv in self.model.state_dict().items()}
+        return r
+    rpred.Predictor.train = spy
+    try:
+        rutil.train_NN(_S(), cov, np.linalg.inv(cov), sigma, tmp, [tmp], data, None, ypositive, True, 2, 1.0,
+                       False, None, 1, factory, {"num_epochs": nep, "batch_size": batch}, usebest)
+    finally:
+        rpred.Predictor.train = orig_train
+    with open(tmp + "X_transform.pkl", "rb") as f:
+        Xt = rutil.CPU_Unpickler(f).load()
+    with open(tmp + "y_transform.pkl", "rb") as f:
+        Yt = rutil.CPU_Unpickler(f).load()
+    best = torch.load(tmp + "best.pth.tar", map_location="cpu", weights_only=False)
+    train_losses, val_metrics = captured["ret"]
+    rec = dict(X_mean=Xt.X_mean.numpy(), X_std=Xt.X_std.numpy(), y_mean=Yt.y_mean.numpy(), y_std=Yt.y_std.numpy(),
+               icov_norm=captured["icov_norm"], data_norm=captured["data_norm"], ntrain=np.int64(captured["ntrain"]),
+               nval=np.int64(captured["nval"]), train_losses=np.asarray(train_losses, np.float64),
+               val_metrics=np.asarray(val_metrics, np.float64), best_epoch=np.int64(best["epoch"]),
+               lr=np.float64(lr), num_epochs=np.int64(nep), batch_size=np.int64(batch))
+    for k, v in captured["state"].items():
+        rec["final/" + k] = v
+    return rec
+
+
+def gen_train_nn_ypos(out):
+    """`ypositive=True` (util.py:1410-1431, 1444-1447, 567-586): a positive data vector emulated in log space.  Targets
+    with both sentinels (an entry above 1e10, entries at / below 0), one training row and one validation row that are
+    non-positive throughout (deleted by the reference before the statistics)."""
+    nin, nout, seed = 5, 4, 311
+    rs = np.random.RandomState(seed)
+    _, cov, _ = synth.gaussian_problem(nin, nout, seed, dense=True, cond=1e2)
+    data = rs.uniform(5.0, 20.0, nout)                  # (the reference's log(1 + C / data^2) of the sigma-scaled covariance, util.py:579-583,
+    sigma = np.sqrt(np.diag(cov))                       #  stays positive definite when its argument is small)
+    A = rs.standard_normal((nout, nin)) * 0.3
+    def theory(x):
+        return data[None, :] * np.exp(0.5 * np.tanh(x @ A.T))
+    ntrain, nval, batch, nep = 201, 51, 50, 4
+    train_x = rs.uniform(-1, 1, (ntrain, nin)); val_x = rs.uniform(-1, 1, (nval, nin))
+    train_y = theory(train_x); val_y = theory(val_x)
+    train_y[3, 1] = 5e10; train_y[7, 0] = 0.0; train_y[11, 2] = -1.0       # clipped to the mask sentinels 1e10 / 1e-30
+    train_y[20, :] = -3.0                                                   # a row that is 1e-30 throughout after clipping: dropped
+    val_y[5, 3] = 0.0; val_y[9, :] = 0.0
+    w0 = synth.weights("ChtoModelv2", nin, nout, seed)
+    tmp = tempfile.mkdtemp(prefix="linna_golden_") + "/"
+    np.savetxt(tmp + "train_samples_x.txt", train_x); np.save(tmp + "train_samples_y.npy", train_y)
+    np.savetxt(tmp + "val_samples_x.txt", val_x); np.save(tmp + "val_samples_y.npy", val_y)
+    rec = _run_reference_train_nn(tmp, cov, sigma, data, w0, nep, batch, 2e-3, ypositive=True)
+    rec.update(train_x=train_x, train_y=train_y, val_x=val_x, val_y=val_y, data=data, cov=cov)
+    out["train_nn_ypos"] = rec
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("train_NN ypositive: rows", rec["ntrain"], rec["nval"], "losses", rec["train_losses"][:4], "val", rec["val_metrics"][:2], flush=True)
+
+
+def gen_train_nn_usebest(out):
+    """`usebest=True` (util.py:1375-1409): the optimizer-seeded samples of `nbest` in front of the designed ones."""
+    nin, nout, seed = 5, 3, 321
+    rs = np.random.RandomState(seed)
+    data, cov, _ = synth.gaussian_problem(nin, nout, seed, dense=True, cond=1e2)
+    sigma = np.sqrt(np.diag(cov))
+    A = rs.standard_normal((nout, nin)) * 0.3
+    def theory(x):
+        return data[None, :] + np.tanh(x @ A.T) * 3 * sigma[None, :]
+    ntrain, nval, nbest, batch, nep = 150, 40, 50, 50, 3
+    xs = {"train": rs.uniform(-1, 1, (ntrain, nin)), "val": rs.uniform(-1, 1, (nval, nin)),
+          "best": 0.1 * rs.standard_normal((nbest, nin)), "best_val": 0.1 * rs.standard_normal((int(nbest / ntrain * nval), nin))}
+    w0 = synth.weights("ChtoModelv2", nin, nout, seed)
+    tmp = tempfile.mkdtemp(prefix="linna_golden_") + "/"
+    np.savetxt(tmp + "train_samples_x.txt", xs["train"]); np.save(tmp + "train_samples_y.npy", theory(xs["train"]))
+    np.savetxt(tmp + "val_samples_x.txt", xs["val"]); np.save(tmp + "val_samples_y.npy", theory(xs["val"]))
+    np.savetxt(tmp + "best_samples_x.txt", xs["best"]); np.save(tmp + "best_samples_y.npy", theory(xs["best"]))
+    np.savetxt(tmp + "best_samples_x_val.txt", xs["best_val"]); np.save(tmp + "best_samples_y_val.npy", theory(xs["best_val"]))
+    rec = _run_reference_train_nn(tmp, cov, sigma, data, w0, nep, batch, 2e-3, usebest=True)
+    rec.update(data=data, cov=cov, **{"x_" + k: v for k, v in xs.items()}, **{"y_" + k: theory(v) for k, v in xs.items()})
+    out["train_nn_usebest"] = rec
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("train_NN usebest: rows", rec["ntrain"], rec["nval"], "losses", rec["train_losses"][:4], flush=True)
+
+
 # ------------------------------------------------------------------ DataLoader order
 def gen_loader_order(out):
     from torch.utils.data import DataLoader
@@ -724,7 +821,7 @@ def gen_cond(out):
     out[c["name"]] = rec
 
 
-GENERATORS = [("cond", gen_cond), ("host_designs", gen_host_designs), ("importance", gen_importance), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn),
+GENERATORS = [("cond", gen_cond), ("host_designs", gen_host_designs), ("importance", gen_importance), ("fixture", gen_fixture), ("serving", gen_serving), ("training", gen_training), ("train_nn", gen_train_nn), ("train_nn_ypos", gen_train_nn_ypos), ("train_nn_usebest", gen_train_nn_usebest),
               ("loader_order", gen_loader_order), ("early_stopping", gen_early_stopping), ("hmc", gen_hmc), ("hmc_move", gen_hmc_move), ("callbacks", gen_callbacks),
               ("init_parity", gen_init_parity), ("train33", gen_train33)]
 

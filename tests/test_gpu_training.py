@@ -265,6 +265,84 @@ def test_train_NN_trajectory_matches_reference(tmp_path):
     assert np.all(np.isfinite(lp(np.zeros((4, 5), np.float32), returntorch=False)))
 
 
+def test_train_NN_ypositive_trajectory_matches_reference(tmp_path):
+    """``ypositive=True`` training (util.py:1410-1431, 1444-1447, 567-586): positive targets emulated in log
+    space.  The reference's run on the same files: rows it drops, log-space statistics, per-step losses and per-epoch
+    validation metrics of 4 epochs (the target's logarithm is taken in the loss kernels: linna_loss_desc_t::ylog), and the
+    trained directory serves through the exp output map."""
+    from linna_amd import util, nn
+    g = cases.golden("train_nn_ypos")
+    out = str(tmp_path) + "/"
+    np.savetxt(out + "train_samples_x.txt", g["train_x"]); np.save(out + "train_samples_y.npy", g["train_y"])
+    np.savetxt(out + "val_samples_x.txt", g["val_x"]); np.save(out + "val_samples_y.npy", g["val_y"])
+    np.save(out + "lr.npy", float(g["lr"]))
+    w0 = synth.weights("ChtoModelv2", 5, 4, 311)
+
+    def factory(in_size, out_size, linearmodel, docpu=False):
+        m = nn.ChtoModelv2(in_size, out_size, linearmodel, docpu=docpu)
+        m.load_state_dict(w0)
+        return m
+
+    cov = g["cov"]
+    model = util.train_NN(None, cov, np.linalg.inv(cov), np.sqrt(np.diag(cov)), out, [out], g["data"], None, True, True, 2,
+                          1.0, False, None, 1, factory, {"num_epochs": int(g["num_epochs"]), "batch_size": int(g["batch_size"])},
+                          False)
+    train_losses, val_metrics = model.train_history
+    assert model.y_transform.ypositive is True
+    np.testing.assert_allclose(model.X_transform.X_mean.numpy(), g["X_mean"], rtol=2e-6, atol=2e-8)
+    np.testing.assert_allclose(model.y_transform.y_mean.numpy(), g["y_mean"], rtol=2e-6)
+    np.testing.assert_allclose(model.y_transform.y_std.numpy(), g["y_std"], rtol=2e-6)
+    assert len(train_losses) == len(g["train_losses"]) == 16                      # 200 rows (one dropped) in batches of 50, 4 epochs
+    np.testing.assert_allclose(train_losses, g["train_losses"], rtol=2e-5)       # (logf on the device against torch.log on the host)
+    np.testing.assert_allclose(val_metrics, g["val_metrics"], rtol=1e-4)
+    ck = torch.load(out + "best.pth.tar", weights_only=True)
+    assert int(ck["epoch"]) == int(g["best_epoch"])
+    for k, v in model.model.state_dict().items():
+        ref = g["final/" + k]
+        np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=3e-4, atol=3e-5 * np.abs(ref).max() + 1e-6, err_msg=k)
+    pm, yinv = util.retrieve_model(out, 5, 4, nn.ChtoModelv2)
+    assert pm.y_transform.ypositive is True
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -1.0, "arg2": 1.0} for i in range(5)]
+    lp = util.Log_prob(g["data"], np.linalg.inv(cov), pm, yinv, util.Transform(priors), 1.0)
+    z = np.random.RandomState(0).standard_normal((16, 5)).astype(np.float32)
+    got = lp(z, returntorch=False)
+    # the oracle on the trained weights: exp output map, same constants
+    from oracle import likelihood
+    emu = likelihood.Emulator("ChtoModelv2", 5, 4, {k: v.cpu().numpy() for k, v in pm.model.state_dict().items()}, g["X_mean"], g["X_std"],
+                              g["y_mean"], g["y_std"], np.sqrt(np.diag(cov)), ypositive=True)
+    ref = likelihood.log_prob(z, emu, priors, g["data"], np.linalg.inv(cov), 1.0)
+    np.testing.assert_allclose(got, ref, rtol=2e-4)
+
+
+def test_train_NN_usebest_matches_reference(tmp_path):
+    """``usebest=True`` (util.py:1375-1409; the 18th entry of model_args.pkl when `nbest` is given, main.py:197): the
+    optimizer-seeded samples go in front of the designed ones, training and validation."""
+    from linna_amd import util, nn
+    g = cases.golden("train_nn_usebest")
+    out = str(tmp_path) + "/"
+    for tag, fx, fy in (("train", "train_samples_x.txt", "train_samples_y.npy"), ("val", "val_samples_x.txt", "val_samples_y.npy"),
+                        ("best", "best_samples_x.txt", "best_samples_y.npy"), ("best_val", "best_samples_x_val.txt", "best_samples_y_val.npy")):
+        np.savetxt(out + fx, g["x_" + tag]); np.save(out + fy, g["y_" + tag])
+    np.save(out + "lr.npy", float(g["lr"]))
+    w0 = synth.weights("ChtoModelv2", 5, 3, 321)
+
+    def factory(in_size, out_size, linearmodel, docpu=False):
+        m = nn.ChtoModelv2(in_size, out_size, linearmodel, docpu=docpu)
+        m.load_state_dict(w0)
+        return m
+
+    cov = g["cov"]
+    model = util.train_NN(None, cov, np.linalg.inv(cov), np.sqrt(np.diag(cov)), out, [out], g["data"], None, False, True, 2,
+                          1.0, False, None, 1, factory, {"num_epochs": int(g["num_epochs"]), "batch_size": int(g["batch_size"])},
+                          True)
+    train_losses, val_metrics = model.train_history
+    assert len(train_losses) == len(g["train_losses"]) == 12                      # (150 + 50) rows in batches of 50, 3 epochs
+    np.testing.assert_allclose(model.X_transform.X_mean.numpy(), g["X_mean"], rtol=2e-6, atol=2e-8)
+    np.testing.assert_allclose(model.y_transform.y_std.numpy(), g["y_std"], rtol=2e-6)
+    np.testing.assert_allclose(train_losses, g["train_losses"], rtol=4e-6)
+    np.testing.assert_allclose(val_metrics, g["val_metrics"], rtol=3e-5)
+
+
 def test_lr_range_test_runs_and_restores_weights(tmp_path):
     from linna_amd import lrfinder
     p, model, pred, eng, B = make_engine("train_mlp_7_5")

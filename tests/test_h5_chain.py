@@ -59,10 +59,24 @@ def test_read_chain_and_cut_reproduces_reference_test():
     assert int(np.median(tau)) * 4 == len(chain) == lp.size
 
 
-def test_walkercut_is_refused_not_ignored():
+def test_walkercut_keeps_the_walkers_of_the_best_cluster(tmp_path):
+    """util.py:57-66, 86-89 (``walkercut=True``): the walkers whose mean log-probability (cast to an integer) falls in the
+    highest KMeans cluster.  10 walkers around -5 and 6 stuck around -50: the cut keeps the ten."""
+    import contextlib, io
     from linna_amd import util
-    with pytest.raises(NotImplementedError):
-        util.read_chain_and_cut(FIXTURE, 2, walkercut=True)
+    rs = np.random.RandomState(0)
+    nt, nw, nd = 300, 16, 2
+    z = rs.standard_normal((nt, nw, nd)).cumsum(0) * 0.05
+    lp = np.where(np.arange(nw)[None, :] < 10, -5.5, -50.5) + 0.3 * rs.standard_normal((nt, nw))
+    path = str(tmp_path / "chemcee_256.h5")
+    ChainStore.write_h5(path, z, np.tanh(z), lp, np.zeros(nw))
+    with contextlib.redirect_stdout(io.StringIO()):
+        chain, lps, d = util.read_chain_and_cut(path, 1, ntimes=2, walkercut=True)
+        full, lpf, _ = util.read_chain_and_cut(path, 1, ntimes=2, walkercut=False)
+    nkeep = len(full) // nw
+    assert chain.shape == (nkeep * 10, nd) and lps.shape == (nkeep, 10)
+    np.testing.assert_array_equal(chain, np.tanh(z)[-nkeep:, :10].reshape(-1, nd))
+    np.testing.assert_array_equal(lps, lp[-nkeep:, :10])
 
 
 def test_ml_sampler_core_reads_a_reference_run_directory(tmp_path):

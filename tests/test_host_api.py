@@ -556,3 +556,43 @@ def test_bench_identity_emulators_are_the_identity():
         assert np.abs(h - x).max() <= 2.5e-7, kind
         nz = sum(int(np.count_nonzero(v)) for v in sd.values()) / float(sum(v.size for v in sd.values()))
         assert nz > 0.8, (kind, nz)
+
+
+def test_nbest_points_are_designed_around_the_best_fit(tmp_path):
+    """``nbest`` (main.py:140-152, util.py:1235-1252): a Nelder-Mead fit of the true theory, then draws from
+    N(best fit, inverse Hessian) with the theory evaluated at them, as ``best_samples_*`` next to the designed points.
+    numdifftools (the reference's Hessian) is absent: ``numerical_hessian`` is checked against the analytic one; the draws
+    are unseeded in the reference as well, so the check is on the files and on where the points lie."""
+    from linna_amd import util
+    rs = np.random.RandomState(3)
+    nd, nout = 3, 5
+    A = rs.standard_normal((nout, nd))
+    truth = np.array([0.3, -0.2, 0.1])
+    data = A @ truth
+    invcov = np.diag(1.0 / rs.uniform(0.01, 0.02, nout))
+
+    def theory(x, outdir=None):
+        return A @ np.asarray(x[1])
+
+    def negloglike(x):
+        d = data - theory([-1, x], None)
+        return d.dot(invcov.dot(d))
+
+    H = util.numerical_hessian(negloglike, truth)
+    np.testing.assert_allclose(H, 2 * A.T @ invcov @ A, rtol=1e-5, atol=1e-6 * np.abs(H).max())
+    out = str(tmp_path) + "/"
+    sampler_ = util.NN_samplerv1(out, [[-1, 1]] * nd)
+    util.generate_training_point(theory, sampler_, None, out, 40, 10, data, invcov, None, negloglike=negloglike, nbest_in=20)
+    bx, by = np.loadtxt(out + "best_samples_x.txt"), np.load(out + "best_samples_y.npy")
+    vx, vy = np.loadtxt(out + "best_samples_x_val.txt"), np.load(out + "best_samples_y_val.npy")
+    assert bx.shape == (20, nd) and by.shape == (20, nout) and vx.shape == (5, nd) and vy.shape == (5, nout)
+    np.testing.assert_allclose(by, bx @ A.T, rtol=1e-12)
+    assert np.all(np.abs(bx.mean(0) - truth) < 0.2)                  # around the best fit, with the fit's own (tiny) errors
+    # a second call finds the files and changes nothing (stage-level idempotence, util.py:1191-1233)
+    util.generate_training_point(theory, sampler_, None, out, 40, 10, data, invcov, None, negloglike=negloglike, nbest_in=20)
+    np.testing.assert_array_equal(bx, np.loadtxt(out + "best_samples_x.txt"))
+    # and train_NN's loader puts them in front (util.py:1375-1409)
+    tx, ty, vx2, vy2, _ = util._load_samples([out], usebest=True)
+    assert len(tx) == 60 and len(vx2) == 15
+    np.testing.assert_array_equal(tx[:20], bx)
+    np.testing.assert_array_equal(vy2[:5], vy)

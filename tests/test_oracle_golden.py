@@ -109,6 +109,41 @@ def test_data_statistics_match_train_NN():
     np.testing.assert_allclose(y_std, g["y_std"], rtol=1e-5)
 
 
+def test_ypositive_statistics_and_loss_constants_match_train_NN():
+    """``ypositive=True`` (util.py:1410-1431, 1444-1447, 567-586) against the live reference's train_NN: rows dropped, the
+    log-space median / MAD, the normalised data vector and the inverse of log(1 + E C E) in the normalised space; then the
+    oracle's training step reproduces the first epoch's per-step losses from the reference's initial weights."""
+    g = cases.golden("train_nn_ypos")
+    sigma = np.sqrt(np.diag(g["cov"]))
+    tx, ty, tyl, vx, vy = training.ypositive_clip(g["train_x"], g["train_y"], g["train_y"], g["val_x"], g["val_y"])
+    assert len(tx) == len(ty) == int(g["ntrain"]) == 200 and len(vx) == len(vy) == int(g["nval"]) == 50
+    assert ty.max() == 1e10 and ty.min() == 1e-30
+    X_mean, X_std, y_mean, y_std = training.data_statistics(tx, ty, tyl, sigma, ypositive=True)
+    np.testing.assert_allclose(X_mean, g["X_mean"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(X_std, g["X_std"], rtol=1e-5)
+    np.testing.assert_allclose(y_mean, g["y_mean"], rtol=2e-6)
+    np.testing.assert_allclose(y_std, g["y_std"], rtol=1e-5)
+    dn = training.normalise_data(g["data"], sigma, y_mean, y_std, ypositive=True)
+    np.testing.assert_allclose(dn, g["data_norm"].reshape(-1), rtol=2e-5, atol=2e-6)
+    ic = training.normalised_inverse_cov(g["cov"], sigma, y_std, ypositive=True, data=g["data"])
+    np.testing.assert_allclose(ic, g["icov_norm"], rtol=2e-4, atol=2e-5 * np.abs(g["icov_norm"]).max())
+    # first epoch: torch.manual_seed(1234) + DataLoader(shuffle) order of 200 rows in batches of 50 (drop_last)
+    import torch
+    from linna_amd import predictor_gpu, util
+    torch.manual_seed(1234)                                          # predictor_gpu.py:221
+    order = predictor_gpu.BatchLoader(util.ArrayDataset(tx, ty), 50, shuffle=True, drop_last=True).epoch_order().numpy()
+    stats = dict(X_mean=g["X_mean"], X_std=g["X_std"], y_mean=g["y_mean"], y_std=g["y_std"], sigma=sigma.astype(np.float32),
+                 data_norm=g["data_norm"].reshape(-1), icov_norm=g["icov_norm"], ypositive=True)
+    params = {k: v.copy() for k, v in synth.weights("ChtoModelv2", 5, 4, 311).items()}
+    opt = training.new_opt_state(params)
+    losses = []
+    for b in range(4):
+        rows = order[b * 50:(b + 1) * 50]
+        l, _ = training.train_step(params, opt, tx[rows], ty[rows].astype(np.float32), stats, "ChtoModelv2", 5, 4, float(g["lr"]))
+        losses.append(float(l))
+    np.testing.assert_allclose(losses, g["train_losses"][:4], rtol=2e-4)
+
+
 def test_hmc_chain_matches_reference_trace():
     g = cases.golden("hmc_trace")
     name = str(g["case"])
