@@ -252,6 +252,15 @@ def driver_rate(lp, nwalkers, nsamp=2000, tmpdir=None, prefix="driver_"):
     x0 = 0.05 * np.random.RandomState(7).standard_normal((nwalkers, NIN))
     out = tempfile.mkdtemp(prefix="linna_bench_chain_", dir=tmpdir)
     prof = {}
+    import gc
+    gcs = {"t": 0.0, "n": 0, "t0": 0.0}
+
+    def gc_cb(phase, info):                # seconds the interpreter's cyclic collector holds the driver's thread
+        if phase == "start":
+            gcs["t0"] = time.perf_counter()
+        else:
+            gcs["t"] += time.perf_counter() - gcs["t0"]; gcs["n"] += 1
+    gc.callbacks.append(gc_cb)
     try:
         drv = sampler.HMCSampler(lp, None, None, NIN, nwalkers, x0=x0, transform=util.Transform(priors))
         with contextlib.redirect_stdout(io.StringIO()):
@@ -262,7 +271,9 @@ def driver_rate(lp, nwalkers, nsamp=2000, tmpdir=None, prefix="driver_"):
         n = sum(len(c) for c in store.chain)
         size = os.path.getsize(os.path.join(out, "chemcee_256.h5"))
     finally:
+        gc.callbacks.remove(gc_cb)
         shutil.rmtree(out, ignore_errors=True)
+    prof["host_gc_s"], prof["gc_collections"] = gcs["t"], gcs["n"]
     checks = n // 100
     bd = {k: round(v, 4) if isinstance(v, float) else v for k, v in sorted(prof.items())}
     bd["checks"] = checks
@@ -400,6 +411,77 @@ def training_rate(device, world, rank, backend, nsteps=150):
         res["allreduce_bytes"] = 4 * (g.numel() + 1)
         res["allreduce_transport"] = "RCCL through linna_allreduce_sum_f32" if ldist.comm_active(g) else "torch.distributed (%s)" % backend
     return res
+
+
+def training_epochs(device, nepochs=60):
+    """Whole epochs of Predictor.train (predictor_gpu.py:268-449) -- optimiser steps, the validation pass, the controller's
+    record, the epoch's one host wait, controller and checkpoint bookkeeping -- at the two ends of the reference's schedule
+    (main.py:22: 10 000 training rows = 20 steps of 500 in iteration 0, 40 000 = 80 steps in iteration 3; 500 / 2000
+    validation rows) for ChtoModelv2(33,33) and ChtoModelv2(26,457) with a dense covariance.  `frac_in_steps` = device time
+    of the optimiser steps / wall time of the epoch loop."""
+    import tempfile
+    import shutil
+    import contextlib
+    import io
+    import torch
+    from linna_amd import nn, util, predictor_gpu
+    out = {}
+    for nin, nout, dense in ((33, 33, False), (26, 457, True)):
+        rs = np.random.RandomState(5)
+        if dense:
+            q, _ = np.linalg.qr(rs.standard_normal((nout, nout)))
+            cov = (q * (np.logspace(0, -2, nout) * 0.1)[None, :]) @ q.T
+            cov = 0.5 * (cov + cov.T)
+        else:
+            cov = np.diag(0.1 * rs.uniform(0.05, 1.0, size=nout))
+        data, sigma = rs.uniform(size=nout), np.sqrt(np.diag(cov))
+        X_mean, X_std = rs.uniform(-0.5, 0.5, nin).astype(np.float32), rs.uniform(0.5, 3.0, nin).astype(np.float32)
+        y_mean, y_std = rs.uniform(-0.5, 0.5, nout).astype(np.float32), rs.uniform(0.5, 2.0, nout).astype(np.float32)
+        t = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+        ytd = util.Y_transform_data(sigma, "cpu")
+        yinv = util.Y_invtransform_class(t(y_mean), t(y_std), t(data), "cpu")
+        largs = (t(data), torch.tensor(cov, dtype=torch.float64), torch.tensor(np.linalg.inv(cov), dtype=torch.float64), ytd, yinv, "cpu")
+        lf, vf = util.Loss_fn(*largs), util.Val_metric_fn(*largs)
+        for n, nv in ((10000, 500), (40000, 2000)):
+            torch.manual_seed(1234)
+            model = nn.ChtoModelv2(nin, nout, None)
+            pred = predictor_gpu.Predictor(nin, nout, model=model, device=device, optim="automatic",
+                                           X_transform=util.X_transform_class(t(X_mean), t(X_std), "cpu", None),
+                                           y_transform=util.Y_transform_class(t(y_mean), t(y_std), "cpu"))
+            A = rs.standard_normal((nout, nin)) * 0.3          # a learnable map: the controller takes its ordinary path (noise targets
+                                                                   # would plateau and trigger the "bad training" re-initialisation every 10 epochs)
+            def mk(m):
+                x = rs.standard_normal((m, nin))
+                return ((X_mean[None, :] + X_std[None, :] * x).astype(np.float32),
+                        (data[None, :] + sigma[None, :] * (3 * np.tanh(x @ A.T) + 0.3 * rs.standard_normal((m, nout)))).astype(np.float32))
+            (X, Y), (VX, VY) = mk(n), mk(nv)
+            loader = predictor_gpu.BatchLoader(util.ArrayDataset(X, Y), 500, shuffle=True, drop_last=True)
+            vloader = predictor_gpu.BatchLoader(util.ArrayDataset(VX, VY), nv, shuffle=False, drop_last=False)
+            pred.outdir = tempfile.mkdtemp(prefix="linna_bench_train_")
+            try:
+                np.save(os.path.join(pred.outdir, "lr.npy"), 1e-4)
+                with contextlib.redirect_stdout(io.StringIO()):
+                    pred.train(loader, 8, lf, vloader, vf)                       # untimed: first-use costs
+                    pred.optim = "automatic"
+                    prof = {}
+                    torch.cuda.synchronize()
+                    pred.train(loader, nepochs, lf, vloader, vf, profile=prof)
+            finally:
+                shutil.rmtree(pred.outdir, ignore_errors=True)
+            ne = max(prof["epochs"], 1)
+            med = lambda k: 1e3 * prof.get(k + "_median_s", 0.0)
+            out["v2_%d_%d.steps_%d" % (nin, nout, n // 500)] = {
+                "epochs": prof["epochs"], "steps_per_epoch": n // 500, "validation_rows": nv,
+                "ms_per_epoch": med("epoch"), "ms_per_epoch_mean": 1e3 * prof["epoch_s"] / ne,
+                "ms_steps_gpu": med("gpu_steps"), "ms_validation_gpu": med("gpu_validation"),
+                "frac_in_steps": med("gpu_steps") / max(med("epoch"), 1e-9),
+                "frac_in_steps_whole_run": prof.get("gpu_steps_s", 0.0) / max(prof["epoch_s"], 1e-12),
+                "host_ms_per_epoch": {k[5:-9]: 1e3 * v for k, v in sorted(prof.items()) if k.startswith("host_") and k.endswith("_median_s")},
+                "final_checkpoint_ms": 1e3 * prof.get("final_checkpoint_s", 0.0),
+                "speculative_epochs": prof.get("speculative_epochs", 0), "speculative_epochs_undone": prof.get("speculative_epochs_undone", 0),
+                "controller_actions": prof.get("controller_actions", {}),
+                "note": "medians over the epochs (host phases partition an epoch's wall time); *_mean / *_whole_run include the epochs that write a checkpoint or re-initialise"}
+    return out
 
 
 def secondary_serving(device, kind, nin, nout, dense, nwalkers=4096, iters=400):
@@ -954,6 +1036,11 @@ def main():
         except Exception as e:                                      # noqa: BLE001
             training = {"error": repr(e)[:300]}
 
+    if training is not None and world == 1 and not args.no_training and "error" not in training:
+        try:
+            training["epoch"] = training_epochs(device)
+        except Exception as e:                                      # noqa: BLE001
+            training["epoch"] = {"error": repr(e)[:300]}
     _at("training done: %s" % (training,))
     # ensemble iterations: every rank takes part (cross-rank partner exchange for N > 1)
     mcmc = None
@@ -994,6 +1081,7 @@ def main():
         res["mcmc"] = mcmc
         if world == 1 and not args.no_driver and isinstance(mcmc, dict) and "error" not in mcmc:
             try:
+                driver_rate(lp, NWALKERS, nsamp=200)               # untimed: first-use costs of a process (pinned buffers, threads, the 8-row engine's stream)
                 res["mcmc"].update(driver_rate(lp, NWALKERS))
                 if os.path.isdir("/dev/shm"):                      # the same run with the chain file in memory: pipeline cost without the disk
                     res["mcmc"].update(driver_rate(lp, NWALKERS, tmpdir="/dev/shm", prefix="driver_shm_"))

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 9   /* 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
+#define LINNA_ABI_VERSION 9   /* 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd, linna_val_metrics, linna_loss_desc_t::ylog; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -371,6 +371,12 @@ int linna_net_train_step(linna_net_t* net, const linna_loss_desc_t* d, const flo
 int linna_val_rows(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp,
                    const float* Y, int ldy, const float* den, int B, float* scratch, float* loss_rows,
                    float* frac_rows, void* stream);
+/* The epoch's record for the host-side controller (predictor_gpu.py:289-312, 339-401) in ONE 4-float device array instead of
+ * two row vectors: out = { *last_train_loss (NaN if NULL), lower median of loss_rows[n] (torch.median), max of frac_rows[n],
+ * lower median of frac_rows[n] } -- Val_metric_fn's three numbers (util.py:1124-1127) behind linna_val_rows; a NaN anywhere makes
+ * the statistic NaN, as torch's reductions do.  n <= 65536. */
+int linna_val_metrics(linna_ctx_t* ctx, const float* loss_rows, const float* frac_rows, int n, const float* last_train_loss,
+                      float* out, void* stream);
 /* gather + input transform of a minibatch: XB[i] = (X[rows[i]] (log10 on flagged cols) - mean)/std */
 int linna_gather_xform(linna_ctx_t* ctx, const float* X, int ldx, const int* ROWS, int B, int nin,
                        const int* log10_flag, const float* xmean, const float* xstd, float* XB, int ldxb,

@@ -127,6 +127,7 @@ _SIGNATURES = {
     "linna_net_train_step_update": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _V, _V, _V, _I, _V, _V, _I, _V, _I, _V, _F, _V, _V, _V, _I,
                                          _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _V]),
     "linna_val_rows": (_I, [_V, C.POINTER(LossDesc), _V, _I, _V, _I, _V, _I, _V, _V, _V, _V]),
+    "linna_val_metrics": (_I, [_V, _V, _V, _I, _V, _V, _V]),
     "linna_gather_xform": (_I, [_V, _V, _I, _V, _I, _I, _V, _V, _V, _V, _I, _V]),
     "linna_adamw_step": (_I, [_V, _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _I, _V]),
     "linna_net_adamw_step": (_I, [_V, _I, _V, _V, _V, _V, _SZ, _V, _V, _F, _F, _F, _I, _V]),

@@ -1392,6 +1392,14 @@ int linna_val_rows(linna_ctx_t*, const linna_loss_desc_t* d, const float* PRED, 
     return launch_val_frac(scratch + 2 * (size_t)B * ld, slots, slots, B, den, frac_rows, st);
 } LINNA_CATCH_INT
 
+int linna_val_metrics(linna_ctx_t*, const float* loss_rows, const float* frac_rows, int n, const float* last_train_loss, float* out,
+                      void* stream) try {
+    if (!loss_rows || !frac_rows || !out || n < 1 || n > (1 << 16)) {
+        set_error("val_metrics: bad arguments (1 <= n <= 65536 validation rows)"); return LINNA_ERR_INVALID;
+    }
+    return launch_val_metrics(loss_rows, frac_rows, n, last_train_loss, out, S(stream));
+} LINNA_CATCH_INT
+
 int linna_gather_xform(linna_ctx_t*, const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg,
                        const float* xmean, const float* xstd, float* XB, int ldxb, void* stream) try {
     return launch_gather_xform(X, ldx, ROWS, B, nin, lg, xmean, xstd, XB, ldxb, S(stream));

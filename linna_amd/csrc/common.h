@@ -84,6 +84,7 @@ int launch_sum_scale(const float* v, int n, float scale, float* out, hipStream_t
 int launch_sum_scale_prepare(const float* v, int n, float scale, float* out, int* step_dev, float* hyper, float b1, float b2,
                              hipStream_t s);
 int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const float* den, float* frac, hipStream_t s);
+int launch_val_metrics(const float* loss, const float* frac, int n, const float* last, float* out, hipStream_t s);
 int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg, const float* xmean,
                         const float* xstd, float* XB, int ldxb, hipStream_t s);
 int launch_colsum(const float* dZ, int ld, int B, int N, float scale, float* db, hipStream_t s);

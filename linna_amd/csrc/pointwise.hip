@@ -290,6 +290,45 @@ __global__ void val_frac_kernel(const float* __restrict__ partial, int slots_ld,
     frac[b] = fabsf(c / den[b] - 1.f);
 }
 
+// The three validation metrics of an epoch (util.py:1124-1127: torch.median(loss), torch.max(frac), torch.median(frac)) on the
+// device, so that the epoch's controller reads ONE small record instead of two row vectors: out[0] = *last (the epoch's last
+// training loss, NaN if null), out[1] = lower median of loss[n], out[2] = max of frac[n], out[3] = lower median of frac[n].
+// Selection by rank counting (thread i counts the elements before x_i in sorted order; n <= a few 10^4: n^2 compares spread over
+// n threads); a NaN anywhere makes the statistic NaN, as torch.median / torch.max do.
+__global__ __launch_bounds__(256) void val_metrics_kernel(const float* __restrict__ loss, const float* __restrict__ frac, int n,
+                                                          const float* __restrict__ last, float* __restrict__ out) {
+    __shared__ float tl[256], tf[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool in = i < n;
+    const float xl = in ? loss[i] : 0.f, xf = in ? frac[i] : 0.f;
+    int rl = 0, rf = 0, nanl = 0, nanf = 0;
+    for (int j0 = 0; j0 < n; j0 += 256) {
+        const int j = j0 + threadIdx.x;
+        tl[threadIdx.x] = j < n ? loss[j] : INFINITY;
+        tf[threadIdx.x] = j < n ? frac[j] : INFINITY;
+        __syncthreads();
+        const int m = min(256, n - j0);
+        for (int k = 0; k < m; ++k) {
+            const float a = tl[k], b = tf[k];
+            rl += (a < xl) | ((a == xl) & (j0 + k < i));
+            rf += (b < xf) | ((b == xf) & (j0 + k < i));
+            nanl |= a != a;
+            nanf |= b != b;
+        }
+        __syncthreads();
+    }
+    if (!in) return;
+    const int mid = (n - 1) / 2;
+    if (i == 0) {
+        out[0] = last ? last[0] : __builtin_nanf("");
+        if (nanl) out[1] = __builtin_nanf("");
+        if (nanf) { out[2] = __builtin_nanf(""); out[3] = __builtin_nanf(""); }
+    }
+    if (!nanl && rl == mid) out[1] = xl;
+    if (!nanf && rf == n - 1) out[2] = xf;
+    if (!nanf && rf == mid) out[3] = xf;
+}
+
 // ------------------------------------------------------------------ minibatch gather + X transform
 __global__ void gather_xform_kernel(const float* __restrict__ X, int ldx, const int* __restrict__ ROWS, int B, int nin,
                                     const int* __restrict__ lg, const float* __restrict__ xmean,
@@ -817,6 +856,10 @@ int launch_sum_scale_prepare(const float* v, int n, float scale, float* out, int
 int launch_val_frac(const float* partial, int slots_ld, int nslots, int B, const float* den, float* frac, hipStream_t s) {
     hipLaunchKernelGGL(val_frac_kernel, grid1d(B, 256), dim3(256), 0, s, partial, slots_ld, nslots, B, den, frac);
     LAUNCH_CHECK("val_frac");
+}
+int launch_val_metrics(const float* loss, const float* frac, int n, const float* last, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(val_metrics_kernel, grid1d(n, 256), dim3(256), 0, s, loss, frac, n, last, out);
+    LAUNCH_CHECK("val_metrics");
 }
 int launch_gather_xform(const float* X, int ldx, const int* ROWS, int B, int nin, const int* lg, const float* xmean,
                         const float* xstd, float* XB, int ldxb, hipStream_t s) {

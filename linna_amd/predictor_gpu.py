@@ -316,12 +316,13 @@ class Predictor(object):
 
     # ------------------------------------------------------------------ training
     def train(self, dataset, num_epochs, loss_fn, val_dataset=None, val_metric_fn=None, initfrombest=False, pool=None,
-              nocpu=False, rank=0, size=1, dist_group=None, checkpoint_every=1, progress=False, patience=500):
-        """predictor_gpu.py:201-449.  ``dist_group``, ``checkpoint_every``, ``progress`` and ``patience`` (the
-        reference hard-wires 500, :256) are additions with the reference's behaviour as default."""
+              nocpu=False, rank=0, size=1, dist_group=None, checkpoint_every=1, progress=False, patience=500, profile=None):
+        """predictor_gpu.py:201-449.  ``dist_group``, ``checkpoint_every``, ``progress``, ``patience`` (the
+        reference hard-wires 500, :256) and ``profile`` (a dict that receives where the epochs' time went) are additions
+        with the reference's behaviour as default."""
         from . import trainer          # the HIP training engine (kept separate from the API shell)
         return trainer.run(self, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrombest, rank, size,
-                           dist_group, checkpoint_every, progress, patience)
+                           dist_group, checkpoint_every, progress, patience, profile)
 
 
 def _t2n(t):

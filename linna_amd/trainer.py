@@ -206,7 +206,7 @@ class TrainEngine(object):
         self._graph_sig = (self.model.flat_params().data_ptr(), id(opt))
 
     # ------------------------------------------------------------------ validation (util.py:1124-1127)
-    def validate_enqueue(self):
+    def validate_enqueue(self, model=None):
         """Launch the validation pass (util.py:1124-1127) without waiting for it: the epoch loop queues it right
         behind the epoch's optimiser steps and reads everything back with ONE synchronisation (three round trips
         per epoch left the GPU idle between them, and an idle MI355X drops its clocks)."""
@@ -221,15 +221,22 @@ class TrainEngine(object):
         _lib.call("linna_gather_xform", self.ctx, _lib.ptr(v["X"]), v["X"].stride(0), None, n, self.nin,
                   _lib.iptr(k["lg"]) if k["lg"] is not None else None, _lib.ptr(k["xmean"]), _lib.ptr(k["xstd"]),
                   _lib.ptr(v["xb"]), v["xb"].stride(0), st)
-        self.model.forward_buffer(v["xb"], n, out=v["pred"])
+        (model if model is not None else self.model).forward_buffer(v["xb"], n, out=v["pred"])      # (a shadow of the model: the epoch loop's snapshot)
         _lib.call("linna_val_rows", self.ctx, C.byref(self.desc), _lib.ptr(v["pred"]), v["pred"].stride(0), _lib.ptr(v["Y"]),
                   v["Y"].stride(0), _lib.ptr(v["den"]), n, _lib.ptr(v["scratch"]), _lib.ptr(v["loss_rows"]),
                   _lib.ptr(v["frac_rows"]), st)
 
+    def metrics_enqueue(self, last_loss, out):
+        """The epoch's record for the controller: out[4] (device) = last training loss, median validation loss, max and
+        median of |chi2_nnd / chi2_Md - 1| (util.py:1124-1127) -- selected on the device (linna_val_metrics)."""
+        v = self.val
+        _lib.call("linna_val_metrics", self.ctx, _lib.ptr(v["loss_rows"]), _lib.ptr(v["frac_rows"]), v["n"],
+                  _lib.ptr(last_loss) if last_loss is not None else None, _lib.ptr(out), _lib.stream())
+
     def validate_finish(self):
-        rows = self.val["rows"].cpu().numpy()
-        loss, frac = rows[0], rows[1]
-        return np.array([_lower_median(loss.tolist()), frac.max(), _lower_median(frac.tolist())], dtype=np.float64)
+        out = torch.empty(4, dtype=torch.float32, device=self.dev)
+        self.metrics_enqueue(None, out)
+        return out[1:].cpu().numpy().astype(np.float64)
 
     def validate(self):
         self.validate_enqueue()
@@ -257,9 +264,71 @@ def _read_lr(pred, engine, rank, size=1, group=None):
     return lr
 
 
+class _EpochProf(object):
+    """Where the epochs of a training run spend their time (``Predictor.train(..., profile={})``): host seconds per phase
+    (the marks partition the loop's wall time) and device seconds of the optimiser steps / the validation pass from event
+    pairs on the launch stream; totals and per-epoch medians (a re-initialisation or a checkpoint write makes single
+    epochs many times longer than the typical one)."""
+
+    def __init__(self, out):
+        self.out, self.t0, self.cur, self.epochs, self.ev = out, None, {}, [], []
+
+    def mark(self, key=None):
+        """Host time since the previous mark goes to ``key``."""
+        if self.out is None:
+            return
+        t = time.perf_counter()
+        if key is not None and self.t0 is not None:
+            self.cur[key] = self.cur.get(key, 0.0) + t - self.t0
+        self.t0 = t
+
+    def event(self):
+        if self.out is None:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def span(self, key, e0, e1):
+        if self.out is not None:
+            self.cur.setdefault("_ev", []).append((key, e0, e1))
+
+    def end_epoch(self):
+        if self.out is not None:
+            self.epochs.append(self.cur)
+            self.cur = {}
+
+    def finish(self, **extra):
+        if self.out is None:
+            return
+        torch.cuda.synchronize()
+        rows = []
+        for ep in self.epochs:
+            r = {"host_" + k: v for k, v in ep.items() if k != "_ev"}
+            for key, a, b in ep.get("_ev", []):
+                r["gpu_" + key] = r.get("gpu_" + key, 0.0) + 1e-3 * a.elapsed_time(b)
+            r["epoch"] = sum(v for k, v in ep.items() if k != "_ev")
+            rows.append(r)
+        keys = sorted({k for r in rows for k in r})
+        for k in keys:
+            col = np.array([r.get(k, 0.0) for r in rows])
+            self.out[k + "_s"] = float(col.sum())
+            self.out[k + "_median_s"] = float(np.median(col)) if len(col) else 0.0
+        self.out.update(extra)
+
+
 def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrombest, rank, size, dist_group,
-        checkpoint_every, progress, patience=500):
-    """The body of ``Predictor.train``; returns (train_losses[steps], val_metrics[epochs, 3])."""
+        checkpoint_every, progress, patience=500, profile=None):
+    """The body of ``Predictor.train``; returns (train_losses[steps], val_metrics[epochs, 3]).
+
+    One host wait per epoch.  Everything the controller reads -- the last training loss and the three validation metrics,
+    selected on the device -- arrives as ONE 4-float record in pinned memory, the per-step losses ride along in a second
+    pinned buffer; while the GPU works through the epoch the host already draws the next epoch's sample order (torch's
+    generator is put back first if the controller then re-initialises the weights, so the random stream is the reference's:
+    train order, validation draw, [Xavier draws], next train order) and ships it, so the next epoch's first step is enqueued
+    as soon as the record has been looked at."""
+    t_run = time.perf_counter()
+    prof = _EpochProf(profile)
     progress = progress or os.environ.get("LINNA_TRAIN_PROGRESS", "0") == "1"   # per-epoch train / validation loss
     torch.manual_seed(1234)                                                     # predictor_gpu.py:221
     size = max(int(size), 1)
@@ -288,38 +357,147 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     best_state = None
     nsteps = len(dataset) // size               # every rank consumes its own batch of B rows per step
     loss_hist = torch.zeros(max(nsteps, 1), dtype=torch.float32, device=engine.dev)
+    rec_dev = torch.zeros(4, dtype=torch.float32, device=engine.dev)
+    rec_pin = torch.zeros(4, dtype=torch.float32).pin_memory()
+    hist_pin = torch.zeros(max(nsteps, 1), dtype=torch.float32).pin_memory()
+    rows_pin = [torch.zeros((max(nsteps, 1), engine.B), dtype=torch.int32).pin_memory() for _ in range(2)]
+    rows_dev = [torch.zeros((max(nsteps, 1), engine.B), dtype=torch.int32, device=engine.dev) for _ in range(2)]
+    pre = {"rows": None, "rng": None}            # the NEXT epoch's sample order, drawn ahead; torch's generator state before the draw
+
+    def draw_rows(slot):
+        """This rank's batches of one epoch on the device (same order on every rank -- same seed; step s of rank r takes
+        global batch s * size + r, dist.rank_batches): one asynchronous copy from pinned memory."""
+        if not nsteps:
+            return None
+        rows_pin[slot].numpy()[...] = dataset.epoch_rows()[rank::size][:nsteps]
+        rows_dev[slot].copy_(rows_pin[slot], non_blocking=True)
+        return rows_dev[slot]
+
+    def drop_prefetch():
+        """The order drawn ahead will not be used as drawn: torch's generator goes back to where it was before the draw."""
+        if pre["rng"] is not None:
+            torch.set_rng_state(pre["rng"])
+            torch.cuda.current_stream().synchronize()      # (its copy from the pinned buffer is done before that is rewritten)
+        pre["rows"], pre["rng"] = None, None
+
+    # -- speculation: the next epoch's steps start BEFORE this epoch's verdict ---------------------------------------------
+    # The controller needs the validation metrics of epoch i, and nearly always answers "carry on".  One rank: epoch i ends
+    # with a device copy of (parameters, m, v, step) into a shadow model; the validation pass of epoch i runs on that shadow
+    # on a stream of its own WHILE the launch stream already works through the steps of epoch i + 1.  When the verdict does
+    # change something -- learning rate / weight decay, a re-initialisation, the best weights restored, a stop -- the live
+    # state is first put back from the shadow (in stream order behind the speculative steps) and epoch i + 1 is enqueued
+    # again: the trajectory is the sequential one, bit for bit.  Checkpoints and the best state are taken from the shadow.
+    spec = (size == 1 and val_dataset is not None and nsteps > 0 and os.environ.get("LINNA_TRAIN_SPECULATE", "1") != "0")
+    shadow, snap, side = model, None, None
+    if spec:
+        import copy
+        shadow = copy.deepcopy(model)                 # same topology, a flat parameter buffer and weight streams of its own
+        snap = dict(m=torch.zeros_like(opt.m), v=torch.zeros_like(opt.v), step=torch.zeros_like(opt.step_dev))
+        side = torch.cuda.Stream(device=engine.dev)
+    last_dev = torch.zeros(1, dtype=torch.float32, device=engine.dev)
+    fly = {"on": False, "epochs": 0, "undone": 0, "quiet": 0, "acted": False, "acts": {}}   # on: a speculative epoch is enqueued on top of the state the verdict is about
+    QUIET = 4           # speculate only after so many consecutive "carry on" verdicts: a controller that is busy (a run
+                        # that keeps restoring its best weights, say) then costs no wasted epochs, a quiet one loses none
+
+    def state_of_epoch():
+        """(parameters, m, v, step) as they were at the end of the epoch the controller is looking at."""
+        if spec:
+            return shadow._flat, snap["m"], snap["v"], snap["step"]
+        return model._flat, opt.m, opt.v, opt.step_dev
+
+    def rollback(why=None):
+        """Before the controller changes anything: undo the speculative steps (stream-ordered copies, no host wait)."""
+        fly["acted"] = True
+        if why is not None:
+            fly["acts"][why] = fly["acts"].get(why, 0) + 1
+        if fly["on"]:
+            model._flat.copy_(shadow._flat)
+            opt.m.copy_(snap["m"]); opt.v.copy_(snap["v"]); opt.step_dev.copy_(snap["step"])
+            model.weights_changed()                   # the training streams are re-laid from the restored parameters
+            fly["on"] = False
+            fly["undone"] += 1
 
     def new_optimizer(lr_now):
         nonlocal opt
+        rollback()
         opt = _AdamWState(model, lr_now, weight_decay=1e-4)
         pred.optim = opt
         engine.prepare_graph(opt)
 
     def halve_lr():
         if opt.lr > 2e-6:
+            rollback()
             print("learning rate too large: {0}".format(opt.lr), flush=True)
             opt.lr = opt.lr / 2.0
             opt.push_hyper()
 
     def reinit():
+        rollback()
+        drop_prefetch()                           # the Xavier draws come BEFORE the next epoch's order in the reference
         model.init_weight()                       # fresh Xavier weights in place (model_old.init_weight(), :323)
 
-    for i in range(num_epochs):
-        from . import dist as ldist
-        # same order on every rank (same seed); step s of rank r takes global batch s * size + r (dist.rank_batches)
-        rows = dataset.epoch_rows()[rank::size][:nsteps]
-        perm = torch.from_numpy(np.ascontiguousarray(rows)).to(engine.dev) if nsteps else None
-        for s in range(nsteps):
-            engine.step(opt, perm[s], loss_hist[s:s + 1])                       # :273-288
-        if val_dataset is not None:
-            val_dataset.epoch_batches()                                         # keeps torch's RNG stream aligned
-            engine.validate_enqueue()                                           # queued behind the steps: one sync per epoch
-        epoch_losses = loss_hist[:nsteps].cpu().numpy().astype(np.float64)
+    def enqueue_steps(perm):
+        e0 = prof.event()
+        for s_ in range(nsteps):
+            engine.step(opt, perm[s_], loss_hist[s_:s_ + 1])                    # :273-288
+        prof.span("steps", e0, prof.event())
+
+    def enqueue_tail():
+        """Behind an epoch's steps: its losses to pinned memory, the state the verdict will be about, the validation pass
+        and the controller's record.  Returns the event behind which the record is in pinned memory."""
+        hist_pin.copy_(loss_hist, non_blocking=True)
+        if val_dataset is None:
+            ev = torch.cuda.Event(); ev.record()
+            return ev
+        val_dataset.epoch_batches()                                             # keeps torch's RNG stream aligned
+        if nsteps:
+            last_dev.copy_(loss_hist[nsteps - 1:nsteps])
+        e1 = prof.event()
+        if not spec:
+            engine.validate_enqueue()                                           # queued behind the steps: one wait per epoch
+            engine.metrics_enqueue(last_dev if nsteps else None, rec_dev)
+            rec_pin.copy_(rec_dev, non_blocking=True)
+            prof.span("validation", e1, prof.event())
+            ev = torch.cuda.Event(); ev.record()
+            return ev
+        shadow._flat.copy_(model._flat)
+        snap["m"].copy_(opt.m); snap["v"].copy_(opt.v); snap["step"].copy_(opt.step_dev)
+        ready = torch.cuda.Event(); ready.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            engine.validate_enqueue(shadow)
+            engine.metrics_enqueue(last_dev, rec_dev)
+            rec_pin.copy_(rec_dev, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(side)
+        return ev
+
+    perm = draw_rows(0)
+    i = 0
+    prof.mark()
+    if num_epochs > 0:
+        enqueue_steps(perm)
+    prof.mark("enqueue_steps")
+    while i < num_epochs:
+        landed = enqueue_tail()
+        prof.mark("enqueue_validation")
+        if i + 1 < num_epochs and nsteps:                                       # the next epoch's order, while the GPU works
+            pre["rng"] = torch.get_rng_state()
+            pre["rows"] = draw_rows((i + 1) & 1)
+        prof.mark("rows")
+        if spec and pre["rows"] is not None and fly["quiet"] >= QUIET:
+            fly["on"] = True
+            fly["epochs"] += 1
+            enqueue_steps(pre["rows"])                                          # epoch i + 1, on the assumption "carry on"
+            prof.mark("enqueue_steps")
+        landed.synchronize()                                                    # THE wait of the epoch
+        prof.mark("wait")
+        epoch_losses = hist_pin.numpy()[:nsteps].astype(np.float64)
         train_losses.extend(epoch_losses.tolist())
         loss = float(epoch_losses[-1]) if nsteps else float("nan")
         is_best = False
+        stop = False
         if val_dataset is not None:
-            vm = engine.validate_finish()
+            vm = rec_pin.numpy()[1:].astype(np.float64)
             val_metrics.append(vm)
             if progress and rank == 0:
                 print("epoch %d  train %.5e  val %.5e" % (i, loss, vm[0]), flush=True)
@@ -331,6 +509,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
             if np.std(recent) < 0.01 * np.mean(recent) and 10 <= i < 120 and i % 10 == 0:      # :319-335
                 print("bad trainning: {0}".format(i), flush=True)
                 lr_now = opt.lr
+                rollback("plateau: re-initialised")
                 reinit()
                 new_optimizer(lr_now)
                 if i > 10 and lr_now > 2e-4:
@@ -339,6 +518,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
             if np.isnan(v0) or v0 > 1e10 or (v0 - old > 5 * old and i != 0) or (loss - told > 5 * told and i != 0):  # :339
                 lr_now = opt.lr
                 restored = False
+                rollback("loss jump / NaN: best weights restored")
                 if best_state is not None:
                     model.flat_params().copy_(best_state)
                     restored = True
@@ -357,6 +537,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
                 criteria = es.step(v0, loss)                                    # :375-401
                 if criteria == 1:
                     if opt.lr > 2e-6:
+                        rollback("early stopping: lr / 2")
                         print("\n learning rate too large: {0}\n".format(opt.lr), flush=True)
                         opt.lr, opt.weight_decay = opt.lr / 2.0, opt.weight_decay / 2
                         opt.push_hyper()
@@ -368,21 +549,45 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
                     # the reference breaks on rank 0 only (predictor_gpu.py:392-393), harmless there because nothing
                     # collective follows; here every rank holds the same metrics (all-reduced loss, replicated
                     # validation set) and the next epoch starts with an all-reduce, so every rank stops
-                    ckpt.record(opt, i, is_best, checkpoint_every, num_epochs, force=True)
-                    last_epoch = i
-                    break
+                    rollback("early stopping: stop")
+                    drop_prefetch()
+                    stop = True
                 if criteria == 3:
                     print("\n weight decay too small: {0}\n".format(opt.weight_decay), flush=True)
                     if opt.weight_decay < 1e0:
+                        rollback("early stopping: weight decay x 2")
                         opt.weight_decay = opt.weight_decay * 2
                         opt.push_hyper()
             old = val_metrics[-1][0]
             told = loss
+        prof.mark("controller")
+        p_, m_, v_, st_ = state_of_epoch() if fly["on"] else (model._flat, opt.m, opt.v, opt.step_dev)
         if is_best:
-            best_state = model.flat_params().clone()                            # device-resident best.pth.tar
-        ckpt.record(opt, i, is_best, checkpoint_every, num_epochs)
+            best_state = p_.clone()                                             # device-resident best.pth.tar
+        ckpt.record(opt, i, is_best, checkpoint_every, num_epochs, force=stop, state=(p_, m_, v_, st_))
+        prof.mark("checkpoint")
+        prof.end_epoch()
         last_epoch = i
+        if stop:
+            break
+        fly["quiet"] = 0 if fly["acted"] else fly["quiet"] + 1
+        fly["acted"] = False
+        i += 1
+        if i < num_epochs and not fly["on"]:                                    # not speculated, or undone: (re)enqueue the epoch
+            if pre["rows"] is not None:
+                perm, pre["rows"], pre["rng"] = pre["rows"], None, None
+            else:
+                perm = draw_rows(i & 1)
+            prof.mark("rows")
+            enqueue_steps(perm)
+            prof.mark("enqueue_steps")
+        else:
+            pre["rows"], pre["rng"] = None, None                                # (the speculative epoch has consumed the order drawn ahead)
+        fly["on"] = False
+    t_loop = time.perf_counter()
     ckpt.finish(opt, last_epoch)                    # best.pth.tar / last.pth.tar are on disk when train() returns
+    prof.finish(epochs=last_epoch + 1, steps_per_epoch=nsteps, total_s=time.perf_counter() - t_run,
+                final_checkpoint_s=time.perf_counter() - t_loop, speculative_epochs=fly["epochs"], speculative_epochs_undone=fly["undone"], controller_actions=dict(fly["acts"]))
     if val_dataset is not None:
         return np.array(train_losses), np.array(val_metrics)
     return np.array(train_losses)
@@ -453,28 +658,31 @@ class _Checkpoints(object):
         self.t_last = time.time()
         self.best, self.best_dirty, self.last_epoch_written = None, False, -1
 
-    def record(self, opt, epoch, is_best, every, num_epochs, force=False):
+    def record(self, opt, epoch, is_best, every, num_epochs, force=False, state=None):
+        """``state`` = (parameters, m, v, step) of the epoch being recorded when that is not the live state (the epoch
+        loop runs one epoch ahead of its verdicts: trainer.run)."""
         if not self.on:
             return
+        p, m, v, step = state if state is not None else (self.model._flat, opt.m, opt.v, opt.step_dev)
         if is_best:
-            self.best = dict(epoch=epoch, p=self.model._flat.detach().clone(),
-                             opt=(opt.m.clone(), opt.v.clone(), opt.step_dev.clone(), opt.lr, opt.weight_decay))
+            self.best = dict(epoch=epoch, p=p.detach().clone(), opt=(m.clone(), v.clone(), step.clone(), opt.lr, opt.weight_decay))
             self.best_dirty = True
         due = is_best or force or (epoch + 1) % max(every, 1) == 0 or epoch + 1 == num_epochs
         if force or epoch + 1 == num_epochs or (due and time.time() - self.t_last >= self.interval):
-            self.write(opt, epoch)
+            self.write(opt, epoch, (p, m, v, step))
 
     def _host_state(self, flat, epoch, optim_dict):
         host = flat.detach().cpu()
         sd = {k: self.model._view(host, k).clone().contiguous() for k in self.model._index}
         return {"epoch": epoch + 1, "state_dict": sd, "optim_dict": optim_dict}
 
-    def write(self, opt, epoch):
+    def write(self, opt, epoch, state=None):
         global _writer
         if _writer is None:
             _writer = _CheckpointWriter()
         out = self.pred.outdir
-        last = self._host_state(self.model._flat, epoch, opt.state_dict())
+        p, m, v, step = state if state is not None else (self.model._flat, opt.m, opt.v, opt.step_dev)
+        last = self._host_state(p, epoch, opt.state_dict(snapshot=(m, v, step, opt.lr, opt.weight_decay)))
         if self.best_dirty and self.best["epoch"] == epoch:
             _writer.put(last, True, out)                                       # last.pth.tar + copy to best.pth.tar
         else:
