@@ -459,13 +459,14 @@ def training_epochs(device, nepochs=60):
             vloader = predictor_gpu.BatchLoader(util.ArrayDataset(VX, VY), nv, shuffle=False, drop_last=False)
             pred.outdir = tempfile.mkdtemp(prefix="linna_bench_train_")
             try:
-                np.save(os.path.join(pred.outdir, "lr.npy"), 1e-4)
                 with contextlib.redirect_stdout(io.StringIO()):
-                    pred.train(loader, 8, lf, vloader, vf)                       # untimed: first-use costs
+                    pred.train(loader, 8, lf, vloader, vf)                       # untimed: first-use costs, and the learning-rate range
+                                                                                 # test of a run without lr.npy (predictor_gpu.py:222-238)
                     pred.optim = "automatic"
                     prof = {}
                     torch.cuda.synchronize()
                     pred.train(loader, nepochs, lf, vloader, vf, profile=prof)
+                lr_used = float(np.load(os.path.join(pred.outdir, "lr.npy")))
             finally:
                 shutil.rmtree(pred.outdir, ignore_errors=True)
             ne = max(prof["epochs"], 1)
@@ -479,7 +480,7 @@ def training_epochs(device, nepochs=60):
                 "host_ms_per_epoch": {k[5:-9]: 1e3 * v for k, v in sorted(prof.items()) if k.startswith("host_") and k.endswith("_median_s")},
                 "final_checkpoint_ms": 1e3 * prof.get("final_checkpoint_s", 0.0),
                 "speculative_epochs": prof.get("speculative_epochs", 0), "speculative_epochs_undone": prof.get("speculative_epochs_undone", 0),
-                "controller_actions": prof.get("controller_actions", {}),
+                "controller_actions": prof.get("controller_actions", {}), "lr": lr_used,
                 "note": "medians over the epochs (host phases partition an epoch's wall time); *_mean / *_whole_run include the epochs that write a checkpoint or re-initialise"}
     return out
 
