@@ -538,13 +538,23 @@ def secondary_serving(device, kind, nin, nout, dense, nwalkers=4096, iters=400):
         # SURVEY 8d prices the dense quadratic form at 2 nout^2 FLOP per evaluation; the kernel takes it as |d L|^2 with the
         # lower-triangular Cholesky factor of the inverse covariance and skips the zero block of the second column pass
         # (nout > 512): `frac` is priced on the FLOP the kernel EXECUTES, `frac_priced` on the algorithmic 2 nout^2
-        skipped = 2.0 * 512 * (nout - 512) if (nout > 512 and os.environ.get("LINNA_DENSE_TRI", "1") != "0"
-                                               and os.environ.get("LINNA_DENSE_FACTORED", "1") != "0") else 0.0
+        # (mode 1: the second column pass starts at row 512; mode 2, 16 blocks: block b of 64 columns runs the rows from 64 b on)
+        tri = _lib.load().linna_dense_tri(-1) if os.environ.get("LINNA_DENSE_FACTORED", "1") != "0" else 0
+        kpad = (nout + 15) // 16 * 16
+        if tri == 2 and 960 < nout <= 1024:
+            quad = 2.0 * sum(64 * (kpad - 64 * b) for b in range(16))
+        elif tri >= 1 and nout > 512:
+            quad = 2.0 * nout * nout - 2.0 * 512 * (nout - 512)
+        else:
+            quad = 2.0 * nout * nout
+        skipped = 2.0 * nout * nout - quad
         tf_exec = nwalkers * (flop_eval - skipped) / (us * 1e-6) / 1e12
         res.update({"achieved_priced": tf, "frac_priced": tf / FP32_MFMA_PEAK_TFLOPS, "achieved": tf_exec, "frac": tf_exec / FP32_MFMA_PEAK_TFLOPS,
                     "executed_flop_per_eval": flop_eval - skipped,
-                    "note": "chi^2 = |d L|^2, L = chol(Sigma^-1) lower triangular: for nout > 512 the second column pass starts at row 512 "
-                            "(bit-identical to the full pass); achieved / frac count the FLOP executed, *_priced SURVEY's 2 nout^2 for the quadratic form"})
+                    "dense_tri_mode": tri,
+                    "note": "chi^2 = |d L|^2, L = chol(Sigma^-1) lower triangular; the zero triangle is skipped block-wise (linna_dense_tri: bit-identical "
+                            "to the full product); achieved / frac count the FLOP executed (zero padding of the 64-column blocks included), *_priced "
+                            "SURVEY's 2 nout^2 for the quadratic form"})
     try:                                   # the oracle on the host, same walkers, and the GPU's lnP against it
         from oracle import likelihood
         emu = _oracle_emulator(kind, nin, nout, model, np.zeros(nin), np.full(nin, 10.0 / np.sqrt(12.0)), data / sigma, np.ones(nout), sigma)

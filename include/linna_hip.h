@@ -278,8 +278,15 @@ int linna_weights_changed(linna_ctx_t* ctx);
  * Returns the previous setting, or LINNA_ERR_INVALID.  Process-wide, not a per-launch argument: the launch path reads
  * one atomic instead of the environment. */
 int linna_engine_rows(int rows);
+/* How the whole-network kernel's dense log-likelihood segment (chi^2 = |d L|^2, L the lower-triangular Cholesky factor of the
+ * inverse covariance; util.py:953-955) skips the factor's zero upper triangle, for log-probability objects created AFTERWARDS:
+ * 0 not at all, 1 the second column pass starts at row 512, 2 (default; LINNA_DENSE_TRI) additionally, for 960 < nout <= 1024,
+ * the balanced assignment: wave w takes the 64-column blocks w and 15 - w, each from its first non-zero row.  Same sums in
+ * the same order in every mode (the skipped products are zeros).  -1 queries.  Returns the previous mode (tests, A/B). */
+int linna_dense_tri(int mode);
 /* The serving program the whole-network kernel would run for this op list on the engine of `rows` rows per workgroup
- * (dense_nout > 0: with a dense inverse covariance of that size as its last segment; dense_nout == -1: the program of
+ * (dense_nout > 0: with a dense inverse covariance of that size as its last segment, in the direct form d S d^T; dense_nout < -1:
+ * of -dense_nout columns in the factored form |d L|^2 under the current linna_dense_tri mode; dense_nout == -1: the program of
  * the one-launch gradient instead, forward segments then the dX chain down to the input), as text: a header line, then one
  * line per segment ("WIDE|SPLIT|SIDE steps passes ncg kc dst zext N").  Host-side planning only -- nothing is launched,
  * no pointer is read -- for tests and diagnostics.  Returns the number of segments, 0 when the network is outside the

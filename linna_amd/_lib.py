@@ -109,6 +109,7 @@ _SIGNATURES = {
     "linna_logprob_destroy": (_I, [_V]),
     "linna_weights_changed": (_I, [_V]),
     "linna_engine_rows": (_I, [_I]),
+    "linna_dense_tri": (_I, [_I]),
     "linna_net_train_launches": (_I, [_V, _I]),
     "linna_program_describe": (_I, [_V, _I, _I, _I, _I, _V, C.c_size_t]),
     "linna_logprob_ws_bytes": (_SZ, [_V, _I, _I]),

@@ -901,7 +901,8 @@ struct linna_logprob {
     StreamCopy packed_g2;                    // forward + dX chain down to the input in one stream (any network: residual blocks, ...)
     bool grad2 = false;
     bool dense_fused = false;                // the streams end in the dense inverse covariance (output map folded in)
-    NsDense dense() const { return NsDense{d.Sfac ? d.Sfac : d.S, d.lds, d.outmap.cscale, d.outmap.cshift, d.Sfac ? 1 : 0}; }
+    int dense_tri = 2;                       // NsDense::tri, fixed when the object is created (the stream's size depends on it)
+    NsDense dense() const { return NsDense{d.Sfac ? d.Sfac : d.S, d.lds, d.outmap.cscale, d.outmap.cshift, d.Sfac ? 1 : 0, dense_tri}; }
 };
 
 struct LpLayout { size_t x0, fwd, d, part, dh, bwd, dx, total; int slots; };
@@ -999,6 +1000,7 @@ int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob
     if (!desc->w && !desc->S) { set_error("logprob_create: need S (dense) or w (diagonal)"); return LINNA_ERR_INVALID; }
     if (!(desc->temperature > 0.f)) { set_error("logprob_create: temperature must be > 0"); return LINNA_ERR_INVALID; }
     linna_logprob* lp = new linna_logprob{ctx, net, *desc};
+    lp->dense_tri = net_stream_dense_tri(-1);
     const NsDense dn = lp->dense();
     const bool want_dense = !desc->w && desc->S && !desc->outmap.cexp &&
                             !(getenv("LINNA_DENSE_FUSED") && getenv("LINNA_DENSE_FUSED")[0] == '0');
@@ -1037,9 +1039,14 @@ int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size
     if (!layers || nlayers < 1 || !buf || !n) { set_error("program_describe: bad arguments"); return LINNA_ERR_INVALID; }
     // (pointers are only compared, never read: a placeholder stands for the dense inverse covariance)
     static float dummy;
-    NsDense dn{&dummy, (dense_nout + 3) & ~3, nullptr, nullptr};
     if (dense_nout == -1) return net_stream_describe(layers, nlayers, in_size, 3, nullptr, rows, 1, buf, n);   // the one-launch gradient's program
-    return net_stream_describe(layers, nlayers, in_size, 0, dense_nout > 0 ? &dn : nullptr, rows, 1, buf, n);
+    const int dn_cols = dense_nout < -1 ? -dense_nout : dense_nout;         // < -1: the factored form (chi^2 = |d L|^2) of -dense_nout columns
+    NsDense dn{&dummy, (dn_cols + 3) & ~3, nullptr, nullptr, dense_nout < -1 ? 1 : 0, net_stream_dense_tri(-1)};
+    return net_stream_describe(layers, nlayers, in_size, 0, dn_cols > 0 ? &dn : nullptr, rows, 1, buf, n);
+} LINNA_CATCH_INT
+int linna_dense_tri(int mode) try {
+    if (mode < -1 || mode > 2) { set_error("linna_dense_tri: %d (-1 query, 0, 1 or 2)", mode); return LINNA_ERR_INVALID; }
+    return net_stream_dense_tri(mode);
 } LINNA_CATCH_INT
 int linna_engine_rows(int rows) try {
     const int prev = net_stream_force_rows(rows);

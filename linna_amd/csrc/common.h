@@ -135,7 +135,10 @@ int launch_step_increment(int* step, hipStream_t s);
 
 // Dense inverse covariance for the whole-network kernel: the output map d = raw * cscale + cshift is folded into the last
 // layer of the weight stream and S (symmetric, [nout][lds]) is appended as one more segment, chi2 = d . (d S).
-struct NsDense { const float* S; int lds; const float* cscale; const float* cshift; int factored = 0; };   // factored: S holds L (S = L L^T), chi2 = |d L|^2
+struct NsDense { const float* S; int lds; const float* cscale; const float* cshift; int factored = 0;   // factored: S holds L (S = L L^T), chi2 = |d L|^2
+                 int tri = 2; };         // how the factor's zero upper triangle is skipped (net_stream_dense_tri): 0 not, 1 short second pass, 2 balanced blocks
+// process-wide default of NsDense::tri for log-probability objects created afterwards (LINNA_DENSE_TRI); returns the previous value
+int net_stream_dense_tri(int mode);
 // net_stream.hip (program-driven whole-network kernel: residual blocks, widths up to 1024)
 bool net_stream_eligible(const linna_layer_t* layers, int nl, int in_size);
 size_t net_stream_packed_floats(const linna_layer_t* layers, int nl, int in_size);

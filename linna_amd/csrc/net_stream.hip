@@ -189,7 +189,10 @@ __global__ void ns_pack_kernel(NsPackArgs p) {
         const int s = g - p.run_first[r];
         const int nl = p.small ? lane : 16 * t + (lane & 15), kl = p.small ? 4 * t : 4 * (lane >> 4);
         int n, k0;
-        if (S.type == NS_WIDE) { n = 512 * p.run_pass[r] + 64 * w + nl; k0 = 16 * s + kl + (p.run_pass[r] ? S.koff2 : 0); }
+        if (S.type == NS_WIDE && S.koff2 < 0) {        // balanced triangular factor: block w from row 64 w, then block 15 - w
+            const int n0 = S.steps - 4 * w, blk = s < n0 ? w : 15 - w;
+            n = 64 * blk + nl; k0 = 16 * (s < n0 ? s : s - n0) + 64 * blk + kl;
+        } else if (S.type == NS_WIDE) { n = 512 * p.run_pass[r] + 64 * w + nl; k0 = 16 * s + kl + (p.run_pass[r] ? S.koff2 : 0); }
         else { n = 64 * (w % S.ncg) + nl; k0 = 16 * ((w / S.ncg) * S.steps + s) + kl; }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (n < S.N && S.Wa && !S.transA && k0 + 3 < S.Ka && (S.lda & 3) == 0 && (reinterpret_cast<uintptr_t>(S.Wa) & 15) == 0) {
@@ -623,18 +626,21 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
         for (int t = 0; t < NACC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (s_type == NS_WIDE) {
+            // the wave's 64-column block of this run: 8 pass + wave -- or, balanced triangular factor (zext < 0), w then 15 - w
+            const int blk = s_zext < 0 ? (pass ? 15 - wave : wave) : 8 * pass + wave;
             if constexpr (SM) {
-                const float b = lbias[s_bias + 512 * pass + 64 * wave + lane];
+                const float b = lbias[s_bias + 64 * blk + lane];
 #pragma unroll
                 for (int r = 0; r < RS; ++r) acc[4 * r] = f32x4{b, b, b, b};
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float b = lbias[s_bias + 16 * (32 * pass + 4 * wave + t) + li];
+                    const float b = lbias[s_bias + 16 * (4 * blk + t) + li];
                     acc[t] = f32x4{b, b, b, b};
                 }
             }
-            ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (pass ? s_kslice : 0));   // (kslice: 0 but for a short second pass)
+            if (s_zext < 0) kleft = s_steps - 4 * blk;             // its rows start at 64 blk
+            ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (s_zext < 0 ? 64 * blk : (pass ? s_kslice : 0)));   // (kslice: 0 but for a short second pass)
         } else {
             ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (wave >> s_ncgl) * s_kslice);
         }
@@ -769,7 +775,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #define q_row(q, e) (SM ? 4 * (q) + (e) : 4 * kq + (e))
 #define q_col(q) (SM ? lane : 16 * (q) + li)
             if (s_type == NS_WIDE) {
-                float* const nxt = act + (P ^ 1) * ABUF + s_dst + 512 * pass + 64 * wave;
+                float* const nxt = act + (P ^ 1) * ABUF + s_dst + (s_zext < 0 ? 64 * (pass ? 15 - wave : wave) : 512 * pass + 64 * wave);
                 // STORE == 3, last network layer: the targets and the per-column constants of delta, fetched by inline-asm
                 // loads the compiler does not count (a visible load in this loop body would turn its counted vmcnt waits
                 // for the weight ring into vmcnt(0) in EVERY step); one explicit wait for all of them
@@ -1366,7 +1372,31 @@ struct NsProgram {
 
 static int ceil16(int k) { return (k + 15) & ~15; }
 // steps of a segment in every wave's stream (a WIDE segment's second pass may be shorter: NsSeg::zext)
-static int ns_seg_steps(const NsSeg& s) { return s.type == NS_WIDE && s.zext > 0 ? s.steps + (s.passes - 1) * s.zext : s.steps * s.passes; }
+// zext < 0: the BALANCED triangular assignment of a 16-block lower-triangular factor -- wave w multiplies column block w
+// (rows from 64 w) and then block 15 - w (rows from 64 (15 - w)): steps - 4 w and steps - 4 (15 - w) steps, 2 steps - 60 in
+// every wave
+static int ns_seg_steps(const NsSeg& s) {
+    if (s.type == NS_WIDE && s.zext < 0) return 2 * s.steps - 60;
+    return s.type == NS_WIDE && s.zext > 0 ? s.steps + (s.passes - 1) * s.zext : s.steps * s.passes;
+}
+static std::atomic<int> g_dense_tri{-1};
+static int ns_dense_tri_resolved() {
+    int m = g_dense_tri.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* env = getenv("LINNA_DENSE_TRI");
+        int v = env ? atoi(env) : 2;
+        if (v < 0 || v > 2) v = 2;
+        int expect = -1;
+        g_dense_tri.compare_exchange_strong(expect, v);
+        m = g_dense_tri.load(std::memory_order_relaxed);
+    }
+    return m;
+}
+int net_stream_dense_tri(int mode) {
+    const int prev = ns_dense_tri_resolved();
+    if (mode >= 0 && mode <= 2) g_dense_tri.store(mode);
+    return prev;
+}
 
 // Translate the op list into segments; ok = false when something does not fit this kernel.
 enum { NS_PROG_FWD = 0, NS_PROG_FWD_NOGRAD = 1, NS_PROG_DX = 2, NS_PROG_DX_INPUT = 3, NS_PROG_FWD_DENSE = 4, NS_PROG_FWD_DXI = 5,
@@ -1567,9 +1597,14 @@ static NsProgram ns_build_one(const linna_layer_t* layers, int nl, int in_size, 
         bias_off += q.bias_pad;
         // the Cholesky factor of a dense inverse covariance (NsDense::factored) is lower triangular: in the second pass (columns
         // >= 512) the rows k < 512 are zero -- that pass starts at k = 512 (bit-identical: the skipped products are zeros)
-        static const bool tri_on = !(getenv("LINNA_DENSE_TRI") && getenv("LINNA_DENSE_TRI")[0] == '0');
-        if (tri_on && s.type == NS_WIDE && dn && dn->factored && L.Wa == dn->S && passes == 2 && ksteps > 32 && !train) { s.kslice = 512; s.zext = ksteps - 32; }
-        q.koff2 = s.type == NS_WIDE ? s.kslice : 0;
+        // tri = 2 and exactly 16 column blocks (960 < nout <= 1024): the balanced assignment instead (ns_seg_steps) -- the zero
+        // rows of EVERY 64-column block are skipped, not only those of the second pass, and every wave runs the same number
+        // of steps: 66 instead of 94 at nout = 1000
+        if (dn && dn->tri > 0 && s.type == NS_WIDE && dn->factored && L.Wa == dn->S && passes == 2 && ksteps > 32 && !train) {
+            if (dn->tri == 2 && (L.N + 63) / 64 == 16 && ksteps > 60) s.zext = -1;
+            else { s.kslice = 512; s.zext = ksteps - 32; }
+        }
+        q.koff2 = s.type == NS_WIDE ? (s.zext < 0 ? -1 : s.kslice) : 0;
         if (!side) G += ns_seg_steps(s);           // (a SIDE segment is not part of the weight stream)
         p.seg.push_back(s); p.pack.push_back(q);
     }
@@ -1738,6 +1773,7 @@ static const NsProgram& ns_build_prog(const linna_layer_t* layers, int nl, int i
         key.append(reinterpret_cast<const char*>(ptrs), sizeof(ptrs));
         key.append(reinterpret_cast<const char*>(&dn->lds), sizeof(int));
         key.append(reinterpret_cast<const char*>(&dn->factored), sizeof(int));
+        key.append(reinterpret_cast<const char*>(&dn->tri), sizeof(int));
     }
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
@@ -1806,6 +1842,11 @@ int launch_net_stream_pack(const linna_layer_t* layers, int nl, int in_size, flo
     for (int i = 0; i < a.nseg; ++i) {
         a.seg[i] = p.pack[i];
         if (p.seg[i].type == NS_SIDE) continue;                 // not in the stream: ns_pack_side_kernel below
+        if (p.seg[i].type == NS_WIDE && p.seg[i].zext < 0) {     // balanced triangular: ONE run of the stream, split per wave (ns_pack_kernel)
+            a.run_seg[nrun] = i; a.run_pass[nrun] = 0; a.run_first[nrun] = first;
+            first += ns_seg_steps(p.seg[i]); ++nrun;
+            continue;
+        }
         for (int ps = 0; ps < p.seg[i].passes; ++ps) {
             a.run_seg[nrun] = i; a.run_pass[nrun] = ps; a.run_first[nrun] = first;
             first += (ps > 0 && p.seg[i].type == NS_WIDE && p.seg[i].zext > 0) ? p.seg[i].zext : p.seg[i].steps; ++nrun;

@@ -156,14 +156,29 @@ def control_group():
 
 
 def _make_control_group():
+    """Create the gloo side group -- and keep it only if EVERY rank has one: ``new_group`` can fail on one node alone
+    (interface selection, say); ranks that disagreed about the group would run `barrier` / `agree` / `broadcast_object` on
+    different groups and wait for each other for CONTROL_TIMEOUT_S.  The answers are MIN-all-reduced on the default
+    group, as `init()` does for the RCCL communicator."""
     import datetime
+    import sys
     if _state["control"] is None and dist.is_initialized() and dist.get_world_size() > 1:
+        grp, err = None, None
         try:
-            _state["control"] = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CONTROL_TIMEOUT_S))
-        except Exception as e:                                  # noqa: BLE001  (same environment on every rank of a node: all fail alike)
-            import sys
-            sys.stderr.write("linna_amd.dist: no gloo control group (%r); control-plane waits stay on the %s group\n" % (e, dist.get_backend()))
-            _state["control"] = None
+            grp = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=CONTROL_TIMEOUT_S))
+        except Exception as e:                                  # noqa: BLE001
+            err = e
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        have = torch.tensor([1.0 if grp is not None else 0.0], dtype=torch.float32, device=dev)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if float(have.item()) < 1.0:
+            if grp is not None:
+                sys.stderr.write("linna_amd.dist: another rank has no gloo control group: dropped here as well; control-plane "
+                                 "waits stay on the %s group\n" % dist.get_backend())
+            else:
+                sys.stderr.write("linna_amd.dist: no gloo control group (%r); control-plane waits stay on the %s group\n" % (err, dist.get_backend()))
+            grp = None
+        _state["control"] = grp
     return _state["control"]
 
 

@@ -1072,7 +1072,8 @@ class SliceEnsembleSampler(EnsembleSampler):
         unbounded round loop handles and the fixed rounds of the one-call path would not."""
         if self.fast is False or self.host_lp or self._fast_ok is False or self.iteration < self._fast_after:
             return False
-        if self.tune and not (self._last_nexp is not None and self._last_nexp < 2.0 * self.nw):
+        # (_last_nexp counts the WHOLE ensemble's expansions when the walkers are sharded over ranks, see _tune_mu)
+        if self.tune and not (self._last_nexp is not None and self._last_nexp < 2.0 * self.nw * (self.world if self._shared() else 1)):
             return False
         return True
 
@@ -1131,6 +1132,7 @@ class SliceEnsembleSampler(EnsembleSampler):
         self._tune_count = self._tune_count + 1 if abs(nexp / (nexp + ncon) - 0.5) < self.tolerance else 0
         if self._tune_count > self.patience:
             self.tune = False
+            self.tune_off_iteration = self.iteration
 
     def _shared(self):
         return self.world > 1 and self.exchange == "allgather"

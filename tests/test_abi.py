@@ -94,6 +94,32 @@ def test_serving_programs_are_planned_on_the_host_without_a_gpu():
     assert nm == 10 and "SIDE" not in tm and " grad 1" in tm.splitlines()[0]                       # forward + backward half
 
 
+def test_dense_factor_planning_without_a_gpu():
+    """``linna_program_describe(dense_nout < -1)``: the dense log-likelihood segment in its factored form under the three
+    ``linna_dense_tri`` modes -- ChtoModelv2(40,1000) on the 16-row engine: 416 steps with the full factor, 384 with the
+    second column pass started at row 512, 356 with the balanced block assignment (66 steps per wave in that segment);
+    widths outside (960, 1024] keep the short second pass."""
+    import torch  # noqa: F401
+    from linna_amd import nn, _lib
+    lib = _lib.load()
+    prev = lib.linna_dense_tri(-1)
+    try:
+        m = nn.ChtoModelv2(40, 1000, None)
+        got = {}
+        for mode in (0, 1, 2):
+            lib.linna_dense_tri(mode)
+            n, t = nn.describe_program(m, 16, dense_nout=-1000)
+            got[mode] = (int(t.split()[2]), t.strip().splitlines()[n])
+        assert [got[k][0] for k in (0, 1, 2)] == [416, 384, 356]
+        assert got[0][1].startswith("WIDE steps 63 passes 2") and " zext 0 " in got[0][1]
+        assert " zext 31 " in got[1][1] and " zext -1 " in got[2][1]
+        for nout, z in ((700, " zext 12 "), (960, " zext 28 "), (961, " zext -1 "), (1024, " zext -1 ")):
+            n, t = nn.describe_program(nn.MLP(10, nout, None, width=64, depth=1), 16, dense_nout=-nout)
+            assert z in t.strip().splitlines()[n], (nout, t)
+    finally:
+        lib.linna_dense_tri(prev)
+
+
 def test_no_kernel_of_the_library_uses_scratch():
     """Every kernel of liblinna_hip.so keeps its working set in registers: the AMDGPU metadata of the bundled gfx950 code
     objects says 0 bytes of private segment for all of them.  (A change of the weight ring's refill order once left the

@@ -286,7 +286,8 @@ def _zeus_driver_job(rank, world):
     d = sampler.ChainStore.load(os.path.join(out, "zeus_256.h5"))
     ens = drv.sampler
     th = np.asarray(d["chain_transformed"])[200:]
-    return d["chain"].shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), bool(ens._fast_ok), ens.noverflow, ens.tune
+    return (d["chain"].shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), bool(ens._fast_ok), ens.noverflow, ens.tune,
+            ens.mu, getattr(ens, "tune_off_iteration", None), ens._fast_steps)
 
 
 def test_zeus_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
@@ -305,6 +306,11 @@ def test_zeus_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
     np.testing.assert_allclose(res[0][2], sig, rtol=0.3)
     assert res[0][3] and res[1][3]                                   # the one-call half step ran on both ranks
     assert res[0][4] == res[1][4]                                    # ... and they redid the same runs on the round loop
+    # ONE mu for the ONE ensemble: tuned from the counts of both ranks, so both carry the same value, leave tuning at the
+    # same iteration and switch to the one-call path at the same iteration (its threshold counts the whole ensemble)
+    assert res[0][5] is False and res[1][5] is False
+    assert res[0][6] == res[1][6] and res[0][7] == res[1][7] and res[0][7] is not None
+    assert res[0][8] == res[1][8] > 0
     assert sorted(os.listdir(tmp_path)) == ["zeus_256.h5"]
 
 

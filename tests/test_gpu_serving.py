@@ -588,6 +588,46 @@ def test_dense_covariance_as_last_segment(nin, nout, width, depth, monkeypatch):
     assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp) and torch.equal(a.naccept, b.naccept)
 
 
+@pytest.mark.parametrize("nout,how", [(16, "direct"), (33, "direct"), (64, "direct"), (33, "singular")])
+def test_dense_covariance_in_the_direct_form_as_a_side_segment(nout, how, monkeypatch):
+    """chi^2 = d S d^T with S itself as the program's last segment (not its Cholesky factor): what a caller gets with
+    LINNA_DENSE_FACTORED=0, and what a singular / indefinite inverse covariance gets by itself (the factorisation fails,
+    util.py:953-955 has no such requirement).  For nout <= 64 that segment is a SIDE segment of the 16-row serving engine
+    (outside the weight stream, net_stream.hip `last_ok`): every engine against the float64 oracle and the layered path."""
+    from oracle import likelihood
+    nin = 8
+    prob = _custom_problem(nin, nout, 900 + nout, 64, 2, dense=True)
+    if how == "singular":
+        w, v = np.linalg.eigh(prob["invcov"])
+        w[:3] = 0.0                                                   # rank-deficient: Cholesky fails, the direct form serves
+        prob["invcov"] = (v * w[None, :]) @ v.T
+    else:
+        monkeypatch.setenv("LINNA_DENSE_FACTORED", "0")
+    fused = build_logprob(None, 1.0, prob=prob)[0]
+    p = fused._ensure()
+    assert "Sfac" not in p["keep"]
+    monkeypatch.setenv("LINNA_DENSE_FUSED", "0")
+    unfused = build_logprob(None, 1.0, prob=prob)[0]
+    unfused._ensure()
+    monkeypatch.delenv("LINNA_DENSE_FUSED")
+    from linna_amd import nn
+    n, txt = nn.describe_program(fused.model.model, 16, dense_nout=nout)
+    assert txt.strip().splitlines()[n].startswith("SIDE"), txt                   # the covariance segment of the 16-row program
+    emu = cases.oracle_emulator(prob)
+    for B in (1, 17, 300):
+        z = (0.7 * np.random.RandomState(B).standard_normal((B, nin))).astype(np.float32)
+        zd = torch.as_tensor(z, device="cuda")
+        ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0, dtype=np.float64)
+        base = unfused.evaluate(zd).cpu().numpy()
+        np.testing.assert_allclose(base, ref, rtol=2e-5)
+        for rows in (0, 4, 8, 16):
+            _lib.engine_rows(rows)
+            got = fused.evaluate(zd).cpu().numpy()
+            np.testing.assert_allclose(got, ref, rtol=2e-5, err_msg="rows %s B %d" % (rows, B))
+            np.testing.assert_allclose(got, base, rtol=2e-5, err_msg="rows %s B %d" % (rows, B))
+    _lib.engine_rows(0)
+
+
 @pytest.mark.parametrize("nout,dense", [(1100, False), (1100, True)])
 def test_networks_wider_than_the_whole_network_kernel(nout, dense):
     """``ChtoModelv2(nin, nout > 1024)`` -- layer8 is nout x nout -- is outside the whole-network kernel (layers <= 1024 wide):
@@ -621,22 +661,36 @@ def test_networks_wider_than_the_whole_network_kernel(nout, dense):
         assert parity.near_relu_kink(z[r], emu, priors), "row %d differs by %.2e of its maximum away from any ReLU kink" % (r, rowerr[r])
 
 
-@pytest.mark.parametrize("nout", [513, 640, 1000, 1024])
-def test_dense_factor_second_pass_starts_at_row_512(nout):
+@pytest.mark.parametrize("nout", [513, 640, 961, 1000, 1024])
+def test_dense_factor_skips_its_zero_triangle(nout):
     """Dense inverse covariances wider than 512: the log-likelihood segment multiplies by the lower-triangular Cholesky
-    factor, whose second column pass (columns >= 512) starts at row 512 -- ``nout = 513`` leaves that pass ONE step, 1024 the
-    full 32.  lnP against the float64 oracle on every engine (bit-identity with the full pass: tools/dense_tri_probe.py)."""
+    factor.  Mode 1: the second column pass (columns >= 512) starts at row 512 -- ``nout = 513`` leaves that pass ONE step,
+    1024 the full 32.  Mode 2 (default), 960 < nout <= 1024: the balanced assignment -- wave w multiplies the 64-column
+    blocks w and 15 - w, each from its first non-zero row (per-wave run lengths, 2 steps - 60 steps in every wave).
+    lnP against the float64 oracle on every engine, and BIT-IDENTICAL between the three modes (the skipped products are
+    zeros; same sums in the same order)."""
     from oracle import likelihood
     from linna_amd import _lib
     prob = _custom_problem(10, nout, 700 + nout, 64, 1, dense=True)
     emu = cases.oracle_emulator(prob)
     z = np.random.RandomState(nout).standard_normal((300, 10)).astype(np.float32) * 0.5
     ref = likelihood.log_prob(z, emu, prob["priors"], prob["data"], prob["invcov"], 1.0, dtype=np.float64)
-    for rows in (16, 8, 4):
-        prev = _lib.engine_rows(rows)
-        try:
-            lp = build_logprob(None, 1.0, prob)[0]
-            got = lp(z, returntorch=False)
-        finally:
-            _lib.engine_rows(prev)
-        np.testing.assert_allclose(got, ref, rtol=2e-5, err_msg="engine %d" % rows)
+    lib = _lib.load()
+    mode0 = lib.linna_dense_tri(-1)
+    assert mode0 == 2
+    try:
+        for rows in (16, 8, 4):
+            prev = _lib.engine_rows(rows)
+            got = {}
+            try:
+                for mode in (0, 1, 2):
+                    lib.linna_dense_tri(mode)                       # (applies to objects created afterwards)
+                    lp = build_logprob(None, 1.0, prob)[0]
+                    got[mode] = lp(z, returntorch=False)
+            finally:
+                _lib.engine_rows(prev)
+            np.testing.assert_allclose(got[2], ref, rtol=2e-5, err_msg="engine %d" % rows)
+            np.testing.assert_array_equal(got[1], got[0], err_msg="engine %d" % rows)
+            np.testing.assert_array_equal(got[2], got[0], err_msg="engine %d" % rows)
+    finally:
+        lib.linna_dense_tri(mode0)
