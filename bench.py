@@ -790,7 +790,9 @@ def slice_rate(lp, sizes=(4096, 128), iters=(100, 600)):
                                   "iterations_per_s": n / dt, "us_per_iteration": 1e6 * dt / n,
                                   "evals_per_walker_per_iteration": (ens.neval - e0) / max(1, ens.iteration - it0) / nw,
                                   "walker_updates_per_s": n * nw / dt, "mu": float(ens.mu),
-                                  "ends_per_side_by_round": ens.m_sched, "trials_by_round": ens.nt_sched}
+                                  "ends_per_side_by_round": ens.m_sched, "trials_by_round": ens.nt_sched,
+                                  # mean fraction of a half ensemble still active behind each round: what the look-ahead is used for
+                                  "trials_used_by_round": ens.round_usage()}
     return out
 
 

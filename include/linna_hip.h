@@ -495,22 +495,25 @@ int linna_slice_commit(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float
  * (linna_slice_init's arithmetic and Philox counters: stream `half`), `nexp_rounds` stepping-out rounds, round r evaluating
  * the `m_sched[r]` bracket ends per side the sequential loop `while lnP(L) > Z0: L -= 1` would visit next, `nshr_rounds`
  * shrinking rounds of `nt_sched[r]` trials each placed as if its predecessors were rejected (linna_slice_draw's rule, stream
- * 2 + half, sub-counter = trials of the earlier rounds + j + 1), and the commit: 2 + 2 (nexp_rounds + nshr_rounds)
- * launches on `stream`, no host synchronisation.  The accepted points are those of the one-point-per-round procedure.
+ * 2 + half, sub-counter = trials of the earlier rounds + j + 1), and the commit (in the last shrinking round's kernel;
+ * bump_step != 0: step_dev[0] += 1 there as well, which saves the caller its linna_step_increment behind the second half
+ * step of an iteration): 1 + 2 (nexp_rounds + nshr_rounds) launches on `stream`, no host synchronisation.  The accepted points are those of the one-point-per-round procedure.
  * Rounds after the first evaluate only the walkers still active (listed and counted on the device), so a schedule that
  * looks further ahead each round (1, 2, 4, 8 ...) costs little and keeps the number of rounds small; rounds behind the one
  * that finished the last walker leave at once.  m_sched / nt_sched: HOST arrays; M = max m_sched, T = max nt_sched:
  *   state[5 ns]  : Z0 | L | R | Wacc | Zacc;  flags[3 ns];  W[2 M ns], Wd[T ns], Zt[max(2 M, T) ns],
  *   list[max(2 M, T) ns] (the trial points of the walkers still active, for the rounds after the first): scratch
- *   counters[4 + nexp_rounds + nshr_rounds]: [0] expansions, [1] contractions (zeroed first when zero_totals),
+ *   counters[5 + 2 (nexp_rounds + nshr_rounds)]: [0] expansions, [1] contractions (zeroed first when zero_totals),
  *       [2] walkers the rounds of a call left unfinished -- they keep their position; the caller treats a non-zero
- *       count as zeus treats its `maxsteps` (an error) -- [3] evaluated points (both cumulative), [4 + r] scratch.
+ *       count as zeus treats its `maxsteps` (an error) -- [3] evaluated points (both cumulative), [4 + r] walkers still
+ *       active after round r of THIS call (stepping-out rounds first), [4 + nr + r] the same summed over the earlier calls,
+ *       [4 + 2 nr] the number of calls (nr = nexp_rounds + nshr_rounds): how much of the look-ahead a run uses.
  * zeus' EnsembleSampler behind sampler.py:728-735. */
 int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
-                          const int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched,
+                          int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched,
                           int nshr_rounds, float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt,
-                          int* list, int* counters, int zero_totals, void* stream);
+                          int* list, int* counters, int zero_totals, int bump_step, void* stream);
 
 /* `nsteps` ensemble iterations in ONE call: 2 nsteps launches of linna_stretch_half_step's kernel with the same Philox
  * counters (step = step_dev[0] + step_offset + i, stream = half), so the chain is bit-identical to a host loop over that

@@ -1109,14 +1109,14 @@ int linna_logprob_eval_slice_points(linna_logprob_t* lp, const float* coords, in
 
 // One half step of the ensemble slice sampler (zeus behind sampler.py:728-735) in ONE call: the differential-move directions
 // and slice heights, `nexp_rounds` speculative stepping-out rounds of `m_sched[r]` bracket ends per side, `nshr_rounds`
-// shrinking rounds of `nt_sched[r]` trials, the commit -- 2 + 2 (nexp_rounds + nshr_rounds) launches, none of which the host waits for.
+// shrinking rounds of `nt_sched[r]` trials with the commit in the last one -- 1 + 2 (nexp_rounds + nshr_rounds) launches, none of which the host waits for.
 // Every evaluation is the whole-network kernel with the trial points formed in its prologue (never written to memory);
 // rounds behind the one that finished the last walker are gated off on the device.
 int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
-                          const int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched, int nshr_rounds,
+                          int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched, int nshr_rounds,
                           float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt, int* list, int* counters,
-                          int zero_totals, void* stream) try {
+                          int zero_totals, int bump_step, void* stream) try {
     if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !mu || !step_dev || !DIR || !state || !flags || !W || !Wd ||
         !Zt || !list || !counters || ns < 1 || nc < 2 || !m_sched || !nt_sched || nexp_rounds < 1 || nshr_rounds < 1 || (half != 0 && half != 1)) {
         set_error("slice_half_step: bad arguments"); return LINNA_ERR_INVALID;
@@ -1154,10 +1154,12 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
         trials += nt;
         TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, nt, Zt, nullptr, r > 0 ? list : nullptr,
                                  r > 0 ? counters + slot - 1 : nullptr, nt, std::max(1, (nt * ns) >> (2 * r)), stream));
+        const bool last = r + 1 == nshr_rounds;         // the commit (and the step counter) ride in the last round's logic kernel
         TRY(launch_slice_shrink_multi(Z0, Zt, L, R, S_idx, Wd, flags, Wacc, Zacc, ns, counters, slot, r > 0 ? slot - 1 : -1, nt, nt_next,
-                                      trials, list, seed, step_dev, 2 + half, st));
+                                      trials, list, seed, step_dev, 2 + half, last ? coords : nullptr, ldc, ndim, logp, DIR, ldd,
+                                      last && bump_step ? 1 : 0, st));
     }
-    return launch_slice_commit_checked(coords, ldc, ndim, logp, S_idx, ns, DIR, ldd, Wacc, Zacc, flags, counters, st);
+    return LINNA_OK;
 } LINNA_CATCH_INT
 
 int linna_stretch_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,

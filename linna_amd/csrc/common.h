@@ -126,7 +126,8 @@ int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float*
                               const int* step_dev, int stream_id_shrink, int ntrial, hipStream_t s);
 int launch_slice_shrink_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, float* W, int* flags, float* Wacc,
                               float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int nt_next,
-                              int trials_so_far, int* list, uint64_t seed, const int* step_dev, int stream_id, hipStream_t s);
+                              int trials_so_far, int* list, uint64_t seed, int* step_dev, int stream_id, float* coords, int ldc,
+                              int ndim, float* logp, const float* DIR, int ldd, int bump, hipStream_t s);
 int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
                                 const float* Wacc, const float* Zacc, const int* flags, int* counters, hipStream_t s);
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,

@@ -660,7 +660,11 @@ __global__ void slice_begin_kernel(const float* __restrict__ logp, const int* __
                                    float* __restrict__ W, int m, int* __restrict__ counters, int nslots, int zero_totals) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
-        for (int i = 0; i < nslots; ++i) counters[4 + i] = 0;
+        for (int i = 0; i < nslots; ++i) {             // [4 + nslots + i]: the same counts summed over the calls so far (usage statistics)
+            counters[4 + nslots + i] += counters[4 + i];
+            counters[4 + i] = 0;
+        }
+        counters[4 + 2 * nslots] += 1;                 // calls
         if (zero_totals) { counters[0] = 0; counters[1] = 0; }
     }
     if (idx >= (size_t)ns * ldd) return;
@@ -716,37 +720,57 @@ __global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const fl
     }
 }
 
+// `coords` != null (the call's LAST shrinking round): the move of every finished walker is applied here (slice_commit_checked_kernel's
+// arithmetic; a walker the rounds of the call left unfinished stays where it is and is counted), and `bump` advances the
+// device step counter behind the second half step of an iteration -- two launches less per iteration.
 __global__ void slice_shrink_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
                                           float* __restrict__ R, const int* __restrict__ S, float* __restrict__ W,
                                           int* __restrict__ flags, float* __restrict__ Wacc, float* __restrict__ Zacc, int ns,
                                           int* __restrict__ counters, int slot, int prev_slot, int ntrial, int nt_next,
                                           int trials_so_far, int* __restrict__ list, uint64_t seed,
-                                          const int* __restrict__ step_dev, int stream_id) {
+                                          int* __restrict__ step_dev, int stream_id, float* __restrict__ coords, int ldc, int ndim,
+                                          float* __restrict__ logp, const float* __restrict__ DIR, int ldd, int bump) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) atomicAdd(counters + 3, ntrial * (prev_slot < 0 ? ns : counters[prev_slot]));
-    if (k >= ns || !flags[3 * k + 2] || (flags[3 * k] | flags[3 * k + 1])) return;   // done, or its bracket never closed
-    if (prev_slot >= 0 && counters[prev_slot] == 0) return;
-    int ncon = 0;
-    bool active = true;
-    float l = L[k], r = R[k];
-    for (int j = 0; j < ntrial && active; ++j) {
-        const float zt = Zt[(size_t)j * ns + k], w = W[(size_t)j * ns + k];
-        if (zt < Z0[k] || isnan(zt)) {
-            if (w < 0.f) l = w; else r = w;
-            ++ncon;
-            if (r - l < 1e-30f) { active = false; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
+    if (k >= ns) return;
+    const uint32_t step = (uint32_t)step_dev[0];
+    const bool mine = flags[3 * k + 2] && !(flags[3 * k] | flags[3 * k + 1]) &&      // not done, and its bracket closed
+                      !(prev_slot >= 0 && counters[prev_slot] == 0);
+    if (mine) {
+        int ncon = 0;
+        bool active = true;
+        float l = L[k], r = R[k];
+        for (int j = 0; j < ntrial && active; ++j) {
+            const float zt = Zt[(size_t)j * ns + k], w = W[(size_t)j * ns + k];
+            if (zt < Z0[k] || isnan(zt)) {
+                if (w < 0.f) l = w; else r = w;
+                ++ncon;
+                if (r - l < 1e-30f) { active = false; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
+            } else {
+                active = false; Wacc[k] = w; Zacc[k] = zt;
+            }
+        }
+        L[k] = l; R[k] = r;
+        if (ncon) atomicAdd(counters + 1, ncon);
+        if (active) {
+            const int pos = atomicAdd(counters + slot, 1);
+            slice_draw_dev(k, S[k], l, r, W, ns, seed, step, stream_id, trials_so_far, nt_next);   // the next round's trials
+            for (int j = 0; j < nt_next; ++j) list[(size_t)pos * nt_next + j] = j * ns + k;
         } else {
-            active = false; Wacc[k] = w; Zacc[k] = zt;
+            flags[3 * k + 2] = 0;
         }
     }
-    L[k] = l; R[k] = r;
-    if (ncon) atomicAdd(counters + 1, ncon);
-    if (active) {
-        const int pos = atomicAdd(counters + slot, 1);
-        slice_draw_dev(k, S[k], l, r, W, ns, seed, (uint32_t)step_dev[0], stream_id, trials_so_far, nt_next);   // the next round's trials
-        for (int j = 0; j < nt_next; ++j) list[(size_t)pos * nt_next + j] = j * ns + k;
-    } else {
-        flags[3 * k + 2] = 0;
+    if (coords) {
+        if (flags[3 * k] | flags[3 * k + 1] | flags[3 * k + 2]) {
+            atomicAdd(counters + 2, 1);
+        } else if (Wacc[k] != 0.f) {
+            const int wk = S[k];
+            const float wa = Wacc[k];
+            for (int d = 0; d < ndim; ++d) coords[(size_t)wk * ldc + d] += wa * DIR[(size_t)k * ldd + d];
+            logp[wk] = Zacc[k];
+        }
+        // (the last round draws no further trials: no thread of this launch uses the counter's value, whichever it reads)
+        if (bump && k == 0) step_dev[0] = (int)step + 1;
     }
 }
 
@@ -967,9 +991,11 @@ int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float*
 }
 int launch_slice_shrink_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, float* W, int* flags, float* Wacc,
                               float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int nt_next,
-                              int trials_so_far, int* list, uint64_t seed, const int* step_dev, int stream_id, hipStream_t s) {
+                              int trials_so_far, int* list, uint64_t seed, int* step_dev, int stream_id, float* coords, int ldc,
+                              int ndim, float* logp, const float* DIR, int ldd, int bump, hipStream_t s) {
     hipLaunchKernelGGL(slice_shrink_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, W, flags, Wacc, Zacc, ns,
-                       counters, slot, prev_slot, ntrial, nt_next, trials_so_far, list, seed, step_dev, stream_id);
+                       counters, slot, prev_slot, ntrial, nt_next, trials_so_far, list, seed, step_dev, stream_id, coords, ldc, ndim,
+                       logp, DIR, ldd, bump);
     LAUNCH_CHECK("slice_shrink_multi");
 }
 int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,

@@ -974,8 +974,15 @@ class SliceEnsembleSampler(EnsembleSampler):
         self.fast = fast
         self._fast_ok = None                              # None: try the entry on the first tuned iteration
         first = self.FAST_FIRST or (8 if ns <= 64 else 4 if ns <= 256 else 2 if ns <= 2048 else 1)   # measured: tools/slice_probe.py
-        self.set_schedule(self._schedule(first, self.FAST_EXPANSIONS, self.FAST_CAP[0]),
-                          self._schedule(2 * first, self.FAST_TRIALS, self.FAST_CAP[1]))
+        if self.FAST_FIRST is None and ns <= 64:
+            # small ensembles (the reference's 128 walkers): every round costs ~30 us of launches whatever it evaluates, and the
+            # usage counters (linna_slice_half_step, `round_usage`) show nothing left behind 8 bracket ends per side or behind 16
+            # trials in 58 000 walker half steps (R5, tools/slice_probe.py): ONE stepping-out round of 8, the second shrinking
+            # round kept as the rescue (16 + 16 trials); a walker beyond that sends the run to the round loop as before
+            self.set_schedule([8], [16, 16])
+        else:
+            self.set_schedule(self._schedule(first, self.FAST_EXPANSIONS, self.FAST_CAP[0]),
+                              self._schedule(2 * first, self.FAST_TRIALS, self.FAST_CAP[1]))
         self._last_nexp = None                            # expansions of the last tuning iteration (whole ensemble)
         self._fast_after = 0                              # no one-call steps before this iteration (set after an overflow)
         self._guarded = False
@@ -1065,6 +1072,20 @@ class SliceEnsembleSampler(EnsembleSampler):
         dev = int(self._fast_bufs["counters"][3].item()) if self._fast_bufs is not None else 0
         return self._neval_host + dev
 
+    def round_usage(self):
+        """How much of the one-call path's look-ahead the run has used: for every stepping-out and shrinking round, the mean
+        fraction of a half ensemble's walkers still active BEHIND it (device counters of linna_slice_half_step; one read)."""
+        if self._fast_bufs is None:
+            return None
+        nr = self.nexp_rounds + self.nshr_rounds
+        c = self._fast_bufs["counters"].cpu().numpy().astype(np.float64)
+        calls = c[4 + 2 * nr] - 1                       # (the counts of the latest call are added by the next one)
+        if calls < 1:
+            return None
+        frac = c[4 + nr:4 + 2 * nr] / (calls * self.half)
+        return {"half_steps": int(calls), "active_after_expand_round": frac[:self.nexp_rounds].tolist(),
+                "active_after_shrink_round": frac[self.nexp_rounds:].tolist()}
+
     def _use_fast(self):
         """The one-call half step serves every ensemble size (measured: 4.8x the round loop at 128 walkers, 1.3x at 4096).
         While mu is still being tuned it is used only once an iteration has needed few expansions: the walkers of a run
@@ -1085,7 +1106,7 @@ class SliceEnsembleSampler(EnsembleSampler):
             nrep = max(2 * self.m, self.nt_fast)
             self._fast_bufs = dict(state=z(5 * ns), W=z(2 * self.m * ns), Wd=z(self.nt_fast * ns), Zt=z(nrep * ns),
                                    list=torch.zeros(nrep * ns, dtype=torch.int32, device=self.dev),
-                                   counters=torch.zeros(4 + self.nexp_rounds + self.nshr_rounds, dtype=torch.int32, device=self.dev))
+                                   counters=torch.zeros(5 + 2 * (self.nexp_rounds + self.nshr_rounds), dtype=torch.int32, device=self.dev))
         b, st = self._fast_bufs, _lib.stream()
         for h in (0, 1):
             S, Cc = halves[h], halves[1 - h]
@@ -1095,14 +1116,14 @@ class SliceEnsembleSampler(EnsembleSampler):
             rc = _lib.load().linna_slice_half_step(
                 self.lp._ensure()["handle"], P(self.coords), self.ld, self.ndim, P(self.logp), I(S), ns, P(comp), ldc, I(cidx), nc,
                 P(self.mu_dev), seed, I(self.step_dev), h, self._m_arr, self.nexp_rounds, self._nt_arr, self.nshr_rounds, P(self.DIR), self.ld,
-                P(b["state"]), I(self.flags), P(b["W"]), P(b["Wd"]), P(b["Zt"]), I(b["list"]), I(b["counters"]), 1 if h == 0 else 0, st)
+                P(b["state"]), I(self.flags), P(b["W"]), P(b["Wd"]), P(b["Zt"]), I(b["list"]), I(b["counters"]), 1 if h == 0 else 0,
+                1 if h == 1 else 0, st)                  # (the second half step's last kernel advances the device step counter)
             if rc != 0:
                 if rc == _lib.ERR_UNSUPPORTED and h == 0 and self._fast_ok is None:
                     self._fast_ok = False
                     return False
                 _lib.check(rc)
         self._fast_ok = True
-        _lib.call("linna_step_increment", self.ctx, I(self.step_dev), st)
         self.iteration += 1
         self._fast_steps = getattr(self, "_fast_steps", 0) + 1
         if self.tune:

@@ -24,3 +24,7 @@ for nw in sizes:
         dt = time.perf_counter() - t0
         print("%5d walkers  %-44s %8.1f us/iteration  %7.0f it/s  mu %.3f  evals/walker/iteration %.1f  tuned %s" % (
             nw, ("one-call m %s nt %s" % (ens.m_sched, ens.nt_sched)) if fast else "rounds", dt / n * 1e6, n / dt, ens.mu, (ens.neval - e0) / n / nw, not ens.tune), flush=True)
+        if fast and ens.round_usage():
+            u = ens.round_usage()
+            print("        still active behind each stepping-out round: %s; behind each shrinking round: %s (mean fraction of a half ensemble, %d half steps); runs redone on the round loop: %d" % (
+                ["%.2e" % v for v in u["active_after_expand_round"]], ["%.2e" % v for v in u["active_after_shrink_round"]], u["half_steps"], ens.noverflow), flush=True)
