@@ -76,18 +76,15 @@ template <int DIR>
 __global__ __launch_bounds__(64 * AC_WAVES) void acorr_update_kernel(const float* __restrict__ CT, int nd, int nwp, int nwc,
                                                                      int a0, int a1, int lo, int hi, int k0, int k1,
                                                                      double* __restrict__ S, double* __restrict__ T, double sign) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int s = blockIdx.x * 64 + lane;
     const int kb = k0 + (blockIdx.y * AC_WAVES + wave) * AC_R;
     if (kb >= k1) return;                                   // (wave-uniform)
     const int d = (blockIdx.x * 64) / nwc;
     const size_t ns = (size_t)nd * nwp, nser = (size_t)nd * nwc;
-    // a chain row's address = (uniform row base, scalar arithmetic) + (this lane's element, one 32-bit register): the loads take
-    // their base from scalar registers.  A row outside the window is replaced by ROW 0 -- the series' reference point, whose
-    // value minus the reference is exactly zero -- so no product needs a select.
-    const unsigned lidx = (unsigned)(d * nwp + (s - d * nwc));
-    const double ref = (double)CT[lidx];
-    auto ldrow = [&](int r, bool ok) { return (CT + (ok ? (size_t)r * ns : (size_t)0))[lidx]; };
+    const float* col = CT + (size_t)d * nwp + (s - d * nwc);
+    const double ref = (double)col[0];
+    auto ldrow = [&](int r) { r = min(max(r, lo), hi - 1); return col[(size_t)r * ns]; };
     constexpr int NW = AC_TT + AC_R - 1, OLD = AC_R - 1;
     double acc[AC_R], win[NW], an[AC_TT];
 #pragma unroll
@@ -97,30 +94,23 @@ __global__ __launch_bounds__(64 * AC_WAVES) void acorr_update_kernel(const float
 #pragma unroll
     for (int j = 0; j < OLD; ++j) {
         const int r = wb + j;
-        win[j] = (double)ldrow(r, r >= lo && r < hi) - ref;
+        const double v = (double)ldrow(r) - ref;
+        win[j] = (r >= lo && r < hi) ? v : 0.0;
     }
     float rw[AC_TT], ra[AC_TT];
 #pragma unroll
-    for (int i = 0; i < AC_TT; ++i) {
-        const int r = wb + OLD + i, t = t0 + i;
-        rw[i] = ldrow(r, r >= lo && r < hi); ra[i] = ldrow(t, t < a1);
-    }
+    for (int i = 0; i < AC_TT; ++i) { rw[i] = ldrow(wb + OLD + i); ra[i] = ldrow(t0 + i); }
     for (; t0 < a1; t0 += AC_TT, wb += AC_TT) {
 #pragma unroll
         for (int i = 0; i < AC_TT; ++i) {
-            win[OLD + i] = (double)rw[i] - ref;
-            an[i] = (double)ra[i] - ref;
-        }
-        if (kb == 0) {
-#pragma unroll
-            for (int i = 0; i < AC_TT; ++i) tsum += an[i];
+            const int r = wb + OLD + i, t = t0 + i;
+            win[OLD + i] = (r >= lo && r < hi) ? (double)rw[i] - ref : 0.0;
+            an[i] = t < a1 ? (double)ra[i] - ref : 0.0;
+            tsum += an[i];
         }
         if (t0 + AC_TT < a1) {
 #pragma unroll
-            for (int i = 0; i < AC_TT; ++i) {
-                const int r = wb + AC_TT + OLD + i, t = t0 + AC_TT + i;
-                rw[i] = ldrow(r, r >= lo && r < hi); ra[i] = ldrow(t, t < a1);
-            }
+            for (int i = 0; i < AC_TT; ++i) { rw[i] = ldrow(wb + AC_TT + OLD + i); ra[i] = ldrow(t0 + AC_TT + i); }
         }
 #pragma unroll
         for (int i = 0; i < AC_TT; ++i)
