@@ -234,7 +234,7 @@ def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
                 "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
-def driver_rate(lp, nwalkers, nsamp=2000, tmpdir=None, prefix="driver_"):
+def driver_rate(lp, nwalkers, nsamp=2000, tmpdir=None, prefix="driver_", method="emcee"):
     """The reference's emcee driver end to end (sampler.py:458-554 -> linna_amd.sampler.HMCSampler.sample): 100 burn-in
     iterations + restart, then `nsamp` iterations with everything a run does -- chain blocks device -> host, the
     reference's HDF5 layout appended every 100 iterations (chain + chain_transformed + log_prob: 1.1 MB per iteration
@@ -262,14 +262,17 @@ def driver_rate(lp, nwalkers, nsamp=2000, tmpdir=None, prefix="driver_"):
             gcs["t"] += time.perf_counter() - gcs["t0"]; gcs["n"] += 1
     gc.callbacks.append(gc_cb)
     try:
-        drv = sampler.HMCSampler(lp, None, None, NIN, nwalkers, x0=x0, transform=util.Transform(priors))
+        if method == "zeus":               # the reference's default sampler (main.py:22), its callback's cadence and 20 % discard
+            drv = sampler.ZeusSampler(lp, NIN, nwalkers, x0=x0, transform=util.Transform(priors))
+        else:
+            drv = sampler.HMCSampler(lp, None, None, NIN, nwalkers, x0=x0, transform=util.Transform(priors))
         with contextlib.redirect_stdout(io.StringIO()):
             t0 = time.perf_counter()
             store = drv.sample(None, nsamp, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True, profile=prof)   # never "converged": runs nsamp
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         n = sum(len(c) for c in store.chain)
-        size = os.path.getsize(os.path.join(out, "chemcee_256.h5"))
+        size = os.path.getsize(os.path.join(out, "zeus_256.h5" if method == "zeus" else "chemcee_256.h5"))
     finally:
         gc.callbacks.remove(gc_cb)
         shutil.rmtree(out, ignore_errors=True)
@@ -280,7 +283,8 @@ def driver_rate(lp, nwalkers, nsamp=2000, tmpdir=None, prefix="driver_"):
     if checks and "gpu_stats_s" in prof:
         bd["stats_us_per_check"] = 1e6 * prof["gpu_stats_s"] / checks
         bd["stats_frac_of_sampling"] = prof["gpu_stats_s"] / max(prof.get("gpu_sampling_s", 0.0), 1e-12)
-    return {prefix + "steps_per_s": (n + 100) / dt, prefix + "iterations": n + 100, prefix + "seconds": dt,
+    burn = 0 if method == "zeus" else 100
+    return {prefix + "steps_per_s": (n + burn) / dt, prefix + "iterations": n + burn, prefix + "seconds": dt,
             prefix + "chain_file_bytes": size, prefix + "tmp_fs": _fs_type(tmpdir or tempfile.gettempdir()),
             prefix + "breakdown": bd}
 
@@ -1119,6 +1123,11 @@ def main():
                     res[key] = fn()
                 except Exception as e:                              # noqa: BLE001
                     res[key] = {"error": repr(e)[:300]}
+            if not args.no_driver and isinstance(res.get("slice", {}).get("walkers_128"), dict):
+                try:                                                # the zeus driver end to end at the reference's ensemble size
+                    res["slice"]["walkers_128"].update(driver_rate(lp, 128, nsamp=3000, method="zeus"))
+                except Exception as e:                              # noqa: BLE001
+                    res["slice"]["walkers_128"]["driver_error"] = repr(e)[:300]
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
             lp.evaluate(z, out=out)
             res["cpu_baseline"] = cpu_baseline(consts, z_host, gpu_out=out.cpu().numpy())
