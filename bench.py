@@ -194,7 +194,7 @@ def _oracle_emulator(kind, nin, nout, model, X_mean, X_std, y_mean, y_std, sigma
     return likelihood.Emulator(kind, nin, nout, w, X_mean, X_std, y_mean, y_std, sigma, **kw)
 
 
-TRAFFIC_FILE = "r04_pmc_traffic.json"
+TRAFFIC_FILE = "r05_pmc_traffic.json"
 
 
 def pmc_traffic():
@@ -1053,7 +1053,7 @@ def main():
         except Exception as e:                                      # noqa: BLE001
             training = {"error": repr(e)[:300]}
 
-    if training is not None and world == 1 and not args.no_training and "error" not in training:
+    if training is not None and world == 1 and not args.no_training and not args.no_secondary and "error" not in training:
         try:
             training["epoch"] = training_epochs(device)
         except Exception as e:                                      # noqa: BLE001
