@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 9   /* 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd, linna_val_metrics, linna_loss_desc_t::ylog; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
+#define LINNA_ABI_VERSION 10   /* 10: + linna_slice_fusion; 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd, linna_val_metrics, linna_loss_desc_t::ylog; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -284,6 +284,11 @@ int linna_engine_rows(int rows);
  * the balanced assignment: wave w takes the 64-column blocks w and 15 - w, each from its first non-zero row.  Same sums in
  * the same order in every mode (the skipped products are zeros).  -1 queries.  Returns the previous mode (tests, A/B). */
 int linna_dense_tri(int mode);
+/* Which launches of linna_slice_half_step are folded into their neighbours, as a mask (default: all that apply): bit 0 -- with ONE
+ * stepping-out round, its logic kernel is not launched: the first shrinking round's evaluation derives its trial points from
+ * the bracket ends' lnP in its prologue and that round's logic kernel does the bookkeeping of both.  The chain is identical
+ * under every mask (same Philox counters, same arithmetic).  -1 queries.  Returns the previous mask (tests, A/B). */
+int linna_slice_fusion(int mask);
 /* The serving program the whole-network kernel would run for this op list on the engine of `rows` rows per workgroup
  * (dense_nout > 0: with a dense inverse covariance of that size as its last segment, in the direct form d S d^T; dense_nout < -1:
  * of -dense_nout columns in the factored form |d L|^2 under the current linna_dense_tri mode; dense_nout == -1: the program of

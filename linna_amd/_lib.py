@@ -11,7 +11,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LINNA_LIB_PATH") or os.path.join(_HERE, "liblinna_hip.so")   # (LINNA_LIB_PATH: a diagnostic build, tools/ns_stamps.py)
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
@@ -110,6 +110,7 @@ _SIGNATURES = {
     "linna_weights_changed": (_I, [_V]),
     "linna_engine_rows": (_I, [_I]),
     "linna_dense_tri": (_I, [_I]),
+    "linna_slice_fusion": (_I, [_I]),
     "linna_net_train_launches": (_I, [_V, _I]),
     "linna_program_describe": (_I, [_V, _I, _I, _I, _I, _V, C.c_size_t]),
     "linna_logprob_ws_bytes": (_SZ, [_V, _I, _I]),
@@ -236,6 +237,15 @@ def iptr(t):
 
 def ld4(w):
     return (int(w) + 3) & ~3
+
+
+def slice_fusion(mask=-1):
+    """Which launches of linna_slice_half_step are folded into their neighbours (a mask, include/linna_hip.h); -1 queries.
+    Returns the previous mask (tests and measurements: the chain is the same under every mask)."""
+    prev = load().linna_slice_fusion(int(mask))
+    if prev < 0:
+        check(prev)
+    return prev
 
 
 def engine_rows(rows=0):

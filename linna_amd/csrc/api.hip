@@ -1048,6 +1048,14 @@ int linna_dense_tri(int mode) try {
     if (mode < -1 || mode > 2) { set_error("linna_dense_tri: %d (-1 query, 0, 1 or 2)", mode); return LINNA_ERR_INVALID; }
     return net_stream_dense_tri(mode);
 } LINNA_CATCH_INT
+// which launches of linna_slice_half_step are folded into their neighbours (bit 0: the one stepping-out round's logic into
+// the first shrinking round; A/B switch, results identical either way)
+static std::atomic<int> g_slice_fusion{7};
+static bool slice_derive_enabled() { return (g_slice_fusion.load() & 1) != 0; }
+int linna_slice_fusion(int mode) try {
+    if (mode < -1 || mode > 7) { set_error("linna_slice_fusion: %d (-1 query, or a mask of bits 0-2)", mode); return LINNA_ERR_INVALID; }
+    return mode < 0 ? g_slice_fusion.load() : g_slice_fusion.exchange(mode);
+} LINNA_CATCH_INT
 int linna_engine_rows(int rows) try {
     const int prev = net_stream_force_rows(rows);
     if (prev < 0) { set_error("linna_engine_rows: %d (0, 4, 8 or 16)", rows); return LINNA_ERR_INVALID; }
@@ -1076,9 +1084,11 @@ int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, v
 
 // `list` / `count` / `mul`: only the trial points list[0 .. count[0] * mul) are evaluated (device-side count; the launch is
 // sized for all nrep * ns); `b_engine`: the batch size the engine is chosen for (the expected number of live rows)
+// the first shrinking round behind one stepping-out round: what the evaluation needs to place its own trials (NsArgs::sl_*)
+struct SliceDerive { const float* Z0; const float* L; const float* R; const float* Ze; int m, nt; uint64_t seed; const int* step_dev; int stream_id; };
 static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
                                 const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
-                                const int* list, const int* count, int mul, int b_engine, void* stream) {
+                                const int* list, const int* count, int mul, int b_engine, void* stream, const SliceDerive* sd = nullptr) {
     if (!lp || !coords || !S_idx || !DIR || !w || !lnP || ns < 1 || nrep < 1) {
         set_error("logprob_eval_slice_points: bad arguments"); return LINNA_ERR_INVALID;
     }
@@ -1093,6 +1103,10 @@ static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ld
     TRY(lp_refresh_stream(lp, b_engine > 0 ? b_engine : nrep * ns, stream, &packed, &rows));
     const linna_net* n = lp->net;
     NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, list, ns, 0ull, count, mul, 0, 0.f, nullptr, 1};
+    if (sd) {
+        mv.sl_Z0 = sd->Z0; mv.sl_L = sd->L; mv.sl_R = sd->R; mv.sl_Zt = sd->Ze; mv.sl_m = sd->m; mv.sl_nt = sd->nt;
+        mv.sl_seed = sd->seed; mv.sl_step = sd->step_dev; mv.sl_stream = sd->stream_id;
+    }
     const NsDense dn = lp->dense();
     const bool df = lp->dense_fused;
     return launch_net_stream(n->Lfull.data(), (int)n->Lfull.size(), n->in_size, packed, DIR, ldd, nrep * ns, d.nin, d.is_flat, d.a1,
@@ -1136,6 +1150,10 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
     TRY(launch_slice_begin(logp, S_idx, ns, ccoords, ldcc, C_idx, nc, ndim, mu, seed, step_dev, half, DIR, ldd, Z0, L, R, flags, W, m_sched[0],
                            counters, nexp_rounds + nshr_rounds, zero_totals, st));
     int slot = 4;
+    // ONE stepping-out round (small ensembles): its logic kernel is not launched -- the first shrinking round's evaluation
+    // derives its trial points from the stepping-out round's results in its prologue (NsArgs::sl_*), and the first shrinking
+    // round's logic kernel does the bookkeeping of both.  The lnP of that round go to W (whose bracket ends are spent).
+    const bool derive = slice_derive_enabled() && nexp_rounds == 1 && m_sched[0] <= 16 && nt_sched[0] <= 32 && nt_sched[0] <= 2 * m_sched[0];
     // rounds after the first evaluate only the walkers still active: the logic kernel of round r lists their trial points
     // (list[pos * nrep + j] = j ns + k, pos = the walker's rank among the active ones) and counts them in counters[slot];
     // round r + 1's launch is sized for all of them, runs the engine chosen for the expected number (a quarter of the
@@ -1145,19 +1163,23 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
         const int m = m_sched[r], m_next = r + 1 < nexp_rounds ? m_sched[r + 1] : 0;
         TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, W, 2 * m, Zt, nullptr, r > 0 ? list : nullptr,
                                  r > 0 ? counters + slot - 1 : nullptr, 2 * m, std::max(1, (2 * m * ns) >> (2 * r)), stream));
-        TRY(launch_slice_expand_multi(Z0, Zt, L, R, S_idx, flags, ns, m, m_next, counters, slot, r > 0 ? slot - 1 : -1, W, Wd, list, seed,
-                                      step_dev, 2 + half, nt_sched[0], st));
+        if (!derive)
+            TRY(launch_slice_expand_multi(Z0, Zt, L, R, S_idx, flags, ns, m, m_next, counters, slot, r > 0 ? slot - 1 : -1, W, Wd, list, seed,
+                                          step_dev, 2 + half, nt_sched[0], st));
     }
     int trials = 0;
     for (int r = 0; r < nshr_rounds; ++r, ++slot) {
         const int nt = nt_sched[r], nt_next = r + 1 < nshr_rounds ? nt_sched[r + 1] : 0;
         trials += nt;
-        TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, nt, Zt, nullptr, r > 0 ? list : nullptr,
-                                 r > 0 ? counters + slot - 1 : nullptr, nt, std::max(1, (nt * ns) >> (2 * r)), stream));
+        const bool dv = derive && r == 0;
+        SliceDerive sd{Z0, L, R, Zt, m_sched[0], nt, seed, step_dev, 2 + half};
+        TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, nt, dv ? W : Zt, nullptr, r > 0 ? list : nullptr,
+                                 r > 0 ? counters + slot - 1 : nullptr, nt, std::max(1, (nt * ns) >> (2 * r)), stream, dv ? &sd : nullptr));
         const bool last = r + 1 == nshr_rounds;         // the commit (and the step counter) ride in the last round's logic kernel
-        TRY(launch_slice_shrink_multi(Z0, Zt, L, R, S_idx, Wd, flags, Wacc, Zacc, ns, counters, slot, r > 0 ? slot - 1 : -1, nt, nt_next,
-                                      trials, list, seed, step_dev, 2 + half, last ? coords : nullptr, ldc, ndim, logp, DIR, ldd,
-                                      last && bump_step ? 1 : 0, st));
+        SliceRound sr{Z0, dv ? W : Zt, L, R, S_idx, Wd, flags, Wacc, Zacc, ns, counters, slot, r > 0 ? slot - 1 : -1, nt, nt_next, trials, list,
+                      seed, step_dev, 2 + half, last ? coords : nullptr, ldc, ndim, logp, DIR, ldd, last && bump_step ? 1 : 0,
+                      Zt, dv ? m_sched[0] : 0, 4};
+        TRY(launch_slice_shrink_multi(sr, st));
     }
     return LINNA_OK;
 } LINNA_CATCH_INT

@@ -37,6 +37,218 @@ __device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t st
     return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// ---- the logic of one shrinking round of linna_slice_half_step for walker k of the half ensemble (pointwise.hip's comment
+// block "one-call half step" has the procedure).  Shared by slice_shrink_multi_kernel and by the tail of the whole-network
+// kernel (net_stream.hip: the last workgroup of a round's evaluation runs this over the walkers, no launch of its own).
+// counters: [0] expansions, [1] contractions, [2] walkers left unfinished by the rounds of a call (sticky),
+//           [3] evaluated points, [4 + r] walkers still active after round r (expand rounds first, then shrink rounds)
+struct SliceRound {
+    const float* Z0; const float* Zt;                  // slice heights [ns]; lnP of this round's trials, [j ns + k]
+    float* L; float* R; const int* S; float* W;        // brackets, the half ensemble's walkers, trial weights [j ns + k] (read; the next round's written)
+    int* flags; float* Wacc; float* Zacc; int ns;
+    int* counters; int slot, prev_slot, ntrial, nt_next, trials_so_far;
+    int* list; uint64_t seed; int* step_dev; int stream_id;
+    float* coords; int ldc, ndim; float* logp; const float* DIR; int ldd, bump;   // coords != null: the call's last round commits
+    // m_derive > 0: this is the first shrinking round behind ONE stepping-out round of m_derive ends per side whose logic kernel
+    // was not launched (the evaluation derived its trials itself, NsArgs::sl_*): its bookkeeping is done here first, from Ze
+    const float* Ze; int m_derive, eslot;
+};
+__device__ __forceinline__ void slice_draw_dev(int k, int wk, float l, float r, float* __restrict__ W, int ns, uint64_t seed,
+                                               uint32_t step, int stream_id, int round, int ntrial) {
+    for (int j = 0; j < ntrial; ++j) {
+        const U4 b = walker_bits(seed, (uint32_t)wk, step, (uint32_t)stream_id, (uint32_t)(round + j + 1));
+        const float w = l + u01(b.x) * (r - l);
+        W[(size_t)j * ns + k] = w;
+        if (w < 0.f) l = w; else r = w;
+    }
+}
+// stepping out over the m ends per side one round evaluated (Zt[j ns + k]: lnP at L - j, j < m, and at R + (j - m)); returns
+// whether the walker is still stepping out
+__device__ __forceinline__ bool slice_expand_walker(int k, int ns, int m, float z0, const float* __restrict__ Zt, float& l, float& r,
+                                                    int* __restrict__ flags, int* __restrict__ counters) {
+    int n = 0;
+    if (flags[3 * k]) {
+        int j = 0;
+        for (; j < m; ++j) { if (Zt[(size_t)j * ns + k] > z0) { l -= 1.f; ++n; } else break; }
+        if (j < m) flags[3 * k] = 0;
+    }
+    if (flags[3 * k + 1]) {
+        int j = 0;
+        for (; j < m; ++j) { if (Zt[(size_t)(m + j) * ns + k] > z0) { r += 1.f; ++n; } else break; }
+        if (j < m) flags[3 * k + 1] = 0;
+    }
+    if (n) atomicAdd(counters + 0, n);
+    return (flags[3 * k] | flags[3 * k + 1]) != 0;
+}
+__device__ __forceinline__ void slice_round_walker(const SliceRound& a, int k) {
+    const int ns = a.ns;
+    if (k == 0) {
+        if (a.m_derive) atomicAdd(a.counters + 3, 2 * a.m_derive * ns);
+        atomicAdd(a.counters + 3, a.ntrial * (a.prev_slot < 0 ? ns : a.counters[a.prev_slot]));      // the points this round evaluated
+    }
+    if (k >= ns) return;
+    const uint32_t step = (uint32_t)a.step_dev[0];
+    if (a.m_derive) {
+        float l = a.L[k], r = a.R[k];
+        const bool out = slice_expand_walker(k, ns, a.m_derive, a.Z0[k], a.Ze, l, r, a.flags, a.counters);
+        a.L[k] = l; a.R[k] = r;
+        if (out) atomicAdd(a.counters + a.eslot, 1);
+        else slice_draw_dev(k, a.S[k], l, r, a.W, ns, a.seed, step, a.stream_id, 0, a.ntrial);   // the trials the evaluation derived
+    }
+    const bool mine = a.flags[3 * k + 2] && !(a.flags[3 * k] | a.flags[3 * k + 1]) &&      // not done, and its bracket closed
+                      !(a.prev_slot >= 0 && a.counters[a.prev_slot] == 0);
+    if (mine) {
+        int ncon = 0;
+        bool active = true;
+        float l = a.L[k], r = a.R[k];
+        const float z0 = a.Z0[k];
+        for (int j = 0; j < a.ntrial && active; ++j) {
+            const float zt = a.Zt[(size_t)j * ns + k], w = a.W[(size_t)j * ns + k];
+            if (zt < z0 || isnan(zt)) {
+                if (w < 0.f) l = w; else r = w;
+                ++ncon;
+                if (r - l < 1e-30f) { active = false; a.Wacc[k] = 0.f; a.Zacc[k] = z0; }   // degenerate: stay put
+            } else {
+                active = false; a.Wacc[k] = w; a.Zacc[k] = zt;
+            }
+        }
+        a.L[k] = l; a.R[k] = r;
+        if (ncon) atomicAdd(a.counters + 1, ncon);
+        if (active) {
+            const int pos = atomicAdd(a.counters + a.slot, 1);
+            slice_draw_dev(k, a.S[k], l, r, a.W, ns, a.seed, step, a.stream_id, a.trials_so_far, a.nt_next);   // the next round's trials
+            for (int j = 0; j < a.nt_next; ++j) a.list[(size_t)pos * a.nt_next + j] = j * ns + k;
+        } else {
+            a.flags[3 * k + 2] = 0;
+        }
+    }
+    if (a.coords) {
+        // the move of every finished walker (slice_commit_checked_kernel's arithmetic); a walker the rounds of the call left
+        // unfinished stays where it is and is counted; `bump` advances the device step counter behind an iteration's second half step
+        if (a.flags[3 * k] | a.flags[3 * k + 1] | a.flags[3 * k + 2]) {
+            atomicAdd(a.counters + 2, 1);
+        } else if (a.Wacc[k] != 0.f) {
+            const int wk = a.S[k];
+            const float wa = a.Wacc[k];
+            for (int d = 0; d < a.ndim; ++d) a.coords[(size_t)wk * a.ldc + d] += wa * a.DIR[(size_t)k * a.ldd + d];
+            a.logp[wk] = a.Zacc[k];
+        }
+        // (the last round draws no further trials: no thread of this launch uses the counter's value, whichever it reads)
+        if (a.bump && k == 0) a.step_dev[0] = (int)step + 1;
+    }
+}
+
+// ---- the same logic with a WAVE per walker (all 64 lanes call with the same k): the bracket ends / trials of a round are loaded,
+// and the Philox draws of the next round made, one per lane; what is sequential in the procedure (a bracket shrinking trial by
+// trial) is a short uniform loop over register values.  One thread per walker ran 16-32 dependent Philox draws and as many
+// dependent loads: 5-10 us per logic kernel, a third of a 128-walker iteration.  Same arithmetic in the same order: same chain.
+__device__ __forceinline__ float wave_lane_f(float v, int j) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j)); }
+// trial j + 1 of (round0 ...) placed as if its predecessors were rejected (slice_draw_dev); lane j < cnt returns w_j
+__device__ __forceinline__ float slice_draw_wave(int lane, int wk, float l, float r, uint64_t seed, uint32_t step, int stream_id,
+                                                 int round0, int cnt) {
+    const U4 b = walker_bits(seed, (uint32_t)wk, step, (uint32_t)stream_id, (uint32_t)(round0 + lane + 1));
+    const float u = u01(b.x);
+    float mine = 0.f;
+    for (int j = 0; j < cnt; ++j) {
+        const float w = l + wave_lane_f(u, j) * (r - l);
+        if (lane == j) mine = w;
+        if (w < 0.f) l = w; else r = w;
+    }
+    return mine;
+}
+// stepping out over m <= 32 ends per side: lanes 0..m-1 the left ends, 32..32+m-1 the right ones; fl / fr updated
+__device__ __forceinline__ void slice_expand_wave(int lane, int k, int ns, int m, float z0, const float* __restrict__ Zt, float& l, float& r,
+                                                  int& fl, int& fr, int* __restrict__ flags, int* __restrict__ counters) {
+    const int side = lane >> 5, j = lane & 31;
+    const float ze = j < m ? Zt[(size_t)(side * m + j) * ns + k] : 0.f;
+    const unsigned long long bal = __ballot(j < m && ze > z0);
+    const int nl = fl ? __builtin_ctzll(~(unsigned long long)(uint32_t)bal) : 0;
+    const int nr = fr ? __builtin_ctzll(~(unsigned long long)(uint32_t)(bal >> 32)) : 0;
+    for (int i = 0; i < nl; ++i) l -= 1.f;
+    for (int i = 0; i < nr; ++i) r += 1.f;
+    if (fl && nl < m) { fl = 0; if (lane == 0) flags[3 * k] = 0; }
+    if (fr && nr < m) { fr = 0; if (lane == 0) flags[3 * k + 1] = 0; }
+    if (lane == 0 && nl + nr) atomicAdd(counters + 0, nl + nr);
+}
+__device__ __forceinline__ void slice_round_wave(const SliceRound& a, int k, int lane) {
+    const int ns = a.ns;
+    if (a.ntrial > 64 || a.nt_next > 64 || a.m_derive > 32) {       // (schedules beyond a wave's lanes: one lane, the plain procedure)
+        if (lane == 0) slice_round_walker(a, k);
+        return;
+    }
+    if (k == 0 && lane == 0) {
+        if (a.m_derive) atomicAdd(a.counters + 3, 2 * a.m_derive * ns);
+        atomicAdd(a.counters + 3, a.ntrial * (a.prev_slot < 0 ? ns : a.counters[a.prev_slot]));      // the points this round evaluated
+    }
+    if (k >= ns) return;
+    const uint32_t step = (uint32_t)a.step_dev[0];
+    const int wk = a.S[k];
+    const float z0 = a.Z0[k];
+    int fl = a.flags[3 * k], fr = a.flags[3 * k + 1], fs = a.flags[3 * k + 2];
+    float l = a.L[k], r = a.R[k];
+    float w = 0.f;                                     // lane j: trial j of this round
+    bool have_w = false;
+    if (a.m_derive) {
+        slice_expand_wave(lane, k, ns, a.m_derive, z0, a.Ze, l, r, fl, fr, a.flags, a.counters);
+        if (lane == 0) { a.L[k] = l; a.R[k] = r; }
+        if (fl | fr) {
+            if (lane == 0) atomicAdd(a.counters + a.eslot, 1);
+        } else {
+            w = slice_draw_wave(lane, wk, l, r, a.seed, step, a.stream_id, 0, a.ntrial);   // the trials the evaluation derived
+            if (lane < a.ntrial) a.W[(size_t)lane * ns + k] = w;
+            have_w = true;
+        }
+    }
+    const bool mine = fs && !(fl | fr) && !(a.prev_slot >= 0 && a.counters[a.prev_slot] == 0);   // not done, and its bracket closed
+    float wacc = 0.f, zacc = 0.f;
+    bool done_now = false;
+    if (mine) {
+        const bool in = lane < a.ntrial;
+        const float zt = in ? a.Zt[(size_t)lane * ns + k] : 0.f;
+        if (!have_w) w = in ? a.W[(size_t)lane * ns + k] : 0.f;
+        const unsigned long long okm = __ballot(in && !(zt < z0 || isnan(zt)));
+        const int ja = okm ? __builtin_ctzll(okm) : a.ntrial;          // the first trial inside the slice
+        int ncon = 0;
+        bool active = true;
+        for (int j = 0; j < ja; ++j) {
+            const float wj = wave_lane_f(w, j);
+            if (wj < 0.f) l = wj; else r = wj;
+            ++ncon;
+            if (r - l < 1e-30f) { active = false; wacc = 0.f; zacc = z0; break; }   // degenerate: stay put
+        }
+        if (active && ja < a.ntrial) { active = false; wacc = wave_lane_f(w, ja); zacc = wave_lane_f(zt, ja); }
+        if (lane == 0) {
+            a.L[k] = l; a.R[k] = r;
+            if (ncon) atomicAdd(a.counters + 1, ncon);
+        }
+        if (active) {
+            int pos = 0;
+            if (lane == 0) pos = atomicAdd(a.counters + a.slot, 1);
+            pos = __builtin_amdgcn_readfirstlane(pos);
+            const float wn = slice_draw_wave(lane, wk, l, r, a.seed, step, a.stream_id, a.trials_so_far, a.nt_next);   // the next round's trials
+            if (lane < a.nt_next) {
+                a.W[(size_t)lane * ns + k] = wn;
+                a.list[(size_t)pos * a.nt_next + lane] = lane * ns + k;
+            }
+        } else {
+            done_now = true;
+            fs = 0;
+            if (lane == 0) { a.flags[3 * k + 2] = 0; a.Wacc[k] = wacc; a.Zacc[k] = zacc; }
+        }
+    }
+    if (a.coords) {
+        if (fl | fr | fs) {
+            if (lane == 0) atomicAdd(a.counters + 2, 1);
+        } else {
+            if (!done_now) { wacc = a.Wacc[k]; zacc = a.Zacc[k]; }
+            if (wacc != 0.f) {
+                for (int d = lane; d < a.ndim; d += 64) a.coords[(size_t)wk * a.ldc + d] += wacc * a.DIR[(size_t)k * a.ldd + d];
+                if (lane == 0) a.logp[wk] = zacc;
+            }
+        }
+        if (a.bump && k == 0 && lane == 0) a.step_dev[0] = (int)step + 1;
+    }
+}
 
 void set_error(const char* fmt, ...);
 int check_hip(hipError_t e, const char* what);
@@ -124,10 +336,7 @@ int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc,
 int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,
                               int m_next, int* counters, int slot, int prev_slot, float* W, float* Wd, int* list, uint64_t seed,
                               const int* step_dev, int stream_id_shrink, int ntrial, hipStream_t s);
-int launch_slice_shrink_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, float* W, int* flags, float* Wacc,
-                              float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int nt_next,
-                              int trials_so_far, int* list, uint64_t seed, int* step_dev, int stream_id, float* coords, int ldc,
-                              int ndim, float* logp, const float* DIR, int ldd, int bump, hipStream_t s);
+int launch_slice_shrink_multi(const SliceRound& a, hipStream_t s);
 int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
                                 const float* Wacc, const float* Zacc, const int* flags, int* counters, hipStream_t s);
 int launch_slice_commit(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,
@@ -175,6 +384,9 @@ struct NsMove {
     unsigned long long seed; const int* step; int step_off; int stream; float a; int* naccept;
     int slice;
     float* chain = nullptr; float* lps = nullptr;      // stretch move: this iteration's row of the chain block ([nw][ndim], [nw]); null: none
+    // slice == 1, sl_Zt != null: the trial weights are derived in the kernel from the one stepping-out round's results (NsArgs::sl_*)
+    const float* sl_Z0 = nullptr; const float* sl_L = nullptr; const float* sl_R = nullptr; const float* sl_Zt = nullptr;
+    int sl_m = 0, sl_nt = 0; unsigned long long sl_seed = 0; const int* sl_step = nullptr; int sl_stream = 0;
 };
 // training / validation forward: every op's output stored for the backward (STORE instantiation)
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,

@@ -138,6 +138,12 @@ struct NsArgs {
     const float* mv_cc; int mv_ldcc; const int* mv_C; int mv_nc;
     unsigned long long mv_seed; const int* mv_step; int mv_step_off; int mv_stream; float mv_a; int* mv_naccept;
     float* mv_chain; float* mv_lps;     // MOVE == 1: row of the chain block this iteration fills (linna_stretch_run), [nw][nin] / [nw]
+    // MOVE == 2, sl_Zt != null: the FIRST shrinking round of a half step whose stepping-out was one round of sl_m bracket ends per
+    // side -- the trial weight of row j ns + k is derived here from that round's results instead of being read: bracket
+    // [L, R] pushed out while lnP at the ends exceeds Z0 (slice_expand_multi_kernel), then trial j placed as if its
+    // predecessors were rejected (slice_draw_dev: Philox (walker, step, stream, sub j + 1)).  Saves the launch between them.
+    const float* sl_Z0; const float* sl_L; const float* sl_R; const float* sl_Zt; int sl_m, sl_nt;
+    unsigned long long sl_seed; const int* sl_step; int sl_stream;
     NsSeg seg[NS_MAXSEG];
 };
 
@@ -416,7 +422,35 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         // coords[S[k]] + w[j*ns + k] * DIR[k]   (what linna_slice_points materialises)
         const int k = grow % a.mv_nc;                                   // mv_nc: ns (walkers per half ensemble)
         const int wk = a.mv_S[k];
-        const float wgt = a.mv_cc[grow];                                // mv_cc: w[nrep * ns]
+        float wgt;
+        if (a.sl_Zt) {
+            // lanes 0 .. 2 m - 1 of the row's 32 hold "lnP at bracket end j exceeds Z0"; the count of leading ones per side is
+            // the number of steps out.  Lane i < nt holds the uniform of trial i; the row walks the trials up to its own.
+            const int ns_ = a.mv_nc, m = a.sl_m, jt = grow / ns_;
+            const float z0 = a.sl_Z0[k];
+            const float zend = a.sl_Zt[(size_t)min(pc0, 2 * m - 1) * ns_ + k];
+            const unsigned long long bal = __ballot(pc0 < 2 * m && zend > z0);
+            const unsigned bits = (unsigned)(bal >> (lane & 32));
+            const unsigned lm = bits & ((1u << m) - 1u), rm = (bits >> m) & ((1u << m) - 1u);
+            const int nl = __builtin_ctz(~lm), nr = __builtin_ctz(~rm);
+            float l = a.sl_L[k], r = a.sl_R[k];
+            for (int j = 0; j < m; ++j) {                               // (one unit at a time: the rounding of slice_expand_multi_kernel)
+                if (j < nl) l -= 1.f;
+                if (j < nr) r += 1.f;
+            }
+            const U4 tb = walker_bits(a.sl_seed, (uint32_t)wk, (uint32_t)a.sl_step[0], (uint32_t)a.sl_stream, (uint32_t)(pc0 + 1));
+            const int myu = __float_as_int(u01(tb.x));
+            wgt = 0.f;
+            for (int jj = 0; jj < a.sl_nt; ++jj) {
+                const int ulo = __builtin_amdgcn_readlane(myu, jj), uhi = __builtin_amdgcn_readlane(myu, 32 + jj);
+                const float u = __int_as_float((lane & 32) ? uhi : ulo);
+                const float w = l + u * (r - l);
+                if (jj == jt) wgt = w;
+                if (jj < jt) { if (w < 0.f) l = w; else r = w; }
+            }
+        } else {
+            wgt = a.mv_cc[grow];                                        // mv_cc: w[nrep * ns]
+        }
 #pragma unroll
         for (int i = 0; i < ZPRE; ++i) {
             const int c = min(pc0 + i * RG, nin - 1);
@@ -2134,6 +2168,8 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         a.mv_cc = mv->cc; a.mv_ldcc = mv->ldcc; a.mv_C = mv->C; a.mv_nc = mv->nc;
         a.mv_seed = mv->seed; a.mv_step = mv->step; a.mv_step_off = mv->step_off; a.mv_stream = mv->stream; a.mv_a = mv->a; a.mv_naccept = mv->naccept;
         a.mv_chain = mv->chain; a.mv_lps = mv->lps;
+        a.sl_Z0 = mv->sl_Z0; a.sl_L = mv->sl_L; a.sl_R = mv->sl_R; a.sl_Zt = mv->sl_Zt; a.sl_m = mv->sl_m; a.sl_nt = mv->sl_nt;
+        a.sl_seed = mv->sl_seed; a.sl_step = mv->sl_step; a.sl_stream = mv->sl_stream;
         if (mv->slice) return ns_launch_kernel<2, false>(a, B, p, rows, s);
         return ns_launch_kernel<1, false>(a, B, p, rows, s);
     }

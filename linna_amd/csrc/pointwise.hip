@@ -642,16 +642,6 @@ __global__ void slice_commit_kernel(float* __restrict__ coords, int ldc, int ndi
 // kernels return per walker on its flags).
 // counters: [0] expansions, [1] contractions, [2] walkers left unfinished by the rounds of a call (sticky),
 //           [3] evaluated points, [4 + r] walkers still active after round r (expand rounds first, then shrink rounds)
-__device__ __forceinline__ void slice_draw_dev(int k, int wk, float l, float r, float* __restrict__ W, int ns, uint64_t seed,
-                                               uint32_t step, int stream_id, int round, int ntrial) {
-    for (int j = 0; j < ntrial; ++j) {
-        const U4 b = walker_bits(seed, (uint32_t)wk, step, (uint32_t)stream_id, (uint32_t)(round + j + 1));
-        const float w = l + u01(b.x) * (r - l);
-        W[(size_t)j * ns + k] = w;
-        if (w < 0.f) l = w; else r = w;
-    }
-}
-
 __global__ void slice_begin_kernel(const float* __restrict__ logp, const int* __restrict__ S, int ns,
                                    const float* __restrict__ cc, int ldcc, const int* __restrict__ C, int nc, int ndim,
                                    const float* __restrict__ mu, uint64_t seed, const int* __restrict__ step_dev,
@@ -692,86 +682,46 @@ __global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const fl
                                           int m, int m_next, int* __restrict__ counters, int slot, int prev_slot, float* __restrict__ W,
                                           float* __restrict__ Wd, int* __restrict__ list, uint64_t seed,
                                           const int* __restrict__ step_dev, int stream_id_shrink, int ntrial) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) atomicAdd(counters + 3, 2 * m * (prev_slot < 0 ? ns : counters[prev_slot]));   // the points this round evaluated
-    if (k >= ns || !(flags[3 * k] | flags[3 * k + 1])) return;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // a wave per walker
+    if (k == 0 && lane == 0) atomicAdd(counters + 3, 2 * m * (prev_slot < 0 ? ns : counters[prev_slot]));   // the points this round evaluated
+    if (k >= ns) return;
+    int fl = flags[3 * k], fr = flags[3 * k + 1];
+    if (!(fl | fr)) return;
     if (prev_slot >= 0 && counters[prev_slot] == 0) return;       // (never: a walker with a flag set was counted)
     const float z0 = Z0[k];
-    int n = 0;
     float l = L[k], r = R[k];
-    if (flags[3 * k]) {
-        int j = 0;
-        for (; j < m; ++j) { if (Zt[(size_t)j * ns + k] > z0) { l -= 1.f; ++n; } else break; }
-        if (j < m) flags[3 * k] = 0;
+    if (m > 32 || m_next > 32 || ntrial > 64) {                     // (schedules beyond a wave's lanes: one lane, the plain procedure)
+        if (lane) return;
+        const bool out = slice_expand_walker(k, ns, m, z0, Zt, l, r, flags, counters);
+        L[k] = l; R[k] = r;
+        if (out) {
+            const int pos = atomicAdd(counters + slot, 1);
+            for (int j = 0; j < m_next; ++j) { W[(size_t)j * ns + k] = l - (float)j; W[(size_t)(m_next + j) * ns + k] = r + (float)j; }
+            for (int j = 0; j < 2 * m_next; ++j) list[(size_t)pos * 2 * m_next + j] = j * ns + k;
+        } else {
+            slice_draw_dev(k, S[k], l, r, Wd, ns, seed, (uint32_t)step_dev[0], stream_id_shrink, 0, ntrial);
+        }
+        return;
     }
-    if (flags[3 * k + 1]) {
-        int j = 0;
-        for (; j < m; ++j) { if (Zt[(size_t)(m + j) * ns + k] > z0) { r += 1.f; ++n; } else break; }
-        if (j < m) flags[3 * k + 1] = 0;
-    }
-    L[k] = l; R[k] = r;
-    if (n) atomicAdd(counters + 0, n);
-    if (flags[3 * k] | flags[3 * k + 1]) {
-        const int pos = atomicAdd(counters + slot, 1);           // rank among the walkers still stepping out: its rows of the next launch
-        for (int j = 0; j < m_next; ++j) { W[(size_t)j * ns + k] = l - (float)j; W[(size_t)(m_next + j) * ns + k] = r + (float)j; }
-        for (int j = 0; j < 2 * m_next; ++j) list[(size_t)pos * 2 * m_next + j] = j * ns + k;
+    slice_expand_wave(lane, k, ns, m, z0, Zt, l, r, fl, fr, flags, counters);
+    if (lane == 0) { L[k] = l; R[k] = r; }
+    if (fl | fr) {
+        int pos = 0;
+        if (lane == 0) pos = atomicAdd(counters + slot, 1);      // rank among the walkers still stepping out: its rows of the next launch
+        pos = __builtin_amdgcn_readfirstlane(pos);
+        const int side = lane >> 5, j = lane & 31;
+        if (j < m_next) W[(size_t)(side * m_next + j) * ns + k] = side ? r + (float)j : l - (float)j;
+        if (lane < 2 * m_next) list[(size_t)pos * 2 * m_next + lane] = lane * ns + k;
     } else {
-        slice_draw_dev(k, S[k], l, r, Wd, ns, seed, (uint32_t)step_dev[0], stream_id_shrink, 0, ntrial);   // first shrink round's trials
+        const float w = slice_draw_wave(lane, S[k], l, r, seed, (uint32_t)step_dev[0], stream_id_shrink, 0, ntrial);   // first shrink round's trials
+        if (lane < ntrial) Wd[(size_t)lane * ns + k] = w;
     }
 }
 
-// `coords` != null (the call's LAST shrinking round): the move of every finished walker is applied here (slice_commit_checked_kernel's
-// arithmetic; a walker the rounds of the call left unfinished stays where it is and is counted), and `bump` advances the
-// device step counter behind the second half step of an iteration -- two launches less per iteration.
-__global__ void slice_shrink_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
-                                          float* __restrict__ R, const int* __restrict__ S, float* __restrict__ W,
-                                          int* __restrict__ flags, float* __restrict__ Wacc, float* __restrict__ Zacc, int ns,
-                                          int* __restrict__ counters, int slot, int prev_slot, int ntrial, int nt_next,
-                                          int trials_so_far, int* __restrict__ list, uint64_t seed,
-                                          int* __restrict__ step_dev, int stream_id, float* __restrict__ coords, int ldc, int ndim,
-                                          float* __restrict__ logp, const float* __restrict__ DIR, int ldd, int bump) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) atomicAdd(counters + 3, ntrial * (prev_slot < 0 ? ns : counters[prev_slot]));
-    if (k >= ns) return;
-    const uint32_t step = (uint32_t)step_dev[0];
-    const bool mine = flags[3 * k + 2] && !(flags[3 * k] | flags[3 * k + 1]) &&      // not done, and its bracket closed
-                      !(prev_slot >= 0 && counters[prev_slot] == 0);
-    if (mine) {
-        int ncon = 0;
-        bool active = true;
-        float l = L[k], r = R[k];
-        for (int j = 0; j < ntrial && active; ++j) {
-            const float zt = Zt[(size_t)j * ns + k], w = W[(size_t)j * ns + k];
-            if (zt < Z0[k] || isnan(zt)) {
-                if (w < 0.f) l = w; else r = w;
-                ++ncon;
-                if (r - l < 1e-30f) { active = false; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
-            } else {
-                active = false; Wacc[k] = w; Zacc[k] = zt;
-            }
-        }
-        L[k] = l; R[k] = r;
-        if (ncon) atomicAdd(counters + 1, ncon);
-        if (active) {
-            const int pos = atomicAdd(counters + slot, 1);
-            slice_draw_dev(k, S[k], l, r, W, ns, seed, step, stream_id, trials_so_far, nt_next);   // the next round's trials
-            for (int j = 0; j < nt_next; ++j) list[(size_t)pos * nt_next + j] = j * ns + k;
-        } else {
-            flags[3 * k + 2] = 0;
-        }
-    }
-    if (coords) {
-        if (flags[3 * k] | flags[3 * k + 1] | flags[3 * k + 2]) {
-            atomicAdd(counters + 2, 1);
-        } else if (Wacc[k] != 0.f) {
-            const int wk = S[k];
-            const float wa = Wacc[k];
-            for (int d = 0; d < ndim; ++d) coords[(size_t)wk * ldc + d] += wa * DIR[(size_t)k * ldd + d];
-            logp[wk] = Zacc[k];
-        }
-        // (the last round draws no further trials: no thread of this launch uses the counter's value, whichever it reads)
-        if (bump && k == 0) step_dev[0] = (int)step + 1;
-    }
+// one shrinking round (SliceRound / slice_round_walker in common.h); with `coords` the call's LAST one: the move of every
+// finished walker is applied and `bump` advances the device step counter -- two launches less per iteration
+__global__ void slice_shrink_multi_kernel(const SliceRound a) {
+    slice_round_wave(a, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63);     // a wave per walker
 }
 
 // the move of every finished walker; a walker the rounds of the call left unfinished stays where it is and is counted
@@ -985,17 +935,12 @@ int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc,
 int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,
                               int m_next, int* counters, int slot, int prev_slot, float* W, float* Wd, int* list, uint64_t seed,
                               const int* step_dev, int stream_id_shrink, int ntrial, hipStream_t s) {
-    hipLaunchKernelGGL(slice_expand_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, flags, ns, m, m_next, counters, slot,
+    hipLaunchKernelGGL(slice_expand_multi_kernel, dim3((ns + 3) / 4), dim3(256), 0, s, Z0, Zt, L, R, S, flags, ns, m, m_next, counters, slot,
                        prev_slot, W, Wd, list, seed, step_dev, stream_id_shrink, ntrial);
     LAUNCH_CHECK("slice_expand_multi");
 }
-int launch_slice_shrink_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, float* W, int* flags, float* Wacc,
-                              float* Zacc, int ns, int* counters, int slot, int prev_slot, int ntrial, int nt_next,
-                              int trials_so_far, int* list, uint64_t seed, int* step_dev, int stream_id, float* coords, int ldc,
-                              int ndim, float* logp, const float* DIR, int ldd, int bump, hipStream_t s) {
-    hipLaunchKernelGGL(slice_shrink_multi_kernel, grid1d(ns, 256), dim3(256), 0, s, Z0, Zt, L, R, S, W, flags, Wacc, Zacc, ns,
-                       counters, slot, prev_slot, ntrial, nt_next, trials_so_far, list, seed, step_dev, stream_id, coords, ldc, ndim,
-                       logp, DIR, ldd, bump);
+int launch_slice_shrink_multi(const SliceRound& a, hipStream_t s) {
+    hipLaunchKernelGGL(slice_shrink_multi_kernel, dim3((a.ns + 3) / 4), dim3(256), 0, s, a);
     LAUNCH_CHECK("slice_shrink_multi");
 }
 int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,

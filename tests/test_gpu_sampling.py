@@ -465,7 +465,9 @@ def test_slice_sampler_fused_trial_points_are_bit_identical():
 
 
 @pytest.mark.parametrize("nw,m_sched,nt_sched", [(34, [1, 1, 2, 3, 8], [1, 3, 7, 21]), (250, [3, 5, 5], [5, 2, 9, 16]),
-                                                 (2050, [1, 2, 4, 8], [2, 4, 8, 16, 32]), (6, [2, 16], [33])])
+                                                 (2050, [1, 2, 4, 8], [2, 4, 8, 16, 32]), (6, [2, 16], [33]),
+                                                 # ONE stepping-out round: its logic rides in the first shrinking round (linna_slice_fusion)
+                                                 (34, [8], [16, 16]), (250, [4], [8, 3]), (130, [16], [32]), (6, [2], [3, 9]), (1026, [3], [5, 7, 30])])
 def test_one_call_slice_schedules_and_ragged_ensembles(nw, m_sched, nt_sched):
     """The rounds after the first evaluate only the trial points of the walkers still active (a device-side list and count,
     read by the evaluation's prologue): whatever the schedule of bracket ends / trials per round and the ensemble size
@@ -485,19 +487,52 @@ def test_one_call_slice_schedules_and_ragged_ensembles(nw, m_sched, nt_sched):
             a.step(); b.step()
             torch.cuda.synchronize()
             ca = a._fast_bufs["counters"].cpu().numpy()
-            if ca[2]:                                    # (a short schedule can leave a walker unfinished: redone below)
-                break
             assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp), it
+            if a.noverflow:                              # (a short schedule left a walker unfinished: the guarded step went back and
+                break                                    #  redid the iteration on the round loop; the counters are the aborted attempt's)
             cb = b.counters.cpu().numpy()
             assert ca[0] == cb[0] and ca[1] == cb[1], (it, ca[:4], cb)
         assert a._fast_ok is True
         # evaluated points: every walker of a half ensemble in the first round of each kind, then only the listed ones
         ns = nw // 2
         per_it = 2 * (2 * m_sched[0] + nt_sched[0]) * ns
-        assert a.neval >= (it + 1) * per_it - 1 or ca[2]
-        assert a.neval < (it + 1) * 2 * (2 * sum(m_sched) + sum(nt_sched)) * ns
+        assert a.neval >= (it + 1) * per_it - 1 or a.noverflow
+        assert a.neval <= (it + 1) * 2 * (2 * sum(m_sched) + sum(nt_sched)) * ns or a.noverflow
     finally:
         _lib.engine_rows(0)
+
+
+@pytest.mark.parametrize("rows", [4, 8, 16])
+def test_slice_fusion_masks_give_the_same_chain(rows):
+    """linna_slice_fusion: with one stepping-out round the half step drops launches by folding their work into the
+    neighbouring ones (the trial points of the first shrinking round derived in the evaluation's prologue from the bracket
+    ends' lnP; ...).  Every mask must give the chain of mask 0, bit for bit, with the same expansion / contraction / point
+    counts -- on each engine of the whole-network kernel (the prologue differs per engine)."""
+    from linna_amd import sampler
+    lp, pred, yinv, prob = build_logprob("mlp_33_33", 2.0)
+    nd = 33
+    prev = _lib.slice_fusion(-1)
+    _lib.engine_rows(rows)
+    try:
+        for nw, sched in [(128, ([8], [16, 16])), (44, ([5], [9])), (600, ([2], [4, 8]))]:
+            x0 = (0.3 * np.random.RandomState(nw).standard_normal((nw, nd))).astype(np.float32)
+            out = {}
+            for mask in (0, 1, 3, 7):
+                _lib.slice_fusion(mask)
+                a = sampler.SliceEnsembleSampler(nw, nd, lp, seed=21, tune=False, mu=0.8, fast=True)
+                a.set_schedule(*sched)
+                a.set_state(x0)
+                for it in range(7):
+                    a._step()                              # (no guard: an unfinished walker is part of the comparison)
+                torch.cuda.synchronize()
+                assert a._fast_ok is True
+                out[mask] = (a.coords.clone(), a.logp.clone(), a._fast_bufs["counters"][:4].cpu().numpy(), int(a.step_dev.item()))
+            for mask in (1, 3, 7):
+                assert torch.equal(out[mask][0], out[0][0]) and torch.equal(out[mask][1], out[0][1]), (nw, mask)
+                assert (out[mask][2] == out[0][2]).all() and out[mask][3] == out[0][3], (nw, mask, out[mask][2], out[0][2])
+    finally:
+        _lib.engine_rows(0)
+        _lib.slice_fusion(prev)
 
 
 @pytest.mark.parametrize("name,nw", [("mlp_33_33", 96), ("v2_33_33", 16), ("mlp_33_33", 1024)])
