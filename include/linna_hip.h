@@ -286,8 +286,11 @@ int linna_engine_rows(int rows);
 int linna_dense_tri(int mode);
 /* Which launches of linna_slice_half_step are folded into their neighbours, as a mask (default: all that apply): bit 0 -- with ONE
  * stepping-out round, its logic kernel is not launched: the first shrinking round's evaluation derives its trial points from
- * the bracket ends' lnP in its prologue and that round's logic kernel does the bookkeeping of both.  The chain is identical
- * under every mask (same Philox counters, same arithmetic).  -1 queries.  Returns the previous mask (tests, A/B). */
+ * the bracket ends' lnP in its prologue and that round's logic kernel does the bookkeeping of both; bit 1 -- the set-up of the
+ * half step (directions, slice heights, initial brackets, the usage counters' roll) is not a launch of its own: the first
+ * evaluation does it in its prologue, each row for its walker, the rows of bracket end 0 writing it for the later launches;
+ * bit 2 -- reserved.  The chain is identical under every mask (same Philox counters, same arithmetic).  -1 queries.
+ * Returns the previous mask (tests, A/B). */
 int linna_slice_fusion(int mask);
 /* The serving program the whole-network kernel would run for this op list on the engine of `rows` rows per workgroup
  * (dense_nout > 0: with a dense inverse covariance of that size as its last segment, in the direct form d S d^T; dense_nout < -1:

@@ -1049,7 +1049,7 @@ int linna_dense_tri(int mode) try {
     return net_stream_dense_tri(mode);
 } LINNA_CATCH_INT
 // which launches of linna_slice_half_step are folded into their neighbours (bit 0: the one stepping-out round's logic into
-// the first shrinking round; A/B switch, results identical either way)
+// the first shrinking round; bit 1: the set-up into the first evaluation's prologue; A/B switch, results identical either way)
 static std::atomic<int> g_slice_fusion{7};
 static bool slice_derive_enabled() { return (g_slice_fusion.load() & 1) != 0; }
 int linna_slice_fusion(int mode) try {
@@ -1088,7 +1088,8 @@ int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, v
 struct SliceDerive { const float* Z0; const float* L; const float* R; const float* Ze; int m, nt; uint64_t seed; const int* step_dev; int stream_id; };
 static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
                                 const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
-                                const int* list, const int* count, int mul, int b_engine, void* stream, const SliceDerive* sd = nullptr) {
+                                const int* list, const int* count, int mul, int b_engine, void* stream, const SliceDerive* sd = nullptr,
+                                const SliceBegin* sb = nullptr) {
     if (!lp || !coords || !S_idx || !DIR || !w || !lnP || ns < 1 || nrep < 1) {
         set_error("logprob_eval_slice_points: bad arguments"); return LINNA_ERR_INVALID;
     }
@@ -1103,6 +1104,7 @@ static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ld
     TRY(lp_refresh_stream(lp, b_engine > 0 ? b_engine : nrep * ns, stream, &packed, &rows));
     const linna_net* n = lp->net;
     NsMove mv{const_cast<float*>(coords), ldc, nullptr, S_idx, w, 0, list, ns, 0ull, count, mul, 0, 0.f, nullptr, 1};
+    mv.sb = sb;
     if (sd) {
         mv.sl_Z0 = sd->Z0; mv.sl_L = sd->L; mv.sl_R = sd->R; mv.sl_Zt = sd->Ze; mv.sl_m = sd->m; mv.sl_nt = sd->nt;
         mv.sl_seed = sd->seed; mv.sl_step = sd->step_dev; mv.sl_stream = sd->stream_id;
@@ -1147,8 +1149,13 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
     float* const Z0 = state; float* const L = state + ns; float* const R = state + 2 * ns;
     float* const Wacc = state + 3 * ns; float* const Zacc = state + 4 * ns;
     hipStream_t st = S(stream);
-    TRY(launch_slice_begin(logp, S_idx, ns, ccoords, ldcc, C_idx, nc, ndim, mu, seed, step_dev, half, DIR, ldd, Z0, L, R, flags, W, m_sched[0],
-                           counters, nexp_rounds + nshr_rounds, zero_totals, st));
+    // the set-up of the half step: a launch of its own, or done by the first evaluation in its prologue (SliceBegin)
+    const bool begin_fused = (g_slice_fusion.load() & 2) != 0;
+    const SliceBegin sb{logp, ccoords, ldcc, C_idx, nc, mu, seed, step_dev, half, m_sched[0], DIR, ldd, Z0, L, R, flags, counters,
+                        nexp_rounds + nshr_rounds, zero_totals};
+    if (!begin_fused)
+        TRY(launch_slice_begin(logp, S_idx, ns, ccoords, ldcc, C_idx, nc, ndim, mu, seed, step_dev, half, DIR, ldd, Z0, L, R, flags, W, m_sched[0],
+                               counters, nexp_rounds + nshr_rounds, zero_totals, st));
     int slot = 4;
     // ONE stepping-out round (small ensembles): its logic kernel is not launched -- the first shrinking round's evaluation
     // derives its trial points from the stepping-out round's results in its prologue (NsArgs::sl_*), and the first shrinking
@@ -1162,7 +1169,8 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
     for (int r = 0; r < nexp_rounds; ++r, ++slot) {
         const int m = m_sched[r], m_next = r + 1 < nexp_rounds ? m_sched[r + 1] : 0;
         TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, W, 2 * m, Zt, nullptr, r > 0 ? list : nullptr,
-                                 r > 0 ? counters + slot - 1 : nullptr, 2 * m, std::max(1, (2 * m * ns) >> (2 * r)), stream));
+                                 r > 0 ? counters + slot - 1 : nullptr, 2 * m, std::max(1, (2 * m * ns) >> (2 * r)), stream, nullptr,
+                                 r == 0 && begin_fused ? &sb : nullptr));
         if (!derive)
             TRY(launch_slice_expand_multi(Z0, Zt, L, R, S_idx, flags, ns, m, m_next, counters, slot, r > 0 ? slot - 1 : -1, W, Wd, list, seed,
                                           step_dev, 2 + half, nt_sched[0], st));

@@ -42,6 +42,13 @@ __device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t st
 // kernel (net_stream.hip: the last workgroup of a round's evaluation runs this over the walkers, no launch of its own).
 // counters: [0] expansions, [1] contractions, [2] walkers left unfinished by the rounds of a call (sticky),
 //           [3] evaluated points, [4 + r] walkers still active after round r (expand rounds first, then shrink rounds)
+// The set-up of a half step (slice_begin_kernel: differential-move direction, slice height, initial bracket, flags, the usage
+// counters' roll) as the first stepping-out round's evaluation does it in its own prologue (net_stream.hip, MOVE == 2): row
+// j ns + k forms its walker's direction and bracket end itself; the rows j = 0 also write them for the later launches.
+struct SliceBegin {
+    const float* logp; const float* cc; int ldcc; const int* C; int nc; const float* mu; uint64_t seed; const int* step; int half, m;
+    float* DIR; int ldd; float* Z0; float* L; float* R; int* flags; int* counters; int nslots, zero_totals;
+};
 struct SliceRound {
     const float* Z0; const float* Zt;                  // slice heights [ns]; lnP of this round's trials, [j ns + k]
     float* L; float* R; const int* S; float* W;        // brackets, the half ensemble's walkers, trial weights [j ns + k] (read; the next round's written)
@@ -387,6 +394,7 @@ struct NsMove {
     // slice == 1, sl_Zt != null: the trial weights are derived in the kernel from the one stepping-out round's results (NsArgs::sl_*)
     const float* sl_Z0 = nullptr; const float* sl_L = nullptr; const float* sl_R = nullptr; const float* sl_Zt = nullptr;
     int sl_m = 0, sl_nt = 0; unsigned long long sl_seed = 0; const int* sl_step = nullptr; int sl_stream = 0;
+    const SliceBegin* sb = nullptr;                     // slice == 1: this evaluation is the half step's first and sets it up (SliceBegin)
 };
 // training / validation forward: every op's output stored for the backward (STORE instantiation)
 int launch_net_stream_store(const linna_layer_t* layers, int nl, int in_size, const float* packed, const float* X, int ldx,

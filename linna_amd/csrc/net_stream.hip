@@ -144,6 +144,7 @@ struct NsArgs {
     // predecessors were rejected (slice_draw_dev: Philox (walker, step, stream, sub j + 1)).  Saves the launch between them.
     const float* sl_Z0; const float* sl_L; const float* sl_R; const float* sl_Zt; int sl_m, sl_nt;
     unsigned long long sl_seed; const int* sl_step; int sl_stream;
+    SliceBegin sb;                      // MOVE == 2, sb.logp != null: the half step's set-up in this launch's prologue (common.h)
     NsSeg seg[NS_MAXSEG];
 };
 
@@ -423,6 +424,41 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         const int k = grow % a.mv_nc;                                   // mv_nc: ns (walkers per half ensemble)
         const int wk = a.mv_S[k];
         float wgt;
+        if (a.sb.logp) {
+            // slice_begin_kernel's arithmetic, per row: two distinct complementary walkers, the direction between them, a uniform
+            // height under the density, a unit bracket placed uniformly around 0; this row's end of it, jt steps out
+            const SliceBegin& b = a.sb;
+            const int jt = grow / a.mv_nc;
+            const U4 rb = walker_bits(b.seed, (uint32_t)wk, (uint32_t)b.step[0], (uint32_t)b.half, 0u);
+            const int ia = (int)(((uint64_t)rb.x * (uint64_t)b.nc) >> 32);
+            int ib = (int)(((uint64_t)rb.y * (uint64_t)(b.nc - 1)) >> 32);
+            ib += (ib >= ia);
+            const int wa = b.C[ia], wb = b.C[ib];
+            const float mu = b.mu[0];
+            const float l = -u01(rb.w);
+            wgt = jt < b.m ? l - (float)jt : l + 1.f + (float)(jt - b.m);
+            const bool first = jt == 0 && prow && row0 + pr < a.B;      // the rows that write the walker's state for the later launches
+#pragma unroll
+            for (int i = 0; i < ZPRE; ++i) {
+                const int c = min(pc0 + i * RG, nin - 1);
+                const float dir = mu * (b.cc[(size_t)wa * b.ldcc + c] - b.cc[(size_t)wb * b.ldcc + c]);
+                zr[i] = a.mv_coords[(size_t)wk * a.mv_ldc + c] + wgt * dir;
+                if (first && pc0 + i * RG < nin) b.DIR[(size_t)k * b.ldd + c] = dir;
+            }
+            if (first && pc0 == 0) {
+                b.Z0[k] = b.logp[wk] + logf(u01(rb.z));
+                b.L[k] = l; b.R[k] = l + 1.f;
+                b.flags[3 * k] = 1; b.flags[3 * k + 1] = 1; b.flags[3 * k + 2] = 1;
+            }
+            if (blockIdx.x == 0 && tid == 0) {
+                for (int i = 0; i < b.nslots; ++i) {       // [4 + nslots + i]: the same counts summed over the calls so far (usage statistics)
+                    b.counters[4 + b.nslots + i] += b.counters[4 + i];
+                    b.counters[4 + i] = 0;
+                }
+                b.counters[4 + 2 * b.nslots] += 1;         // calls
+                if (b.zero_totals) { b.counters[0] = 0; b.counters[1] = 0; }
+            }
+        } else {
         if (a.sl_Zt) {
             // lanes 0 .. 2 m - 1 of the row's 32 hold "lnP at bracket end j exceeds Z0"; the count of leading ones per side is
             // the number of steps out.  Lane i < nt holds the uniform of trial i; the row walks the trials up to its own.
@@ -455,6 +491,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         for (int i = 0; i < ZPRE; ++i) {
             const int c = min(pc0 + i * RG, nin - 1);
             zr[i] = a.mv_coords[(size_t)wk * a.mv_ldc + c] + wgt * a.Z[(size_t)k * a.ldz + c];   // Z: DIR[ns][ldz]
+        }
         }
     }
 #pragma unroll
@@ -2170,6 +2207,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         a.mv_chain = mv->chain; a.mv_lps = mv->lps;
         a.sl_Z0 = mv->sl_Z0; a.sl_L = mv->sl_L; a.sl_R = mv->sl_R; a.sl_Zt = mv->sl_Zt; a.sl_m = mv->sl_m; a.sl_nt = mv->sl_nt;
         a.sl_seed = mv->sl_seed; a.sl_step = mv->sl_step; a.sl_stream = mv->sl_stream;
+        if (mv->sb) a.sb = *mv->sb;
         if (mv->slice) return ns_launch_kernel<2, false>(a, B, p, rows, s);
         return ns_launch_kernel<1, false>(a, B, p, rows, s);
     }
