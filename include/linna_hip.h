@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 10   /* 10: + linna_slice_fusion; 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd, linna_val_metrics, linna_loss_desc_t::ylog; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
+#define LINNA_ABI_VERSION 10   /* 10: + linna_slice_fusion, linna_slice_half_step(expect_rows); 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd, linna_val_metrics, linna_loss_desc_t::ylog; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -516,12 +516,18 @@ int linna_slice_commit(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float
  *       count as zeus treats its `maxsteps` (an error) -- [3] evaluated points (both cumulative), [4 + r] walkers still
  *       active after round r of THIS call (stepping-out rounds first), [4 + nr + r] the same summed over the earlier calls,
  *       [4 + 2 nr] the number of calls (nr = nexp_rounds + nshr_rounds): how much of the look-ahead a run uses.
+ * expect_rows (HOST array of nr ints, or null): the number of trial points the caller expects round r to evaluate (entry r for
+ *   the stepping-out rounds, nexp_rounds + r for the shrinking ones; the first round of each kind evaluates every walker and
+ *   its entry is ignored) -- the evaluation of a later round is sized for every walker but runs the ENGINE (4 / 8 / 16 rows per
+ *   workgroup) that suits this number: 60 points on the 16-row engine take 56 us, on the 4-row engine 29.  null: a quarter of
+ *   the previous round's.  A wrong expectation costs time, never results of another chain... the lnP of one point differs in
+ *   the last bits between engines (another summation order), as everywhere else in this library.
  * zeus' EnsembleSampler behind sampler.py:728-735. */
 int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
                           int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched,
                           int nshr_rounds, float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt,
-                          int* list, int* counters, int zero_totals, int bump_step, void* stream);
+                          int* list, int* counters, int zero_totals, int bump_step, const int* expect_rows, void* stream);
 
 /* `nsteps` ensemble iterations in ONE call: 2 nsteps launches of linna_stretch_half_step's kernel with the same Philox
  * counters (step = step_dev[0] + step_offset + i, stream = half), so the chain is bit-identical to a host loop over that

@@ -155,7 +155,7 @@ _SIGNATURES = {
     "linna_slice_draw": (_I, [_V, _V, _V, _V, _V, _V, _I, _U64, _V, _I, _I, _I, _V]),
     "linna_slice_shrink": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _I, _I, _V]),
     "linna_slice_commit": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _V, _V]),
-    "linna_slice_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _V, _U64, _V, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _V]),
+    "linna_slice_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _V, _U64, _V, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _V, _V]),
 }
 EXPORTED = tuple(_SIGNATURES)
 

@@ -1132,7 +1132,7 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
                           int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched, int nshr_rounds,
                           float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt, int* list, int* counters,
-                          int zero_totals, int bump_step, void* stream) try {
+                          int zero_totals, int bump_step, const int* expect_rows, void* stream) try {
     if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !mu || !step_dev || !DIR || !state || !flags || !W || !Wd ||
         !Zt || !list || !counters || ns < 1 || nc < 2 || !m_sched || !nt_sched || nexp_rounds < 1 || nshr_rounds < 1 || (half != 0 && half != 1)) {
         set_error("slice_half_step: bad arguments"); return LINNA_ERR_INVALID;
@@ -1163,13 +1163,14 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
     const bool derive = slice_derive_enabled() && nexp_rounds == 1 && m_sched[0] <= 16 && nt_sched[0] <= 32 && nt_sched[0] <= 2 * m_sched[0];
     // rounds after the first evaluate only the walkers still active: the logic kernel of round r lists their trial points
     // (list[pos * nrep + j] = j ns + k, pos = the walker's rank among the active ones) and counts them in counters[slot];
-    // round r + 1's launch is sized for all of them, runs the engine chosen for the expected number (a quarter of the
-    // walkers per round) and leaves at the counted one.  Because only those walkers are evaluated, the later rounds can look
+    // round r + 1's launch is sized for all of them, runs the engine chosen for the expected number (`expect_rows`: what the
+    // caller has seen in the usage counters of its earlier calls; without it a quarter of the walkers per round) and leaves
+    // at the counted one.  Because only those walkers are evaluated, the later rounds can look
     // further ahead for nothing (m_sched / nt_sched grow) and the call needs few rounds.
     for (int r = 0; r < nexp_rounds; ++r, ++slot) {
         const int m = m_sched[r], m_next = r + 1 < nexp_rounds ? m_sched[r + 1] : 0;
         TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, W, 2 * m, Zt, nullptr, r > 0 ? list : nullptr,
-                                 r > 0 ? counters + slot - 1 : nullptr, 2 * m, std::max(1, (2 * m * ns) >> (2 * r)), stream, nullptr,
+                                 r > 0 ? counters + slot - 1 : nullptr, 2 * m, expect_rows && r > 0 ? std::max(1, expect_rows[r]) : std::max(1, (2 * m * ns) >> (2 * r)), stream, nullptr,
                                  r == 0 && begin_fused ? &sb : nullptr));
         if (!derive)
             TRY(launch_slice_expand_multi(Z0, Zt, L, R, S_idx, flags, ns, m, m_next, counters, slot, r > 0 ? slot - 1 : -1, W, Wd, list, seed,
@@ -1182,7 +1183,8 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
         const bool dv = derive && r == 0;
         SliceDerive sd{Z0, L, R, Zt, m_sched[0], nt, seed, step_dev, 2 + half};
         TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, nt, dv ? W : Zt, nullptr, r > 0 ? list : nullptr,
-                                 r > 0 ? counters + slot - 1 : nullptr, nt, std::max(1, (nt * ns) >> (2 * r)), stream, dv ? &sd : nullptr));
+                                 r > 0 ? counters + slot - 1 : nullptr, nt,
+                                 expect_rows && r > 0 ? std::max(1, expect_rows[nexp_rounds + r]) : std::max(1, (nt * ns) >> (2 * r)), stream, dv ? &sd : nullptr));
         const bool last = r + 1 == nshr_rounds;         // the commit (and the step counter) ride in the last round's logic kernel
         SliceRound sr{Z0, dv ? W : Zt, L, R, S_idx, Wd, flags, Wacc, Zacc, ns, counters, slot, r > 0 ? slot - 1 : -1, nt, nt_next, trials, list,
                       seed, step_dev, 2 + half, last ? coords : nullptr, ldc, ndim, logp, DIR, ldd, last && bump_step ? 1 : 0,

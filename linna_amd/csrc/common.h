@@ -145,6 +145,14 @@ __device__ __forceinline__ void slice_round_walker(const SliceRound& a, int k) {
     }
 }
 
+// counters[i] += the sum over the block's waves of v (wave-uniform); every thread of the block calls
+__device__ __forceinline__ void block_add_counter(int* __restrict__ counter, int v, int* lds_slot) {
+    if (threadIdx.x == 0) *lds_slot = 0;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(lds_slot, v);
+    __syncthreads();
+    if (threadIdx.x == 0 && *lds_slot) atomicAdd(counter, *lds_slot);
+}
 // ---- the same logic with a WAVE per walker (all 64 lanes call with the same k): the bracket ends / trials of a round are loaded,
 // and the Philox draws of the next round made, one per lane; what is sequential in the procedure (a bracket shrinking trial by
 // trial) is a short uniform loop over register values.  One thread per walker ran 16-32 dependent Philox draws and as many
@@ -165,7 +173,7 @@ __device__ __forceinline__ float slice_draw_wave(int lane, int wk, float l, floa
 }
 // stepping out over m <= 32 ends per side: lanes 0..m-1 the left ends, 32..32+m-1 the right ones; fl / fr updated
 __device__ __forceinline__ void slice_expand_wave(int lane, int k, int ns, int m, float z0, const float* __restrict__ Zt, float& l, float& r,
-                                                  int& fl, int& fr, int* __restrict__ flags, int* __restrict__ counters) {
+                                                  int& fl, int& fr, int* __restrict__ flags, int& nexp) {
     const int side = lane >> 5, j = lane & 31;
     const float ze = j < m ? Zt[(size_t)(side * m + j) * ns + k] : 0.f;
     const unsigned long long bal = __ballot(j < m && ze > z0);
@@ -175,12 +183,14 @@ __device__ __forceinline__ void slice_expand_wave(int lane, int k, int ns, int m
     for (int i = 0; i < nr; ++i) r += 1.f;
     if (fl && nl < m) { fl = 0; if (lane == 0) flags[3 * k] = 0; }
     if (fr && nr < m) { fr = 0; if (lane == 0) flags[3 * k + 1] = 0; }
-    if (lane == 0 && nl + nr) atomicAdd(counters + 0, nl + nr);
+    nexp += nl + nr;
 }
-__device__ __forceinline__ void slice_round_wave(const SliceRound& a, int k, int lane) {
+// nexp / ncon: this walker's expansions / contractions, which the caller adds to counters[0] / [1] (summed over the block first:
+// one atomic per walker on one address cost 10-15 us of a 4096-walker round)
+__device__ __forceinline__ void slice_round_wave(const SliceRound& a, int k, int lane, int& nexp, int& ncon_out) {
     const int ns = a.ns;
     if (a.ntrial > 64 || a.nt_next > 64 || a.m_derive > 32) {       // (schedules beyond a wave's lanes: one lane, the plain procedure)
-        if (lane == 0) slice_round_walker(a, k);
+        if (lane == 0) slice_round_walker(a, k);                    //  -- counts itself
         return;
     }
     if (k == 0 && lane == 0) {
@@ -196,7 +206,7 @@ __device__ __forceinline__ void slice_round_wave(const SliceRound& a, int k, int
     float w = 0.f;                                     // lane j: trial j of this round
     bool have_w = false;
     if (a.m_derive) {
-        slice_expand_wave(lane, k, ns, a.m_derive, z0, a.Ze, l, r, fl, fr, a.flags, a.counters);
+        slice_expand_wave(lane, k, ns, a.m_derive, z0, a.Ze, l, r, fl, fr, a.flags, nexp);
         if (lane == 0) { a.L[k] = l; a.R[k] = r; }
         if (fl | fr) {
             if (lane == 0) atomicAdd(a.counters + a.eslot, 1);
@@ -224,10 +234,8 @@ __device__ __forceinline__ void slice_round_wave(const SliceRound& a, int k, int
             if (r - l < 1e-30f) { active = false; wacc = 0.f; zacc = z0; break; }   // degenerate: stay put
         }
         if (active && ja < a.ntrial) { active = false; wacc = wave_lane_f(w, ja); zacc = wave_lane_f(zt, ja); }
-        if (lane == 0) {
-            a.L[k] = l; a.R[k] = r;
-            if (ncon) atomicAdd(a.counters + 1, ncon);
-        }
+        if (lane == 0) { a.L[k] = l; a.R[k] = r; }
+        ncon_out += ncon;
         if (active) {
             int pos = 0;
             if (lane == 0) pos = atomicAdd(a.counters + a.slot, 1);

@@ -677,22 +677,21 @@ __global__ void slice_begin_kernel(const float* __restrict__ logp, const int* __
 
 // Zt[j*ns + k]: lnP at L - j (j < m) and at R + (j - m) (m <= j < 2m) of the bracket this round started from; the next
 // round looks at m_next ends per side (0: this is the last stepping-out round)
-__global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
-                                          float* __restrict__ R, const int* __restrict__ S, int* __restrict__ flags, int ns,
-                                          int m, int m_next, int* __restrict__ counters, int slot, int prev_slot, float* __restrict__ W,
-                                          float* __restrict__ Wd, int* __restrict__ list, uint64_t seed,
-                                          const int* __restrict__ step_dev, int stream_id_shrink, int ntrial) {
-    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // a wave per walker
+__device__ __forceinline__ int slice_expand_multi_wave(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
+                                                       float* __restrict__ R, const int* __restrict__ S, int* __restrict__ flags, int ns,
+                                                       int m, int m_next, int* __restrict__ counters, int slot, int prev_slot, float* __restrict__ W,
+                                                       float* __restrict__ Wd, int* __restrict__ list, uint64_t seed,
+                                                       const int* __restrict__ step_dev, int stream_id_shrink, int ntrial, int k, int lane) {
     if (k == 0 && lane == 0) atomicAdd(counters + 3, 2 * m * (prev_slot < 0 ? ns : counters[prev_slot]));   // the points this round evaluated
-    if (k >= ns) return;
+    if (k >= ns) return 0;
     int fl = flags[3 * k], fr = flags[3 * k + 1];
-    if (!(fl | fr)) return;
-    if (prev_slot >= 0 && counters[prev_slot] == 0) return;       // (never: a walker with a flag set was counted)
+    if (!(fl | fr)) return 0;
+    if (prev_slot >= 0 && counters[prev_slot] == 0) return 0;     // (never: a walker with a flag set was counted)
     const float z0 = Z0[k];
     float l = L[k], r = R[k];
     if (m > 32 || m_next > 32 || ntrial > 64) {                     // (schedules beyond a wave's lanes: one lane, the plain procedure)
-        if (lane) return;
-        const bool out = slice_expand_walker(k, ns, m, z0, Zt, l, r, flags, counters);
+        if (lane) return 0;
+        const bool out = slice_expand_walker(k, ns, m, z0, Zt, l, r, flags, counters);        // (counts itself)
         L[k] = l; R[k] = r;
         if (out) {
             const int pos = atomicAdd(counters + slot, 1);
@@ -701,9 +700,10 @@ __global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const fl
         } else {
             slice_draw_dev(k, S[k], l, r, Wd, ns, seed, (uint32_t)step_dev[0], stream_id_shrink, 0, ntrial);
         }
-        return;
+        return 0;
     }
-    slice_expand_wave(lane, k, ns, m, z0, Zt, l, r, fl, fr, flags, counters);
+    int nexp = 0;
+    slice_expand_wave(lane, k, ns, m, z0, Zt, l, r, fl, fr, flags, nexp);
     if (lane == 0) { L[k] = l; R[k] = r; }
     if (fl | fr) {
         int pos = 0;
@@ -716,12 +716,28 @@ __global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const fl
         const float w = slice_draw_wave(lane, S[k], l, r, seed, (uint32_t)step_dev[0], stream_id_shrink, 0, ntrial);   // first shrink round's trials
         if (lane < ntrial) Wd[(size_t)lane * ns + k] = w;
     }
+    return nexp;
+}
+__global__ void slice_expand_multi_kernel(const float* __restrict__ Z0, const float* __restrict__ Zt, float* __restrict__ L,
+                                          float* __restrict__ R, const int* __restrict__ S, int* __restrict__ flags, int ns,
+                                          int m, int m_next, int* __restrict__ counters, int slot, int prev_slot, float* __restrict__ W,
+                                          float* __restrict__ Wd, int* __restrict__ list, uint64_t seed,
+                                          const int* __restrict__ step_dev, int stream_id_shrink, int ntrial) {
+    __shared__ int sums[1];
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;      // a wave per walker
+    const int nexp = slice_expand_multi_wave(Z0, Zt, L, R, S, flags, ns, m, m_next, counters, slot, prev_slot, W, Wd, list, seed, step_dev,
+                                             stream_id_shrink, ntrial, k, lane);
+    block_add_counter(counters + 0, nexp, sums);
 }
 
 // one shrinking round (SliceRound / slice_round_walker in common.h); with `coords` the call's LAST one: the move of every
 // finished walker is applied and `bump` advances the device step counter -- two launches less per iteration
 __global__ void slice_shrink_multi_kernel(const SliceRound a) {
-    slice_round_wave(a, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63);     // a wave per walker
+    __shared__ int sums[2];
+    int nexp = 0, ncon = 0;
+    slice_round_wave(a, blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), threadIdx.x & 63, nexp, ncon);     // a wave per walker
+    block_add_counter(a.counters + 0, nexp, sums);
+    block_add_counter(a.counters + 1, ncon, sums + 1);
 }
 
 // the move of every finished walker; a walker the rounds of the call left unfinished stays where it is and is counted
@@ -935,12 +951,12 @@ int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc,
 int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,
                               int m_next, int* counters, int slot, int prev_slot, float* W, float* Wd, int* list, uint64_t seed,
                               const int* step_dev, int stream_id_shrink, int ntrial, hipStream_t s) {
-    hipLaunchKernelGGL(slice_expand_multi_kernel, dim3((ns + 3) / 4), dim3(256), 0, s, Z0, Zt, L, R, S, flags, ns, m, m_next, counters, slot,
+    hipLaunchKernelGGL(slice_expand_multi_kernel, dim3((ns + 15) / 16), dim3(1024), 0, s, Z0, Zt, L, R, S, flags, ns, m, m_next, counters, slot,
                        prev_slot, W, Wd, list, seed, step_dev, stream_id_shrink, ntrial);
     LAUNCH_CHECK("slice_expand_multi");
 }
 int launch_slice_shrink_multi(const SliceRound& a, hipStream_t s) {
-    hipLaunchKernelGGL(slice_shrink_multi_kernel, dim3((a.ns + 3) / 4), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(slice_shrink_multi_kernel, dim3((a.ns + 15) / 16), dim3(1024), 0, s, a);
     LAUNCH_CHECK("slice_shrink_multi");
 }
 int launch_slice_commit_checked(float* coords, int ldc, int ndim, float* logp, const int* S, int ns, const float* DIR, int ldd,

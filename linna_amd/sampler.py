@@ -992,6 +992,7 @@ class SliceEnsembleSampler(EnsembleSampler):
         """Bracket ends per side of each stepping-out round and trials of each shrinking round of the one-call path."""
         self.m_sched, self.nt_sched = [int(v) for v in m_sched], [int(v) for v in nt_sched]
         self.m, self.nt_fast = max(self.m_sched), max(self.nt_sched)         # (scratch sizes)
+        self._expect, self._expect_base, self._expect_seen, self.expected_rows = None, (0.0, np.zeros(0)), -1, None
         self.nexp_rounds, self.nshr_rounds = len(self.m_sched), len(self.nt_sched)
         self._m_arr = (C.c_int * self.nexp_rounds)(*self.m_sched)
         self._nt_arr = (C.c_int * self.nshr_rounds)(*self.nt_sched)
@@ -1108,6 +1109,7 @@ class SliceEnsembleSampler(EnsembleSampler):
                                    list=torch.zeros(nrep * ns, dtype=torch.int32, device=self.dev),
                                    counters=torch.zeros(5 + 2 * (self.nexp_rounds + self.nshr_rounds), dtype=torch.int32, device=self.dev))
         b, st = self._fast_bufs, _lib.stream()
+        self._refresh_expectation()
         for h in (0, 1):
             S, Cc = halves[h], halves[1 - h]
             comp, ldc, cidx, nc = self.coords, self.ld, Cc, self.half
@@ -1117,7 +1119,7 @@ class SliceEnsembleSampler(EnsembleSampler):
                 self.lp._ensure()["handle"], P(self.coords), self.ld, self.ndim, P(self.logp), I(S), ns, P(comp), ldc, I(cidx), nc,
                 P(self.mu_dev), seed, I(self.step_dev), h, self._m_arr, self.nexp_rounds, self._nt_arr, self.nshr_rounds, P(self.DIR), self.ld,
                 P(b["state"]), I(self.flags), P(b["W"]), P(b["Wd"]), P(b["Zt"]), I(b["list"]), I(b["counters"]), 1 if h == 0 else 0,
-                1 if h == 1 else 0, st)                  # (the second half step's last kernel advances the device step counter)
+                1 if h == 1 else 0, self._expect, st)    # (the second half step's last kernel advances the device step counter)
             if rc != 0:
                 if rc == _lib.ERR_UNSUPPORTED and h == 0 and self._fast_ok is None:
                     self._fast_ok = False
@@ -1135,6 +1137,42 @@ class SliceEnsembleSampler(EnsembleSampler):
                     raise _FastOverflow()
             self._tune_mu(int(c[0]), int(c[1]))
         return True
+
+    EXPECT_AT = (16, 64, 256)       # one-call iterations after which the usage counters are read (then every 1024)
+    USE_EXPECT = True               # (False: the later rounds' engines by the fixed rule, a quarter of the previous round's -- A/B)
+
+    def _refresh_expectation(self):
+        """The rounds after the first evaluate only the walkers still active; their launch is sized for all but runs the
+        engine (4 / 8 / 16 rows per workgroup) that suits the EXPECTED number of trial points -- 60 points cost 56 us on the
+        16-row engine and 29 on the 4-row one.  The expectation is what the usage counters have shown since the last look
+        (mean active fraction behind each round x the next round's points per walker x 1.25 + 8; a round that has
+        practically never run gets the 16-row engine, whose launch has the fewest workgroups to dismiss), read at fixed iteration
+        counts so that a run is reproducible: 16, 64, 256, then every 1024 one-call iterations (one small device read each)."""
+        n = getattr(self, "_fast_steps", 0)
+        if not self.USE_EXPECT:
+            return
+        if not (n in self.EXPECT_AT or (n and n % 1024 == 0)) or n == getattr(self, "_expect_seen", -1):
+            return
+        self._expect_seen = n
+        nr = self.nexp_rounds + self.nshr_rounds
+        c = self._fast_bufs["counters"].cpu().numpy().astype(np.float64)
+        calls, cum = c[4 + 2 * nr] - 1, c[4 + nr:4 + 2 * nr]
+        last_calls, last_cum = self._expect_base
+        if len(last_cum) != nr:
+            last_calls, last_cum = 0.0, np.zeros(nr)
+        if calls - last_calls < 8:
+            return
+        frac = (cum - last_cum) / ((calls - last_calls) * self.half)
+        self._expect_base = (calls, cum.copy())
+        pts = [2 * m for m in self.m_sched] + list(self.nt_sched)
+        rows = [1] * nr
+        for i in range(nr):
+            if i and i != self.nexp_rounds:
+                mean = pts[i] * frac[i - 1] * self.half
+                # (a round that practically never runs: the engine with the fewest workgroups to launch and dismiss)
+                rows[i] = int(mean * 1.25) + 8 if mean >= 0.5 else 1 << 20
+        self._expect = (C.c_int * nr)(*rows)
+        self.expected_rows = rows
 
     def _tune_mu(self, nexp, ncon):
         """zeus: mu *= 2 nexp / (nexp + ncon) until the expansion fraction stays within ``tolerance`` of 1/2 for

@@ -16,7 +16,8 @@ masks = [int(v) for v in os.environ.get("SLICE_FUSION", "").split(",") if v] or 
 for nw in sizes:
     for fast, pts, mask in ([] if os.environ.get("SLICE_ONLY_FAST") else [(False, 0, None)]) + [(True, p, f) for p in (scheds or points) for f in masks]:
         if mask is not None:
-            _lib.slice_fusion(mask)
+            _lib.slice_fusion(mask & 7)
+            sampler.SliceEnsembleSampler.USE_EXPECT = not (mask & 8)      # (bit 3 of SLICE_FUSION: engines of the later rounds by the fixed rule)
         sampler.SliceEnsembleSampler.FAST_FIRST = (pts or None) if not scheds else None
         ens = sampler.SliceEnsembleSampler(nw, 33, lp, seed=1, fast=fast)
         if fast and scheds:
@@ -32,6 +33,8 @@ for nw in sizes:
         dt = time.perf_counter() - t0
         print("%5d walkers  %-44s %8.1f us/iteration  %7.0f it/s  mu %.3f  evals/walker/iteration %.1f  tuned %s" % (
             nw, ("one-call m %s nt %s%s" % (ens.m_sched, ens.nt_sched, "" if mask is None else " fusion %d" % mask)) if fast else "rounds", dt / n * 1e6, n / dt, ens.mu, (ens.neval - e0) / n / nw, not ens.tune), flush=True)
+        if fast:
+            print("        expected trial points by round (engine choice of the later rounds): %s after %d one-call iterations" % (ens.expected_rows, getattr(ens, "_fast_steps", 0)), flush=True)
         if fast and ens.round_usage():
             u = ens.round_usage()
             print("        still active behind each stepping-out round: %s; behind each shrinking round: %s (mean fraction of a half ensemble, %d half steps); runs redone on the round loop: %d" % (
