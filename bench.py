@@ -778,12 +778,12 @@ def slice_rate(lp, sizes=(4096, 128), iters=(100, 600)):
     per second on the headline problem, at the bench's 4096 walkers and at the reference's own ensemble size (cosmolike:
     128 walkers), with the evaluations one iteration costs (stepping out + shrinking, per walker)."""
     import torch
-    from linna_amd import sampler
+    from linna_amd import sampler, _lib
     out = {}
     for nw, n in zip(sizes, iters):
         ens = sampler.SliceEnsembleSampler(nw, NIN, lp, seed=1)
         ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nw, NIN)))
-        ens.run(max(30, n // 4), store=False)                # tunes mu (zeus' first iterations), ramps the clocks
+        ens.run(max(80, n // 4), store=False)                # tunes mu (zeus' first iterations), ramps the clocks; the later rounds' engines settle (iteration 64)
         torch.cuda.synchronize()
         e0, it0 = ens.neval, ens.iteration
         t0 = time.perf_counter()
@@ -796,7 +796,9 @@ def slice_rate(lp, sizes=(4096, 128), iters=(100, 600)):
                                   "walker_updates_per_s": n * nw / dt, "mu": float(ens.mu),
                                   "ends_per_side_by_round": ens.m_sched, "trials_by_round": ens.nt_sched,
                                   # mean fraction of a half ensemble still active behind each round: what the look-ahead is used for
-                                  "trials_used_by_round": ens.round_usage()}
+                                  "trials_used_by_round": ens.round_usage(),
+                                  # the engine of a later round's launch follows the points the counters let it expect (2^20: never ran)
+                                  "expected_points_by_round": ens.expected_rows, "fusion_mask": _lib.slice_fusion(-1)}
     return out
 
 
