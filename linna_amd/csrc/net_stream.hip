@@ -1007,6 +1007,44 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     }
                 }
                 int gj = 0;
+                if constexpr (!LB && !DXE && !STORE) {
+                    // serving: SIXTEEN partials in flight per trip -- 2 columns of 8 K parts, 4 of 4, 8 of 2 -- before the first sum
+                    // (one LDS round trip for what the loop below makes 2 / 4 / 8 of: 256 output columns were 8 trips of ~130
+                    // cycles behind the barrier); the sums in the order of the loop below
+                    auto reduce_trips = [&](auto NBc, auto NKc) {
+                        constexpr int NB = decltype(NBc)::value, NK = decltype(NKc)::value;
+                        for (int c0 = sc0; c0 < (srow ? s_zext : 0); c0 += NB * RGS) {
+                            const float* src[NB]; bool in[NB]; float v[NB], bs[NB], x[NB][NK];
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) {
+                                const int c = c0 + j * RGS;
+                                in[j] = c < ncol;
+                                const int cc = in[j] ? c : sc0;                             // (a readable address)
+                                src[j] = part + (cc >> 6) * PW + sr * 64 + ((cc & 63) ^ sw);
+                                bs[j] = lbias[s_bias + cc];
+                                v[j] = 0.f;
+                            }
+#pragma unroll
+                            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                                for (int kp = 0; kp < NK; ++kp) x[j][kp] = src[j][(kp << s_ncgl) * PW];
+#pragma unroll
+                            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                                for (int kp = 0; kp < NK; ++kp) v[j] += x[j][kp];
+#pragma unroll
+                            for (int j = 0; j < NB; ++j) {
+                                const int c = c0 + j * RGS;
+                                float r = v[j] + bs[j];
+                                if (s_relu) r = fmaxf(r, 0.f);
+                                if (c < s_zext) cur[c] = in[j] ? r : 0.f;
+                            }
+                        }
+                    };
+                    if (nkp == NW) reduce_trips(std::integral_constant<int, 2>{}, std::integral_constant<int, NW>{});
+                    else if (nkp == NW / 2) reduce_trips(std::integral_constant<int, 4>{}, std::integral_constant<int, NW / 2>{});
+                    else reduce_trips(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+                } else
                 for (int c = sc0; c < (srow ? s_zext : 0); c += RGS, ++gj) {
                     float v = 0.f;
                     if (c < ncol) {
