@@ -980,7 +980,13 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         const int rr = q_row(t, e);
                         part[wave * PW + rr * 64 + (q_col(t) ^ (SM ? 32 * (rr & 1) : 16 * kq))] = fin[t][e];
                     }
+#ifdef NS_STAMPS_FINE
+                if (fine) NS_STAMP();              // partials written (issued)
+#endif
                 lds_barrier();
+#ifdef NS_STAMPS_FINE
+                if (fine) NS_STAMP();              // first barrier passed
+#endif
                 // thread (row sr, lane sc0 of RGS): columns sc0, sc0+RGS, ...; wave of (K part kp, group cg) = kp*ncg + cg.
                 // 16 rows: the prologue's 32 threads per row; 8 / 4 rows: ALL 512 threads, 64 / 128 per row (with 32 per row
                 // three quarters of a 4-row workgroup watched the other quarter reduce)
@@ -1008,42 +1014,31 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 }
                 int gj = 0;
                 if constexpr (!LB && !DXE && !STORE) {
-                    // serving: SIXTEEN partials in flight per trip -- 2 columns of 8 K parts, 4 of 4, 8 of 2 -- before the first sum
-                    // (one LDS round trip for what the loop below makes 2 / 4 / 8 of: 256 output columns were 8 trips of ~130
-                    // cycles behind the barrier); the sums in the order of the loop below
-                    auto reduce_trips = [&](auto NBc, auto NKc) {
-                        constexpr int NB = decltype(NBc)::value, NK = decltype(NKc)::value;
-                        for (int c0 = sc0; c0 < (srow ? s_zext : 0); c0 += NB * RGS) {
-                            const float* src[NB]; bool in[NB]; float v[NB], bs[NB], x[NB][NK];
+                    // serving: FOUR adjacent columns per thread and trip, as 16-byte LDS accesses (the swizzle moves whole groups of
+                    // 16 / 32 columns, the biases start at multiples of 64): a quarter of the LDS instructions of the column-per-
+                    // trip loop below, and all K parts of a trip in flight -- 256 output columns were 8 trips of ~130 cycles
+                    // each behind the barrier.  The sums in the order of the loop below.
+                    auto reduce4 = [&](auto NKc) {
+                        constexpr int NK = decltype(NKc)::value;
+                        for (int c = 4 * sc0; c < (srow ? s_zext : 0); c += 4 * RGS) {
+                            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (c < ncol) {
+                                const float* src = part + (c >> 6) * PW + sr * 64 + ((c & 63) ^ sw);
+                                f32x4 x[NK];
 #pragma unroll
-                            for (int j = 0; j < NB; ++j) {
-                                const int c = c0 + j * RGS;
-                                in[j] = c < ncol;
-                                const int cc = in[j] ? c : sc0;                             // (a readable address)
-                                src[j] = part + (cc >> 6) * PW + sr * 64 + ((cc & 63) ^ sw);
-                                bs[j] = lbias[s_bias + cc];
-                                v[j] = 0.f;
+                                for (int kp = 0; kp < NK; ++kp) x[kp] = *reinterpret_cast<const f32x4*>(src + (kp << s_ncgl) * PW);
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + s_bias + c);
+#pragma unroll
+                                for (int kp = 0; kp < NK; ++kp) v += x[kp];
+                                v += b;
+                                if (s_relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                             }
-#pragma unroll
-                            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                                for (int kp = 0; kp < NK; ++kp) x[j][kp] = src[j][(kp << s_ncgl) * PW];
-#pragma unroll
-                            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                                for (int kp = 0; kp < NK; ++kp) v[j] += x[j][kp];
-#pragma unroll
-                            for (int j = 0; j < NB; ++j) {
-                                const int c = c0 + j * RGS;
-                                float r = v[j] + bs[j];
-                                if (s_relu) r = fmaxf(r, 0.f);
-                                if (c < s_zext) cur[c] = in[j] ? r : 0.f;
-                            }
+                            *reinterpret_cast<f32x4*>(cur + c) = v;
                         }
                     };
-                    if (nkp == NW) reduce_trips(std::integral_constant<int, 2>{}, std::integral_constant<int, NW>{});
-                    else if (nkp == NW / 2) reduce_trips(std::integral_constant<int, 4>{}, std::integral_constant<int, NW / 2>{});
-                    else reduce_trips(std::integral_constant<int, 8>{}, std::integral_constant<int, 2>{});
+                    if (nkp == NW) reduce4(std::integral_constant<int, NW>{});
+                    else if (nkp == NW / 2) reduce4(std::integral_constant<int, NW / 2>{});
+                    else reduce4(std::integral_constant<int, 2>{});
                 } else
                 for (int c = sc0; c < (srow ? s_zext : 0); c += RGS, ++gj) {
                     float v = 0.f;
@@ -1117,6 +1112,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                         }
                     }
                 }
+#ifdef NS_STAMPS_FINE
+                if (fine) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); NS_STAMP(); }   // reduce done
+#endif
                 lds_barrier();
                 NS_STAMP();
                 ++si;
@@ -1249,8 +1247,32 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) part[wave * PW + (4 * kq + e) * 64 + ((16 * t + li) ^ (16 * kq))] = acc[t][e];
                         }
+#ifdef NS_STAMPS_FINE
+                    if (fine) NS_STAMP();          // SIDE: MFMAs issued, partials written
+#endif
                     lds_barrier();
-                    {
+#ifdef NS_STAMPS_FINE
+                    if (fine) NS_STAMP();          // SIDE: first barrier passed
+#endif
+                    if constexpr (!LB) {               // (serving: four adjacent columns per thread, 16-byte accesses -- the SPLIT reduce's form)
+                        float* const cur = act + P * ABUF + pr * LD + s_dst;
+                        const int ncol = 16 * treal, sw = 16 * (pr >> 2);
+                        for (int c = 4 * pc0; c < s_zext; c += 4 * RG) {
+                            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (c < ncol) {
+                                const float* src = part + pr * 64 + (c ^ sw);
+                                f32x4 x[NW];
+#pragma unroll
+                                for (int kp = 0; kp < NW; ++kp) x[kp] = *reinterpret_cast<const f32x4*>(src + kp * PW);
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + s_bias + c);
+#pragma unroll
+                                for (int kp = 0; kp < NW; ++kp) v += x[kp];
+                                v += b;
+                                if (s_relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
+                            }
+                            *reinterpret_cast<f32x4*>(cur + c) = v;
+                        }
+                    } else {
                         float* const cur = act + P * ABUF + pr * LD + s_dst;
                         const int ncol = 16 * treal, sw = 16 * (pr >> 2);
                         for (int c = pc0; c < s_zext; c += RG) {
@@ -1278,6 +1300,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             }
                         }
                     }
+#ifdef NS_STAMPS_FINE
+                    if (fine) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); NS_STAMP(); }   // SIDE: reduce done
+#endif
                     lds_barrier();
                     NS_STAMP();
                     ++si;

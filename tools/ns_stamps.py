@@ -37,3 +37,11 @@ print("phase   median cycles   (max over waves, median over blocks)")
 for i in range(n - 1):
     print("%2d -> %2d %10.0f %10.0f" % (i, i + 1, np.median(d[:, :, i]), np.median(d[:, :, i].max(1))))
 print("total per wave median %.0f cycles" % np.median(t[:, :, n - 1] - t[:, :, 0]))
+if os.environ.get("NS_STAMPS_WAVES"):
+    # per wave: when it reaches every stamp, relative to the workgroup's first wave there (median over blocks) -- who lags in a run
+    rel = t[:, :, :n] - t[:, :, :n].min(axis=1, keepdims=True)
+    print("lag behind the first wave at each stamp (cycles, median over blocks), one row per wave:")
+    for w in range(8):
+        print("wave %d " % w + " ".join("%6.0f" % np.median(rel[:, w, i]) for i in range(n)))
+    longest = int(np.argmax(np.median(d, axis=(0, 1))))
+    print("duration of phase %d -> %d per wave (median over blocks): %s" % (longest, longest + 1, " ".join("%.0f" % np.median(d[:, w, longest]) for w in range(8))))
