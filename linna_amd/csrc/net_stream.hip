@@ -960,6 +960,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 if (fine) NS_STAMP();              // epilogue done (LDS writes and stores issued)
 #endif
                 if (++pass == s_passes) {
+#ifdef NS_NOBAR_PROBE
+                    // TIMING PROBE ONLY (results are garbage): no barrier between two single-pass WIDE segments -- the upper bound of what
+                    // replacing these barriers by per-wave "my columns are written" flags could gain
+                    if (!(NX.type == NS_WIDE && s_passes == 1 && si + 1 < nseg))
+#endif
                     lds_barrier();
                     NS_STAMP();
                     P ^= 1; pass = 0; ++si;
