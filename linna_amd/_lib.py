@@ -239,6 +239,27 @@ def ld4(w):
     return (int(w) + 3) & ~3
 
 
+class quiet_gc(object):
+    """Around a loop that keeps the GPU fed from the host: every object alive now is put aside (``gc.freeze``: constant time;
+    no collection first -- that alone held a 1.5 s run for 0.15 s) so that the cyclic collector's passes inside the loop look
+    at the loop's own garbage only.  A full pass over an interpreter with torch and numpy loaded holds the thread for
+    50-70 ms; the launches queued ahead of it last a few ms -- three such passes were 13 % of a 20 000-iteration run at 128
+    walkers (bench.py `host_gc_s`).  ``gc.unfreeze`` at the end hands everything back to the collector."""
+
+    def __enter__(self):
+        import gc
+        self.on = gc.isenabled() and os.environ.get("LINNA_QUIET_GC", "1") != "0"      # (LINNA_QUIET_GC=0: A/B)
+        if self.on:
+            gc.freeze()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self.on:
+            gc.unfreeze()
+        return False
+
+
 def slice_fusion(mask=-1):
     """Which launches of linna_slice_half_step are folded into their neighbours (a mask, include/linna_hip.h); -1 queries.
     Returns the previous mask (tests and measurements: the chain is the same under every mask)."""

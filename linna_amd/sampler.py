@@ -1486,32 +1486,33 @@ def _run_blocks(ens, rk, store, dchain, done, nsamp, ncheck, incremental, begin_
     dev = ens.dev
     stats = torch.cuda.Stream(device=dev) if rk.rank == 0 else None
     pending = None
-    while done < nsamp:
-        with prof.both("sampling"):
-            c, l = ens.run(ncheck)
-        c, l, acc = rk.gather(ens, c, l)
-        stop = False
-        if rk.rank == 0 and pending is not None:
-            with prof.host("wait_check"), torch.cuda.stream(stats):
-                stop = decide(pending, done)
-            pending = None
-        if rk.bcast(stop):
-            break
-        done += ncheck
-        if rk.rank == 0:
-            with prof.both("theta"):
-                th = ens.theta_of(c)
-            with prof.host("store_append"):
-                store.append(c, th, l, acc)                               # device tensors: copied off this thread
-                if incremental:
-                    store.flush(final=False)
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
-            stats.wait_event(ready)
-            with torch.cuda.stream(stats), prof.both("stats", stats):
-                c.record_stream(stats)
-                dchain.append(c)
-                pending = begin_check(done)
+    with _lib.quiet_gc():                 # (no full pass of the cyclic collector while the launch queue is a few ms deep)
+        while done < nsamp:
+            with prof.both("sampling"):
+                c, l = ens.run(ncheck)
+            c, l, acc = rk.gather(ens, c, l)
+            stop = False
+            if rk.rank == 0 and pending is not None:
+                with prof.host("wait_check"), torch.cuda.stream(stats):
+                    stop = decide(pending, done)
+                pending = None
+            if rk.bcast(stop):
+                break
+            done += ncheck
+            if rk.rank == 0:
+                with prof.both("theta"):
+                    th = ens.theta_of(c)
+                with prof.host("store_append"):
+                    store.append(c, th, l, acc)                               # device tensors: copied off this thread
+                    if incremental:
+                        store.flush(final=False)
+                ready = torch.cuda.Event()
+                ready.record(torch.cuda.current_stream(dev))
+                stats.wait_event(ready)
+                with torch.cuda.stream(stats), prof.both("stats", stats):
+                    c.record_stream(stats)
+                    dchain.append(c)
+                    pending = begin_check(done)
     if rk.rank == 0 and pending is not None:                              # the last block's check: printed, not acted upon
         with prof.host("wait_check"), torch.cuda.stream(stats):
             decide(pending, done)

@@ -477,6 +477,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     if num_epochs > 0:
         enqueue_steps(perm)
     prof.mark("enqueue_steps")
+    gcq = _lib.quiet_gc().__enter__()        # (the epochs' launches are queued 2-9 ms ahead: no full collector pass inside the loop)
     while i < num_epochs:
         landed = enqueue_tail()
         prof.mark("enqueue_validation")
@@ -584,6 +585,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
         else:
             pre["rows"], pre["rng"] = None, None                                # (the speculative epoch has consumed the order drawn ahead)
         fly["on"] = False
+    gcq.__exit__(None, None, None)
     t_loop = time.perf_counter()
     ckpt.finish(opt, last_epoch)                    # best.pth.tar / last.pth.tar are on disk when train() returns
     prof.finish(epochs=last_epoch + 1, steps_per_epoch=nsteps, total_s=time.perf_counter() - t_run,
