@@ -711,6 +711,14 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 }
             }
             if (s_zext < 0) kleft = s_steps - 4 * blk;             // its rows start at 64 blk
+#ifdef NS_REBAL_PROBE
+            // TIMING PROBE ONLY (results are garbage): the first-dispatched wave of each SIMD wins the matrix pipe (NOTES R5); here it
+            // runs NS_REBAL_PROBE steps more per long single-pass run and its partner as many fewer -- what moving the tail of the
+            // partner's k range over to it would do to the run's length
+            if constexpr (!SM && STORE == 0 && !GRAD) {
+                if (s_passes == 1 && s_steps >= 16 && s_zext == 0) kleft += wave < 4 ? NS_REBAL_PROBE : -NS_REBAL_PROBE;
+            }
+#endif
             ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (s_zext < 0 ? 64 * blk : (pass ? s_kslice : 0)));   // (kslice: 0 but for a short second pass)
         } else {
             ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (wave >> s_ncgl) * s_kslice);
@@ -1328,7 +1336,19 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     };
     using T_ = std::true_type; using F_ = std::false_type;
 #define NS_STEP(U, RF) if constexpr (U < R) step(std::integral_constant<int, U>{}, RF{});
+#ifdef NS_REBAL_PROBE
+    int gadj = 0;
+    if constexpr (!SM && STORE == 0 && !GRAD) {
+        for (int j = 0; j < nseg; ++j) {
+            const NsSeg Sj = ka->seg[__builtin_amdgcn_readfirstlane(j)];
+            if (Sj.type == NS_WIDE && Sj.passes == 1 && Sj.steps >= 16 && Sj.zext == 0) gadj += NS_REBAL_PROBE;
+        }
+    }
+    const int Gw = a.G + (wave < 4 ? gadj : -gadj);
+    const int ngroups = Gw / R, rem = Gw - ngroups * R;
+#else
     const int ngroups = a.G / R, rem = a.G - ngroups * R;
+#endif
 #pragma unroll 1
     for (int it = 0; it < ngroups; ++it) {
         NS_STEP(0, T_) NS_STEP(1, T_) NS_STEP(2, T_) NS_STEP(3, T_) NS_STEP(4, T_) NS_STEP(5, T_) NS_STEP(6, T_) NS_STEP(7, T_)
