@@ -779,6 +779,21 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
 #endif
         } else {
+#ifdef NS_ACC4
+            // experiment: the four accumulators in rotation (a dependent MFMA four instructions behind its producer instead of two)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][t][s], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (refill) {
+                    if (s == 1) { Bq[RU][0] = wload(0); Bq[RU][1] = wload(1); }
+                    if (s == 3) { Bq[RU][2] = wload(2); Bq[RU][3] = wload(3); }
+                }
+            }
+#else
 #pragma unroll
             for (int h = 0; h < NT; h += 2) {
 #pragma unroll
@@ -791,6 +806,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     Bq[RU][h + 1] = wload(h + 1);
                 }
             }
+#endif
         }
         if constexpr (refill) wadvance();
         if (--kleft == 0) {
