@@ -135,6 +135,23 @@ def test_no_kernel_of_the_library_uses_scratch():
     assert max(k["vgpr"] for k in ks) <= 256
 
 
+def test_slice_fusion_switch_without_a_gpu():
+    """``linna_slice_fusion``: a process-wide mask, queried with -1, returns the previous value, refuses masks outside bits 0-2
+    with LINNA_ERR_INVALID and a text (no launch, no GPU needed)."""
+    from linna_amd import _lib
+    lib = _lib.load()
+    prev = lib.linna_slice_fusion(-1)
+    assert 0 <= prev <= 7
+    try:
+        assert lib.linna_slice_fusion(0) == prev and lib.linna_slice_fusion(-1) == 0
+        assert lib.linna_slice_fusion(5) == 0 and lib.linna_slice_fusion(-1) == 5
+        rc = lib.linna_slice_fusion(8)
+        assert rc < 0 and "linna_slice_fusion" in lib.linna_last_error().decode()
+        assert lib.linna_slice_fusion(-1) == 5                 # (a refused call changes nothing)
+    finally:
+        lib.linna_slice_fusion(prev)
+
+
 def test_gradient_program_planning_without_a_gpu():
     """``linna_program_describe(dense_nout = -1)``: the program of the one-launch gradient for ChtoModelv2(33,33) on the 16-row
     engine -- the forward segments with the hidden h of the residual blocks as SIDE segments (R4: they pay in this launch

@@ -535,6 +535,41 @@ def test_slice_fusion_masks_give_the_same_chain(rows):
         _lib.slice_fusion(prev)
 
 
+def test_slice_later_rounds_follow_the_usage_counters():
+    """The launches of the rounds after the first run the engine that suits the number of trial points the usage counters
+    have shown (``expect_rows`` of linna_slice_half_step, refreshed at one-call iterations 16, 64, ...): with ONE engine forced
+    for every launch the expectation cannot change a bit of the chain -- same coordinates with and without it -- and after 70
+    iterations it holds sane numbers: at most every point of a round, 2^20 for a round that has practically never run."""
+    from linna_amd import sampler
+    lp, pred, yinv, prob = build_logprob("mlp_33_33", 2.0)
+    nw, nd = 600, 33
+    x0 = (0.3 * np.random.RandomState(3).standard_normal((nw, nd))).astype(np.float32)
+    _lib.engine_rows(4)
+    try:
+        out = {}
+        for use in (True, False):
+            sampler.SliceEnsembleSampler.USE_EXPECT = use
+            a = sampler.SliceEnsembleSampler(nw, nd, lp, seed=5, tune=False, mu=0.8, fast=True)
+            a.set_state(x0)
+            a.run(70, store=False)
+            torch.cuda.synchronize()
+            assert a._fast_ok is True and a.noverflow == 0
+            out[use] = (a.coords.clone(), a.logp.clone(), a.expected_rows)
+        assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1])
+        rows = out[True][2]
+        assert out[False][2] is None and rows is not None and len(rows) == a.nexp_rounds + a.nshr_rounds
+        pts = [2 * m for m in a.m_sched] + list(a.nt_sched)
+        for i, r in enumerate(rows):
+            if i in (0, a.nexp_rounds):
+                assert r == 1                                   # (the first round of each kind evaluates every walker: entry unused)
+            else:
+                assert r == 1 << 20 or 8 <= r <= pts[i] * a.half * 1.25 + 8
+        assert rows[a.nexp_rounds + 1] < 1 << 20               # the second shrinking round does run (a few % of the walkers)
+    finally:
+        sampler.SliceEnsembleSampler.USE_EXPECT = True
+        _lib.engine_rows(0)
+
+
 @pytest.mark.parametrize("name,nw", [("mlp_33_33", 96), ("v2_33_33", 16), ("mlp_33_33", 1024)])
 def test_one_call_slice_half_step_equals_the_round_loop(name, nw):
     """linna_slice_half_step (speculative rounds: several bracket ends / trials per evaluation launch, a fixed launch
