@@ -505,7 +505,9 @@ int linna_slice_commit(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float
  * shrinking rounds of `nt_sched[r]` trials each placed as if its predecessors were rejected (linna_slice_draw's rule, stream
  * 2 + half, sub-counter = trials of the earlier rounds + j + 1), and the commit (in the last shrinking round's kernel;
  * bump_step != 0: step_dev[0] += 1 there as well, which saves the caller its linna_step_increment behind the second half
- * step of an iteration): 1 + 2 (nexp_rounds + nshr_rounds) launches on `stream`, no host synchronisation.  The accepted points are those of the one-point-per-round procedure.
+ * step of an iteration): at most 1 + 2 (nexp_rounds + nshr_rounds) launches on `stream` (linna_slice_fusion folds the set-up
+ * and, with one stepping-out round, that round's logic into the evaluations: 5 launches for 1 + 2 rounds), no host
+ * synchronisation.  The accepted points are those of the one-point-per-round procedure.
  * Rounds after the first evaluate only the walkers still active (listed and counted on the device), so a schedule that
  * looks further ahead each round (1, 2, 4, 8 ...) costs little and keeps the number of rounds small; rounds behind the one
  * that finished the last walker leave at once.  m_sched / nt_sched: HOST arrays; M = max m_sched, T = max nt_sched:
