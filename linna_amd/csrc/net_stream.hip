@@ -1042,8 +1042,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     }
                 }
                 int gj = 0;
-                if constexpr (!LB && !DXE && !STORE) {
-                    // serving: FOUR adjacent columns per thread and trip, as 16-byte LDS accesses (the swizzle moves whole groups of
+                if constexpr ((!LB && !DXE && !STORE) || (LB && !SM)) {
+                    // serving (and the one-launch gradient on the 16-row engine): FOUR adjacent columns per thread and trip, as 16-byte LDS accesses (the swizzle moves whole groups of
                     // 16 / 32 columns, the biases start at multiples of 64): a quarter of the LDS instructions of the column-per-
                     // trip loop below, and all K parts of a trip in flight -- 256 output columns were 8 trips of ~130 cycles
                     // each behind the barrier.  The sums in the order of the loop below.
@@ -1053,16 +1053,37 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                             if (c < ncol) {
                                 const float* src = part + (c >> 6) * PW + sr * 64 + ((c & 63) ^ sw);
-                                f32x4 x[NK];
-#pragma unroll
-                                for (int kp = 0; kp < NK; ++kp) x[kp] = *reinterpret_cast<const f32x4*>(src + (kp << s_ncgl) * PW);
+                                constexpr int CH = LB && NK > 4 ? 4 : NK;        // K parts in flight (the gradient launch has no 32 registers to spare)
                                 const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + s_bias + c);
 #pragma unroll
-                                for (int kp = 0; kp < NK; ++kp) v += x[kp];
+                                for (int k0 = 0; k0 < NK; k0 += CH) {
+                                    f32x4 x[CH];
+#pragma unroll
+                                    for (int kp = 0; kp < CH; ++kp) x[kp] = *reinterpret_cast<const f32x4*>(src + ((k0 + kp) << s_ncgl) * PW);
+#pragma unroll
+                                    for (int kp = 0; kp < CH; ++kp) v += x[kp];
+                                }
                                 v += b;
                                 if (s_relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                             }
-                            *reinterpret_cast<f32x4*>(cur + c) = v;
+                            if constexpr (LB) {
+                                // the gate: four sign bits of the tensor this gradient belongs to (bit columns s_mbit + c ..; c & 31 <= 28)
+                                const bool mine = c < ((s_gn + 63) & ~63);
+                                if (s_mbit >= 0) {
+                                    const unsigned nib = mine ? (lbits[sr * nbw + ((s_mbit + c) >> 5)] >> (c & 31)) & 0xFu : 0u;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] : 0.f;
+                                }
+                                *reinterpret_cast<f32x4*>(cur + c) = v;
+                                if (s_gbit >= 0) {
+                                    // the signs of these activations: the eight threads of a 32-column word OR their nibbles together
+                                    unsigned w32 = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (c & 31);
+                                    w32 |= __shfl_xor(w32, 1, 64); w32 |= __shfl_xor(w32, 2, 64); w32 |= __shfl_xor(w32, 4, 64);
+                                    if ((sc0 & 7) == 0 && mine) lbits[sr * nbw + ((s_gbit + c) >> 5)] = w32;
+                                }
+                            } else {
+                                *reinterpret_cast<f32x4*>(cur + c) = v;
+                            }
                         }
                     };
                     if (nkp == NW) reduce4(std::integral_constant<int, NW>{});
@@ -1283,23 +1304,42 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #ifdef NS_STAMPS_FINE
                     if (fine) NS_STAMP();          // SIDE: first barrier passed
 #endif
-                    if constexpr (!LB) {               // (serving: four adjacent columns per thread, 16-byte accesses -- the SPLIT reduce's form)
+                    if constexpr (true) {              // (four adjacent columns per thread, 16-byte accesses -- the SPLIT reduce's form)
                         float* const cur = act + P * ABUF + pr * LD + s_dst;
                         const int ncol = 16 * treal, sw = 16 * (pr >> 2);
                         for (int c = 4 * pc0; c < s_zext; c += 4 * RG) {
                             f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
                             if (c < ncol) {
                                 const float* src = part + pr * 64 + (c ^ sw);
-                                f32x4 x[NW];
-#pragma unroll
-                                for (int kp = 0; kp < NW; ++kp) x[kp] = *reinterpret_cast<const f32x4*>(src + kp * PW);
+                                constexpr int CH = LB ? 4 : NW;
                                 const f32x4 b = *reinterpret_cast<const f32x4*>(lbias + s_bias + c);
 #pragma unroll
-                                for (int kp = 0; kp < NW; ++kp) v += x[kp];
+                                for (int k0 = 0; k0 < NW; k0 += CH) {
+                                    f32x4 x[CH];
+#pragma unroll
+                                    for (int kp = 0; kp < CH; ++kp) x[kp] = *reinterpret_cast<const f32x4*>(src + (k0 + kp) * PW);
+#pragma unroll
+                                    for (int kp = 0; kp < CH; ++kp) v += x[kp];
+                                }
                                 v += b;
                                 if (s_relu) v = f32x4{fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f)};
                             }
-                            *reinterpret_cast<f32x4*>(cur + c) = v;
+                            if constexpr (LB) {         // a backward SIDE segment (d/dh) is gated by the sign bits of h; a forward one records them
+                                const bool mine = c < ((s_gn + 63) & ~63);
+                                if (s_mbit >= 0) {
+                                    const unsigned nib = mine ? (lbits[pr * nbw + ((s_mbit + c) >> 5)] >> (c & 31)) & 0xFu : 0u;
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = ((nib >> e) & 1u) ? v[e] : 0.f;
+                                }
+                                *reinterpret_cast<f32x4*>(cur + c) = v;
+                                if (s_gbit >= 0) {
+                                    unsigned w32 = ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (c & 31);
+                                    w32 |= __shfl_xor(w32, 1, 64); w32 |= __shfl_xor(w32, 2, 64); w32 |= __shfl_xor(w32, 4, 64);
+                                    if ((pc0 & 7) == 0 && mine) lbits[pr * nbw + ((s_gbit + c) >> 5)] = w32;
+                                }
+                            } else {
+                                *reinterpret_cast<f32x4*>(cur + c) = v;
+                            }
                         }
                     } else {
                         float* const cur = act + P * ABUF + pr * LD + s_dst;
