@@ -1304,7 +1304,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
 #ifdef NS_STAMPS_FINE
                     if (fine) NS_STAMP();          // SIDE: first barrier passed
 #endif
-                    if constexpr (true) {              // (four adjacent columns per thread, 16-byte accesses -- the SPLIT reduce's form)
+                    {                                  // four adjacent columns per thread, 16-byte accesses: the SPLIT reduce's form
                         float* const cur = act + P * ABUF + pr * LD + s_dst;
                         const int ncol = 16 * treal, sw = 16 * (pr >> 2);
                         for (int c = 4 * pc0; c < s_zext; c += 4 * RG) {
@@ -1339,33 +1339,6 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                                 }
                             } else {
                                 *reinterpret_cast<f32x4*>(cur + c) = v;
-                            }
-                        }
-                    } else {
-                        float* const cur = act + P * ABUF + pr * LD + s_dst;
-                        const int ncol = 16 * treal, sw = 16 * (pr >> 2);
-                        for (int c = pc0; c < s_zext; c += RG) {
-                            float v = 0.f;
-                            if (c < ncol) {
-                                const float* src = part + pr * 64 + (c ^ sw);
-                                float x[NW];
-#pragma unroll
-                                for (int kp = 0; kp < NW; ++kp) x[kp] = src[kp * PW];
-#pragma unroll
-                                for (int kp = 0; kp < NW; ++kp) v += x[kp];
-                                v += lbias[s_bias + c];
-                                if (s_relu) v = fmaxf(v, 0.f);
-                                if constexpr (LB) {     // a backward SIDE segment (d/dh): gated by the sign bits of h
-                                    if (s_mbit >= 0 && !(c < ((s_gn + 63) & ~63) && ((lbits[pr * nbw + ((s_mbit + c) >> 5)] >> (c & 31)) & 1u))) v = 0.f;
-                                }
-                            }
-                            cur[c] = v;
-                            if constexpr (LB) {
-                                if (s_gbit >= 0) {      // the sign of this h, for the gate of its gradient (the SPLIT reduce's form)
-                                    const unsigned long long bb = __ballot(v > 0.f);
-                                    const bool mine = c < ((s_gn + 63) & ~63);
-                                    if ((lane & 31) == 0 && mine) lbits[pr * nbw + ((s_gbit + c) >> 5)] = (unsigned)(bb >> (lane & 32));
-                                }
                             }
                         }
                     }
