@@ -592,6 +592,24 @@ def _problem33(device, kind):
     return lp, model
 
 
+def production_rates(device):
+    """The reference's OWN configuration: the network it hard-wires (ChtoModelv2(33,33), nn.py:59-133) at the ensemble size its
+    runs use (128 walkers: 64 proposals per half step = 16 workgroups of the 4-row engine, whose time is the small-batch floor
+    of the whole-network kernel).  Raw sampler rates -- the emcee stretch move and zeus' slice move -- and the
+    latency of one 64-row evaluation."""
+    import torch
+    lp2, model = _problem33(device, "ChtoModelv2")
+    z = torch.as_tensor(np.random.RandomState(5).standard_normal((64, NIN)).astype(np.float32), device=device)
+    out = torch.empty(64, dtype=torch.float32, device=device)
+    us = _events_us(lambda: lp2.evaluate(z, out=out), 2000)
+    _, em = mcmc_rate(lp2, 128, nsteps=3000, warm=500)
+    zs = slice_rate(lp2, sizes=(128,), iters=(600,))["walkers_128"]
+    return {"workload": "ChtoModelv2(33,33), diagonal inverse covariance, 128 walkers (the reference's network at the reference's ensemble size)",
+            "us_per_64_row_evaluation": us, "emcee_iterations_per_s": em["steps_per_s"], "emcee_acceptance": em["acceptance"],
+            "zeus_iterations_per_s": zs["iterations_per_s"], "zeus_evals_per_walker_per_iteration": zs["evals_per_walker_per_iteration"],
+            "zeus_path": zs["path"]}
+
+
 def _events_us(fn, iters, warm_s=0.3):
     """Average time of `fn` in microseconds: HIP events on the launch stream around `iters` back-to-back calls, after a
     clock-ramp warm-up."""
@@ -1120,7 +1138,8 @@ def main():
                     res[key] = secondary_serving(device, *spec)
                 except Exception as e:                              # noqa: BLE001
                     res[key] = {"error": repr(e)[:300]}
-            for key, fn in (("hmc", lambda: hmc_rate(device)), ("slice", lambda: slice_rate(lp))):   # configs[4]; the default sampler
+            for key, fn in (("hmc", lambda: hmc_rate(device)), ("slice", lambda: slice_rate(lp)),   # configs[4]; the default sampler
+                            ("production_128", lambda: production_rates(device))):
                 try:
                     res[key] = fn()
                 except Exception as e:                              # noqa: BLE001
