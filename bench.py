@@ -77,7 +77,7 @@ class _Watchdog(object):
                 return False
             self.done = True
         self.timer.cancel()
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=sys.__stdout__, flush=True)
         return True
 
     def failed(self, exc):
@@ -91,7 +91,7 @@ class _Watchdog(object):
             self.done = True
         if self.rank == 0 and self.line is not None:
             self.line["watchdog"] = "a section after the headline raised %s at stage '%s'; the remaining sections are missing from this line" % (repr(exc)[:200], self.stage)
-            print(json.dumps(self.line), flush=True)
+            print(json.dumps(self.line), file=sys.__stdout__, flush=True)      # (sys.stdout may be redirected by the section that hangs)
         os._exit(self.EXIT_RAISED)
 
     def _fire(self):
@@ -101,7 +101,7 @@ class _Watchdog(object):
             self.done = True
         if self.rank == 0 and self.line is not None:
             self.line["watchdog"] = "sections after the headline did not finish within %.0f s (last stage: %s); they are missing from this line" % (self.seconds, self.stage)
-            print(json.dumps(self.line), flush=True)
+            print(json.dumps(self.line), file=sys.__stdout__, flush=True)      # (sys.stdout may be redirected by the section that hangs)
         sys.stderr.write("[bench rank %d] watchdog: leaving at stage '%s'\n" % (self.rank, self.stage))
         sys.stderr.flush()
         os._exit(self.EXIT_HANG)
@@ -1134,17 +1134,20 @@ def main():
             res["rccl_ranks"] = comm_ranks          # linna_comm_info: ranks of the library's communicator (0 = torch.distributed carries the data path)
         if not args.no_secondary:
             for key, spec in (("chto_v2", ("ChtoModelv2", 33, 33, False)), ("dense_1000", ("ChtoModelv2", 40, 1000, True))):
+                _at("secondary: " + key)
                 try:
                     res[key] = secondary_serving(device, *spec)
                 except Exception as e:                              # noqa: BLE001
                     res[key] = {"error": repr(e)[:300]}
             for key, fn in (("hmc", lambda: hmc_rate(device)), ("slice", lambda: slice_rate(lp)),   # configs[4]; the default sampler
                             ("production_128", lambda: production_rates(device))):
+                _at("secondary: " + key)
                 try:
                     res[key] = fn()
                 except Exception as e:                              # noqa: BLE001
                     res[key] = {"error": repr(e)[:300]}
-            if not args.no_driver and isinstance(res.get("slice", {}).get("walkers_128"), dict):
+            if world == 1 and not args.no_driver and isinstance(res.get("slice", {}).get("walkers_128"), dict):   # (the drivers shard over the default process group: an N = 1 measurement)
+                _at("secondary: zeus driver")
                 try:                                                # the zeus driver end to end at the reference's ensemble size
                     res["slice"]["walkers_128"].update(driver_rate(lp, 128, nsamp=3000, method="zeus"))
                 except Exception as e:                              # noqa: BLE001
