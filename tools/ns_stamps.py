@@ -22,7 +22,12 @@ else:
     p = bench_paths.problem("ChtoModelv2", nin, nout, which != "v2")
     lp = p["lp"]
 z = torch.randn(B, nin, device="cuda"); out = torch.empty(B, device="cuda")
-if os.environ.get("NS_STAMPS_GRAD"):                 # the one-launch gradient (HMC) instead of the evaluation
+if os.environ.get("NS_STAMPS_STRETCH"):              # the one-launch stretch half step of an ensemble of 2 B walkers instead
+    from linna_amd import sampler
+    ens = sampler.EnsembleSampler(2 * B, nin, lp, seed=1)
+    ens.set_state(0.05 * np.random.RandomState(7).standard_normal((2 * B, nin)))
+    ens.run(6, store=False)
+elif os.environ.get("NS_STAMPS_GRAD"):               # the one-launch gradient (HMC) instead of the evaluation
     g = torch.empty(B, nin, device="cuda")
     for _ in range(5): lp.evaluate_with_grad(z, out=out, grad=g)
 else:
