@@ -1155,24 +1155,35 @@ class SliceEnsembleSampler(EnsembleSampler):
             return
         self._expect_seen = n
         nr = self.nexp_rounds + self.nshr_rounds
-        c = self._fast_bufs["counters"].cpu().numpy().astype(np.float64)
-        calls, cum = c[4 + 2 * nr] - 1, c[4 + nr:4 + 2 * nr]
-        last_calls, last_cum = self._expect_base
-        if len(last_cum) != nr:
-            last_calls, last_cum = 0.0, np.zeros(nr)
-        if calls - last_calls < 8:
+        rows, base = self.expected_points(self._fast_bufs["counters"].cpu().numpy(), self.m_sched, self.nt_sched, self.half, self._expect_base)
+        if rows is None:
             return
-        frac = (cum - last_cum) / ((calls - last_calls) * self.half)
-        self._expect_base = (calls, cum.copy())
-        pts = [2 * m for m in self.m_sched] + list(self.nt_sched)
-        rows = [1] * nr
-        for i in range(nr):
-            if i and i != self.nexp_rounds:
-                mean = pts[i] * frac[i - 1] * self.half
-                # (a round that practically never runs: the engine with the fewest workgroups to launch and dismiss)
-                rows[i] = int(mean * 1.25) + 8 if mean >= 0.5 else 1 << 20
+        self._expect_base = base
         self._expect = (C.c_int * nr)(*rows)
         self.expected_rows = rows
+
+    @staticmethod
+    def expected_points(counters, m_sched, nt_sched, half, base=None):
+        """From the usage counters of linna_slice_half_step (include/linna_hip.h: ``[4 + nr + r]`` walkers still active behind
+        round r summed over the earlier calls, ``[4 + 2 nr]`` the calls) and the counters' state at the last look
+        (``base`` = (calls, sums)): the trial points each round is expected to evaluate -- entry r of the stepping-out rounds,
+        ``len(m_sched) + r`` of the shrinking ones; 1 for the first round of each kind (it evaluates every walker), 2^20 for a
+        round whose mean is below half a point -- and the new ``base``.  (None, base) when fewer than 8 calls are new."""
+        nexp, nr = len(m_sched), len(m_sched) + len(nt_sched)
+        c = np.asarray(counters, np.float64)
+        calls, cum = c[4 + 2 * nr] - 1, c[4 + nr:4 + 2 * nr]
+        last_calls, last_cum = base if base is not None and len(base[1]) == nr else (0.0, np.zeros(nr))
+        if calls - last_calls < 8:
+            return None, base
+        frac = (cum - last_cum) / ((calls - last_calls) * half)
+        pts = [2 * m for m in m_sched] + list(nt_sched)
+        rows = [1] * nr
+        for i in range(nr):
+            if i and i != nexp:
+                mean = pts[i] * frac[i - 1] * half
+                # (a round that practically never runs: the engine with the fewest workgroups to launch and dismiss)
+                rows[i] = int(mean * 1.25) + 8 if mean >= 0.5 else 1 << 20
+        return rows, (calls, cum.copy())
 
     def _tune_mu(self, nexp, ncon):
         """zeus: mu *= 2 nexp / (nexp + ncon) until the expansion fraction stays within ``tolerance`` of 1/2 for

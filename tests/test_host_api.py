@@ -596,3 +596,39 @@ def test_nbest_points_are_designed_around_the_best_fit(tmp_path):
     assert len(tx) == 60 and len(vx2) == 15
     np.testing.assert_array_equal(tx[:20], bx)
     np.testing.assert_array_equal(vy2[:5], vy)
+
+
+def test_slice_round_expectation_from_usage_counters():
+    """``SliceEnsembleSampler.expected_points``: the engine hint of the later slice rounds (linna_slice_half_step's
+    ``expect_rows``) from the device's usage counters -- mean walkers still active behind a round x the next round's points per
+    walker x 1.25 + 8; the first round of each kind unused (1); a round that practically never runs 2^20; differences since
+    the last look, not the whole history; nothing from fewer than 8 new calls."""
+    import torch  # noqa: F401  (the module imports it)
+    from linna_amd.sampler import SliceEnsembleSampler as S
+    m_sched, nt_sched, half = [2, 4, 8], [4, 8, 16, 32], 2048
+    nr = 7
+    c = np.zeros(5 + 2 * nr)
+    calls = 201                                          # (the latest call's counts are rolled by the next one: 200 counted)
+    c[4 + 2 * nr] = calls
+    c[4 + nr:4 + 2 * nr] = np.array([0.0037, 0.0, 0.0, 0.0846, 6e-5, 0.0, 0.0]) * 200 * half
+    rows, base = S.expected_points(c, m_sched, nt_sched, half)
+    assert rows[0] == 1 and rows[3] == 1
+    assert rows[1] == int(8 * 0.0037 * half * 1.25) + 8 == 83                   # second stepping-out round: 2 x 4 ends per walker still active
+    assert rows[2] == 1 << 20 and rows[6] == 1 << 20                            # nobody has ever been behind those
+    assert rows[4] == int(8 * 0.0846 * half * 1.25) + 8 and 1400 < rows[4] < 2048   # second shrinking round: the 8-row engine
+    assert rows[5] == int(16 * 6e-5 * half * 1.25) + 8 == 10
+    assert base[0] == 200 and np.allclose(base[1], c[4 + nr:4 + 2 * nr])
+    # the next look sees only what happened since: the walkers now finish earlier
+    c2 = c.copy()
+    c2[4 + 2 * nr] = 401
+    c2[4 + nr:4 + 2 * nr] += np.array([0.0, 0.0, 0.0, 0.01, 0.0, 0.0, 0.0]) * 200 * half
+    rows2, base2 = S.expected_points(c2, m_sched, nt_sched, half, base)
+    assert rows2[1] == 1 << 20 and rows2[4] == int(8 * 0.01 * half * 1.25) + 8 and base2[0] == 400
+    # too few new calls: no change
+    c3 = c2.copy(); c3[4 + 2 * nr] = 405
+    assert S.expected_points(c3, m_sched, nt_sched, half, base2) == (None, base2)
+    # one stepping-out round, two shrinking rounds (the small ensembles): entry 1 is a first round, entry 2 the rescue
+    c4 = np.zeros(5 + 2 * 3); c4[4 + 2 * 3] = 101
+    rows4, _ = S.expected_points(c4, [8], [16, 16], 64)
+    assert rows4 == [1, 1, 1 << 20]
+
