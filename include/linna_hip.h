@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LINNA_ABI_VERSION 10   /* 10: + linna_slice_fusion, linna_slice_half_step(expect_rows); 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd, linna_val_metrics, linna_loss_desc_t::ylog; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
+#define LINNA_ABI_VERSION 11   /* 11: every descriptor struct a caller fills (linna_gemm_t, linna_layer_t, linna_logprob_desc_t, linna_loss_desc_t) starts with `uint32_t struct_size` = its sizeof in the caller's header, checked by the entries that take it -- a binding built against another layout is refused instead of read at wrong offsets; linna_slice_init / linna_slice_half_step(maxsteps): zeus' stepping-out budget; the shrinking test is zeus' `Z0 < lnP`; 10: + linna_slice_fusion, linna_slice_half_step(expect_rows); 9: + linna_stretch_run, linna_chain_append_t, linna_acorr_*, linna_chain_meanstd, linna_val_metrics, linna_loss_desc_t::ylog; 8: + the exception barrier (LINNA_ERR_INTERNAL, linna_debug_raise) and linna_logprob_desc_t GREW by one pointer (Sfac, appended: a binding compiled against the v7 struct must be rebuilt -- linna_logprob_create copies the struct at the new size); 4: + linna_comm_* (RCCL); 5: + linna_net_prepare, linna_net_forward_loss; 6: + linna_net_adamw_step, linna_net_train_step, linna_net_train_step_update; 7: + linna_engine_rows, linna_slice_half_step, linna_program_describe, linna_net_train_launches, linna_logprob_grad_leapfrog, linna_hmc_start */
 
 typedef struct linna_ctx linna_ctx_t;
 typedef struct linna_net linna_net_t;
@@ -103,6 +103,7 @@ typedef struct {
 } linna_gemm_pair_t;
 
 typedef struct {
+    uint32_t struct_size;   /* = sizeof of this struct in the CALLER's header; checked by every entry that takes it (LINNA_ERR_INVALID otherwise) */
     linna_gemm_pair_t p[2];
     int npairs;
     int M, N;
@@ -159,6 +160,7 @@ int linna_linear_bwd(linna_ctx_t* ctx, const float* dY, int lddy, const float* X
 #define LINNA_OP_INSKIP 2     /* out += alpha*(X0 W^T + b), X0 = network input (nn.py:195)     */
 
 typedef struct {
+    uint32_t struct_size;   /* = sizeof of this struct in the CALLER's header; checked by every entry that takes it (LINNA_ERR_INVALID otherwise) */
     int op;
     int K, C, N;
     int relu;
@@ -240,6 +242,7 @@ int linna_gauss_loglike_dense(linna_ctx_t* ctx, const float* D, int ldd, int B, 
  * -> network -> Y transform -> *sigma -> log-likelihood/T + ln prior.  The struct holds
  * device pointers to constants (all caller-owned). */
 typedef struct {
+    uint32_t struct_size;   /* = sizeof of this struct in the CALLER's header; checked by every entry that takes it (LINNA_ERR_INVALID otherwise) */
     int nin, nout;
     const int* is_flat; const float* a1; const float* a2;       /* priors, [nin] */
     const int* log10_flag; const float* xmean; const float* xstd;
@@ -335,6 +338,7 @@ int linna_logprob_grad_leapfrog(linna_logprob_t* lp, float* Q, int ldq, int B, v
  * den_b = max(chisqMd_b, nout/2) is precomputed per dataset row (linna_chi2_md).
  * ROWS (int32, may be NULL = identity) selects minibatch rows out of the resident dataset. */
 typedef struct {
+    uint32_t struct_size;   /* = sizeof of this struct in the CALLER's header; checked by every entry that takes it (LINNA_ERR_INVALID otherwise) */
     int nout;
     const float* sigma; const float* ymean; const float* ystd;   /* [nout] */
     const float* data_norm;                                       /* [nout] */
@@ -475,11 +479,16 @@ int linna_step_increment(linna_ctx_t* ctx, int* step_dev, void* stream);
  * direction mu*(c_a - c_b) from two distinct complementary walkers, a slice height
  * Z0 = logp + log u, a unit bracket [L, R] placed at random around 0; stepping out pushes an end
  * out while the density there exceeds Z0; shrinking draws w ~ U(L, R) and pulls the bracket in to
- * rejected trials.  flags[3k..3k+2] = {left active, right active, shrinking}; counters[0..2] =
- * {expansions, contractions, walkers still active after this call} (device int32, caller zeroes). */
+ * rejected trials (accepted iff Z0 < lnP there, zeus' comparison).  `mu_dev[0]` is the whole scale of the direction: a caller
+ * with zeus' semantics of mu (direction 2 mu (c_a - c_b), moves.py) passes 2 mu.  `maxsteps` is zeus' stepping-out budget
+ * (its default: 10000): at most J = floor(maxsteps u) steps to the left and maxsteps - 1 - J to the right (Philox stream
+ * `stream_id`, sub-counter 1).  flags[3k..3k+2] = {steps left of J while the left end is still stepping out (0: closed), the
+ * same for the right end and K, still shrinking}; counters[0..2] = {expansions, contractions, walkers still active after
+ * this call} (device int32, caller zeroes). */
 int linna_slice_init(linna_ctx_t* ctx, const float* logp, const int* S_idx, int ns, const float* ccoords, int ldcc,
                      const int* C_idx, int nc, int ndim, const float* mu_dev, uint64_t seed, const int* step_dev,
-                     int stream_id, float* DIR, int ldd, float* Z0, float* L, float* R, int* flags, void* stream);
+                     int stream_id, float* DIR, int ldd, float* Z0, float* L, float* R, int* flags, int maxsteps,
+                     void* stream);
 /* Q[j*ns + k] = coords[S[k]] + w[j*ns + k] * DIR[k], j < nrep */
 int linna_slice_points(linna_ctx_t* ctx, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
                        const float* DIR, int ldd, const float* w, float* Q, int ldq, int nrep, void* stream);
@@ -524,12 +533,14 @@ int linna_slice_commit(linna_ctx_t* ctx, float* coords, int ldc, int ndim, float
  *   workgroup) that suits this number: 60 points on the 16-row engine take 56 us, on the 4-row engine 29.  null: a quarter of
  *   the previous round's.  A wrong expectation costs time, never results of another chain... the lnP of one point differs in
  *   the last bits between engines (another summation order), as everywhere else in this library.
+ * maxsteps: zeus' stepping-out budget, as in linna_slice_init.
  * zeus' EnsembleSampler behind sampler.py:728-735. */
 int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim, float* logp, const int* S_idx, int ns,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
                           int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched,
                           int nshr_rounds, float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt,
-                          int* list, int* counters, int zero_totals, int bump_step, const int* expect_rows, void* stream);
+                          int* list, int* counters, int zero_totals, int bump_step, const int* expect_rows, int maxsteps,
+                          void* stream);
 
 /* `nsteps` ensemble iterations in ONE call: 2 nsteps launches of linna_stretch_half_step's kernel with the same Philox
  * counters (step = step_dev[0] + step_offset + i, stream = half), so the chain is bit-identical to a host loop over that

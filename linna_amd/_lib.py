@@ -11,10 +11,26 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LINNA_LIB_PATH") or os.path.join(_HERE, "liblinna_hip.so")   # (LINNA_LIB_PATH: a diagnostic build, tools/ns_stamps.py)
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_float_p = C.c_void_p   # device pointers travel as void*
 c_int_p = C.c_void_p
+
+
+class _Sized(C.Structure):
+    """A descriptor struct of include/linna_hip.h that starts with ``uint32_t struct_size`` (ABI 11): filled in on
+    construction; elements of a ctypes ARRAY are not constructed -- use ``sized_array``."""
+
+    def __init__(self, *a, **k):
+        C.Structure.__init__(self, *a, **k)
+        self.struct_size = C.sizeof(type(self))
+
+
+def sized_array(cls, n):
+    arr = (cls * n)()
+    for i in range(n):
+        arr[i].struct_size = C.sizeof(cls)
+    return arr
 
 
 class GemmPair(C.Structure):
@@ -22,8 +38,8 @@ class GemmPair(C.Structure):
                 ("alay", C.c_int), ("blay", C.c_int)]
 
 
-class Gemm(C.Structure):
-    _fields_ = [("p", GemmPair * 2), ("npairs", C.c_int), ("M", C.c_int), ("N", C.c_int),
+class Gemm(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("p", GemmPair * 2), ("npairs", C.c_int), ("M", C.c_int), ("N", C.c_int),
                 ("C", C.c_void_p), ("ldc", C.c_int), ("bias0", C.c_void_p), ("bias1", C.c_void_p),
                 ("alpha0", C.c_float), ("R", C.c_void_p), ("ldr", C.c_int), ("relu", C.c_int),
                 ("mask", C.c_void_p), ("ldmask", C.c_int), ("cscale", C.c_void_p), ("cshift", C.c_void_p),
@@ -32,8 +48,8 @@ class Gemm(C.Structure):
                 ("flags", C.c_int)]
 
 
-class Layer(C.Structure):
-    _fields_ = [("op", C.c_int), ("K", C.c_int), ("C", C.c_int), ("N", C.c_int), ("relu", C.c_int),
+class Layer(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("op", C.c_int), ("K", C.c_int), ("C", C.c_int), ("N", C.c_int), ("relu", C.c_int),
                 ("alpha", C.c_float), ("W", C.c_void_p), ("b", C.c_void_p),
                 ("W1", C.c_void_p), ("b1", C.c_void_p), ("W2", C.c_void_p), ("b2", C.c_void_p), ("Ws", C.c_void_p),
                 ("gW", C.c_void_p), ("gb", C.c_void_p), ("gW1", C.c_void_p), ("gb1", C.c_void_p),
@@ -45,15 +61,15 @@ class ColMap(C.Structure):
                 ("cshift2", C.c_void_p)]
 
 
-class LogprobDesc(C.Structure):
-    _fields_ = [("nin", C.c_int), ("nout", C.c_int), ("is_flat", C.c_void_p), ("a1", C.c_void_p), ("a2", C.c_void_p),
+class LogprobDesc(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("nin", C.c_int), ("nout", C.c_int), ("is_flat", C.c_void_p), ("a1", C.c_void_p), ("a2", C.c_void_p),
                 ("log10_flag", C.c_void_p), ("xmean", C.c_void_p), ("xstd", C.c_void_p), ("outmap", ColMap),
                 ("S", C.c_void_p), ("lds", C.c_int), ("Ssym", C.c_void_p), ("w", C.c_void_p), ("gscale", C.c_void_p),
                 ("temperature", C.c_float), ("Sfac", C.c_void_p)]
 
 
-class LossDesc(C.Structure):
-    _fields_ = [("nout", C.c_int), ("sigma", C.c_void_p), ("ymean", C.c_void_p), ("ystd", C.c_void_p),
+class LossDesc(_Sized):
+    _fields_ = [("struct_size", C.c_uint32), ("nout", C.c_int), ("sigma", C.c_void_p), ("ymean", C.c_void_p), ("ystd", C.c_void_p),
                 ("data_norm", C.c_void_p), ("Cinv", C.c_void_p), ("ldc", C.c_int), ("ylog", C.c_int)]
 
 
@@ -149,13 +165,13 @@ _SIGNATURES = {
     "linna_hmc_kick_drift": (_I, [_V, _I, _I, _V, _F, _F, _V, _I, _V, _I, _V, _I, _V]),
     "linna_hmc_accept": (_I, [_V, _I, _I, _V, _U64, _V, _V, _V, _I, _V, _I, _V, _V, _I, _V, _V, _I, _V, _V, _V, _V]),
     "linna_step_increment": (_I, [_V, _V, _V]),
-    "linna_slice_init": (_I, [_V, _V, _V, _I, _V, _I, _V, _I, _I, _V, _U64, _V, _I, _V, _I, _V, _V, _V, _V, _V]),
+    "linna_slice_init": (_I, [_V, _V, _V, _I, _V, _I, _V, _I, _I, _V, _U64, _V, _I, _V, _I, _V, _V, _V, _V, _I, _V]),
     "linna_slice_points": (_I, [_V, _V, _I, _I, _V, _I, _V, _I, _V, _V, _I, _I, _V]),
     "linna_slice_expand": (_I, [_V, _V, _V, _V, _V, _V, _V, _I, _V, _I, _V]),
     "linna_slice_draw": (_I, [_V, _V, _V, _V, _V, _V, _I, _U64, _V, _I, _I, _I, _V]),
     "linna_slice_shrink": (_I, [_V, _V, _V, _V, _V, _V, _V, _V, _V, _I, _V, _I, _I, _V]),
     "linna_slice_commit": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _V, _V]),
-    "linna_slice_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _V, _U64, _V, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _V, _V]),
+    "linna_slice_half_step": (_I, [_V, _V, _I, _I, _V, _V, _I, _V, _I, _V, _I, _V, _U64, _V, _I, _V, _I, _V, _I, _V, _I, _V, _V, _V, _V, _V, _V, _V, _I, _I, _V, _I, _V]),
 }
 EXPORTED = tuple(_SIGNATURES)
 

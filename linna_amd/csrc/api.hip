@@ -43,9 +43,15 @@ static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); 
 
 #define TRY(expr) do { int rc__ = (expr); if (rc__ != LINNA_OK) return rc__; } while (0)
 
+// a descriptor struct filled against another layout of include/linna_hip.h is refused, not read at wrong offsets
+#define CHECK_STRUCT(ptr, T, who) do { if ((ptr)->struct_size != sizeof(T)) { \
+        set_error("%s: " #T "::struct_size is %u, this library's sizeof is %zu -- set it to sizeof(" #T ") of the header you built against; " \
+                  "a mismatch means that header is not this library's (LINNA_ABI_VERSION %d)", who, (unsigned)(ptr)->struct_size, sizeof(T), LINNA_ABI_VERSION); \
+        return LINNA_ERR_INVALID; } } while (0)
 static GemmArgs gemm_zero() {
     GemmArgs a;
     std::memset(&a, 0, sizeof a);
+    a.struct_size = (uint32_t)sizeof(GemmArgs);
     a.npairs = 1;
     a.alpha0 = 1.f;
     return a;
@@ -238,6 +244,7 @@ int linna_event_destroy(void* ev) try { return check_hip(hipEventDestroy((hipEve
 // ------------------------------------------------------------------ GEMM
 int linna_gemm_f32(linna_ctx_t*, const linna_gemm_t* d, void* stream) try {
     if (!d) { set_error("gemm: null descriptor"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_gemm_t, "gemm");
     return gemm_launch(*d, S(stream));
 } LINNA_CATCH_INT
 int linna_gemm_dot_slots(int M, int N) try { return gemm_slots(M, N); } LINNA_CATCH_INT
@@ -286,6 +293,8 @@ int linna_linear_bwd(linna_ctx_t*, const float* dY, int lddy, const float* X, in
 // ------------------------------------------------------------------ network
 int linna_net_create(linna_ctx_t* ctx, const linna_layer_t* layers, int nlayers, int in_size, linna_net_t** out) try {
     if (!layers || nlayers < 1 || !out) { set_error("net_create: bad arguments"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(layers, linna_layer_t, "net_create");          // (the first entry's size is the array's stride: check it before walking)
+    for (int i = 1; i < nlayers; ++i) CHECK_STRUCT(layers + i, linna_layer_t, "net_create");
     linna_net* n = new linna_net();
     n->ctx = ctx; n->in_size = in_size; n->has_inskip = false; n->max_w = in_size; n->max_c = 4;
     int width = in_size;
@@ -468,11 +477,14 @@ static bool net_tb_usable(const linna_net* n, int B) {
     return n->stream_tb == 1 && n->packed_tb.ready() && net_stream_rows(B) == 4;     // (batches of up to 1024 rows)
 }
 int linna_loss_targets(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* YN, int ldyn, void* stream) try {
-    if (!d || !Y || !YN || nrows < 1 || ldyn < d->nout) { set_error("loss_targets: bad arguments"); return LINNA_ERR_INVALID; }
+    if (!d || !Y || !YN || nrows < 1) { set_error("loss_targets: bad arguments"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "loss_targets");
+    if (ldyn < d->nout) { set_error("loss_targets: ldyn %d < nout %d", ldyn, d->nout); return LINNA_ERR_INVALID; }
     return launch_loss_targets(Y, ldy, nrows, *d, YN, ldyn, S(stream));
 } LINNA_CATCH_INT
 int linna_net_prepare_loss(linna_net_t* n, const linna_loss_desc_t* d) try {
     if (!n || !d) { set_error("net_prepare_loss: null argument"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "net_prepare_loss");
     const NsDense dn{d->Cinv, d->ldc, nullptr, nullptr};
     if (n->stream_loss < 0 || n->loss_dn.S != dn.S || n->loss_dn.lds != dn.lds) net_ensure_loss(n, dn);
     return LINNA_OK;
@@ -497,6 +509,8 @@ int linna_net_forward_loss(linna_net_t* n, const linna_loss_desc_t* d, const flo
                            int ldp, const float* YN, int ldyn, const float* den, float inv_batch, float* loss_rows,
                            float* loss_mean, float* dPRED, int lddp, float* hyper, int* step_dev, float b1, float b2,
                            void* stream) try {
+    if (!d) { set_error("net_forward_loss: null loss descriptor"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "net_forward_loss");
     return net_forward_loss_impl(n, d, X, ldx, ROWS, B, lg, xmean, xstd, XB, ldxb, ws, PRED, ldp, YN, ldyn, den, inv_batch, loss_rows,
                                  loss_mean, dPRED, lddp, hyper, step_dev, b1, b2, stream, false);
 } LINNA_CATCH_INT
@@ -564,6 +578,8 @@ int linna_net_train_step(linna_net_t* n, const linna_loss_desc_t* d, const float
                          float* loss_mean, float* dPRED, int lddp, void* bwd_ws, float* hyper, int* step_dev, float b1, float b2,
                          void* stream) try {
     if (!bwd_ws) { set_error("net_train_step: backward workspace required"); return LINNA_ERR_INVALID; }
+    if (!d) { set_error("net_train_step: null loss descriptor"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "net_train_step");
     TRY(net_train_ensure_loss(n, d, stream));
     if (net_tb_usable(n, B)) {
         // two launches: forward + loss + dX chain, then every parameter gradient (the batch mean of the loss riding in it)
@@ -993,6 +1009,7 @@ extern "C" {
 
 int linna_logprob_create(linna_ctx_t* ctx, linna_net_t* net, const linna_logprob_desc_t* desc, linna_logprob_t** out) try {
     if (!net || !desc || !out) { set_error("logprob_create: null argument"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(desc, linna_logprob_desc_t, "logprob_create");
     if (desc->nin != net->in_size || desc->nout != net->out_size) {
         set_error("logprob_create: network is %d->%d, descriptor says %d->%d", net->in_size, net->out_size, desc->nin, desc->nout);
         return LINNA_ERR_INVALID;
@@ -1037,6 +1054,8 @@ int linna_logprob_destroy(linna_logprob_t* lp) try {
 int linna_weights_changed(linna_ctx_t*) try { g_weights_epoch.fetch_add(1); return LINNA_OK; } LINNA_CATCH_INT
 int linna_program_describe(const linna_layer_t* layers, int nlayers, int in_size, int rows, int dense_nout, char* buf, size_t n) try {
     if (!layers || nlayers < 1 || !buf || !n) { set_error("program_describe: bad arguments"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(layers, linna_layer_t, "program_describe");
+    for (int i = 1; i < nlayers; ++i) CHECK_STRUCT(layers + i, linna_layer_t, "program_describe");
     // (pointers are only compared, never read: a placeholder stands for the dense inverse covariance)
     static float dummy;
     if (dense_nout == -1) return net_stream_describe(layers, nlayers, in_size, 3, nullptr, rows, 1, buf, n);   // the one-launch gradient's program
@@ -1085,7 +1104,7 @@ int linna_logprob_eval_if(linna_logprob_t* lp, const float* Z, int ldz, int B, v
 // `list` / `count` / `mul`: only the trial points list[0 .. count[0] * mul) are evaluated (device-side count; the launch is
 // sized for all nrep * ns); `b_engine`: the batch size the engine is chosen for (the expected number of live rows)
 // the first shrinking round behind one stepping-out round: what the evaluation needs to place its own trials (NsArgs::sl_*)
-struct SliceDerive { const float* Z0; const float* L; const float* R; const float* Ze; int m, nt; uint64_t seed; const int* step_dev; int stream_id; };
+struct SliceDerive { const float* Z0; const float* L; const float* R; const float* Ze; int m, nt; uint64_t seed; const int* step_dev; int stream_id; const int* flags; };
 static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ldc, int ndim, const int* S_idx, int ns,
                                 const float* DIR, int ldd, const float* w, int nrep, float* lnP, const int* gate,
                                 const int* list, const int* count, int mul, int b_engine, void* stream, const SliceDerive* sd = nullptr,
@@ -1107,7 +1126,7 @@ static int lp_eval_slice_points(linna_logprob_t* lp, const float* coords, int ld
     mv.sb = sb;
     if (sd) {
         mv.sl_Z0 = sd->Z0; mv.sl_L = sd->L; mv.sl_R = sd->R; mv.sl_Zt = sd->Ze; mv.sl_m = sd->m; mv.sl_nt = sd->nt;
-        mv.sl_seed = sd->seed; mv.sl_step = sd->step_dev; mv.sl_stream = sd->stream_id;
+        mv.sl_seed = sd->seed; mv.sl_step = sd->step_dev; mv.sl_stream = sd->stream_id; mv.sl_flags = sd->flags;
     }
     const NsDense dn = lp->dense();
     const bool df = lp->dense_fused;
@@ -1132,11 +1151,12 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
                           const float* ccoords, int ldcc, const int* C_idx, int nc, const float* mu, uint64_t seed,
                           int* step_dev, int half, const int* m_sched, int nexp_rounds, const int* nt_sched, int nshr_rounds,
                           float* DIR, int ldd, float* state, int* flags, float* W, float* Wd, float* Zt, int* list, int* counters,
-                          int zero_totals, int bump_step, const int* expect_rows, void* stream) try {
+                          int zero_totals, int bump_step, const int* expect_rows, int maxsteps, void* stream) try {
     if (!lp || !coords || !logp || !S_idx || !ccoords || !C_idx || !mu || !step_dev || !DIR || !state || !flags || !W || !Wd ||
         !Zt || !list || !counters || ns < 1 || nc < 2 || !m_sched || !nt_sched || nexp_rounds < 1 || nshr_rounds < 1 || (half != 0 && half != 1)) {
         set_error("slice_half_step: bad arguments"); return LINNA_ERR_INVALID;
     }
+    if (maxsteps < 1) { set_error("slice_half_step: maxsteps %d < 1", maxsteps); return LINNA_ERR_INVALID; }
     for (int r = 0; r < nexp_rounds; ++r) if (m_sched[r] < 1) { set_error("slice_half_step: m_sched[%d] = %d", r, m_sched[r]); return LINNA_ERR_INVALID; }
     for (int r = 0; r < nshr_rounds; ++r) if (nt_sched[r] < 1) { set_error("slice_half_step: nt_sched[%d] = %d", r, nt_sched[r]); return LINNA_ERR_INVALID; }
     const linna_logprob_desc_t& d = lp->d;
@@ -1152,10 +1172,10 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
     // the set-up of the half step: a launch of its own, or done by the first evaluation in its prologue (SliceBegin)
     const bool begin_fused = (g_slice_fusion.load() & 2) != 0;
     const SliceBegin sb{logp, ccoords, ldcc, C_idx, nc, mu, seed, step_dev, half, m_sched[0], DIR, ldd, Z0, L, R, flags, counters,
-                        nexp_rounds + nshr_rounds, zero_totals};
+                        nexp_rounds + nshr_rounds, zero_totals, maxsteps};
     if (!begin_fused)
         TRY(launch_slice_begin(logp, S_idx, ns, ccoords, ldcc, C_idx, nc, ndim, mu, seed, step_dev, half, DIR, ldd, Z0, L, R, flags, W, m_sched[0],
-                               counters, nexp_rounds + nshr_rounds, zero_totals, st));
+                               counters, nexp_rounds + nshr_rounds, zero_totals, maxsteps, st));
     int slot = 4;
     // ONE stepping-out round (small ensembles): its logic kernel is not launched -- the first shrinking round's evaluation
     // derives its trial points from the stepping-out round's results in its prologue (NsArgs::sl_*), and the first shrinking
@@ -1181,7 +1201,7 @@ int linna_slice_half_step(linna_logprob_t* lp, float* coords, int ldc, int ndim,
         const int nt = nt_sched[r], nt_next = r + 1 < nshr_rounds ? nt_sched[r + 1] : 0;
         trials += nt;
         const bool dv = derive && r == 0;
-        SliceDerive sd{Z0, L, R, Zt, m_sched[0], nt, seed, step_dev, 2 + half};
+        SliceDerive sd{Z0, L, R, Zt, m_sched[0], nt, seed, step_dev, 2 + half, flags};
         TRY(lp_eval_slice_points(lp, coords, ldc, ndim, S_idx, ns, DIR, ldd, Wd, nt, dv ? W : Zt, nullptr, r > 0 ? list : nullptr,
                                  r > 0 ? counters + slot - 1 : nullptr, nt,
                                  expect_rows && r > 0 ? std::max(1, expect_rows[nexp_rounds + r]) : std::max(1, (nt * ns) >> (2 * r)), stream, dv ? &sd : nullptr));
@@ -1394,6 +1414,8 @@ size_t linna_loss_scratch_bytes(int B, int nout) try { return (loss_scratch_floa
 
 int linna_chi2_md(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int ldy, int nrows, float* scratch,
                   float* den, void* stream) try {
+    if (!d) { set_error("chi2_md: null loss descriptor"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "chi2_md");
     const int slots = gemm_slots(nrows, d->nout);
     TRY(chi2_partials(d, 1, nullptr, 0, Y, ldy, nullptr, nrows, scratch, false, S(stream)));
     return launch_loss_rows(0, scratch + 2 * (size_t)nrows * ld4(d->nout), slots, slots, nrows, nullptr, nullptr,
@@ -1403,6 +1425,8 @@ int linna_chi2_md(linna_ctx_t*, const linna_loss_desc_t* d, const float* Y, int 
 int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y,
                                   int ldy, const float* den, const int* ROWS, int B, float* scratch, float* loss_rows,
                                   float* loss_mean, float* dPRED, int lddp, float inv_batch, void* stream) try {
+    if (!d) { set_error("chi2_ratio_loss_fwd_bwd: null loss descriptor"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "chi2_ratio_loss_fwd_bwd");
     const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
     hipStream_t st = S(stream);
     if (ctx && d->nout <= 64 && lddp >= 0) {
@@ -1425,6 +1449,8 @@ int linna_chi2_ratio_loss_fwd_bwd(linna_ctx_t* ctx, const linna_loss_desc_t* d, 
 
 int linna_val_rows(linna_ctx_t*, const linna_loss_desc_t* d, const float* PRED, int ldp, const float* Y, int ldy,
                    const float* den, int B, float* scratch, float* loss_rows, float* frac_rows, void* stream) try {
+    if (!d) { set_error("val_rows: null loss descriptor"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "val_rows");
     const int ld = ld4(d->nout), slots = gemm_slots(B, d->nout);
     hipStream_t st = S(stream);
     TRY(chi2_partials(d, 0, PRED, ldp, Y, ldy, nullptr, B, scratch, false, st));
@@ -1518,6 +1544,8 @@ int linna_net_train_step_update(linna_net_t* net, const linna_loss_desc_t* d, co
                                 float* loss_mean, float* dPRED, int lddp, void* bwd_ws, float* params, float* m, float* v,
                                 size_t n, float* hyper, int* step_dev, float b1, float b2, float eps, void* stream) try {
     if (!net || !params || !m || !v || !hyper || !step_dev || !bwd_ws || B < 1) { set_error("net_train_step_update: bad arguments"); return LINNA_ERR_INVALID; }
+    if (!d) { set_error("net_train_step_update: null loss descriptor"); return LINNA_ERR_INVALID; }
+    CHECK_STRUCT(d, linna_loss_desc_t, "net_train_step_update");
     static const bool off = getenv("LINNA_ADAMW_IN_GEMM") && getenv("LINNA_ADAMW_IN_GEMM")[0] == '0';
     if (off || net->has_inskip) { set_error("net_train_step_update: switched off / input-skip network"); return LINNA_ERR_UNSUPPORTED; }
     TRY(net_train_ensure_loss(net, d, stream));
@@ -1610,10 +1638,11 @@ int linna_step_increment(linna_ctx_t*, int* step_dev, void* stream) try { return
 
 int linna_slice_init(linna_ctx_t*, const float* logp, const int* S_idx, int ns, const float* cc, int ldcc, const int* C_idx,
                      int nc, int ndim, const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR,
-                     int ldd, float* Z0, float* L, float* R, int* flags, void* stream) try {
+                     int ldd, float* Z0, float* L, float* R, int* flags, int maxsteps, void* stream) try {
     if (ns < 1 || nc < 2) { set_error("slice_init: need >= 2 complementary walkers"); return LINNA_ERR_INVALID; }
+    if (maxsteps < 1) { set_error("slice_init: maxsteps %d < 1", maxsteps); return LINNA_ERR_INVALID; }
     return launch_slice_init(logp, S_idx, ns, cc, ldcc, C_idx, nc, ndim, mu, seed, step_dev, stream_id, DIR, ldd, Z0, L, R,
-                             flags, S(stream));
+                             flags, maxsteps, S(stream));
 } LINNA_CATCH_INT
 int linna_slice_points(linna_ctx_t*, const float* coords, int ldc, int ndim, const int* S_idx, int ns, const float* DIR,
                        int ldd, const float* w, float* Q, int ldq, int nrep, void* stream) try {

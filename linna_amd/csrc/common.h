@@ -48,7 +48,22 @@ __device__ __forceinline__ U4 walker_bits(uint64_t seed, uint32_t w, uint32_t st
 struct SliceBegin {
     const float* logp; const float* cc; int ldcc; const int* C; int nc; const float* mu; uint64_t seed; const int* step; int half, m;
     float* DIR; int ldd; float* Z0; float* L; float* R; int* flags; int* counters; int nslots, zero_totals;
+    int maxsteps;                                       // zeus' stepping-out budget (slice_budget)
 };
+// zeus' stepping-out budget (Neal 2003, Fig. 3; zeus ensemble.py: J = floor(maxsteps U), K = (maxsteps - 1) - J): at most J steps
+// to the left and K to the right.  flags[3k] / flags[3k + 1] hold what is LEFT of them while that side is still stepping out and
+// 0 once it is closed (an end below the slice, or the budget spent); flags[3k + 2]: still shrinking.
+__device__ __forceinline__ void slice_budget(uint64_t seed, uint32_t wk, uint32_t step, uint32_t stream, int maxsteps, int& J, int& K) {
+    const U4 b = walker_bits(seed, wk, step, stream, 1u);
+    J = min((int)floorf((float)maxsteps * u01(b.x)), maxsteps - 1);       // (the fp32 product may round up to maxsteps itself)
+    K = maxsteps - 1 - J;
+}
+// a side with `f` steps left saw `above` leading bracket ends over the slice among the m evaluated: steps taken; f becomes what is left
+__device__ __forceinline__ int slice_side_steps(int& f, int above, int m) {
+    const int n = min(above, f);
+    f = (n == m && n < f) ? f - n : 0;
+    return n;
+}
 struct SliceRound {
     const float* Z0; const float* Zt;                  // slice heights [ns]; lnP of this round's trials, [j ns + k]
     float* L; float* R; const int* S; float* W;        // brackets, the half ensemble's walkers, trial weights [j ns + k] (read; the next round's written)
@@ -74,15 +89,22 @@ __device__ __forceinline__ void slice_draw_dev(int k, int wk, float l, float r, 
 __device__ __forceinline__ bool slice_expand_walker(int k, int ns, int m, float z0, const float* __restrict__ Zt, float& l, float& r,
                                                     int* __restrict__ flags, int* __restrict__ counters) {
     int n = 0;
-    if (flags[3 * k]) {
+    int fl = flags[3 * k], fr = flags[3 * k + 1];
+    if (fl) {
         int j = 0;
-        for (; j < m; ++j) { if (Zt[(size_t)j * ns + k] > z0) { l -= 1.f; ++n; } else break; }
-        if (j < m) flags[3 * k] = 0;
+        for (; j < m; ++j) { if (!(Zt[(size_t)j * ns + k] > z0)) break; }
+        const int nl = slice_side_steps(fl, j, m);
+        for (int i = 0; i < nl; ++i) l -= 1.f;
+        n += nl;
+        flags[3 * k] = fl;
     }
-    if (flags[3 * k + 1]) {
+    if (fr) {
         int j = 0;
-        for (; j < m; ++j) { if (Zt[(size_t)(m + j) * ns + k] > z0) { r += 1.f; ++n; } else break; }
-        if (j < m) flags[3 * k + 1] = 0;
+        for (; j < m; ++j) { if (!(Zt[(size_t)(m + j) * ns + k] > z0)) break; }
+        const int nr = slice_side_steps(fr, j, m);
+        for (int i = 0; i < nr; ++i) r += 1.f;
+        n += nr;
+        flags[3 * k + 1] = fr;
     }
     if (n) atomicAdd(counters + 0, n);
     return (flags[3 * k] | flags[3 * k + 1]) != 0;
@@ -111,7 +133,7 @@ __device__ __forceinline__ void slice_round_walker(const SliceRound& a, int k) {
         const float z0 = a.Z0[k];
         for (int j = 0; j < a.ntrial && active; ++j) {
             const float zt = a.Zt[(size_t)j * ns + k], w = a.W[(size_t)j * ns + k];
-            if (zt < z0 || isnan(zt)) {
+            if (!(z0 < zt)) {                               // zeus accepts iff Z0 < lnP(x'); NaN rejects
                 if (w < 0.f) l = w; else r = w;
                 ++ncon;
                 if (r - l < 1e-30f) { active = false; a.Wacc[k] = 0.f; a.Zacc[k] = z0; }   // degenerate: stay put
@@ -177,12 +199,13 @@ __device__ __forceinline__ void slice_expand_wave(int lane, int k, int ns, int m
     const int side = lane >> 5, j = lane & 31;
     const float ze = j < m ? Zt[(size_t)(side * m + j) * ns + k] : 0.f;
     const unsigned long long bal = __ballot(j < m && ze > z0);
-    const int nl = fl ? __builtin_ctzll(~(unsigned long long)(uint32_t)bal) : 0;
-    const int nr = fr ? __builtin_ctzll(~(unsigned long long)(uint32_t)(bal >> 32)) : 0;
+    const int fl0 = fl, fr0 = fr;
+    const int nl = slice_side_steps(fl, __builtin_ctzll(~(unsigned long long)(uint32_t)bal), m);
+    const int nr = slice_side_steps(fr, __builtin_ctzll(~(unsigned long long)(uint32_t)(bal >> 32)), m);
     for (int i = 0; i < nl; ++i) l -= 1.f;
     for (int i = 0; i < nr; ++i) r += 1.f;
-    if (fl && nl < m) { fl = 0; if (lane == 0) flags[3 * k] = 0; }
-    if (fr && nr < m) { fr = 0; if (lane == 0) flags[3 * k + 1] = 0; }
+    if (lane == 0 && fl != fl0) flags[3 * k] = fl;
+    if (lane == 0 && fr != fr0) flags[3 * k + 1] = fr;
     nexp += nl + nr;
 }
 // nexp / ncon: this walker's expansions / contractions, which the caller adds to counters[0] / [1] (summed over the block first:
@@ -223,7 +246,7 @@ __device__ __forceinline__ void slice_round_wave(const SliceRound& a, int k, int
         const bool in = lane < a.ntrial;
         const float zt = in ? a.Zt[(size_t)lane * ns + k] : 0.f;
         if (!have_w) w = in ? a.W[(size_t)lane * ns + k] : 0.f;
-        const unsigned long long okm = __ballot(in && !(zt < z0 || isnan(zt)));
+        const unsigned long long okm = __ballot(in && z0 < zt);          // zeus accepts iff Z0 < lnP(x'); NaN rejects
         const int ja = okm ? __builtin_ctzll(okm) : a.ntrial;          // the first trial inside the slice
         int ncon = 0;
         bool active = true;
@@ -336,7 +359,7 @@ int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const i
                       const float* U, float* X, int ldx, float* lnp, float* G, int* naccept, hipStream_t s);
 int launch_slice_init(const float* logp, const int* S, int ns, const float* cc, int ldcc, const int* C, int nc, int ndim,
                       const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0,
-                      float* L, float* R, int* flags, hipStream_t s);
+                      float* L, float* R, int* flags, int maxsteps, hipStream_t s);
 int launch_slice_points(const float* coords, int ldc, int ndim, const int* S, int ns, const float* DIR, int ldd,
                         const float* w, float* Q, int ldq, int nrep, hipStream_t s);
 int launch_slice_expand(const float* Z0, const float* ZL, const float* ZR, float* L, float* R, int* flags, int ns,
@@ -347,7 +370,7 @@ int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, co
                         float* Zacc, int ns, int* counters, int slot, int ntrial, hipStream_t s);
 int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc, int ldcc, const int* C, int nc, int ndim,
                        const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0, float* L,
-                       float* R, int* flags, float* W, int m, int* counters, int nslots, int zero_totals, hipStream_t s);
+                       float* R, int* flags, float* W, int m, int* counters, int nslots, int zero_totals, int maxsteps, hipStream_t s);
 int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,
                               int m_next, int* counters, int slot, int prev_slot, float* W, float* Wd, int* list, uint64_t seed,
                               const int* step_dev, int stream_id_shrink, int ntrial, hipStream_t s);
@@ -402,6 +425,7 @@ struct NsMove {
     // slice == 1, sl_Zt != null: the trial weights are derived in the kernel from the one stepping-out round's results (NsArgs::sl_*)
     const float* sl_Z0 = nullptr; const float* sl_L = nullptr; const float* sl_R = nullptr; const float* sl_Zt = nullptr;
     int sl_m = 0, sl_nt = 0; unsigned long long sl_seed = 0; const int* sl_step = nullptr; int sl_stream = 0;
+    const int* sl_flags = nullptr;                      // the stepping-out budgets left (flags[3k], flags[3k + 1])
     const SliceBegin* sb = nullptr;                     // slice == 1: this evaluation is the half step's first and sets it up (SliceBegin)
 };
 // training / validation forward: every op's output stored for the backward (STORE instantiation)

@@ -143,7 +143,7 @@ struct NsArgs {
     // [L, R] pushed out while lnP at the ends exceeds Z0 (slice_expand_multi_kernel), then trial j placed as if its
     // predecessors were rejected (slice_draw_dev: Philox (walker, step, stream, sub j + 1)).  Saves the launch between them.
     const float* sl_Z0; const float* sl_L; const float* sl_R; const float* sl_Zt; int sl_m, sl_nt;
-    unsigned long long sl_seed; const int* sl_step; int sl_stream;
+    unsigned long long sl_seed; const int* sl_step; int sl_stream; const int* sl_flags;
     SliceBegin sb;                      // MOVE == 2, sb.logp != null: the half step's set-up in this launch's prologue (common.h)
     NsSeg seg[NS_MAXSEG];
 };
@@ -448,7 +448,9 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             if (first && pc0 == 0) {
                 b.Z0[k] = b.logp[wk] + logf(u01(rb.z));
                 b.L[k] = l; b.R[k] = l + 1.f;
-                b.flags[3 * k] = 1; b.flags[3 * k + 1] = 1; b.flags[3 * k + 2] = 1;
+                int J, K;
+                slice_budget(b.seed, (uint32_t)wk, (uint32_t)b.step[0], (uint32_t)b.half, b.maxsteps, J, K);
+                b.flags[3 * k] = J; b.flags[3 * k + 1] = K; b.flags[3 * k + 2] = 1;
             }
             if (blockIdx.x == 0 && tid == 0) {
                 for (int i = 0; i < b.nslots; ++i) {       // [4 + nslots + i]: the same counts summed over the calls so far (usage statistics)
@@ -468,7 +470,8 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             const unsigned long long bal = __ballot(pc0 < 2 * m && zend > z0);
             const unsigned bits = (unsigned)(bal >> (lane & 32));
             const unsigned lm = bits & ((1u << m) - 1u), rm = (bits >> m) & ((1u << m) - 1u);
-            const int nl = __builtin_ctz(~lm), nr = __builtin_ctz(~rm);
+            // (never more steps than the budget of that side has left: slice_side_steps in common.h)
+            const int nl = min(__builtin_ctz(~lm), a.sl_flags[3 * k]), nr = min(__builtin_ctz(~rm), a.sl_flags[3 * k + 1]);
             float l = a.sl_L[k], r = a.sl_R[k];
             for (int j = 0; j < m; ++j) {                               // (one unit at a time: the rounding of slice_expand_multi_kernel)
                 if (j < nl) l -= 1.f;
@@ -2323,7 +2326,7 @@ int launch_net_stream(const linna_layer_t* layers, int nl, int in_size, const fl
         a.mv_seed = mv->seed; a.mv_step = mv->step; a.mv_step_off = mv->step_off; a.mv_stream = mv->stream; a.mv_a = mv->a; a.mv_naccept = mv->naccept;
         a.mv_chain = mv->chain; a.mv_lps = mv->lps;
         a.sl_Z0 = mv->sl_Z0; a.sl_L = mv->sl_L; a.sl_R = mv->sl_R; a.sl_Zt = mv->sl_Zt; a.sl_m = mv->sl_m; a.sl_nt = mv->sl_nt;
-        a.sl_seed = mv->sl_seed; a.sl_step = mv->sl_step; a.sl_stream = mv->sl_stream;
+        a.sl_seed = mv->sl_seed; a.sl_step = mv->sl_step; a.sl_stream = mv->sl_stream; a.sl_flags = mv->sl_flags;
         if (mv->sb) a.sb = *mv->sb;
         if (mv->slice) return ns_launch_kernel<2, false>(a, B, p, rows, s);
         return ns_launch_kernel<1, false>(a, B, p, rows, s);

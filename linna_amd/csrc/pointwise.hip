@@ -535,7 +535,7 @@ __global__ void slice_init_kernel(const float* __restrict__ logp, const int* __r
                                   const float* __restrict__ cc, int ldcc, const int* __restrict__ C, int nc, int ndim,
                                   const float* __restrict__ mu, uint64_t seed, const int* __restrict__ step_dev,
                                   int stream_id, float* __restrict__ DIR, int ldd, float* __restrict__ Z0,
-                                  float* __restrict__ L, float* __restrict__ R, int* __restrict__ flags) {
+                                  float* __restrict__ L, float* __restrict__ R, int* __restrict__ flags, int maxsteps) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)ns * ldd) return;
     const int k = (int)(idx / ldd), d = (int)(idx % ldd);
@@ -551,7 +551,9 @@ __global__ void slice_init_kernel(const float* __restrict__ logp, const int* __r
         Z0[k] = logp[wk] + logf(u01(r.z));           // log of a uniform height under the density
         const float l = -u01(r.w);
         L[k] = l; R[k] = l + 1.f;
-        flags[3 * k] = 1; flags[3 * k + 1] = 1; flags[3 * k + 2] = 1;
+        int J, K;
+        slice_budget(seed, (uint32_t)wk, (uint32_t)step_dev[0], (uint32_t)stream_id, maxsteps, J, K);
+        flags[3 * k] = J; flags[3 * k + 1] = K; flags[3 * k + 2] = 1;
     }
 }
 
@@ -572,9 +574,11 @@ __global__ void slice_expand_kernel(const float* __restrict__ Z0, const float* _
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ns) return;
     int n = 0;
-    if (flags[3 * k]) { if (ZL[k] > Z0[k]) { L[k] -= 1.f; ++n; } else flags[3 * k] = 0; }
-    if (flags[3 * k + 1]) { if (ZR[k] > Z0[k]) { R[k] += 1.f; ++n; } else flags[3 * k + 1] = 0; }
-    if (n) { atomicAdd(counters + 0, n); atomicAdd(counters + slot, 1); }   // [0] expansions, [slot] still-active count
+    int fl = flags[3 * k], fr = flags[3 * k + 1];                           // steps left of the budget; 0: that side is closed
+    if (fl) { const int s = slice_side_steps(fl, ZL[k] > Z0[k] ? 1 : 0, 1); if (s) L[k] -= 1.f; n += s; flags[3 * k] = fl; }
+    if (fr) { const int s = slice_side_steps(fr, ZR[k] > Z0[k] ? 1 : 0, 1); if (s) R[k] += 1.f; n += s; flags[3 * k + 1] = fr; }
+    if (n) atomicAdd(counters + 0, n);                                      // [0] expansions
+    if (fl | fr) atomicAdd(counters + slot, 1);                             // [slot] still-active count
 }
 
 // ntrial trials per launch, drawn as the SEQUENTIAL procedure would draw them if every earlier one
@@ -606,7 +610,7 @@ __global__ void slice_shrink_kernel(const float* __restrict__ Z0, const float* _
     bool active = true;
     for (int j = 0; j < ntrial && active; ++j) {
         const float zt = Zt[(size_t)j * ns + k], w = W[(size_t)j * ns + k];
-        if (zt < Z0[k] || isnan(zt)) {
+        if (!(Z0[k] < zt)) {                                 // zeus accepts iff Z0 < lnP(x'); NaN rejects
             if (w < 0.f) L[k] = w; else R[k] = w;
             ++ncon;
             if (R[k] - L[k] < 1e-30f) { active = false; Wacc[k] = 0.f; Zacc[k] = Z0[k]; }   // degenerate: stay put
@@ -647,7 +651,8 @@ __global__ void slice_begin_kernel(const float* __restrict__ logp, const int* __
                                    const float* __restrict__ mu, uint64_t seed, const int* __restrict__ step_dev,
                                    int stream_id, float* __restrict__ DIR, int ldd, float* __restrict__ Z0,
                                    float* __restrict__ L, float* __restrict__ R, int* __restrict__ flags,
-                                   float* __restrict__ W, int m, int* __restrict__ counters, int nslots, int zero_totals) {
+                                   float* __restrict__ W, int m, int* __restrict__ counters, int nslots, int zero_totals,
+                                   int maxsteps) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx == 0) {
         for (int i = 0; i < nslots; ++i) {             // [4 + nslots + i]: the same counts summed over the calls so far (usage statistics)
@@ -670,7 +675,9 @@ __global__ void slice_begin_kernel(const float* __restrict__ logp, const int* __
         Z0[k] = logp[wk] + logf(u01(r.z));
         const float l = -u01(r.w);
         L[k] = l; R[k] = l + 1.f;
-        flags[3 * k] = 1; flags[3 * k + 1] = 1; flags[3 * k + 2] = 1;
+        int J, K;
+        slice_budget(seed, (uint32_t)wk, (uint32_t)step_dev[0], (uint32_t)stream_id, maxsteps, J, K);
+        flags[3 * k] = J; flags[3 * k + 1] = K; flags[3 * k + 2] = 1;
         for (int j = 0; j < m; ++j) { W[(size_t)j * ns + k] = l - (float)j; W[(size_t)(m + j) * ns + k] = l + 1.f + (float)j; }
     }
 }
@@ -913,9 +920,9 @@ int launch_hmc_accept(int B, int ndim, const float* mass, uint64_t seed, const i
 }
 int launch_slice_init(const float* logp, const int* S, int ns, const float* cc, int ldcc, const int* C, int nc, int ndim,
                       const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0,
-                      float* L, float* R, int* flags, hipStream_t s) {
+                      float* L, float* R, int* flags, int maxsteps, hipStream_t s) {
     hipLaunchKernelGGL(slice_init_kernel, grid1d((size_t)ns * ldd, 256), dim3(256), 0, s, logp, S, ns, cc, ldcc, C, nc, ndim,
-                       mu, seed, step_dev, stream_id, DIR, ldd, Z0, L, R, flags);
+                       mu, seed, step_dev, stream_id, DIR, ldd, Z0, L, R, flags, maxsteps);
     LAUNCH_CHECK("slice_init");
 }
 int launch_slice_points(const float* coords, int ldc, int ndim, const int* S, int ns, const float* DIR, int ldd,
@@ -943,9 +950,9 @@ int launch_slice_shrink(const float* Z0, const float* Zt, float* L, float* R, co
 }
 int launch_slice_begin(const float* logp, const int* S, int ns, const float* cc, int ldcc, const int* C, int nc, int ndim,
                        const float* mu, uint64_t seed, const int* step_dev, int stream_id, float* DIR, int ldd, float* Z0, float* L,
-                       float* R, int* flags, float* W, int m, int* counters, int nslots, int zero_totals, hipStream_t s) {
+                       float* R, int* flags, float* W, int m, int* counters, int nslots, int zero_totals, int maxsteps, hipStream_t s) {
     hipLaunchKernelGGL(slice_begin_kernel, grid1d((size_t)ns * ldd, 256), dim3(256), 0, s, logp, S, ns, cc, ldcc, C, nc, ndim, mu,
-                       seed, step_dev, stream_id, DIR, ldd, Z0, L, R, flags, W, m, counters, nslots, zero_totals);
+                       seed, step_dev, stream_id, DIR, ldd, Z0, L, R, flags, W, m, counters, nslots, zero_totals, maxsteps);
     LAUNCH_CHECK("slice_begin");
 }
 int launch_slice_expand_multi(const float* Z0, const float* Zt, float* L, float* R, const int* S, int* flags, int ns, int m,

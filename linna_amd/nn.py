@@ -267,7 +267,7 @@ class _Emulator(object):
         if self._net is not None and self._net_sig == sig:
             return self._net
         self._destroy_net()
-        arr = (_lib.Layer * len(self.ops))()
+        arr = _lib.sized_array(_lib.Layer, len(self.ops))
         for i, op in enumerate(self.ops):
             L = arr[i]
             L.op, L.K, L.C, L.N, L.relu, L.alpha = op.op, op.K, op.C, op.N, op.relu, op.alpha
@@ -422,7 +422,7 @@ class ResBlock_batchnorm(object):
 def describe_program(model, rows=16, dense_nout=0):
     """The serving program the whole-network kernel would run for ``model`` on the engine of ``rows`` rows per workgroup, as
     text (``linna_program_describe``: host-side planning, no GPU needed; parameter pointers are placeholders)."""
-    arr = (_lib.Layer * len(model.ops))()
+    arr = _lib.sized_array(_lib.Layer, len(model.ops))
     nxt = [4096]
 
     def fake(n):                                            # distinct, 16-byte aligned, never read

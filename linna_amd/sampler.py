@@ -13,8 +13,10 @@ the walker loop they delegate to emcee.  Here the ensemble lives on the GPU:
 * walkers shard across ranks (one process per GPU): every rank advances its own
   sub-ensemble, chain state is gathered with one RCCL all-gather per flush.
 
-The emcee arithmetic itself is third-party code absent from the reference tree: it is
-restated from the published algorithm (see oracle/sampling.py) and checked statistically.
+The emcee and zeus arithmetic itself is third-party code absent from the reference tree: both moves are
+restated from the published algorithms; the test suite replays the kernels against its own numpy
+restatements of them (``stretch_half_step`` / ``slice_half_step`` in the repo's oracle/sampling.py --
+test infrastructure, never imported here) and checks the posteriors statistically.
 """
 import ctypes as C
 import os
@@ -931,8 +933,10 @@ class SliceEnsembleSampler(EnsembleSampler):
     round) and shrinking (nw/2 points per round) until every walker has accepted.  ``mu`` is tuned
     during the first iterations as zeus does: ``mu *= 2 nexp / (nexp + ncon)`` until the expansion
     fraction stays within ``tolerance`` of 1/2 for ``patience`` iterations.  Third-party algorithm
-    restated from the publication (zeus-mcmc is not in the reference tree): parity unpinned,
-    checked statistically.
+    restated from the publication (zeus-mcmc is not in the reference tree): parity unpinned; every half step is replayed
+    decision by decision against ``oracle.sampling.slice_half_step`` (tests/test_gpu_slice_replay.py) and the posterior is
+    checked statistically.  ``mu`` has zeus' meaning (direction ``2 mu (c_a - c_b)``), ``maxsteps`` is zeus' stepping-out
+    budget (``J = floor(maxsteps u)`` steps to the left at most, ``maxsteps - 1 - J`` to the right).
     """
 
     FAST_EXPANSIONS = 12            # at least so many per side and half step on the one-call path (a tuned mu needs about one)
@@ -946,7 +950,8 @@ class SliceEnsembleSampler(EnsembleSampler):
         z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=self.dev)
         ns = self.half
         self.mu = float(mu)
-        self.mu_dev = torch.full((1,), self.mu, dtype=torch.float32, device=self.dev)
+        # zeus' direction is 2 mu (c_a - c_b) (moves.DifferentialMove.get_direction); the kernels multiply by mu_dev[0]
+        self.mu_dev = torch.full((1,), 2.0 * self.mu, dtype=torch.float32, device=self.dev)
         self.tune, self.tolerance, self.patience, self.maxsteps, self.maxiter = tune, tolerance, patience, maxsteps, maxiter
         self._tune_count = 0
         self.DIR, self.Q2 = z(ns, self.ld), z(2 * ns, self.ld)
@@ -987,6 +992,9 @@ class SliceEnsembleSampler(EnsembleSampler):
         self._fast_after = 0                              # no one-call steps before this iteration (set after an overflow)
         self._guarded = False
         self.noverflow = 0                                # runs redone on the round loop
+        # test hook: called behind every half step with (half index, S, dict of the device arrays Z0 / L / R / Wacc / Zacc of the
+        # half ensemble) -- tests/test_gpu_slice_replay.py replays each half step against oracle.sampling.slice_half_step
+        self.probe = None
 
     def set_schedule(self, m_sched, nt_sched):
         """Bracket ends per side of each stepping-out round and trials of each shrinking round of the one-call path."""
@@ -1013,7 +1021,7 @@ class SliceEnsembleSampler(EnsembleSampler):
     # is known: its evaluation is gated on the device-side count (linna_logprob_eval_if), so when round
     # r turns out to have been the last, round r+1 costs a few empty launches.  The count travels over
     # a second stream into pinned memory, so waiting for it does not wait for round r+1.
-    def _run_rounds(self, enqueue, maxrounds):
+    def _run_rounds(self, enqueue, maxrounds, what="expansions"):
         if self._cs is None:
             self._cs = torch.cuda.Stream(device=self.dev)
             self._pin = torch.zeros(2, dtype=torch.int32).pin_memory()
@@ -1037,6 +1045,8 @@ class SliceEnsembleSampler(EnsembleSampler):
                     return                              # round r-1 finished every walker; round r (queued) is gated off
             pending = (landed, r & 1)
         pending[0].synchronize()
+        if int(self._pin[pending[1]]) != 0:              # zeus: RuntimeError behind `maxiter` passes (sampler.py:728: maxiter=1E5)
+            raise RuntimeError("Number of %s exceeded maximum limit! Make sure that the pdf is well-defined." % what)
 
     def _eval_if(self, Q, Z, gate):
         if self.host_lp:                                # host callbacks: evaluated whatever the gate says (results of a
@@ -1119,12 +1129,16 @@ class SliceEnsembleSampler(EnsembleSampler):
                 self.lp._ensure()["handle"], P(self.coords), self.ld, self.ndim, P(self.logp), I(S), ns, P(comp), ldc, I(cidx), nc,
                 P(self.mu_dev), seed, I(self.step_dev), h, self._m_arr, self.nexp_rounds, self._nt_arr, self.nshr_rounds, P(self.DIR), self.ld,
                 P(b["state"]), I(self.flags), P(b["W"]), P(b["Wd"]), P(b["Zt"]), I(b["list"]), I(b["counters"]), 1 if h == 0 else 0,
-                1 if h == 1 else 0, self._expect, st)    # (the second half step's last kernel advances the device step counter)
+                1 if h == 1 else 0, self._expect, int(self.maxsteps), st)    # (the second half step's last kernel advances the device step counter)
             if rc != 0:
                 if rc == _lib.ERR_UNSUPPORTED and h == 0 and self._fast_ok is None:
                     self._fast_ok = False
                     return False
                 _lib.check(rc)
+            if self.probe is not None:
+                s5 = b["state"]
+                self.probe(h, S, dict(Z0=s5[:ns], L=s5[ns:2 * ns], R=s5[2 * ns:3 * ns], Wacc=s5[3 * ns:4 * ns], Zacc=s5[4 * ns:],
+                                      counters=b["counters"], fast=True))
         self._fast_ok = True
         self.iteration += 1
         self._fast_steps = getattr(self, "_fast_steps", 0) + 1
@@ -1198,7 +1212,7 @@ class SliceEnsembleSampler(EnsembleSampler):
         self._last_nexp = nexp
         nexp = max(1, nexp)
         self.mu *= 2.0 * nexp / (nexp + ncon)
-        self.mu_dev.fill_(self.mu)
+        self.mu_dev.fill_(2.0 * self.mu)
         self._tune_count = self._tune_count + 1 if abs(nexp / (nexp + ncon) - 0.5) < self.tolerance else 0
         if self._tune_count > self.patience:
             self.tune = False
@@ -1228,7 +1242,7 @@ class SliceEnsembleSampler(EnsembleSampler):
         torch.cuda.current_stream(self.dev).synchronize()
         self.coords.copy_(k["coords"]); self.logp.copy_(k["logp"]); self.naccept.copy_(k["naccept"]); self.step_dev.copy_(k["step_dev"])
         self.mu, self.tune, self._tune_count, self._last_nexp = k["mu"], k["tune"], k["tune_count"], k["last_nexp"]
-        self.mu_dev.fill_(self.mu)
+        self.mu_dev.fill_(2.0 * self.mu)
         self.iteration, self._dev_steps, self._neval_host = k["iteration"], k["dev_steps"], k["neval"]
         self._rs.set_state(k["rs"]); self._split_pos, self._split_dev = k["split_pos"], k["split_dev"]
         self._split_idx[:] = k["split_idx"]
@@ -1285,7 +1299,7 @@ class SliceEnsembleSampler(EnsembleSampler):
                 comp, cidx, nc = self._allgather_complement(Cc)
             _lib.call("linna_slice_init", self.ctx, P(self.logp), _lib.iptr(S), ns, P(comp), ldc, _lib.iptr(cidx), nc, ndim,
                       P(self.mu_dev), seed, _lib.iptr(self.step_dev), h, P(self.DIR), self.ld, P(self.Z0), P(self.L),
-                      P(self.R), _lib.iptr(self.flags), st)
+                      P(self.R), _lib.iptr(self.flags), int(self.maxsteps), st)
 
             def expand_round(r, slot, gate):            # stepping out, both ends per round
                 self._eval_points(S, self.LR, 2, gate)
@@ -1305,10 +1319,13 @@ class SliceEnsembleSampler(EnsembleSampler):
                 _lib.call("linna_slice_shrink", self.ctx, P(self.Z0), P(self.Z2), P(self.L), P(self.R), P(self.W),
                           _lib.iptr(self.flags), P(self.Wacc), P(self.Zacc), ns, _lib.iptr(self.counters), slot, nt, st)
 
-            self._run_rounds(expand_round, self.maxsteps)
-            self._run_rounds(shrink_round, (self.maxsteps + nt - 1) // nt)
+            # (a side steps out at most maxsteps - 1 times: its budget; shrinking is bounded by zeus' `maxiter` passes only)
+            self._run_rounds(expand_round, min(int(self.maxsteps), int(self.maxiter)) + 1)
+            self._run_rounds(shrink_round, (int(self.maxiter) + nt - 1) // nt, "contractions")
             _lib.call("linna_slice_commit", self.ctx, P(self.coords), self.ld, ndim, P(self.logp), _lib.iptr(S), ns,
                       P(self.DIR), self.ld, P(self.Wacc), P(self.Zacc), st)
+            if self.probe is not None:
+                self.probe(h, S, dict(Z0=self.Z0, L=self.L, R=self.R, Wacc=self.Wacc, Zacc=self.Zacc, counters=self.counters, fast=False))
         _lib.call("linna_step_increment", self.ctx, _lib.iptr(self.step_dev), st)
         self.iteration += 1
         if self.tune:                                   # zeus: mu *= 2 nexp / (nexp + ncon)

@@ -57,8 +57,32 @@ def test_struct_layouts_match_header_sizes():
     from linna_amd import _lib
     assert ctypes.sizeof(_lib.GemmPair) == 40
     assert ctypes.sizeof(_lib.ColMap) == 40
-    assert ctypes.sizeof(_lib.Layer) == 24 + 14 * 8
-    assert ctypes.sizeof(_lib.LossDesc) == 8 + 5 * 8 + 8
+    assert ctypes.sizeof(_lib.Layer) == 32 + 14 * 8             # struct_size + 5 ints + alpha = 28 -> 32, 14 pointers
+    assert ctypes.sizeof(_lib.LossDesc) == 8 + 5 * 8 + 8        # struct_size + nout, 5 pointers, ldc + ylog
+    assert ctypes.sizeof(_lib.LogprobDesc) == 16 + 6 * 8 + 40 + 8 + 8 + 3 * 8 + 8 + 8
+    for cls in (_lib.Gemm, _lib.Layer, _lib.LogprobDesc, _lib.LossDesc):
+        assert cls._fields_[0][0] == "struct_size" and cls().struct_size == ctypes.sizeof(cls)
+    arr = _lib.sized_array(_lib.Layer, 3)
+    assert [a.struct_size for a in arr] == [ctypes.sizeof(_lib.Layer)] * 3
+
+
+def test_a_descriptor_of_another_layout_is_refused():
+    """ABI 11: every descriptor struct starts with ``struct_size``; an entry handed a struct whose size field is not this
+    library's sizeof returns LINNA_ERR_INVALID with both numbers in the message instead of reading fields at wrong offsets
+    (host-only entry here: linna_program_describe walks a linna_layer_t array; the GPU suite covers linna_logprob_create)."""
+    from linna_amd import _lib, nn
+    lib = _lib.load()
+    model = nn.ChtoModelv2(33, 33, None)
+    assert "WIDE" in nn.describe_program(model)[1]             # (the binding's own array carries the size: accepted)
+    arr = (_lib.Layer * 2)()                                   # (ctypes arrays are zero-filled: struct_size 0)
+    buf = ctypes.create_string_buffer(256)
+    rc = lib.linna_program_describe(arr, 2, 33, 16, 0, buf, 256)
+    msg = lib.linna_last_error().decode()
+    assert rc == -1 and "struct_size is 0" in msg and str(ctypes.sizeof(_lib.Layer)) in msg, (rc, msg)
+    arr = _lib.sized_array(_lib.Layer, 2)
+    arr[1].struct_size = 136                                   # the ABI 10 size of the same struct
+    rc = lib.linna_program_describe(arr, 2, 33, 16, 0, buf, 256)
+    assert rc == -1 and "struct_size is 136" in lib.linna_last_error().decode()
 
 
 def test_no_gpu_means_loud_failure():
