@@ -291,6 +291,36 @@ def barrier(group=None):
         dist.barrier(group=group)
 
 
+ENTRY_TIMEOUT_S = float(os.environ.get("LINNA_ENTRY_TIMEOUT_S", "120"))
+
+
+def enter(what, group=None, timeout=None):
+    """Fail fast when a collective entry point (a sampling driver, a data-parallel training run) is called on a SUBSET of the
+    ranks: every rank of ``group`` must arrive here within ``timeout`` seconds (``LINNA_ENTRY_TIMEOUT_S``, default 120), else
+    the ranks that did arrive raise ``RuntimeError`` naming the call and -- on rank 0 -- the ranks that are missing.  Without
+    it such a call parks on the control plane's side group, whose timeout is a week by design (rank 0 may run the user's
+    theory code for hours while the others wait), silently.  ``torch.distributed.monitored_barrier`` on the gloo side
+    group; a run whose control plane has no gloo group (``init()`` could not make one) is not checked."""
+    if world_size(group) == 1 or not (dist.is_available() and dist.is_initialized()):
+        return
+    g = group
+    if g is None:
+        g = _state["control"] if _state["control"] is not None else (None if dist.get_backend() == "gloo" else False)
+    elif dist.get_backend(g) != "gloo":
+        g = False
+    if g is False:
+        return
+    import datetime
+    t = ENTRY_TIMEOUT_S if timeout is None else float(timeout)
+    try:
+        dist.monitored_barrier(group=g, timeout=datetime.timedelta(seconds=t), wait_all_ranks=True)
+    except Exception as e:                                      # noqa: BLE001  (gloo raises RuntimeError / DistBackendError)
+        raise RuntimeError("%s was entered by rank %d, but not by every one of the %d ranks within %.0f s: the call is collective "
+                           "(walkers / batches are sharded over the ranks, chain blocks gathered) and must be made on every rank "
+                           "of the run -- guard rank-0-only code with `if rank == 0`, not this call.  [%s]"
+                           % (what, rank(group), world_size(group), t, str(e).splitlines()[0][:300])) from None
+
+
 def broadcast_object(obj, src=0):
     """Rank ``src``'s picklable object on every rank, over the control plane (the result of a host-only phase)."""
     if world_size() == 1 or not (dist.is_available() and dist.is_initialized()):

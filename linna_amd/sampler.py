@@ -1416,21 +1416,48 @@ class BatchedHMC(object):
 
 # ------------------------------------------------------------------ drivers with the reference's names
 class _Ranks(object):
-    """How a driver's ensemble is split over the ranks of a run (``linna_amd.dist.init()``; the reference farms the
-    walkers' log-probability calls out over its MPI pool, util.py:99-256): the ``nwalkers`` walkers of the ONE ensemble
-    are sharded, ``nwalkers / world`` per GPU; every half step draws its stretch / slice partners from the
-    complementary walkers of ALL ranks (one all-gather per half step), chain blocks are all-gathered per convergence
-    check, rank 0 alone keeps the chain file and the convergence statistics and tells the others when to stop."""
+    """How a driver's ensemble is split over the ranks of a run (``linna_amd.dist.init()``; the reference farms the walkers'
+    log-probability calls out over its MPI pool, util.py:99-256).  Three modes (``exchange``; ``LINNA_ENSEMBLE_EXCHANGE``):
 
-    def __init__(self, nwalkers, group):
+    * ``"local"`` -- the default whenever every rank's share holds a valid ensemble (``nwalkers / world >= 2 ndim``, emcee's and
+      zeus' own floor): ``nwalkers / world`` walkers per GPU as a SUB-ENSEMBLE of its own -- stretch / slice partners from the
+      rank's LOCAL complementary half, the slice sampler's mu tuned per sub-ensemble -- no collective inside an iteration;
+      chain blocks are gathered once per convergence check ("an RCCL gather for chain state"), rank 0 alone keeps the chain
+      file ([iterations, nwalkers, ndim], walker blocks in rank order) and the statistics over ALL walkers and tells the
+      others when to stop.  Sub-ensembles are valid ensemble samplers of the same posterior, so the merged chain is too.
+    * ``"root"`` -- shares too small for that: the whole ensemble runs on rank 0, the other ranks wait at the end of the call.
+    * ``"allgather"`` -- on request only: ONE ensemble sharded, partners from the complementary walkers of ALL ranks, i.e. one
+      all-gather per half step.  A small collective's latency is of the order of the 30 us half step it follows: this mode is
+      slower than one GPU at every ensemble size measured and exists for runs that need the one-ensemble
+      chain (its mu is tuned from the all-reduced counts)."""
+
+    def __init__(self, nwalkers, group, ndim=None, exchange=None):
         from . import dist as ldist
-        self.group, self.world, self.rank = group, ldist.world_size(group), ldist.rank(group)
-        if self.world > 1 and nwalkers % (2 * self.world):
-            raise ValueError("nwalkers = %d cannot be split into even halves over %d ranks" % (nwalkers, self.world))
+        self.group, self.real_world, self.rank = group, ldist.world_size(group), ldist.rank(group)
+        want = exchange or os.environ.get("LINNA_ENSEMBLE_EXCHANGE") or "auto"
+        if want not in ("auto", "local", "root", "allgather"):
+            raise ValueError("exchange = %r (auto, local, root or allgather)" % (want,))
+        even = nwalkers % (2 * self.real_world) == 0
+        if self.real_world == 1:
+            mode = "single"
+        elif want == "allgather" or want == "local":
+            if not even:
+                raise ValueError("nwalkers = %d cannot be split into even halves over %d ranks" % (nwalkers, self.real_world))
+            mode = want
+        elif want == "root":
+            mode = "root"
+        else:
+            mode = "local" if even and (ndim is None or nwalkers // self.real_world >= 2 * ndim) else "root"
+        self.mode = mode
+        self.active = mode != "root" or self.rank == 0               # (root: ranks > 0 do not sample)
+        self.world = 1 if mode in ("single", "root") else self.real_world   # ranks that exchange data inside the sampling loop
         self.nw = nwalkers // self.world
-        self.exchange = "allgather" if self.world > 1 else "none"
+        self.exchange = "allgather" if mode == "allgather" else "none"
+        self.ens_group = group                                       # the sampler's group (chain gathers)
 
     def mine(self, x0):
+        if self.world == 1:
+            return np.asarray(x0)
         return np.asarray(x0)[self.rank * self.nw:(self.rank + 1) * self.nw]
 
     def bcast(self, obj):
@@ -1451,9 +1478,9 @@ class _Ranks(object):
         return c, l, ldist.gather_rows(ens.naccept.float(), self.group)
 
     def barrier(self):
-        if self.world > 1:
-            import torch.distributed as tdist
-            tdist.barrier(group=self.group)
+        if self.real_world > 1:
+            from . import dist as ldist
+            ldist.barrier(self.group)
 
 
 class _Prof(object):
@@ -1552,11 +1579,13 @@ def _run_blocks(ens, rk, store, dchain, done, nsamp, ncheck, incremental, begin_
 class HMCSampler(object):
     """The reference's emcee driver (sampler.py:389-554): burn-in, restart from the best region,
     sample until the integrated autocorrelation time and the mean/std drift have converged.
-    Multi-rank runs shard the walkers (``_Ranks``)."""
+    Multi-rank runs give every rank a sub-ensemble of ``nwalkers / world`` walkers and gather the chain once per convergence
+    check (``_Ranks``); every rank of the run must make the call (``dist.enter`` raises within two minutes otherwise)."""
 
     def __init__(self, lnp, dlnp, ddlnp, ndim, nwalkers, x0=None, m=None, transform=None, torchspeed=False, seed=0,
-                 dist_group=None):
+                 dist_group=None, exchange=None):
         self.lnp, self.dlnp, self.ddlnp = lnp, dlnp, ddlnp
+        self.exchange = exchange                             # how a multi-rank run splits the ensemble (_Ranks); None: automatic
         self.transform, self.x0, self.nparams, self.nwalkers = transform, x0, ndim, nwalkers
         self.m = np.ones(ndim) if m is None else m
         self.sampler = None
@@ -1571,9 +1600,14 @@ class HMCSampler(object):
         import time
         t_start = time.perf_counter()
         prof = _Prof(profile)
-        rk = _Ranks(self.nwalkers, self.group)
+        from . import dist as ldist
+        ldist.enter("sampler.HMCSampler.sample", self.group)
+        rk = _Ranks(self.nwalkers, self.group, self.nparams, self.exchange)
         filename = os.path.join(outdir, "chemcee_256.h5")
         store = ChainStore(filename, self.transform)
+        if not rk.active:                                    # ("root": the whole ensemble runs on rank 0)
+            rk.barrier()
+            return store
         x0 = self.x0
         resume = False
         if rk.rank == 0 and store.exists():
@@ -1650,20 +1684,27 @@ class HMCSampler(object):
 class ZeusSampler(object):
     """sampler.py:699-737: zeus' ensemble slice sampler (``SliceEnsembleSampler``) with the reference's
     convergence callback (IAT on the last 80 %, sampler.py:684,729; mean/std drift) and file names.
-    Multi-rank runs shard the walkers (``_Ranks``)."""
+    Multi-rank runs give every rank a sub-ensemble with a mu of its own and gather the chain once per convergence check
+    (``_Ranks``); every rank of the run must make the call (``dist.enter``)."""
 
-    def __init__(self, lnp, ndim, nwalkers, x0=None, transform=None, seed=0, dist_group=None):
+    def __init__(self, lnp, ndim, nwalkers, x0=None, transform=None, seed=0, dist_group=None, exchange=None):
         self.lnp, self.transform, self.x0, self.nparams, self.nwalkers = lnp, transform, x0, ndim, nwalkers
         self.sampler = None
         self.seed, self.group = seed, dist_group
+        self.exchange = exchange                             # how a multi-rank run splits the ensemble (_Ranks); None: automatic
 
     def sample(self, pool, nsamp, outdir="./", progress=False, overwrite=False, ntimes=10, tautol=0.01, incremental=True,
                meanshift=0.1, stdshift=0.1, nk=2, ncheck=100, profile=None):
         import time
         t_start = time.perf_counter()
         prof = _Prof(profile)
-        rk = _Ranks(self.nwalkers, self.group)
+        from . import dist as ldist
+        ldist.enter("sampler.ZeusSampler.sample", self.group)
+        rk = _Ranks(self.nwalkers, self.group, self.nparams, self.exchange)
         store = ChainStore(os.path.join(outdir, "zeus_256.h5"), self.transform)
+        if not rk.active:                                    # ("root": the whole ensemble runs on rank 0)
+            rk.barrier()
+            return store
         x0 = self.x0
         if rk.rank == 0:
             if store.exists() and overwrite:

@@ -249,7 +249,7 @@ def slice_tune_mu(mu, nexp, ncon, count, tolerance=0.05, patience=5):
     expansion fraction within ``tolerance`` of 1/2 ``patience`` + 1 times in a row ends tuning.
     Returns (mu, count, still_tuning)."""
     nexp = max(1, nexp)
-    mu = mu * 2.0 * nexp / (nexp + ncon)
+    mu = mu * (2.0 * nexp / (nexp + ncon))            # (zeus: ``self.mu *= 2.0 * nexp / (nexp + ncon)`` -- the factor first)
     count = count + 1 if abs(nexp / (nexp + ncon) - 0.5) < tolerance else 0
     return mu, count, not count > patience
 

@@ -192,3 +192,73 @@ def test_control_plane_waits_do_not_sit_in_the_data_path_group():
     assert ret[1][0] >= 7.0                                   # rank 1 really waited past the 3 s
     for r in (0, 1):
         assert ret[r][1] is True and ret[r][2] == {"chain": [1, 2, 3]} and ret[r][3] == 3.0
+
+
+def _ranks_job(rank, world):
+    from linna_amd import sampler
+    out = {}
+    for nw, ndim, ex in [(256, 33, None), (128, 33, None), (66, 33, None), (4, 2, None), (6, 2, None), (256, 33, "allgather"),
+                         (256, 33, "root"), (128, 33, "local")]:
+        rk = sampler._Ranks(nw, None, ndim, ex)
+        out[(nw, ndim, ex)] = (rk.mode, rk.active, rk.world, rk.nw, rk.exchange, len(rk.mine(np.zeros((nw, ndim)))))
+    try:
+        sampler._Ranks(130, None, 3, "allgather")
+        out["odd"] = "accepted"
+    except ValueError as e:
+        out["odd"] = str(e)
+    return out
+
+
+def test_how_a_driver_splits_its_ensemble_over_two_ranks():
+    """sampler._Ranks: per-rank sub-ensembles with the LOCAL complementary half whenever a rank's share is
+    a valid ensemble of its own (>= 2 ndim walkers), the whole ensemble on rank 0 below that, the per-half-step all-gather
+    only on request."""
+    r0, r1 = _run(_ranks_job)
+    for r, rank in ((r0, 0), (r1, 1)):
+        assert r[(256, 33, None)] == ("local", True, 2, 128, "none", 128)
+        assert r[(128, 33, None)][0] == "root"                       # 64 walkers per rank < 2 x 33
+        assert r[(66, 33, None)][0] == "root"                        # (66 is not a multiple of 4 either)
+        assert r[(4, 2, None)] == ("root", rank == 0, 1, 4, "none", 4)   # the reference's own test size: rank 0 alone
+        assert r[(6, 2, None)][0] == "root"
+        assert r[(256, 33, "allgather")] == ("allgather", True, 2, 128, "allgather", 128)
+        assert r[(256, 33, "root")] == ("root", rank == 0, 1, 256, "none", 256)
+        assert r[(128, 33, "local")] == ("local", True, 2, 64, "none", 64)   # forced below the floor: the caller's business
+        assert "cannot be split" in r["odd"]
+
+
+def _enter_worker(rank, world, port, ret):
+    import time
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from linna_amd import dist as ldist
+    assert ldist.init(backend="gloo", comm=False) == world
+    ldist.enter("both ranks arrive", timeout=20.0)                # every rank arrives: returns
+    t0 = time.time()
+    if rank == 0:
+        try:
+            ldist.enter("sampler.ZeusSampler.sample", timeout=3.0)     # rank 1 never makes this call
+            ret[rank] = ("returned", time.time() - t0)
+        except RuntimeError as e:
+            ret[rank] = (str(e), time.time() - t0)
+    else:
+        time.sleep(6.0)
+        ret[rank] = ("absent", time.time() - t0)
+    os._exit(0)                                                   # (the side group is broken by design after the timeout: no shutdown)
+
+
+def test_a_driver_called_on_a_subset_of_ranks_raises_within_seconds():
+    """ZeusSampler.sample called on rank 0 only used to park on the control plane's gloo group,
+    whose timeout is a week.  dist.enter (first line of both drivers) bounds the wait and names the call."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    procs = [ctx.Process(target=_enter_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    msg, dt = ret[0]
+    assert "sampler.ZeusSampler.sample was entered by rank 0, but not by every one of the 2 ranks within 3 s" in msg, msg
+    assert "must be made on every rank" in msg and 2.5 < dt < 15.0
+    assert ret[1][0] == "absent"

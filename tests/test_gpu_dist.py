@@ -218,26 +218,36 @@ def _driver_job(rank, world):
     out = os.environ["LINNA_TEST_SHARED_DIR"]
     nw = 256                                                          # walkers of the ONE ensemble: 128 per rank
     x0 = util.invTransform(priors)(means)[None, :] + 0.01 * np.random.RandomState(10 + rank).standard_normal((nw, ndim))
-    drv = sampler.HMCSampler(lp, None, None, ndim, nw, x0=x0, transform=util.Transform(priors), seed=5)
+    drv = sampler.HMCSampler(lp, None, None, ndim, nw, x0=x0, transform=util.Transform(priors), seed=5,
+                             exchange=os.environ.get("LINNA_TEST_EXCHANGE") or None)
     with contextlib.redirect_stdout(io.StringIO()):
         drv.sample(None, 1000, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True)      # never "converged": 1000 iterations
+    if os.environ.get("LINNA_TEST_EXCHANGE") != "allgather":
+        assert drv.exchange is None
     d = sampler.ChainStore.load(os.path.join(out, "chemcee_256.h5"))                        # every rank reads rank 0's file
     th = np.asarray(d["chain_transformed"])[600:]
-    return d["chain"].shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), np.asarray(d["accepted"]).sum()
+    acc = np.asarray(d["accepted"])
+    assert acc.shape[-1] == nw and (acc.reshape(-1, nw)[-1] > 0).all()     # acceptance counts of ALL walkers, rank order
+    return d["chain"].shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), acc.sum(), acc.reshape(-1, nw)[-1]
 
 
-def test_emcee_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
-    """The reference's emcee driver on two ranks: 256 walkers of ONE ensemble, 128 per rank, partners drawn from both
-    ranks' complementary halves, chain blocks all-gathered per check, rank 0 alone writes chemcee_256.h5 (the layout the
-    one-rank run writes: [iterations, 256, ndim]) and decides when to stop; both ranks read the same file afterwards."""
+@pytest.mark.parametrize("exchange", ["", "allgather"])
+def test_emcee_driver_over_two_ranks(tmp_path, monkeypatch, exchange):
+    """The reference's emcee driver on two ranks, 256 walkers, 128 per rank.  Default: every rank a sub-ensemble of its own
+    (partners from the LOCAL complementary half, no collective inside an iteration), chain blocks gathered once per check;
+    on request (``exchange="allgather"``) ONE ensemble with the partners of both ranks.  Either way rank 0 alone writes
+    chemcee_256.h5 in the layout the one-rank run writes ([iterations, 256, ndim]) and decides when to stop from the
+    statistics over all 256 walkers; both ranks read the same file afterwards."""
     from test_gpu_sampling import _gaussian_33
     monkeypatch.setenv("LINNA_TEST_SHARED_DIR", str(tmp_path))
+    monkeypatch.setenv("LINNA_TEST_EXCHANGE", exchange)
     ndim, means, cov, priors = _gaussian_33()
     res = _run(_driver_job)
     sig = np.sqrt(np.diag(cov))
     assert res[0][0] == res[1][0] == (1000, 256, ndim)
     np.testing.assert_array_equal(res[0][1], res[1][1])
     assert np.max(np.abs(res[0][1] - means) / sig) < 0.3 and res[0][3] > 0     # 400 steps x 256 walkers, tau ~ 100: a plumbing check
+    assert np.array_equal(np.asarray(res[0][4]), np.asarray(res[1][4]))
     np.testing.assert_allclose(res[0][2], sig, rtol=0.3)
     assert sorted(os.listdir(tmp_path)) == ["chemcee_256.h5"]
 
@@ -280,7 +290,7 @@ def _zeus_driver_job(rank, world):
     out = os.environ["LINNA_TEST_SHARED_DIR"]
     nw = 136                                                          # 68 per rank (> 2 ndim in total)
     x0 = util.invTransform(priors)(means)[None, :] + 0.001 * np.random.RandomState(3 + rank).standard_normal((nw, ndim))
-    drv = sampler.ZeusSampler(lp, ndim, nw, x0=x0, transform=util.Transform(priors), seed=2)
+    drv = sampler.ZeusSampler(lp, ndim, nw, x0=x0, transform=util.Transform(priors), seed=2, exchange="allgather")
     with contextlib.redirect_stdout(io.StringIO()):
         drv.sample(None, 400, outdir=out, ntimes=1e9, tautol=1e-9)
     d = sampler.ChainStore.load(os.path.join(out, "zeus_256.h5"))
@@ -312,6 +322,72 @@ def test_zeus_driver_shards_one_ensemble_over_the_ranks(tmp_path, monkeypatch):
     assert res[0][6] == res[1][6] and res[0][7] == res[1][7] and res[0][7] is not None
     assert res[0][8] == res[1][8] > 0
     assert sorted(os.listdir(tmp_path)) == ["zeus_256.h5"]
+
+
+def _zeus_local_job(rank, world):
+    import contextlib
+    import io
+    from linna_amd import sampler, util
+    from oracle import sampling as osamp
+    from test_gpu_sampling import identity_emulator_logprob, _gaussian_33
+    ndim, means, cov, priors = _gaussian_33()
+    lp = identity_emulator_logprob(ndim, means, cov, priors)
+    out = os.environ["LINNA_TEST_SHARED_DIR"]
+    nw = int(os.environ["LINNA_TEST_NW"])
+    x0 = util.invTransform(priors)(means)[None, :] + 0.001 * np.random.RandomState(3).standard_normal((nw, ndim))
+    drv = sampler.ZeusSampler(lp, ndim, nw, x0=x0, transform=util.Transform(priors), seed=2)
+    log = io.StringIO()
+    with contextlib.redirect_stdout(log):
+        store = drv.sample(None, 600, outdir=out, ntimes=1e9, tautol=1e-9)
+    d = sampler.ChainStore.load(os.path.join(out, "zeus_256.h5"))
+    ens = drv.sampler
+    chain = np.asarray(d["chain"])
+    th = np.asarray(d["chain_transformed"])[300:]
+    per_rank_mean = [th[:, r * (nw // world):(r + 1) * (nw // world)].reshape(-1, ndim).mean(0) for r in range(world)]
+    # the convergence statistics of the drivers see ALL walkers: tau of the stored chain as the oracle's estimator computes it
+    tau = osamp.integrated_time(chain[120:]) if rank == 0 else None
+    return (chain.shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), per_rank_mean,
+            None if ens is None else (ens.nw, ens.exchange, ens.mu, ens.tune, bool(ens._fast_ok), ens.world), tau)
+
+
+def test_zeus_driver_gives_every_rank_a_sub_ensemble_by_default(tmp_path, monkeypatch):
+    """The default multi-rank mode: 264 walkers = two sub-ensembles of 132 (>= 2 x 33), slice directions
+    from the LOCAL complementary half, mu tuned PER SUB-ENSEMBLE (two different values), no collective inside an iteration;
+    the merged chain in rank 0's zeus_256.h5 -- layout [iterations, 264, ndim], walker blocks in rank order -- carries the
+    33-D posterior within the bounds of the one-ensemble test, and so does each rank's half of it."""
+    from test_gpu_sampling import _gaussian_33
+    monkeypatch.setenv("LINNA_TEST_SHARED_DIR", str(tmp_path))
+    monkeypatch.setenv("LINNA_TEST_NW", "264")
+    ndim, means, cov, priors = _gaussian_33()
+    res = _run(_zeus_local_job)
+    sig = np.sqrt(np.diag(cov))
+    assert res[0][0] == res[1][0] == (600, 264, ndim)
+    np.testing.assert_array_equal(res[0][1], res[1][1])              # both ranks read the same file
+    assert np.max(np.abs(res[0][1] - means) / sig) < 0.3
+    np.testing.assert_allclose(res[0][2], sig, rtol=0.3)
+    for r in (0, 1):                                                 # each sub-ensemble on its own, too (half the samples)
+        assert np.max(np.abs(res[0][3][r] - means) / sig) < 0.45
+    e0, e1 = res[0][4], res[1][4]
+    assert e0[0] == e1[0] == 132 and e0[1] == e1[1] == "none" and e0[5] == 2
+    assert e0[3] is False and e1[3] is False and e0[4] and e1[4]     # both tuned, both on the one-call path
+    assert e0[2] != e1[2] and 0.3 < e0[2] / e1[2] < 3.0              # a mu per sub-ensemble
+    assert np.all(np.isfinite(res[0][5])) and np.all(res[0][5] > 1)  # tau over all 264 walkers
+    assert sorted(os.listdir(tmp_path)) == ["zeus_256.h5"]
+
+
+def test_an_ensemble_too_small_to_split_runs_on_rank_0(tmp_path, monkeypatch):
+    """128 walkers on two ranks would leave 64 < 2 x 33 per rank: the whole ensemble runs on rank 0 ("root"), rank 1 waits at
+    the end of the call and reads the same file."""
+    from test_gpu_sampling import _gaussian_33
+    monkeypatch.setenv("LINNA_TEST_SHARED_DIR", str(tmp_path))
+    monkeypatch.setenv("LINNA_TEST_NW", "128")
+    ndim, means, cov, priors = _gaussian_33()
+    res = _run(_zeus_local_job)
+    assert res[0][0] == res[1][0] == (600, 128, ndim)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert res[0][4][0] == 128 and res[1][4] is None                 # rank 1 never built a sampler
+    sig = np.sqrt(np.diag(cov))
+    assert np.max(np.abs(res[0][1] - means) / sig) < 0.35
 
 
 def _bench2(extra_env, *argv):
