@@ -209,15 +209,16 @@ def pmc_traffic():
         return None
 
 
-def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
+def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500, exchange="none"):
     """Ensemble (stretch-move) iterations per second with every walker advanced once per iteration: 2 half steps, each
     ONE launch (proposal -> whole-network lnP of nwalkers/2 -> accept).  N > 1: EVERY rank runs this with its own
-    ``nwalkers`` walkers and draws the stretch partners of a half step from the complementary walkers of ALL ranks
-    (one RCCL all-gather of [nwalkers/2, ndim] per half step through linna_allgather_f32): one ensemble of
-    N x nwalkers walkers; the rate is that of the slowest rank between two barriers."""
+    ``nwalkers`` walkers; ``exchange="none"`` (the drivers' default, sampler._Ranks "local"): a sub-ensemble per rank, partners
+    from the rank's own complementary half, no collective inside an iteration; ``"allgather"``: the partners of a half step
+    from the complementary walkers of ALL ranks (one RCCL all-gather of [nwalkers/2, ndim] per half step through
+    linna_allgather_f32): one ensemble of N x nwalkers walkers.  The rate is that of the slowest rank between two barriers."""
     import torch
     from linna_amd import sampler
-    ens = sampler.EnsembleSampler(nwalkers, NIN, lp, seed=1, exchange="allgather" if world > 1 else "none")
+    ens = sampler.EnsembleSampler(nwalkers, NIN, lp, seed=1, exchange=exchange if world > 1 else "none")
     ens.set_state(0.05 * np.random.RandomState(7 + ens.rank).standard_normal((nwalkers, NIN)))
     ens.run(warm, store=False)             # untimed: > 50 ms of work, past the clock ramp
     torch.cuda.synchronize()
@@ -230,7 +231,9 @@ def mcmc_rate(lp, nwalkers, world=1, sync=None, nsteps=1000, warm=500):
         sync()
     dt = time.perf_counter() - t0
     return dt, {"steps_per_s": nsteps / dt, "walker_updates_per_s": nsteps * nwalkers * world / dt,
-                "walkers_total": nwalkers * world, "exchange": "allgather of the complementary half per half step" if world > 1 else "none",
+                "walkers_total": nwalkers * world,
+                "exchange": ("allgather of the complementary half per half step" if exchange == "allgather" else
+                             "none: a sub-ensemble per rank (the drivers' default), chain gathered per convergence check") if world > 1 else "none",
                 "acceptance": float(ens.naccept.float().mean()) / ens.iteration}
 
 
@@ -820,6 +823,177 @@ def slice_rate(lp, sizes=(4096, 128), iters=(100, 600)):
     return out
 
 
+def notebook_2d(device):
+    """The ONE configuration the reference publishes a rate for (docs/notebooks/multivariate_gaussian_distribution.ipynb:
+    105,135,165,195 -- tqdm of its four iterations: 34.61 / 31.54 / 34.10 / 33.66 it/s; hardware not stated, the paths are
+    the author's cluster): zeus, 4 walkers, ``ChtoModelv2(2,2)``, 2-D Gaussian, CPU, pool=None.  Here: the reference's own
+    fixture checkpoint of exactly that model (tests/golden/2dgaussian_Fulltconn = the reference's tests/test_data) through
+    ``ZeusSampler`` / ``HMCSampler`` (everything a run does: chain file in the reference's HDF5 layout, theta of every sample,
+    convergence statistics every 100 iterations), and the numpy oracle's per-walker ``Log_prob`` loop on one host core priced
+    at the evaluations zeus needed per iteration.  At 4 walkers a half step is two proposals: the GPU runs at its launch
+    floor, the point of the figure is what a user of the notebook sees."""
+    import shutil
+    import tempfile
+    import contextlib
+    import io
+    import torch
+    from linna_amd import sampler, util, nn
+    fix = os.path.join(ROOT, "tests", "golden", "2dgaussian_Fulltconn", "iter_0/")
+    model, yinv = util.retrieve_model(fix, 2, 2, nn.ChtoModelv2)
+    priors = [{"param": "test_%d" % i, "dist": "flat", "arg1": -2.0, "arg2": 2.0} for i in range(2)]
+    data, cov = np.array([0.1, 1.0]), np.diag([0.5, 0.2])
+    lp = util.Log_prob(data, np.linalg.inv(cov), model, yinv, util.Transform(priors), 1.0, util.gaussianlogliklihood, nograd=True)
+    nw, out = 4, {"published_it_per_s": [34.61, 31.54, 34.10, 33.66],
+                  "published_source": "docs/notebooks/multivariate_gaussian_distribution.ipynb:105,135,165,195 (zeus, 4 walkers, CPU; hardware unspecified)"}
+    x0 = np.zeros((nw, 2)) + 1e-3 * np.random.RandomState(0).standard_normal((nw, 2))
+    for method, nsamp in (("zeus", 3000), ("emcee", 6000)):
+        tmp = tempfile.mkdtemp(prefix="linna_bench_nb_")
+        try:
+            mk = lambda: (sampler.ZeusSampler(lp, 2, nw, x0=x0, transform=util.Transform(priors)) if method == "zeus"
+                          else sampler.HMCSampler(lp, None, None, 2, nw, x0=x0, transform=util.Transform(priors)))
+            with contextlib.redirect_stdout(io.StringIO()):
+                mk().sample(None, 300, outdir=tmp, ntimes=1e9, tautol=1e-9, overwrite=True)     # untimed: first-use costs
+                drv = mk()
+                t0 = time.perf_counter()
+                store = drv.sample(None, nsamp, outdir=tmp, ntimes=1e9, tautol=1e-9, overwrite=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            n = sum(len(c) for c in store.chain) + (100 if method == "emcee" else 0)
+            th = np.concatenate([np.asarray(c) for c in store.chain_transformed])
+            th = th[len(th) // 4:]
+            rec = {"it_per_s": n / dt, "iterations": n, "seconds": dt, "vs_published_median": n / dt / 33.88,
+                   "posterior_mean": th.reshape(-1, 2).mean(0).tolist(), "posterior_std": th.reshape(-1, 2).std(0).tolist()}
+            if method == "zeus" and drv.sampler is not None:
+                rec["evals_per_walker_per_iteration"] = drv.sampler.neval / max(1, drv.sampler.iteration) / nw
+                rec["mu"] = drv.sampler.mu
+            out[method] = rec
+        except Exception as e:                                      # noqa: BLE001
+            out[method] = {"error": repr(e)[:300]}
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    try:
+        from oracle import likelihood
+        w = {k: v.detach().cpu().numpy().copy() for k, v in model.model.state_dict().items()}
+        g = np.load(os.path.join(ROOT, "tests", "golden", "fixture2d.npz"))
+        emu = likelihood.Emulator("ChtoModelv2", 2, 2, w, g["X_mean"], g["X_std"], g["y_mean"], g["y_std"], g["sigma"])
+        z = np.random.RandomState(1).standard_normal((64, 2)).astype(np.float32) * 0.5
+        ic = np.linalg.inv(cov).astype(np.float32)
+        f = lambda: likelihood.log_prob_per_walker(z, emu, priors, data.astype(np.float32), ic, 1.0)
+        ref = f()
+        got = lp(z, returntorch=False)
+        cb = _cpu_timed(f, len(z), "evals/s", "oracle per-walker Log_prob loop, ChtoModelv2(2,2) fixture, one core", budget_s=3.0)
+        epi = out.get("zeus", {}).get("evals_per_walker_per_iteration")
+        cb["max_rel_err_vs_oracle"] = float(np.max(np.abs(got - ref) / np.abs(ref)))
+        if epi:
+            cb["zeus_it_per_s_at_that_rate"] = cb["value"] / (nw * epi)
+        out["cpu_baseline"] = cb
+    except Exception as e:                                          # noqa: BLE001
+        out["cpu_baseline"] = {"error": repr(e)[:300]}
+    return out
+
+
+def e2e(device, nwalkers=128, nepoch=40, ntrain=2000, nval=200):
+    """Where the wall time of a whole ``ml_sampler_core`` run goes (main.py:139-334) once the kernels are fast: the README
+    problem (33-D Gaussian, identity theory, flat priors), the network the reference hard-wires (ChtoModelv2(33,33)), emcee,
+    128 walkers, the reference's 4-iteration temperature schedule with REDUCED sizes (`ntrain` training points per iteration
+    instead of 10 000, `nepoch` epochs instead of 4500 -- stated in the object) -- seconds per stage from the product's own
+    stage marks (linna_amd._lib.stage): design of the training points, the user's theory() calls, text I/O of the samples,
+    loading them back, the LR range test, the epochs, checkpoints, model retrieval, burn-in + sampling + statistics + chain
+    file (the driver's own profile), chain read-back."""
+    import shutil
+    import tempfile
+    import contextlib
+    import io
+    import torch
+    from linna_amd import main as lmain, nn, _lib
+    rs = np.random.RandomState(0)
+    ndim = NIN
+    means = rs.uniform(size=ndim)
+    cov = np.diag(0.1 * rs.uniform(0.2, 1.0, size=ndim))
+    init = rs.uniform(size=ndim)
+    priors = [{"param": "p%d" % i, "dist": "flat", "arg1": -5.0, "arg2": 5.0} for i in range(ndim)]
+    tmp = tempfile.mkdtemp(prefix="linna_bench_e2e_")
+    prof = {}
+    n_theory = [0]
+
+    def theory(x, outdir):
+        n_theory[0] += 1
+        return x[1]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), _lib.stage_profile(prof):
+            t0 = time.perf_counter()
+            chain, lps = lmain.ml_sampler_core(
+                [ntrain] * 4, [nval] * 4, [2, 2, 5, 4], [5, 5, 10, 15], [0.03, 0.03, 0.02, 0.01], [0.2] * 4, [0.15] * 4, tmp + "/", theory,
+                priors, means, cov, init, None, nwalkers, "cuda", None, False, [4.0, 2.0, 1.0, 1.0], nnmodel_in=nn.ChtoModelv2,
+                params={"trainingoption": 1, "num_epochs": nepoch, "batch_size": 500}, method="emcee")
+            torch.cuda.synchronize()
+            total = time.perf_counter() - t0
+        its = []
+        for i in range(4):
+            from linna_amd import sampler
+            d = sampler.ChainStore.load(os.path.join(tmp, "iter_%d" % i, "chemcee_256"))
+            its.append(int(d["chain"].shape[0]))
+        sig = np.sqrt(np.diag(cov))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    top = {k: v for k, v in prof.items() if "." not in k}
+    sub = {k: round(v, 4) for k, v in sorted(prof.items()) if "." in k}
+    other = total - sum(top.values())
+    return {"workload": "ml_sampler_core, README 33-D Gaussian, ChtoModelv2(33,33), emcee, %d walkers, 4 iterations x (%d train + %d val "
+                        "points, %d epochs of batch 500) [the reference's schedule: 10000 + 500 points, up to 4500 epochs]" % (nwalkers, ntrain, nval, nepoch),
+            "total_s": total, "stage_s": {k: round(v, 4) for k, v in sorted(top.items(), key=lambda kv: -kv[1])},
+            "stage_frac": {k: round(v / total, 4) for k, v in sorted(top.items(), key=lambda kv: -kv[1])},
+            "substage_s": sub, "unaccounted_s": round(other, 4), "theory_calls": n_theory[0], "sampling_iterations_by_iteration": its,
+            "posterior_mean_dev_sigma_max": float(np.max(np.abs(chain.mean(0) - means) / sig)),
+            "posterior_std_ratio_minmax": [float(np.min(chain.std(0) / sig)), float(np.max(chain.std(0) / sig))],
+            "samples_returned": int(len(chain))}
+
+
+def rate_vs_walkers(lp, sizes=(64, 128, 256, 512, 1024, 2048, 4096), nsteps=600):
+    """Stretch-move iterations per second against the ensemble size on the headline problem: what an ensemble costs.  Up to
+    2048 walkers a half step (<= 1024 proposals) is ONE workgroup's time for the whole network (the small-batch floor): the
+    iteration rate is flat and walker updates per second grow with the ensemble -- walkers are free up to there."""
+    import torch
+    from linna_amd import sampler
+    out = {}
+    for nw in sizes:
+        ens = sampler.EnsembleSampler(nw, NIN, lp, seed=1)
+        ens.set_state(0.05 * np.random.RandomState(7).standard_normal((nw, NIN)))
+        ens.run(200, store=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ens.run(nsteps, store=False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[str(nw)] = {"it_per_s": nsteps / dt, "us_per_half_step": 0.5e6 * dt / nsteps, "walker_updates_per_s": nsteps * nw / dt}
+    return out
+
+
+def summary(res):
+    """The secondary figures in one compact object, LAST in the line (the driver keeps the line's tail): microseconds and
+    fraction of the fp32-MFMA peak per workload, sampler rates, the end-to-end total."""
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    r = lambda v, n=4: None if v is None else round(float(v), n)
+    return {
+        "headline_us": r(1e3 * res["ms_per_step"], 2), "headline_frac": r(g(res, "roofline", "frac")),
+        "training_ms_per_step": r(g(res, "training", "ms_per_step")), "training_frac": r(g(res, "training", "roofline", "frac")),
+        "chto_v2_us": r(g(res, "chto_v2", "us_per_launch"), 2), "chto_v2_frac": r(g(res, "chto_v2", "frac")),
+        "dense_1000_us": r(g(res, "dense_1000", "us_per_launch"), 2), "dense_1000_frac": r(g(res, "dense_1000", "frac")),
+        "hmc_v2_us_per_grad": r(g(res, "hmc", "chto_v2", "us_per_gradient_eval"), 2), "hmc_v2_frac": r(g(res, "hmc", "chto_v2", "frac")),
+        "hmc_mlp_us_per_grad": r(g(res, "hmc", "mlp", "us_per_gradient_eval"), 2), "hmc_mlp_frac": r(g(res, "hmc", "mlp", "frac")),
+        "mcmc_4096_it_s": r(g(res, "mcmc", "steps_per_s"), 1), "mcmc_128_it_s": r(g(res, "mcmc", "walkers_128", "steps_per_s"), 1),
+        "mcmc_128_driver_it_s": r(g(res, "mcmc", "walkers_128", "driver_steps_per_s"), 1),
+        "slice_4096_it_s": r(g(res, "slice", "walkers_4096", "iterations_per_s"), 1), "slice_128_it_s": r(g(res, "slice", "walkers_128", "iterations_per_s"), 1),
+        "slice_128_evals_per_walker": r(g(res, "slice", "walkers_128", "evals_per_walker_per_iteration"), 2),
+        "production_128_us_per_eval": r(g(res, "production_128", "us_per_64_row_evaluation"), 2),
+        "production_128_emcee_it_s": r(g(res, "production_128", "emcee_iterations_per_s"), 1), "production_128_zeus_it_s": r(g(res, "production_128", "zeus_iterations_per_s"), 1),
+        "notebook_2d_zeus_it_s": r(g(res, "notebook_2d", "zeus", "it_per_s"), 1), "notebook_2d_emcee_it_s": r(g(res, "notebook_2d", "emcee", "it_per_s"), 1),
+        "notebook_2d_published_it_s": 33.9, "e2e_total_s": r(g(res, "e2e", "total_s"), 2),
+        "e2e_largest_stage": (max(res["e2e"]["stage_s"].items(), key=lambda kv: kv[1]) if g(res, "e2e", "stage_s") else None),
+        "cpu_baseline_evals_s": r(g(res, "cpu_baseline", "value"), 0),
+    }
+
+
 def time_dominant_kernel(lp, z, out, iters):
     """HIP-event timing (events recorded on the launch stream) of the dominant kernel: the
     whole-network serving kernel net_stream_kernel<6, 0, false, 0, 16> -- ONE launch per step evaluates prior map,
@@ -1084,13 +1258,19 @@ def main():
     try:
         sync = (lambda: (dist.barrier(), torch.cuda.synchronize())) if world > 1 else None
         quick = world > 1 and args.backend != "nccl"                 # (a gloo rehearsal stages every all-gather through the host)
-        dt_m, mcmc = mcmc_rate(lp, NWALKERS, world, sync, 100 if quick else 1000, 20 if quick else 500)
+        def slowest(dt_m, m):
+            if world > 1:
+                tm = torch.tensor([dt_m], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                k = dt_m / float(tm.item())
+                m["steps_per_s"] *= k
+                m["walker_updates_per_s"] *= k
+            return m
+        mcmc = slowest(*mcmc_rate(lp, NWALKERS, world, sync, 100 if quick else 1000, 20 if quick else 500))
         if world > 1:
-            tm = torch.tensor([dt_m], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            k = dt_m / float(tm.item())
-            mcmc["steps_per_s"] *= k
-            mcmc["walker_updates_per_s"] *= k
+            # the one-ensemble mode (partners from every rank: an all-gather per half step) beside the default: DESIGN section 6
+            # predicts it SLOWER than one GPU -- the driver's N = 2 / 4 / 8 runs measure that prediction
+            mcmc["one_ensemble_allgather"] = slowest(*mcmc_rate(lp, NWALKERS, world, sync, 100 if quick else 1000, 20 if quick else 500, "allgather"))
     except Exception as e:                                          # noqa: BLE001
         mcmc = {"error": repr(e)[:300]}
 
@@ -1146,6 +1326,21 @@ def main():
                     res[key] = fn()
                 except Exception as e:                              # noqa: BLE001
                     res[key] = {"error": repr(e)[:300]}
+            if world == 1:
+                _at("secondary: rate_vs_walkers")
+                try:
+                    if isinstance(res.get("mcmc"), dict):
+                        res["mcmc"]["rate_vs_walkers"] = rate_vs_walkers(lp)
+                except Exception as e:                              # noqa: BLE001
+                    res["mcmc"]["rate_vs_walkers"] = {"error": repr(e)[:300]}
+                for key, fn in (("notebook_2d", lambda: notebook_2d(device)), ("e2e", lambda: e2e(device))):
+                    if key == "e2e" and args.no_driver:
+                        continue
+                    _at("secondary: " + key)
+                    try:
+                        res[key] = fn()
+                    except Exception as e:                          # noqa: BLE001
+                        res[key] = {"error": repr(e)[:300]}
             if world == 1 and not args.no_driver and isinstance(res.get("slice", {}).get("walkers_128"), dict):   # (the drivers shard over the default process group: an N = 1 measurement)
                 _at("secondary: zeus driver")
                 try:                                                # the zeus driver end to end at the reference's ensemble size
@@ -1155,6 +1350,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # the CPU leg is an N = 1 measurement
             lp.evaluate(z, out=out)
             res["cpu_baseline"] = cpu_baseline(consts, z_host, gpu_out=out.cpu().numpy())
+        try:
+            res["summary"] = summary(res)            # LAST: the driver keeps the tail of the line
+        except Exception as e:                      # noqa: BLE001
+            res["summary"] = {"error": repr(e)[:300]}
         if dog is None:
             print(json.dumps(res), flush=True)
         else:

@@ -255,6 +255,49 @@ def ld4(w):
     return (int(w) + 3) & ~3
 
 
+class _Stage(object):
+    __slots__ = ("name", "t0")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if stage_profile.current is not None:
+            import time
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        d = stage_profile.current
+        if d is not None:
+            import time
+            d[self.name] = d.get(self.name, 0.0) + time.perf_counter() - self.t0
+        return False
+
+
+def stage(name):
+    """``with stage("theory"):`` -- wall seconds of a stage of a whole run (``ml_sampler_core``: main.py:139-334), added to the
+    dict a caller installed with ``stage_profile``; without one the block costs two attribute reads.  Stages nest (an inner
+    stage's seconds are also inside its parent's): names carry their parent as a prefix."""
+    return _Stage(name)
+
+
+class stage_profile(object):
+    """``with stage_profile(d):`` -- every ``stage(...)`` block inside adds its wall seconds to ``d`` (bench.py's ``e2e``)."""
+    current = None
+
+    def __init__(self, d):
+        self.d = d
+
+    def __enter__(self):
+        self.prev, stage_profile.current = stage_profile.current, self.d
+        return self.d
+
+    def __exit__(self, *exc):
+        stage_profile.current = self.prev
+        return False
+
+
 class quiet_gc(object):
     """Around a loop that keeps the GPU fed from the host: every object alive now is put aside (``gc.freeze``: constant time;
     no collection first -- that alone held a 1.5 s run for 0.15 s) so that the cyclic collector's passes inside the loop look

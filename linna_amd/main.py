@@ -17,6 +17,7 @@ from .nn import *  # noqa: F401,F403
 from .util import (limit_threads_to_quota, Transform, invTransform, NN_samplerv1, generate_training_point, train_NN, retrieve_model, Log_prob,
                    gaussianlogliklihood, run_mcmc, read_chain_and_cut, LogPrior, logp_theory_data)
 from . import nn as lnn
+from ._lib import stage
 
 
 def ml_sampler(outdir, theory, priors, data, cov, init, pool, nwalkers, gpunode, omegab2cut=None, nepoch=4500,
@@ -94,7 +95,8 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
         chain = None
         if i > 0:
             prev = os.path.join(outdir, "iter_{0}/".format(i - 1), filename[:-3])
-            chain, _, _ = read_chain_and_cut(prev, nk, ntimes, method=method)
+            with stage("read_chain_and_cut"):
+                chain, _, _ = read_chain_and_cut(prev, nk, ntimes, method=method)
         nnsampler = NN_samplerv1(outdir_in, prior_range)
         nbest_in = nbest[i] if isinstance(nbest, list) else nbest                # main.py:140-152
         if nbest_in is not None and nbest_in <= 0:
@@ -108,9 +110,10 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
                 d = data - theory([-1, x], tempdir)
                 return d.dot(inv_cov.dot(d))
         if rank == 0:
-            generate_training_point(theory, nnsampler, pool, outdir_in, nt, nv, data, inv_cov, chain, nsigma=nsigma,
-                                    omegab2cut=omegab2cut, options=params.get("trainingoption", 0), negloglike=negloglike,
-                                    nbest_in=nbest_in, chisqcut=chisqcut)
+            with stage("training_points"):
+                generate_training_point(theory, nnsampler, pool, outdir_in, nt, nv, data, inv_cov, chain, nsigma=nsigma,
+                                        omegab2cut=omegab2cut, options=params.get("trainingoption", 0), negloglike=negloglike,
+                                        nbest_in=nbest_in, chisqcut=chisqcut)
         chain = None
         gc.collect()
         ldist.barrier()                                                          # the training points are on disk
@@ -122,12 +125,14 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
                 pickle.dump(args, f)
         if (master or world > 1) and not ldist.agree(os.path.isfile(os.path.join(outdir_in, "finish.pkl"))):
             args[15] = nnmodel_in
-            train_NN(*args, device=device if str(device).startswith("cuda") else "cuda", rank=rank)   # every rank: data parallel
+            with stage("train_NN"):
+                train_NN(*args, device=device if str(device).startswith("cuda") else "cuda", rank=rank)   # every rank: data parallel
             if master:
                 with open(os.path.join(outdir_in, "finish.pkl"), "wb") as f:     # train_gpu.py:36-38
                     pickle.dump([True], f)
         ldist.barrier()                                                          # checkpoints and transform pickles are on disk
-        model, y_invtransform_data = retrieve_model(outdir_in, len(init), len(data), nnmodel_in)
+        with stage("retrieve_model"):
+            model, y_invtransform_data = retrieve_model(outdir_in, len(init), len(data), nnmodel_in)
         if ldist.agree(any(os.path.isfile(os.path.join(outdir_in, filename[:-3] + ext)) for ext in (".h5", ".npz"))):   # main.py:273-274
             continue
         log_prob = Log_prob(data.astype(np.float32), inv_cov.astype(np.float32), model, y_invtransform_data, transform,
@@ -135,12 +140,14 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
                             externalloglike=externalloglike)
         if pool is not None:
             pool.noduplicate = True                                              # main.py:282-283
-        store = run_mcmc(nnsampler, outdir_in, method, ndim, nwalkers, init, log_prob, pool=pool, transform=transform,
-                         ntimes=ntimes, tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
+        with stage("run_mcmc"):
+            store = run_mcmc(nnsampler, outdir_in, method, ndim, nwalkers, init, log_prob, pool=pool, transform=transform,
+                             ntimes=ntimes, tautol=tautol, meanshift=meanshift, stdshift=stdshift, nk=nk)
         if pool is not None:
             pool.noduplicate_close()                                             # main.py:285-286
     last = os.path.join(outdir, "iter_{0}/".format(len(ntrainArr) - 1), filename[:-3])
-    chain, _, d = read_chain_and_cut(last, nk, ntimes, method=method)
+    with stage("read_chain_and_cut"):
+        chain, _, d = read_chain_and_cut(last, nk, ntimes, method=method)
     log_prob_samples_x = d["log_prob"].reshape(-1)                               # main.py:291
     if "nimp" in params and rank == 0:                                           # main.py:297-334 (rank 0 owns the files)
         f_samples, f_lp = os.path.join(outdir, "samples_im.npy"), os.path.join(outdir, "log_prob_samples_x.npy")

@@ -130,6 +130,9 @@ class DeviceChain(object):
             buf = torch.empty((cap, self.nd, self.nwp), dtype=torch.float32, device=self.dev)
             if self.n:
                 buf[:self.n] = self.ct[:self.n]
+                # the old buffer may belong to ANOTHER stream's pool (a resumed run fills the chain on the default stream, the
+                # in-loop appends run on the statistics stream): the caching allocator must not hand it out while this copy reads it
+                self.ct.record_stream(torch.cuda.current_stream(self.dev))
             self.ct = buf
         for i0 in range(0, len(z), 32768):                   # (grid.y of the transposing kernel is the step count)
             blk = z[i0:i0 + 32768]
@@ -689,7 +692,7 @@ def read_chain_and_cut(chainname, nk, ntimes=20, walkercut=False, method="emcee"
     if torch.cuda.is_available():                   # the same estimator, batched on the device (see DeviceChain)
         dc = DeviceChain()
         dc.append(np.asarray(d["chain"], np.float32))
-        tau = dc.integrated_time()
+        tau = dc.integrated_time(all_walkers=True)              # util.py:78-80 uses every walker; a one-shot call
     else:
         tau = integrated_time(d["chain"])
     nkeep = int(np.nanmedian(tau) * nk)

@@ -336,9 +336,11 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
         from . import dist as ldist
         ldist.init()        # rendezvous + the library's RCCL communicator (no-op when the launcher already did; predictor_gpu.py:240-252)
     model = pred.model
-    engine = TrainEngine(pred, dataset, loss_fn, val_dataset, world_size=size, dist_group=dist_group)
+    with _lib.stage("train_NN.engine_setup"):
+        engine = TrainEngine(pred, dataset, loss_fn, val_dataset, world_size=size, dist_group=dist_group)
     if pred.optim == "automatic" or pred.optim is None:
-        lr = _read_lr(pred, engine, rank, size, dist_group)
+        with _lib.stage("train_NN.lr_range_test"):
+            lr = _read_lr(pred, engine, rank, size, dist_group)
     else:
         lr = float(getattr(pred.optim, "lr", 1e-3))
     lr = lr * size                                                              # :246
@@ -477,117 +479,118 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     if num_epochs > 0:
         enqueue_steps(perm)
     prof.mark("enqueue_steps")
-    gcq = _lib.quiet_gc().__enter__()        # (the epochs' launches are queued 2-9 ms ahead: no full collector pass inside the loop)
-    while i < num_epochs:
-        landed = enqueue_tail()
-        prof.mark("enqueue_validation")
-        if i + 1 < num_epochs and nsteps:                                       # the next epoch's order, while the GPU works
-            pre["rng"] = torch.get_rng_state()
-            pre["rows"] = draw_rows((i + 1) & 1)
-        prof.mark("rows")
-        if spec and pre["rows"] is not None and fly["quiet"] >= QUIET:
-            fly["on"] = True
-            fly["epochs"] += 1
-            enqueue_steps(pre["rows"])                                          # epoch i + 1, on the assumption "carry on"
-            prof.mark("enqueue_steps")
-        landed.synchronize()                                                    # THE wait of the epoch
-        prof.mark("wait")
-        epoch_losses = hist_pin.numpy()[:nsteps].astype(np.float64)
-        train_losses.extend(epoch_losses.tolist())
-        loss = float(epoch_losses[-1]) if nsteps else float("nan")
-        is_best = False
-        stop = False
-        if val_dataset is not None:
-            vm = rec_pin.numpy()[1:].astype(np.float64)
-            val_metrics.append(vm)
-            if progress and rank == 0:
-                print("epoch %d  train %.5e  val %.5e" % (i, loss, vm[0]), flush=True)
-            if pred.outdir is not None:
-                is_best = vm[0] < pred.best_val_loss
-                if is_best:
-                    pred.best_val_loss = vm[0]
-            recent = np.array(val_metrics[-10:])[:, 0]
-            if np.std(recent) < 0.01 * np.mean(recent) and 10 <= i < 120 and i % 10 == 0:      # :319-335
-                print("bad trainning: {0}".format(i), flush=True)
-                lr_now = opt.lr
-                rollback("plateau: re-initialised")
-                reinit()
-                new_optimizer(lr_now)
-                if i > 10 and lr_now > 2e-4:
-                    halve_lr()
-            v0 = val_metrics[-1][0]
-            if np.isnan(v0) or v0 > 1e10 or (v0 - old > 5 * old and i != 0) or (loss - told > 5 * told and i != 0):  # :339
-                lr_now = opt.lr
-                restored = False
-                rollback("loss jump / NaN: best weights restored")
-                if best_state is not None:
-                    model.flat_params().copy_(best_state)
-                    restored = True
-                elif pred.outdir is not None:
-                    drain_checkpoints()                                         # (no best yet in this run: an older file)
-                    restored = pred.load_checkpoint(ismpi=False)
-                if not restored:
-                    reinit()
-                new_optimizer(lr_now)
-                if np.isnan(v0) or v0 > 1e10 or (v0 - old > 10 * old):
-                    if i > 10:
-                        halve_lr()
-                if not np.isnan(v0) and (v0 - old > 5 * old):
-                    val_metrics[-1][0] = old
-            else:
-                criteria = es.step(v0, loss)                                    # :375-401
-                if criteria == 1:
-                    if opt.lr > 2e-6:
-                        rollback("early stopping: lr / 2")
-                        print("\n learning rate too large: {0}\n".format(opt.lr), flush=True)
-                        opt.lr, opt.weight_decay = opt.lr / 2.0, opt.weight_decay / 2
-                        opt.push_hyper()
-                    else:
-                        es.cooling = 0
-                if criteria == 2:
-                    print("early stop", flush=True)
-                    print("learning rate", opt.lr, flush=True)
-                    # the reference breaks on rank 0 only (predictor_gpu.py:392-393), harmless there because nothing
-                    # collective follows; here every rank holds the same metrics (all-reduced loss, replicated
-                    # validation set) and the next epoch starts with an all-reduce, so every rank stops
-                    rollback("early stopping: stop")
-                    drop_prefetch()
-                    stop = True
-                if criteria == 3:
-                    print("\n weight decay too small: {0}\n".format(opt.weight_decay), flush=True)
-                    if opt.weight_decay < 1e0:
-                        rollback("early stopping: weight decay x 2")
-                        opt.weight_decay = opt.weight_decay * 2
-                        opt.push_hyper()
-            old = val_metrics[-1][0]
-            told = loss
-        prof.mark("controller")
-        p_, m_, v_, st_ = state_of_epoch() if fly["on"] else (model._flat, opt.m, opt.v, opt.step_dev)
-        if is_best:
-            best_state = p_.clone()                                             # device-resident best.pth.tar
-        ckpt.record(opt, i, is_best, checkpoint_every, num_epochs, force=stop, state=(p_, m_, v_, st_))
-        prof.mark("checkpoint")
-        prof.end_epoch()
-        last_epoch = i
-        if stop:
-            break
-        fly["quiet"] = 0 if fly["acted"] else fly["quiet"] + 1
-        fly["acted"] = False
-        i += 1
-        if i < num_epochs and not fly["on"]:                                    # not speculated, or undone: (re)enqueue the epoch
-            if pre["rows"] is not None:
-                perm, pre["rows"], pre["rng"] = pre["rows"], None, None
-            else:
-                perm = draw_rows(i & 1)
+    with _lib.stage("train_NN.epochs"), _lib.quiet_gc():   # (the epochs' launches are queued 2-9 ms ahead: no full collector pass inside the loop;
+                                             #  a context manager: an exception inside the loop hands the objects back to the collector)
+        while i < num_epochs:
+            landed = enqueue_tail()
+            prof.mark("enqueue_validation")
+            if i + 1 < num_epochs and nsteps:                                       # the next epoch's order, while the GPU works
+                pre["rng"] = torch.get_rng_state()
+                pre["rows"] = draw_rows((i + 1) & 1)
             prof.mark("rows")
-            enqueue_steps(perm)
-            prof.mark("enqueue_steps")
-        else:
-            pre["rows"], pre["rng"] = None, None                                # (the speculative epoch has consumed the order drawn ahead)
-        fly["on"] = False
-    gcq.__exit__(None, None, None)
+            if spec and pre["rows"] is not None and fly["quiet"] >= QUIET:
+                fly["on"] = True
+                fly["epochs"] += 1
+                enqueue_steps(pre["rows"])                                          # epoch i + 1, on the assumption "carry on"
+                prof.mark("enqueue_steps")
+            landed.synchronize()                                                    # THE wait of the epoch
+            prof.mark("wait")
+            epoch_losses = hist_pin.numpy()[:nsteps].astype(np.float64)
+            train_losses.extend(epoch_losses.tolist())
+            loss = float(epoch_losses[-1]) if nsteps else float("nan")
+            is_best = False
+            stop = False
+            if val_dataset is not None:
+                vm = rec_pin.numpy()[1:].astype(np.float64)
+                val_metrics.append(vm)
+                if progress and rank == 0:
+                    print("epoch %d  train %.5e  val %.5e" % (i, loss, vm[0]), flush=True)
+                if pred.outdir is not None:
+                    is_best = vm[0] < pred.best_val_loss
+                    if is_best:
+                        pred.best_val_loss = vm[0]
+                recent = np.array(val_metrics[-10:])[:, 0]
+                if np.std(recent) < 0.01 * np.mean(recent) and 10 <= i < 120 and i % 10 == 0:      # :319-335
+                    print("bad trainning: {0}".format(i), flush=True)
+                    lr_now = opt.lr
+                    rollback("plateau: re-initialised")
+                    reinit()
+                    new_optimizer(lr_now)
+                    if i > 10 and lr_now > 2e-4:
+                        halve_lr()
+                v0 = val_metrics[-1][0]
+                if np.isnan(v0) or v0 > 1e10 or (v0 - old > 5 * old and i != 0) or (loss - told > 5 * told and i != 0):  # :339
+                    lr_now = opt.lr
+                    restored = False
+                    rollback("loss jump / NaN: best weights restored")
+                    if best_state is not None:
+                        model.flat_params().copy_(best_state)
+                        restored = True
+                    elif pred.outdir is not None:
+                        drain_checkpoints()                                         # (no best yet in this run: an older file)
+                        restored = pred.load_checkpoint(ismpi=False)
+                    if not restored:
+                        reinit()
+                    new_optimizer(lr_now)
+                    if np.isnan(v0) or v0 > 1e10 or (v0 - old > 10 * old):
+                        if i > 10:
+                            halve_lr()
+                    if not np.isnan(v0) and (v0 - old > 5 * old):
+                        val_metrics[-1][0] = old
+                else:
+                    criteria = es.step(v0, loss)                                    # :375-401
+                    if criteria == 1:
+                        if opt.lr > 2e-6:
+                            rollback("early stopping: lr / 2")
+                            print("\n learning rate too large: {0}\n".format(opt.lr), flush=True)
+                            opt.lr, opt.weight_decay = opt.lr / 2.0, opt.weight_decay / 2
+                            opt.push_hyper()
+                        else:
+                            es.cooling = 0
+                    if criteria == 2:
+                        print("early stop", flush=True)
+                        print("learning rate", opt.lr, flush=True)
+                        # the reference breaks on rank 0 only (predictor_gpu.py:392-393), harmless there because nothing
+                        # collective follows; here every rank holds the same metrics (all-reduced loss, replicated
+                        # validation set) and the next epoch starts with an all-reduce, so every rank stops
+                        rollback("early stopping: stop")
+                        drop_prefetch()
+                        stop = True
+                    if criteria == 3:
+                        print("\n weight decay too small: {0}\n".format(opt.weight_decay), flush=True)
+                        if opt.weight_decay < 1e0:
+                            rollback("early stopping: weight decay x 2")
+                            opt.weight_decay = opt.weight_decay * 2
+                            opt.push_hyper()
+                old = val_metrics[-1][0]
+                told = loss
+            prof.mark("controller")
+            p_, m_, v_, st_ = state_of_epoch() if fly["on"] else (model._flat, opt.m, opt.v, opt.step_dev)
+            if is_best:
+                best_state = p_.clone()                                             # device-resident best.pth.tar
+            ckpt.record(opt, i, is_best, checkpoint_every, num_epochs, force=stop, state=(p_, m_, v_, st_))
+            prof.mark("checkpoint")
+            prof.end_epoch()
+            last_epoch = i
+            if stop:
+                break
+            fly["quiet"] = 0 if fly["acted"] else fly["quiet"] + 1
+            fly["acted"] = False
+            i += 1
+            if i < num_epochs and not fly["on"]:                                    # not speculated, or undone: (re)enqueue the epoch
+                if pre["rows"] is not None:
+                    perm, pre["rows"], pre["rng"] = pre["rows"], None, None
+                else:
+                    perm = draw_rows(i & 1)
+                prof.mark("rows")
+                enqueue_steps(perm)
+                prof.mark("enqueue_steps")
+            else:
+                pre["rows"], pre["rng"] = None, None                                # (the speculative epoch has consumed the order drawn ahead)
+            fly["on"] = False
     t_loop = time.perf_counter()
-    ckpt.finish(opt, last_epoch)                    # best.pth.tar / last.pth.tar are on disk when train() returns
+    with _lib.stage("train_NN.final_checkpoint"):
+        ckpt.finish(opt, last_epoch)                # best.pth.tar / last.pth.tar are on disk when train() returns
     prof.finish(epochs=last_epoch + 1, steps_per_epoch=nsteps, total_s=time.perf_counter() - t_run,
                 final_checkpoint_s=time.perf_counter() - t_loop, speculative_epochs=fly["epochs"], speculative_epochs_undone=fly["undone"], controller_actions=dict(fly["acts"]))
     if val_dataset is not None:

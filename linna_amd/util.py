@@ -678,7 +678,8 @@ def train_NN(nnsampler, cov, inv_cov, sigma, outdir_in, outdir_list, data, dolog
         y_transform_data.pickle(os.path.join(outdir_in, "y_transform_data.pkl"))
         y_invtransform_data.pickle(os.path.join(outdir_in, "y_invtransform_data.pkl"))
     data_tensor = torch.from_numpy(np.asarray(data).astype(np.float32))
-    train_x, train_y, val_x, val_y, train_y_last = _load_samples(outdir_list, usebest)
+    with _lib.stage("train_NN.load_samples"):
+        train_x, train_y, val_x, val_y, train_y_last = _load_samples(outdir_list, usebest)
     print(train_x.shape, train_y.shape, val_x.shape, val_y.shape)
     if ypositive:
         # util.py:1410-1431: positive data vectors are emulated in log space.  Clip to [1e-30, 1e10] (both ends are the
@@ -906,12 +907,18 @@ def generate_training_point(theory, nnsampler, pool, outdir, ntrain, nval, data,
     for tag, n in (("train", ntrain), ("val", nval)):
         fx, fy = os.path.join(outdir, tag + "_samples_x.txt"), os.path.join(outdir, tag + "_samples_y.npy")
         if not os.path.isfile(fx):
-            np.savetxt(fx, design(n))
+            with _lib.stage("training_points.design"):
+                pts = design(n)
+            with _lib.stage("training_points.text_io"):
+                np.savetxt(fx, pts)
         sub = os.path.join(outdir, tag + "/")
         os.makedirs(sub, exist_ok=True)
         if not os.path.isfile(fy):
-            x = np.loadtxt(fx)
-            np.save(fy, nnsampler.generate_training_data(zip(range(len(x)), x), theory, pool=pool, args=[sub]))
+            with _lib.stage("training_points.text_io"):
+                x = np.loadtxt(fx)
+            with _lib.stage("training_points.theory"):
+                y = nnsampler.generate_training_data(zip(range(len(x)), x), theory, pool=pool, args=[sub])
+            np.save(fy, y)
         if chisqcut is not None:
             chisqcut_all(data, invcov, chisqcut, fy, fx)
     if negloglike is not None:
