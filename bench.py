@@ -892,11 +892,12 @@ def notebook_2d(device):
     return out
 
 
-def e2e(device, nwalkers=128, nepoch=40, ntrain=2000, nval=200):
+def e2e(device, nwalkers=128, nepoch=200, ntrain=10000, nval=500):
     """Where the wall time of a whole ``ml_sampler_core`` run goes (main.py:139-334) once the kernels are fast: the README
     problem (33-D Gaussian, identity theory, flat priors), the network the reference hard-wires (ChtoModelv2(33,33)), emcee,
-    128 walkers, the reference's 4-iteration temperature schedule with REDUCED sizes (`ntrain` training points per iteration
-    instead of 10 000, `nepoch` epochs instead of 4500 -- stated in the object) -- seconds per stage from the product's own
+    128 walkers, the reference's 4-iteration schedule (10 000 training + 500 validation points per iteration, temperatures
+    4, 2, 1, 1) with `nepoch` epochs per iteration instead of the reference's cap of 4500 (its early stopping ends most runs
+    far below the cap; stated in the object) -- seconds per stage from the product's own
     stage marks (linna_amd._lib.stage): design of the training points, the user's theory() calls, text I/O of the samples,
     loading them back, the LR range test, the epochs, checkpoints, model retrieval, burn-in + sampling + statistics + chain
     file (the driver's own profile), chain read-back."""
@@ -1072,6 +1073,8 @@ def main():
     ap.add_argument("--no-driver", action="store_true", help="skip mcmc.driver_steps_per_s (a 2.3 GB chain file in the temporary directory)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                                                       "rehearse the multi-rank path on a box with fewer GPUs)")
+    ap.add_argument("--only", default="", help="comma-separated secondary objects to run alone (notebook_2d, e2e, slice, production_128, "
+                    "rate_vs_walkers, hmc, chto_v2, dense_1000): one JSON object with just those, no headline")
     ap.add_argument("--launch-check", action="store_true", help="ranks only rendezvous (linna_amd.dist.init), sum their ranks over "
                     "the process group and rank 0 prints that: what the CPU test of the self-launcher runs (no GPU needed)")
     args = ap.parse_args()
@@ -1120,6 +1123,14 @@ def main():
 
     _stage("process group up: %s" % collectives)
     lp, model, consts = build_problem(device)
+    if args.only:
+        fns = {"notebook_2d": lambda: notebook_2d(device), "e2e": lambda: e2e(device), "slice": lambda: slice_rate(lp),
+               "production_128": lambda: production_rates(device), "rate_vs_walkers": lambda: rate_vs_walkers(lp), "hmc": lambda: hmc_rate(device),
+               "chto_v2": lambda: secondary_serving(device, "ChtoModelv2", 33, 33, False),
+               "dense_1000": lambda: secondary_serving(device, "ChtoModelv2", 40, 1000, True),
+               "training": lambda: training_rate(device, 1, 0, args.backend)}
+        print(json.dumps({k: fns[k]() for k in args.only.split(",")}), flush=True)
+        return
     z_host = np.random.RandomState(100 + rank).standard_normal((NWALKERS, NIN)).astype(np.float32)
     z = torch.as_tensor(z_host, device=device)
     out = torch.empty(NWALKERS, dtype=torch.float32, device=device)

@@ -308,11 +308,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     // launcher fills gbit / mbit), measured SLOWER on its 4-row engine (155.4 against 152.4 us per step at (26,457): the
     // gate loads are not what its run ends wait for, the ballots and bit writes of every forward epilogue are extra) -- off.
     constexpr bool LB = G2;
-#ifdef NS_EARLY_REFILL
-    constexpr bool LATE_REFILL = false;
-#else
     constexpr bool LATE_REFILL = true;             // see `step`
-#endif
     static_assert(ROWS == 16 || ROWS == 8 || ROWS == 4, "rows per workgroup");
     static_assert(R % 2 == 0, "the A double buffer alternates with the ring slot parity");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -657,12 +653,6 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // raw: __syncthreads() would drain the weight stream
     asm volatile("" ::: "memory");
-#ifdef NS_PRIO
-    if (wave >= 4) __builtin_amdgcn_s_setprio(NS_PRIO);          // experiment: static priority for the second-dispatched half
-#endif
-#ifdef NS_STAGGER
-    if (wave >= 4) __builtin_amdgcn_s_sleep(NS_STAGGER);
-#endif
     NS_STAMP();
 
     // ---- 4. the step loop
@@ -714,14 +704,6 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 }
             }
             if (s_zext < 0) kleft = s_steps - 4 * blk;             // its rows start at 64 blk
-#ifdef NS_REBAL_PROBE
-            // TIMING PROBE ONLY (results are garbage): the first-dispatched wave of each SIMD wins the matrix pipe (NOTES R5); here it
-            // runs NS_REBAL_PROBE steps more per long single-pass run and its partner as many fewer -- what moving the tail of the
-            // partner's k range over to it would do to the run's length
-            if constexpr (!SM && STORE == 0 && !GRAD) {
-                if (s_passes == 1 && s_steps >= 16 && s_zext == 0) kleft += wave < 4 ? NS_REBAL_PROBE : -NS_REBAL_PROBE;
-            }
-#endif
             ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (s_zext < 0 ? 64 * blk : (pass ? s_kslice : 0)));   // (kslice: 0 but for a short second pass)
         } else {
             ap = act_lds + 4u * (uint32_t)(P * ABUF + arow * LD + ak + (wave >> s_ncgl) * s_kslice);
@@ -731,9 +713,6 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#ifdef NS_STAGGER
-        if (wave >= 4) __builtin_amdgcn_s_sleep(NS_STAGGER);     // experiment: SIMD partners half a step apart (-DNS_STAGGER=n x 64 cycles)
-#endif
     };
     load_seg();
     begin_run();
@@ -747,24 +726,10 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
         // steps are in flight instead of R).  Not in the merged training launch: its register allocation does not survive
         // the longer slot lifetimes (2.3 KB of scratch per lane, +40 % on the step).
         constexpr int RU = LATE_REFILL ? (U + R - 1) % R : U;
-#ifdef NS_ALTPRIO
-        // experiment: the two waves of a SIMD take turns at the higher issue priority every R / 2 steps, so that neither runs
-        // ahead of the other by thousands of cycles inside a segment (-DNS_ALTPRIO)
-        if constexpr (U == 0) { if (wave < 4) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        if constexpr (U == R / 2) { if (wave < 4) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1); }
-#endif
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(Aq[U & 1]) :: "memory");
         a_read(Aq[(U + 1) & 1]);                   // next step's A (speculative at a run end)
         const f32x4 av = Aq[U & 1];
         if constexpr (SM) {
-#ifdef NS_SM_EARLY
-            // experiment (R4): the L1-fill-bound engines request the refill at the TOP of the step (the slot the previous step
-            // consumed: no MFMA of this step reads it) instead of behind its MFMAs
-            if constexpr (refill) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) Bq[RU][t] = wload(t);
-            }
-#endif
             // acc[4 r + c] += A(rows of set r, k chunk c, element e) x B(k chunk c = load c, element e); ABID = block 4 c + r
 #define NS_M4(r, c, e) acc[4 * (r) + (c)] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], Bq[U][c][e], acc[4 * (r) + (c)], 4, 4 * (c) + (r), 0);
 #define NS_M4R(r, e) NS_M4(r, 0, e) NS_M4(r, 1, e) NS_M4(r, 2, e) NS_M4(r, 3, e)
@@ -775,28 +740,11 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
             }
 #undef NS_M4R
 #undef NS_M4
-#ifndef NS_SM_EARLY
             if constexpr (refill) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) Bq[RU][t] = wload(t);
             }
-#endif
         } else {
-#ifdef NS_ACC4
-            // experiment: the four accumulators in rotation (a dependent MFMA four instructions behind its producer instead of two)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], Bq[U][t][s], acc[t], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr (refill) {
-                    if (s == 1) { Bq[RU][0] = wload(0); Bq[RU][1] = wload(1); }
-                    if (s == 3) { Bq[RU][2] = wload(2); Bq[RU][3] = wload(3); }
-                }
-            }
-#else
 #pragma unroll
             for (int h = 0; h < NT; h += 2) {
 #pragma unroll
@@ -809,7 +757,6 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                     Bq[RU][h + 1] = wload(h + 1);
                 }
             }
-#endif
         }
         if constexpr (refill) wadvance();
         if (--kleft == 0) {
@@ -987,11 +934,6 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
                 if (fine) NS_STAMP();              // epilogue done (LDS writes and stores issued)
 #endif
                 if (++pass == s_passes) {
-#ifdef NS_NOBAR_PROBE
-                    // TIMING PROBE ONLY (results are garbage): no barrier between two single-pass WIDE segments -- the upper bound of what
-                    // replacing these barriers by per-wave "my columns are written" flags could gain
-                    if (!(NX.type == NS_WIDE && s_passes == 1 && si + 1 < nseg))
-#endif
                     lds_barrier();
                     NS_STAMP();
                     P ^= 1; pass = 0; ++si;
@@ -1368,19 +1310,7 @@ __global__ __launch_bounds__(64 * NS_NW, 1) void net_stream_kernel(NsArgs a) {
     };
     using T_ = std::true_type; using F_ = std::false_type;
 #define NS_STEP(U, RF) if constexpr (U < R) step(std::integral_constant<int, U>{}, RF{});
-#ifdef NS_REBAL_PROBE
-    int gadj = 0;
-    if constexpr (!SM && STORE == 0 && !GRAD) {
-        for (int j = 0; j < nseg; ++j) {
-            const NsSeg Sj = ka->seg[__builtin_amdgcn_readfirstlane(j)];
-            if (Sj.type == NS_WIDE && Sj.passes == 1 && Sj.steps >= 16 && Sj.zext == 0) gadj += NS_REBAL_PROBE;
-        }
-    }
-    const int Gw = a.G + (wave < 4 ? gadj : -gadj);
-    const int ngroups = Gw / R, rem = Gw - ngroups * R;
-#else
     const int ngroups = a.G / R, rem = a.G - ngroups * R;
-#endif
 #pragma unroll 1
     for (int it = 0; it < ngroups; ++it) {
         NS_STEP(0, T_) NS_STEP(1, T_) NS_STEP(2, T_) NS_STEP(3, T_) NS_STEP(4, T_) NS_STEP(5, T_) NS_STEP(6, T_) NS_STEP(7, T_)

@@ -98,9 +98,9 @@ def ml_sampler_core(ntrainArr, nvalArr, nkeepArr, ntimesArr, ntautolArr, meanshi
             with stage("read_chain_and_cut"):
                 chain, _, _ = read_chain_and_cut(prev, nk, ntimes, method=method)
         nnsampler = NN_samplerv1(outdir_in, prior_range)
-        nbest_in = nbest[i] if isinstance(nbest, list) else nbest                # main.py:140-152
-        if nbest_in is not None and nbest_in <= 0:
-            nbest_in = None
+        nbest_in = nbest                                                         # main.py:140-145: only a LIST entry <= 0 means "none"
+        if isinstance(nbest, list):
+            nbest_in = nbest[i] if nbest[i] > 0 else None
         negloglike = None
         if nbest_in is not None:
             import tempfile

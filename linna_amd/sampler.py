@@ -1007,6 +1007,8 @@ class SliceEnsembleSampler(EnsembleSampler):
         self.nexp_rounds, self.nshr_rounds = len(self.m_sched), len(self.nt_sched)
         self._m_arr = (C.c_int * self.nexp_rounds)(*self.m_sched)
         self._nt_arr = (C.c_int * self.nshr_rounds)(*self.nt_sched)
+        if getattr(self, "_fast_bufs", None) is not None:              # (a schedule change mid-run: keep the evaluation count)
+            self._neval_host += int(self._fast_bufs["counters"][3].item())
         self._fast_bufs = None
 
     @staticmethod
@@ -1270,10 +1272,29 @@ class SliceEnsembleSampler(EnsembleSampler):
                 self.noverflow += 1
                 self._fast_after = snap["iteration"] + 1 << 30       # (this attempt: round loop only)
                 out = body()
-                self._fast_after = self.iteration + 200                # the one-call path again after 200 quiet iterations
+                # a posterior whose brackets have a heavy tail (few walkers, directions between near neighbours: the 2-D
+                # notebook problem at 4 walkers overflowed every few iterations) would otherwise spend its run on the round
+                # loop: the schedule looks further ahead from now on -- the added rounds evaluate only the walkers still
+                # active and cost a few gated-off launches -- and the one-call path stays in use; at the deepest level the
+                # old rule applies (200 quiet iterations on the round loop)
+                self._fast_after = self.iteration if self._escalate() else self.iteration + 200
             return out
         finally:
             self._guarded = False
+
+    ESCALATIONS = 2                 # times an overflow may deepen the schedule (x4 stepping-out steps, x2 trials each time)
+
+    def _escalate(self):
+        """Deepen the one-call path's look-ahead after an overflow: four times the stepping-out steps per side, twice the
+        trials, in rounds that double (at most 32 bracket ends per side / 64 trials per round: a wave's lanes in the logic
+        kernels).  False at the deepest level."""
+        lvl = getattr(self, "_esc_level", 0)
+        if lvl >= self.ESCALATIONS:
+            return False
+        self._esc_level = lvl + 1
+        self.set_schedule(self._schedule(self.m_sched[0], 4 * sum(self.m_sched), 32),
+                          self._schedule(self.nt_sched[0], 2 * sum(self.nt_sched), 64))
+        return True
 
     def _use_fast_possible(self):
         return not (self.fast is False or self.host_lp or self._fast_ok is False)
@@ -1627,7 +1648,7 @@ class HMCSampler(object):
         print("start", flush=True)
         if not resume:
             print("burnin...", flush=True)                                   # sampler.py:519-529
-            with prof.host("burnin"):
+            with prof.host("burnin"), _lib.stage("run_mcmc.burnin"):
                 ens.set_state(rk.mine(x0))
                 c, l = ens.run(burnin)
                 c, l, _ = rk.gather(ens, c, l)
@@ -1672,9 +1693,10 @@ class HMCSampler(object):
                     np.max(np.abs(old_tau - tau) / tau), np.min(np.abs(old_tau - tau) / tau), np.max(tau), n), flush=True)
             return bool(converged)
 
-        done = _run_blocks(ens, rk, store, dchain, done, nsamp, ncheck, incremental, lambda n: dchain.tau_begin(), decide, prof)
+        with _lib.stage("run_mcmc.blocks"):
+            done = _run_blocks(ens, rk, store, dchain, done, nsamp, ncheck, incremental, lambda n: dchain.tau_begin(), decide, prof)
         if rk.rank == 0:
-            with prof.host("final_flush"):
+            with prof.host("final_flush"), _lib.stage("run_mcmc.final_flush"):
                 store.flush()
         rk.barrier()                                                          # the file is complete before any rank reads it
         prof.finish(total_s=time.perf_counter() - t_start, iterations=done, writer_fetch_s=store.busy["fetch"],
@@ -1743,10 +1765,11 @@ class ZeusSampler(object):
                 converged = converged and bool(dchain.checkmeanstd(max(2, int(nk * tau)), meanshift, stdshift))
             return bool(converged)
 
-        done = _run_blocks(ens, rk, store, dchain, done, min(nsamp, 100000), ncheck, incremental,
-                           lambda n: dchain.tau_begin(discard=int(n * 0.2)), decide, prof)
+        with _lib.stage("run_mcmc.blocks"):
+            done = _run_blocks(ens, rk, store, dchain, done, min(nsamp, 100000), ncheck, incremental,
+                               lambda n: dchain.tau_begin(discard=int(n * 0.2)), decide, prof)
         if rk.rank == 0:
-            with prof.host("final_flush"):
+            with prof.host("final_flush"), _lib.stage("run_mcmc.final_flush"):
                 store.flush()
         rk.barrier()
         prof.finish(total_s=time.perf_counter() - t_start, iterations=done, writer_fetch_s=store.busy["fetch"],

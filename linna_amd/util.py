@@ -811,9 +811,14 @@ class NN_samplerv1(object):
 
     def gensample_chain_randomsample(self, Nsamples, chain_in, nsigma, omegab2cut=None):
         """util.py:864-897: uniform random draws (seed 123456) from the previous chain inside the prior box."""
-        chain = _apply_cuts(np.array(chain_in, copy=True), omegab2cut)
-        for i in range(chain.shape[1]):
-            chain = chain[(chain[:, i] > self.prior_range[i][0]) & (chain[:, i] < self.prior_range[i][1])]
+        # (the reference filters column by column, one boolean-indexed copy of the chain per parameter: the same rows in the
+        #  same order from ONE mask -- at 33 parameters and a million kept samples the copies were the largest host stage of an
+        #  iteration that was not the user's theory code, bench.py `e2e`)
+        chain = np.asarray(chain_in)
+        if omegab2cut is not None:
+            chain = _apply_cuts(np.array(chain, copy=True), omegab2cut)
+        pr = np.asarray(self.prior_range, dtype=np.float64)
+        chain = chain[np.all((chain > pr[None, :, 0]) & (chain < pr[None, :, 1]), axis=1)]
         np.random.seed(self.seed)
         return chain[np.random.randint(0, len(chain), int(Nsamples))]
 
@@ -933,7 +938,8 @@ def generate_training_point(theory, nnsampler, pool, outdir, ntrain, nval, data,
         if not os.path.isfile(fbx):
             x0 = np.loadtxt(os.path.join(outdir, "train_samples_x.txt"))[0]
             best = minimize(negloglike, x0, method="Nelder-Mead", tol=1e-6).x
-            inv_hess = np.linalg.inv(makepositivedefinite(numerical_hessian(negloglike, best)))
+            widths = np.array([hi - lo for lo, hi in nnsampler.prior_range], np.float64)
+            inv_hess = np.linalg.inv(makepositivedefinite(numerical_hessian(negloglike, best, scale=widths)))
             np.savetxt(fbx, multivariate_normal.rvs(mean=best, cov=inv_hess, size=nbest_in, random_state=None))
             np.savetxt(fbv, multivariate_normal.rvs(mean=best, cov=inv_hess, size=int(nbest_in / ntrain * nval), random_state=None))
         if not os.path.isfile(os.path.join(outdir, "best_samples_y.npy")):
@@ -959,19 +965,62 @@ def makepositivedefinite(cov, fcut=0.99):
     return eigvec @ np.diag(eigvals) @ eigvec.T
 
 
-def numerical_hessian(f, x):
-    """Central second differences of a scalar function (stands in for numdifftools.Hessian, util.py:1240)."""
+def numerical_hessian(f, x, rel_step=None, check=True, scale=None):
+    """Central second differences of a scalar function -- stands in for ``numdifftools.Hessian`` (util.py:1240; third party,
+    absent from the reference tree and from this image: PARITY UNPINNED for this matrix).
+
+    Steps ``h_i = rel_step s_i`` with ``s_i = scale_i`` (the caller's parameter scales: ``generate_training_point`` passes the
+    prior widths) or ``|x_i| + 1e-2`` without them.  ``f`` is the chi^2 of an EXTERNAL theory code whose own noise (an
+    iterative solver, an interpolation table; the Nelder-Mead fit before this call stops at 1e-6) is amplified by
+    ``1 / h^2`` in a second difference, so one fixed step is wrong for somebody: with ``rel_step=None`` each diagonal element
+    is taken at 1e-3, 2e-3, ... (doubling, up to 1.6e-2) until two consecutive steps agree within 10 %, keeping the larger of
+    the two -- or, if none do, the step of the closest pair (a step-doubling consistency check: the idea of numdifftools'
+    Richardson sequence without its extrapolation); the off-diagonals use the steps so chosen.
+    ``LINNA_HESSIAN_STEP`` / ``rel_step`` fix the step.  ``check``: warn when the matrix is not positive definite before
+    ``makepositivedefinite`` reshapes its spectrum (util.py:38-48) -- the draws around the best fit then follow the repair,
+    not the likelihood."""
     x = np.asarray(x, np.float64)
     n = len(x)
-    h = 1e-4 * (np.abs(x) + 1e-2)
-    H = np.zeros((n, n))
+    if rel_step is None and os.environ.get("LINNA_HESSIAN_STEP"):
+        rel_step = float(os.environ["LINNA_HESSIAN_STEP"])
+    base = np.abs(x) + 1e-2 if scale is None else np.asarray(scale, np.float64)
     f0 = f(x)
+
+    def diag(i, h):
+        e = np.zeros(n); e[i] = h
+        return (f(x + e) - 2 * f0 + f(x - e)) / h ** 2
+    if rel_step is not None:
+        h = rel_step * base
+        d = np.array([diag(i, h[i]) for i in range(n)])
+    else:
+        steps = [1e-3 * 2 ** k for k in range(5)]
+        h, d = np.empty(n), np.empty(n)
+        for i in range(n):
+            vals = [diag(i, steps[0] * base[i])]
+            best = None                                       # (difference, index of the larger step of the pair)
+            for k in range(1, len(steps)):
+                vals.append(diag(i, steps[k] * base[i]))
+                diff = abs(vals[k] - vals[k - 1])
+                if best is None or diff < best[0]:
+                    best = (diff, k)
+                if diff <= 0.1 * max(abs(vals[k]), abs(vals[k - 1]), 1e-300):
+                    best = (diff, k)
+                    break
+            h[i], d[i] = steps[best[1]] * base[i], vals[best[1]]
+    H = np.diag(d)
     for i in range(n):
         ei = np.zeros(n); ei[i] = h[i]
-        H[i, i] = (f(x + ei) - 2 * f0 + f(x - ei)) / h[i] ** 2
         for j in range(i):
             ej = np.zeros(n); ej[j] = h[j]
             H[i, j] = H[j, i] = (f(x + ei + ej) - f(x + ei - ej) - f(x - ei + ej) + f(x - ei - ej)) / (4 * h[i] * h[j])
+    if check:
+        w = np.linalg.eigvalsh(0.5 * (H + H.T))
+        if not np.all(w > 0):
+            import warnings
+            warnings.warn("numerical_hessian: %d of %d eigenvalues are not positive (smallest %.3g, largest %.3g): the best-fit "
+                          "point is not a minimum at this step size, or the theory is too noisy for second differences; "
+                          "makepositivedefinite will reshape the spectrum (set LINNA_HESSIAN_STEP to change the step)"
+                          % (int((w <= 0).sum()), n, w.min(), w.max()), RuntimeWarning)
     return H
 
 

@@ -334,6 +334,51 @@ def test_slice_ensemble_posterior_33d_gaussian():
     assert ens.neval / (ens.iteration * nw) < 40            # speculative rounds (8 bracket ends per side, 16 trials), inactive lanes included
 
 
+def test_slice_engine_choice_and_overflow_fallback_keep_the_posterior():
+    """with the engines of the later rounds left AUTOMATIC (chosen from the usage counters at fixed iterations) a
+    walker's stored lnP and its trial lnP may come from different engines (last-bit differences): the chain is then no longer
+    bit-equal to the ``USE_EXPECT = False`` chain -- bit equality across the switch holds per engine only
+    (test_slice_later_rounds_follow_the_usage_counters) -- but it must sample the same posterior: means within the
+    Monte-Carlo error of each other and of the truth.  And a run whose one-call path overflows mid-run (a schedule one
+    stepping-out step deep) is redone on the round loop, deepens its schedule and goes on: still the posterior."""
+    from linna_amd import sampler, util
+    ndim, means, cov, priors = _gaussian_33()
+    lp = identity_emulator_logprob(ndim, means, cov, priors)
+    sig = np.sqrt(np.diag(cov))
+    nw = 600
+    z0 = util.invTransform(priors)(means)[None, :] + 0.001 * np.random.RandomState(2).standard_normal((nw, ndim))
+    out = {}
+    try:
+        for use in (True, False):
+            sampler.SliceEnsembleSampler.USE_EXPECT = use
+            ens = sampler.SliceEnsembleSampler(nw, ndim, lp, seed=7)
+            ens.set_state(z0)
+            ens.run(300, store=False)
+            c, _ = ens.run(400)
+            th = ens.theta_of(c).cpu().numpy().reshape(-1, ndim)
+            out[use] = (th.mean(0), th.std(0), ens.expected_rows)
+            assert ens._fast_ok is True and not ens.tune
+    finally:
+        sampler.SliceEnsembleSampler.USE_EXPECT = True
+    assert out[True][2] is not None and out[False][2] is None       # the automatic choice was live in one run only
+    for use in (True, False):
+        assert np.max(np.abs(out[use][0] - means) / sig) < 0.06
+        np.testing.assert_allclose(out[use][1], sig, rtol=0.07)
+    assert np.max(np.abs(out[True][0] - out[False][0]) / sig) < 0.08  # two independent estimates of the same mean
+    # overflow mid-run: one stepping-out step per side is not enough for every walker
+    ens = sampler.SliceEnsembleSampler(nw, ndim, lp, seed=8)
+    ens.set_state(z0)
+    ens.run(300, store=False)
+    ens.set_schedule([1], [4, 8])
+    c, l = ens.run(300)
+    assert ens.noverflow >= 1 and getattr(ens, "_esc_level", 0) >= 1 and sum(ens.m_sched) > 1     # redone, and looking further ahead now
+    th = ens.theta_of(c).cpu().numpy().reshape(-1, ndim)
+    assert np.max(np.abs(th.mean(0) - means) / sig) < 0.08
+    np.testing.assert_allclose(th.std(0), sig, rtol=0.08)
+    np.testing.assert_allclose(lp.evaluate(torch.nn.functional.pad(c[-1], (0, ens.ld - ndim))).cpu().numpy(), l[-1].cpu().numpy(),
+                               rtol=1e-4, atol=1e-4)
+
+
 def test_zeus_driver_smoke(tmp_path):
     """tests/test_sampler.py:4-14 of the reference (``test_zeus``) on the emulator path."""
     from linna_amd import sampler, util

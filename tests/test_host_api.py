@@ -598,6 +598,34 @@ def test_nbest_points_are_designed_around_the_best_fit(tmp_path):
     np.testing.assert_array_equal(vy2[:5], vy)
 
 
+def test_numerical_hessian_with_a_noisy_theory_and_a_saddle():
+    """the chi^2 of an external theory code carries its own noise, which a second difference amplifies by 1 / h^2.
+    With ~1e-7 relative noise the step-doubling choice keeps the curvatures within a few per cent (a fixed 1e-4 step is off by
+    factors); a best-fit point that is no minimum warns before makepositivedefinite reshapes the spectrum."""
+    import warnings
+    from linna_amd import util
+    rs = np.random.RandomState(5)
+    nd = 4
+    A = rs.standard_normal((8, nd))
+    x0 = np.array([0.4, -1.2, 0.05, 2.0])
+    Q = A.T @ A
+    noise = np.random.RandomState(9)
+
+    def f(x):
+        v = 50.0 + (x - x0) @ Q @ (x - x0)
+        return v * (1.0 + 1e-7 * noise.standard_normal())
+    H = util.numerical_hessian(f, x0, scale=np.full(nd, 4.0))             # (parameter scales: the widths of the priors)
+    assert np.abs(np.diag(H) - 2 * np.diag(Q)).max() < 0.05 * np.abs(np.diag(Q)).max()
+    assert np.abs(H - 2 * Q).max() < 0.1 * np.abs(Q).max()
+    Hfixed = util.numerical_hessian(f, x0, rel_step=1e-5)                 # a small fixed step drowns in the same noise
+    assert np.abs(np.diag(Hfixed) - 2 * np.diag(Q)).max() > np.abs(np.diag(H) - 2 * np.diag(Q)).max()
+    saddle = lambda x: x[0] ** 2 - x[1] ** 2
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        util.numerical_hessian(saddle, np.zeros(2))
+    assert any("not positive" in str(m.message) for m in w)
+
+
 def test_slice_round_expectation_from_usage_counters():
     """``SliceEnsembleSampler.expected_points``: the engine hint of the later slice rounds (linna_slice_half_step's
     ``expect_rows``) from the device's usage counters -- mean walkers still active behind a round x the next round's points per
