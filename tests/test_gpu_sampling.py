@@ -531,10 +531,10 @@ def test_one_call_slice_schedules_and_ragged_ensembles(nw, m_sched, nt_sched):
         for it in range(6):
             a.step(); b.step()
             torch.cuda.synchronize()
-            ca = a._fast_bufs["counters"].cpu().numpy()
             assert torch.equal(a.coords, b.coords) and torch.equal(a.logp, b.logp), it
-            if a.noverflow:                              # (a short schedule left a walker unfinished: the guarded step went back and
-                break                                    #  redid the iteration on the round loop; the counters are the aborted attempt's)
+            if a.noverflow:                              # (a short schedule left a walker unfinished: the guarded step went back,
+                break                                    #  redid the iteration on the round loop and deepened the schedule: new buffers)
+            ca = a._fast_bufs["counters"].cpu().numpy()
             cb = b.counters.cpu().numpy()
             assert ca[0] == cb[0] and ca[1] == cb[1], (it, ca[:4], cb)
         assert a._fast_ok is True
