@@ -194,7 +194,7 @@ def _oracle_emulator(kind, nin, nout, model, X_mean, X_std, y_mean, y_std, sigma
     return likelihood.Emulator(kind, nin, nout, w, X_mean, X_std, y_mean, y_std, sigma, **kw)
 
 
-TRAFFIC_FILE = "r05_pmc_traffic.json"
+TRAFFIC_FILE = "r06_pmc_traffic.json"
 
 
 def pmc_traffic():
