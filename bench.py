@@ -981,7 +981,7 @@ def summary(res):
         "chto_v2_us": r(g(res, "chto_v2", "us_per_launch"), 2), "chto_v2_frac": r(g(res, "chto_v2", "frac")),
         "dense_1000_us": r(g(res, "dense_1000", "us_per_launch"), 2), "dense_1000_frac": r(g(res, "dense_1000", "frac")),
         "hmc_v2_us_per_grad": r(g(res, "hmc", "chto_v2", "us_per_gradient_eval"), 2), "hmc_v2_frac": r(g(res, "hmc", "chto_v2", "frac")),
-        "hmc_mlp_us_per_grad": r(g(res, "hmc", "mlp", "us_per_gradient_eval"), 2), "hmc_mlp_frac": r(g(res, "hmc", "mlp", "frac")),
+        "hmc_mlp_us_per_grad": r(g(res, "hmc", "mlp4x512", "us_per_gradient_eval"), 2), "hmc_mlp_frac": r(g(res, "hmc", "mlp4x512", "frac")),
         "mcmc_4096_it_s": r(g(res, "mcmc", "steps_per_s"), 1), "mcmc_128_it_s": r(g(res, "mcmc", "walkers_128", "steps_per_s"), 1),
         "mcmc_128_driver_it_s": r(g(res, "mcmc", "walkers_128", "driver_steps_per_s"), 1),
         "slice_4096_it_s": r(g(res, "slice", "walkers_4096", "iterations_per_s"), 1), "slice_128_it_s": r(g(res, "slice", "walkers_128", "iterations_per_s"), 1),

@@ -610,13 +610,30 @@ def median_absolute_deviation(y, median, dim):
     return torch.abs(y - median).median(axis=dim).values
 
 
+_TXT_CACHE = {}
+
+
+def _loadtxt_cached(path):
+    """``np.loadtxt`` of a sample file, parsed once per (path, size, mtime): every iteration of ``ml_sampler_core`` re-reads the
+    ``*_samples_x.txt`` of ALL earlier iterations (util.py:1346-1373) -- ten parses of 10 000 x ndim text for a four-iteration
+    run (bench.py `e2e`: train_NN.load_samples).  The array handed out is a copy."""
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
+    hit = _TXT_CACHE.get(key)
+    if hit is None:
+        if len(_TXT_CACHE) >= 64:
+            _TXT_CACHE.clear()
+        hit = _TXT_CACHE[key] = np.loadtxt(path)
+    return hit.copy()
+
+
 def _load_samples(outdir_list, usebest=False):
     """util.py:1342-1409: concatenate the samples of all iterations so far; ``usebest``: with the optimizer-seeded samples
     (``best_samples_*``, util.py:1235-1252) in front."""
     tx, ty, vx, vy = [], [], [], []
     for outdir in outdir_list:
-        for lst, name, loader in ((tx, "train_samples_x.txt", np.loadtxt), (ty, "train_samples_y.npy", np.load),
-                                  (vx, "val_samples_x.txt", np.loadtxt), (vy, "val_samples_y.npy", np.load)):
+        for lst, name, loader in ((tx, "train_samples_x.txt", _loadtxt_cached), (ty, "train_samples_y.npy", np.load),
+                                  (vx, "val_samples_x.txt", _loadtxt_cached), (vy, "val_samples_y.npy", np.load)):
             a = loader(os.path.join(outdir, name))
             if len(a) > 1:
                 lst.append(a)
