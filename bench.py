@@ -1249,7 +1249,10 @@ def main():
                   "ms_per_step": 1e3 * float(ts.item()) / args.steps}
 
     # secondary figure, every rank takes part (collective inside): training throughput on the configs[2] shape.
-    # Guarded: a failure here must not cost the headline line.
+    # Guarded: a failure here must not cost the headline line.  (N > 1: every finished section goes into the held line at once --
+    # the watchdog prints that dict, so a section that hangs later costs only itself and what follows it.)
+    if rank == 0 and strong is not None:
+        res["strong_scaling"] = strong
     _at("strong scaling done")
     training = None
     if not args.no_training:
@@ -1263,6 +1266,8 @@ def main():
             training["epoch"] = training_epochs(device)
         except Exception as e:                                      # noqa: BLE001
             training["epoch"] = {"error": repr(e)[:300]}
+    if rank == 0 and training is not None:
+        res["training"] = training
     _at("training done: %s" % (training,))
     # ensemble iterations: every rank takes part (cross-rank partner exchange for N > 1)
     mcmc = None
@@ -1279,8 +1284,12 @@ def main():
             return m
         mcmc = slowest(*mcmc_rate(lp, NWALKERS, world, sync, 100 if quick else 1000, 20 if quick else 500))
         if world > 1:
+            if rank == 0:
+                res["mcmc"] = mcmc                                   # (held by the watchdog from here on)
+            _at("mcmc (sub-ensembles) done; one-ensemble all-gather leg")
             # the one-ensemble mode (partners from every rank: an all-gather per half step) beside the default: DESIGN section 6
-            # predicts it SLOWER than one GPU -- the driver's N = 2 / 4 / 8 runs measure that prediction
+            # predicts it SLOWER than one GPU -- the driver's N = 2 / 4 / 8 runs measure that prediction.  The first data-path
+            # all-gather of a run with more than one rank: behind everything else that needs every rank.
             mcmc["one_ensemble_allgather"] = slowest(*mcmc_rate(lp, NWALKERS, world, sync, 100 if quick else 1000, 20 if quick else 500, "allgather"))
     except Exception as e:                                          # noqa: BLE001
         mcmc = {"error": repr(e)[:300]}
