@@ -335,6 +335,7 @@ def run(pred, dataset, num_epochs, loss_fn, val_dataset, val_metric_fn, initfrom
     if size > 1:
         from . import dist as ldist
         ldist.init()        # rendezvous + the library's RCCL communicator (no-op when the launcher already did; predictor_gpu.py:240-252)
+        ldist.enter("Predictor.train (data parallel, size = %d)" % size, dist_group)   # every rank must be here: fail within minutes, not never
     model = pred.model
     with _lib.stage("train_NN.engine_setup"):
         engine = TrainEngine(pred, dataset, loss_fn, val_dataset, world_size=size, dist_group=dist_group)
