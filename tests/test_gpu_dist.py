@@ -220,7 +220,7 @@ def _driver_job(rank, world):
     x0 = util.invTransform(priors)(means)[None, :] + 0.01 * np.random.RandomState(10 + rank).standard_normal((nw, ndim))
     drv = sampler.HMCSampler(lp, None, None, ndim, nw, x0=x0, transform=util.Transform(priors), seed=5,
                              exchange=os.environ.get("LINNA_TEST_EXCHANGE") or None)
-    with contextlib.redirect_stdout(io.StringIO()):
+    with contextlib.redirect_stdout(io.StringIO()) as log:
         drv.sample(None, 1000, outdir=out, ntimes=1e9, tautol=1e-9, incremental=True)      # never "converged": 1000 iterations
     if os.environ.get("LINNA_TEST_EXCHANGE") != "allgather":
         assert drv.exchange is None
@@ -228,6 +228,14 @@ def _driver_job(rank, world):
     th = np.asarray(d["chain_transformed"])[600:]
     acc = np.asarray(d["accepted"])
     assert acc.shape[-1] == nw and (acc.reshape(-1, nw)[-1] > 0).all()     # acceptance counts of ALL walkers, rank order
+    if rank == 0:
+        # the statistic the stop rule reads is the one-rank statistic of the file's chain: tau over ALL 256 walkers
+        import re
+        from oracle import sampling as osamp
+        checks = re.findall(r"max tau, ninter: \S+, \S+, (\S+), (\d+)", log.getvalue())
+        tau_max, n_last = float(checks[-1][0]), int(checks[-1][1])
+        ref = osamp.integrated_time(np.asarray(d["chain"], np.float64)[:n_last]).max()
+        assert n_last == 1000 and abs(tau_max - ref) < 2e-3 * ref, (tau_max, ref, n_last)
     return d["chain"].shape, th.reshape(-1, ndim).mean(0), th.reshape(-1, ndim).std(0), acc.sum(), acc.reshape(-1, nw)[-1]
 
 
